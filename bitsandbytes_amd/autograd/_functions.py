@@ -1,0 +1,129 @@
+"""``matmul_4bit`` and its autograd function — reference ``bitsandbytes/autograd/_functions.py:300-491``.
+
+Forward is one ``bitsandbytes::gemm_4bit`` op call for every M (the op's MI355X kernel picks the
+wave64 dot kernel or the MFMA kernel); backward is ``grad_A = grad_out @ dequantize_4bit(B)``.
+Double-quantised states pass their pieces straight into the op so the absmax reconstruction is
+fused into the GEMM kernel.
+"""
+from __future__ import annotations
+
+from typing import Optional
+from warnings import warn
+
+import torch
+
+from .. import functional as F
+
+
+def _is_compiling() -> bool:
+    return torch.compiler.is_compiling()
+
+
+def _gemm_4bit_from_state(A: torch.Tensor, B: torch.Tensor, quant_state: F.QuantState, bias):
+    """Call the gemm_4bit op with the (possibly nested) statistics of ``quant_state``."""
+    if not quant_state.nested:
+        return torch.ops.bitsandbytes.gemm_4bit.default(
+            A, B, quant_state.shape, quant_state.absmax, quant_state.blocksize, quant_state.quant_type, bias=bias
+        )
+    if quant_state.state2.blocksize != 256:
+        raise NotImplementedError("nested quantization with state2.blocksize != 256 is not supported")
+    return torch.ops.bitsandbytes.gemm_4bit.default(
+        A,
+        B,
+        quant_state.shape,
+        quant_state.state2.absmax,
+        quant_state.blocksize,
+        quant_state.quant_type,
+        bias=bias,
+        absmax_8bit=quant_state.absmax,
+        absmax_code=quant_state.state2.code,
+        absmax_offset=quant_state.offset,
+    )
+
+
+class MatMul4Bit(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, B, out=None, bias=None, quant_state: Optional[F.QuantState] = None):
+        ctx.is_empty = A.numel() == 0
+        if ctx.is_empty:
+            ctx.A, ctx.B, ctx.bias = A, B, bias
+            w_shape = quant_state.shape
+            tail = w_shape[1:] if A.shape[-1] == w_shape[0] else w_shape[:1]
+            return torch.empty(A.shape[:-1] + tail, dtype=A.dtype, device=A.device)
+
+        B = B.view(-1, 1)  # canonical packed layout; quant_state.shape carries N and K
+        output = _gemm_4bit_from_state(A, B, quant_state, bias)
+        if out is not None:
+            out.copy_(output)
+            output = out
+
+        ctx.state = quant_state
+        ctx.dtype_A, ctx.dtype_B = A.dtype, B.dtype
+        ctx.dtype_bias = None if bias is None else bias.dtype
+        ctx.tensors = (None, B) if any(ctx.needs_input_grad[:2]) else (None, None)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        if ctx.is_empty:
+            grad_bias = None if ctx.bias is None else torch.zeros_like(ctx.bias)
+            return torch.zeros_like(ctx.A), torch.zeros_like(ctx.B), None, grad_bias, None
+
+        need_A, _, _, need_bias, _ = ctx.needs_input_grad
+        _, B = ctx.tensors
+        grad_A = grad_bias = None
+        if need_bias:
+            grad_bias = grad_output.sum(0, dtype=ctx.dtype_bias)
+        if need_A:
+            # dequantize gives [N, K]; grad_out[M, N] @ W[N, K] = grad_A[M, K]
+            grad_A = torch.matmul(grad_output, F.dequantize_4bit(B, ctx.state).to(grad_output.dtype))
+        return grad_A, None, None, grad_bias, None
+
+
+def matmul_4bit(
+    A: torch.Tensor,
+    B: torch.Tensor,
+    quant_state: F.QuantState,
+    out: Optional[torch.Tensor] = None,
+    bias: Optional[torch.Tensor] = None,
+):
+    """``A @ dequant(B).T (+ bias)`` with ``B`` the packed 4-bit weight of a ``[N, K]`` matrix
+    (reference autograd/_functions.py:407-491)."""
+    if quant_state is None:
+        raise ValueError("quant_state is required")
+    if len(quant_state.shape) != 2:
+        raise ValueError("matmul_4bit: quant_state.shape must be 2D [N, K]")
+
+    B = B.view(-1, 1)
+    K = A.shape[-1]
+
+    # Legacy: weight quantised from a [K, N] tensor (A's inner dim matches shape[0], not shape[1]).
+    if K == quant_state.shape[0] and K != quant_state.shape[1]:
+        if not _is_compiling():
+            warn(
+                f"matmul_4bit: weight was quantized from a [K, N] tensor (quant_state.shape="
+                f"{list(quant_state.shape)}). Re-quantize from the weight in [N, K] (out_features, in_features) "
+                "orientation. This will be an error in a future version.",
+                DeprecationWarning,
+                stacklevel=2,
+            )
+        W = F.dequantize_4bit(B, quant_state).to(A.dtype)
+        result = torch.nn.functional.linear(A, W.t(), bias)
+        if out is not None:
+            out.copy_(result)
+            return out
+        return result
+
+    needs_grad = torch.is_grad_enabled() and (A.requires_grad or (bias is not None and bias.requires_grad))
+    if needs_grad:
+        return MatMul4Bit.apply(A, B, out, bias, quant_state)
+
+    if A.numel() == 0:
+        if out is not None:
+            return out
+        return torch.empty((*A.shape[:-1], quant_state.shape[0]), dtype=A.dtype, device=A.device)
+    result = _gemm_4bit_from_state(A, B, quant_state, bias)
+    if out is not None:
+        out.copy_(result)
+        return out
+    return result

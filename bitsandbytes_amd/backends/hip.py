@@ -1,0 +1,285 @@
+"""Device kernels for the ``bitsandbytes::*`` 4-bit ops on MI355X — the ``"cuda"`` dispatch key is
+what PyTorch-ROCm uses for HIP devices (reference ``bitsandbytes/__init__.py:26-36``).
+
+Takes the place of the 4-bit part of the reference's ``bitsandbytes/backends/cuda/ops.py:299-982``:
+same per-op glue (contiguity, output allocation, raw current stream, device guard), but the
+dispatcher for ``gemm_4bit`` is MI355X-specific (:func:`_gemm_4bit_route`) instead of the reference's
+per-arch heuristic tables (:583-843), and every native call goes to ``libbitsandbytes_mi355x.so``.
+
+PyTorch is plumbing here (allocation, streams); all arithmetic of the path happens in the HIP
+library. The one library GEMM that remains is the reference's own large-M / misaligned-K strategy:
+dequantize once, then ``F.linear`` on hipBLASLt (reference :904-916).
+"""
+from __future__ import annotations
+
+from collections.abc import Sequence
+from math import prod
+from typing import Optional
+from warnings import warn
+
+import torch
+
+from .._ops import register_kernel
+from ..cextension import lib
+
+_DT_NAME = {torch.float32: "fp32", torch.float16: "fp16", torch.bfloat16: "bf16"}
+_DT_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+_QT_CODE = {"fp4": 1, "nf4": 2}
+
+# Largest M routed to the fused kernels; above it one dequantize + hipBLASLt GEMM moves fewer bytes
+# per FLOP than re-streaming the packed weight per 64-row slab. Calibrated on MI355X.
+FUSED_MAX_M = 128
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch._C._cuda_getCurrentRawStream(t.device.index)
+
+
+class _device_of:
+    """Make the tensor's device current for the duration of a native call (multi-GPU processes only;
+    reference functional.py:80-88)."""
+
+    def __init__(self, t: torch.Tensor):
+        self.idx = t.device.index
+        self.prev = None
+
+    def __enter__(self):
+        if torch.cuda.device_count() > 1:
+            self.prev = torch.cuda.current_device()
+            if self.prev != self.idx:
+                torch.cuda.set_device(self.idx)
+            else:
+                self.prev = None
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------ quantize_4bit
+@register_kernel("bitsandbytes::quantize_4bit", "cuda")
+def _(A: torch.Tensor, blocksize: int, quant_type: str, quant_storage: torch.dtype):
+    if blocksize not in (32, 64, 128, 256, 512, 1024, 2048, 4096):
+        raise ValueError(f"invalid blocksize {blocksize}")
+    if quant_type not in _QT_CODE:
+        raise ValueError(f"quant_type must be 'nf4' or 'fp4', got {quant_type!r}")
+    if A.dtype not in _DT_CODE:
+        raise ValueError(f"Blockwise 4bit quantization only supports 16/32-bit floats, but got {A.dtype}")
+    A = A.contiguous()
+    n = A.numel()
+    absmax = torch.empty((-(n // -blocksize),), device=A.device, dtype=torch.float32)
+    out = torch.empty(((n + 1) // (quant_storage.itemsize * 2), 1), device=A.device, dtype=quant_storage)
+    with _device_of(A):
+        # stream-ordered variant of cquantize_blockwise_<T>_<q> (which is pinned to the NULL stream)
+        lib.bnb_mi355x_quantize_4bit(
+            A.data_ptr(), _DT_CODE[A.dtype], absmax.data_ptr(), out.data_ptr(), blocksize, n, _QT_CODE[quant_type],
+            _stream(A),
+        )
+    return out, absmax
+
+
+# ------------------------------------------------------------------------------------------ dequantize_4bit
+def _dequantize_4bit_impl(A, absmax, blocksize, quant_type, dtype, out):
+    if dtype not in _DT_NAME:
+        raise ValueError(f"Blockwise 4bit dequantization only supports 16/32-bit floats, but got {dtype}")
+    if quant_type not in _QT_CODE:
+        raise ValueError(f"quant_type must be 'nf4' or 'fp4', got {quant_type!r}")
+    if absmax.dtype != torch.float32:
+        raise ValueError(f"absmax must be float32, got {absmax.dtype}")
+    A = A.contiguous()
+    absmax = absmax.contiguous()
+    fn = getattr(lib, f"cdequantize_blockwise_{_DT_NAME[dtype]}_{quant_type}")
+    with _device_of(A):
+        fn(None, A.data_ptr(), absmax.data_ptr(), out.data_ptr(), blocksize, out.numel(), _stream(A))
+
+
+@register_kernel("bitsandbytes::dequantize_4bit", "cuda")
+def _(A, absmax, blocksize: int, quant_type: str, shape: Sequence[int], dtype: torch.dtype) -> torch.Tensor:
+    out = torch.empty(tuple(shape), dtype=dtype, device=A.device)
+    _dequantize_4bit_impl(A, absmax, blocksize, quant_type, dtype, out)
+    return out
+
+
+@register_kernel("bitsandbytes::dequantize_4bit.out", "cuda")
+def _(A, absmax, blocksize: int, quant_type: str, shape: Sequence[int], dtype: torch.dtype, out: torch.Tensor):
+    if tuple(out.shape) != tuple(shape):
+        raise ValueError(f"Expected out.shape == {tuple(shape)}, got {tuple(out.shape)}")
+    if out.dtype != dtype:
+        raise ValueError(f"Expected out.dtype == {dtype}, got {out.dtype}")
+    if not out.is_contiguous():
+        raise ValueError("out must be contiguous")
+    _dequantize_4bit_impl(A, absmax, blocksize, quant_type, dtype, out)
+
+
+# ------------------------------------------------------------------------------------------ 8-bit blockwise
+@register_kernel("bitsandbytes::quantize_blockwise", "cuda")
+def _(A: torch.Tensor, code: torch.Tensor, blocksize: int):
+    if code.dtype != torch.float32:
+        raise ValueError(f"code must be float32, got {code.dtype}")
+    if blocksize not in (64, 128, 256, 512, 1024, 2048, 4096):
+        raise ValueError(f"invalid blocksize {blocksize}")
+    if A.dtype not in _DT_CODE:
+        raise ValueError(f"Blockwise quantization only supports 16/32-bit floats, but got {A.dtype}")
+    A = A.contiguous()
+    code = code.contiguous()
+    n = A.numel()
+    absmax = torch.empty((-(n // -blocksize),), device=A.device, dtype=torch.float32)
+    out = torch.empty_like(A, dtype=torch.uint8)
+    with _device_of(A):
+        lib.bnb_mi355x_quantize_8bit(
+            code.data_ptr(), A.data_ptr(), _DT_CODE[A.dtype], absmax.data_ptr(), out.data_ptr(), blocksize, n, _stream(A)
+        )
+    return out, absmax
+
+
+def _dequantize_blockwise_impl(A, absmax, code, blocksize, dtype, out):
+    if dtype not in _DT_NAME:
+        raise ValueError(f"Blockwise dequantization only supports 16/32-bit floats, but got {dtype}")
+    if A.dtype != torch.uint8:
+        raise ValueError(f"A must be uint8, got {A.dtype}")
+    if blocksize <= 0 or (blocksize & (blocksize - 1)):
+        raise ValueError(f"blocksize must be a positive power of two, got {blocksize}")
+    A = A.contiguous()
+    fn = getattr(lib, f"cdequantize_blockwise_{_DT_NAME[dtype]}")
+    with _device_of(A):
+        fn(code.contiguous().data_ptr(), A.data_ptr(), absmax.contiguous().data_ptr(), out.data_ptr(), blocksize,
+           A.numel(), _stream(A))
+
+
+@register_kernel("bitsandbytes::dequantize_blockwise", "cuda")
+def _(A, absmax, code, blocksize: int, dtype: torch.dtype) -> torch.Tensor:
+    out = torch.empty_like(A, dtype=dtype)
+    _dequantize_blockwise_impl(A, absmax, code, blocksize, dtype, out)
+    return out
+
+
+@register_kernel("bitsandbytes::dequantize_blockwise.out", "cuda")
+def _(A, absmax, code, blocksize: int, dtype: torch.dtype, out: torch.Tensor) -> None:
+    if out.dtype != dtype:
+        raise ValueError(f"Expected out.dtype == {dtype}, got {out.dtype}")
+    if out.shape != A.shape:
+        raise ValueError(f"Expected out.shape == {A.shape}, got {out.shape}")
+    _dequantize_blockwise_impl(A, absmax, code, blocksize, dtype, out)
+
+
+# ------------------------------------------------------------------------------------------ gemv_4bit (legacy)
+def _gemv_4bit_impl(A, B, shapeB, absmax, code, blocksize, out):
+    if blocksize not in (32, 64, 128, 256, 512, 1024, 2048, 4096):
+        raise ValueError(f"invalid blocksize {blocksize}")
+    if A.dtype not in _DT_NAME:
+        raise ValueError(f"A must be float16, bfloat16, or float32, got {A.dtype}")
+    if A.numel() != A.shape[-1]:
+        raise ValueError(f"gemv_4bit: A must be a single row vector, got shape {tuple(A.shape)}")
+    N, K = int(shapeB[0]), int(shapeB[1])
+    A = A.contiguous()
+    B = B.contiguous()
+    fn = getattr(lib, f"cgemm_4bit_inference_naive_{_DT_NAME[A.dtype]}")
+    with _device_of(A):
+        # (m = N, n = 1, k = K, ..., lda = N, ldb = (K+1)//2, ldc = N) as reference backends/cuda/ops.py:550-556
+        fn(N, 1, K, A.data_ptr(), B.data_ptr(), absmax.contiguous().data_ptr(), code.contiguous().data_ptr(),
+           out.data_ptr(), N, (K + 1) // 2, N, blocksize, _stream(A))
+
+
+@register_kernel("bitsandbytes::gemv_4bit", "cuda")
+def _(A, B, shapeB: Sequence[int], absmax, code, blocksize: int) -> torch.Tensor:
+    out = torch.empty((*A.shape[:-1], shapeB[0]), device=A.device, dtype=A.dtype)
+    _gemv_4bit_impl(A, B, shapeB, absmax, code, blocksize, out)
+    return out
+
+
+@register_kernel("bitsandbytes::gemv_4bit.out", "cuda")
+def _(A, B, shapeB: Sequence[int], absmax, code, blocksize: int, out: torch.Tensor) -> None:
+    expected = (*A.shape[:-1], shapeB[0])
+    if tuple(out.shape) != tuple(expected):
+        raise ValueError(f"Expected out.shape == {expected}, got {tuple(out.shape)}")
+    if out.dtype != A.dtype:
+        raise ValueError(f"Expected out.dtype == {A.dtype}, got {out.dtype}")
+    _gemv_4bit_impl(A, B, shapeB, absmax, code, blocksize, out)
+
+
+# ------------------------------------------------------------------------------------------ gemm_4bit
+def _gemm_4bit_route(dtype: torch.dtype, M: int, N: int, K: int, blocksize: int) -> str:
+    """MI355X routing: 'fused' (HIP dot / MFMA kernels, chosen inside the library by M) or 'unfused'
+    (dequantize + hipBLASLt). Replaces reference backends/cuda/ops.py:814-843,921-962."""
+    if K % blocksize != 0:
+        warn(
+            f"inner dimension ({K}) is not aligned for fast kernel with blocksize={blocksize}, "
+            "falling back to slower implementation.",
+            UserWarning,
+        )
+        return "unfused"
+    if dtype == torch.float32:
+        # no fp32 MFMA fast path worth having here (1/16 of the bf16 rate): dot kernel for tiny M only
+        return "fused" if M <= 4 else "unfused"
+    return "fused" if M <= FUSED_MAX_M else "unfused"
+
+
+def _gemm_4bit_fused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8bit, absmax_code, absmax_offset,
+                     kernel: int = 0):
+    K = A.shape[-1]
+    M = A.numel() // K
+    N = int(shapeB[0])
+    if K != shapeB[1]:
+        raise RuntimeError(f"A inner dim ({K}) does not match weight ({shapeB[1]})")
+    if absmax.dtype != torch.float32:
+        raise RuntimeError(f"absmax must be float32, got {absmax.dtype}")
+    if bias is not None:
+        if bias.ndim != 1:
+            raise RuntimeError(f"bias must be 1D, got {bias.ndim}D")
+        if bias.dtype != A.dtype:
+            raise RuntimeError(f"bias dtype ({bias.dtype}) must match A dtype ({A.dtype})")
+        bias = bias.contiguous()
+    if A.dtype not in _DT_CODE:
+        raise RuntimeError(f"unsupported dtype {A.dtype}")
+    A = A.contiguous()
+    B = B.contiguous()
+    out = torch.empty((*A.shape[:-1], N), dtype=A.dtype, device=A.device)
+    offset32 = absmax_offset.to(dtype=torch.float32) if absmax_offset is not None else None
+    with _device_of(A):
+        lib.bnb_mi355x_gemm_4bit(
+            kernel, _DT_CODE[A.dtype], A.data_ptr(), B.data_ptr(), absmax.contiguous().data_ptr(),
+            _ptr(absmax_8bit if absmax_8bit is None else absmax_8bit.contiguous()),
+            _ptr(absmax_code if absmax_code is None else absmax_code.contiguous()), _ptr(offset32), None,
+            out.data_ptr(), _ptr(bias), M, N, K, blocksize, _QT_CODE[quant_type], _stream(A),
+        )
+    return out
+
+
+def _gemm_4bit_unfused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8bit, absmax_code, absmax_offset):
+    if absmax_8bit is not None:
+        absmax_dq = torch.empty_like(absmax_8bit, dtype=torch.float32)
+        _dequantize_blockwise_impl(absmax_8bit, absmax, absmax_code, 256, torch.float32, absmax_dq)
+        absmax = absmax_dq + absmax_offset
+    W = torch.empty(tuple(shapeB), dtype=A.dtype, device=A.device)
+    _dequantize_4bit_impl(B, absmax, blocksize, quant_type, A.dtype, W)
+    return torch.nn.functional.linear(A, W, bias)
+
+
+@register_kernel("bitsandbytes::gemm_4bit", "cuda")
+def _(
+    A: torch.Tensor,
+    B: torch.Tensor,
+    shapeB: Sequence[int],
+    absmax: torch.Tensor,
+    blocksize: int,
+    quant_type: str,
+    bias: Optional[torch.Tensor] = None,
+    absmax_8bit: Optional[torch.Tensor] = None,
+    absmax_code: Optional[torch.Tensor] = None,
+    absmax_offset: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    K = A.shape[-1]
+    M = A.numel() // K if K else 0
+    route = _gemm_4bit_route(A.dtype, M, int(shapeB[0]), K, blocksize)
+    args = (A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8bit, absmax_code, absmax_offset)
+    if route == "fused":
+        return _gemm_4bit_fused(*args)
+    return _gemm_4bit_unfused(*args)
+
+
+__all__ = ["FUSED_MAX_M", "prod"]

@@ -1,0 +1,100 @@
+"""Native-library loader for the MI355X backend.
+
+Plays the role of the reference's ``bitsandbytes/cextension.py`` (:348-405) for this path, with one
+deliberate difference: there is no CPU library and no deferred-error mock. The product path needs
+``libbitsandbytes_mi355x.so`` (built by ``make -C bitsandbytes_amd/csrc`` / ``__graft_entry__.build()``);
+if it is missing, ``lib`` is a stub whose every attribute access raises, so any attempt to compute
+without the HIP library fails loudly instead of falling back to something else.
+
+ctypes signatures mirror the reference's (``bitsandbytes/backends/cuda/ops.py:16-66``).
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import logging
+import os
+from pathlib import Path
+
+logger = logging.getLogger(__name__)
+
+PACKAGE_DIR = Path(__file__).resolve().parent
+LIB_NAME = "libbitsandbytes_mi355x.so"
+LIB_PATH = Path(os.environ.get("BNB_MI355X_LIBRARY", PACKAGE_DIR / LIB_NAME))
+
+
+class MissingNativeLibrary:
+    """Stands in for the library when it cannot be loaded. Import succeeds (so that host-only code —
+    QuantState, op schemas, fake kernels — stays usable), any native call raises."""
+
+    def __init__(self, reason: str):
+        self._reason = reason
+
+    def __getattr__(self, name):
+        raise RuntimeError(
+            f"bitsandbytes_amd: native symbol '{name}' requested but {LIB_NAME} is not loaded ({self._reason}). "
+            f"Build it with `make -C {PACKAGE_DIR / 'csrc'}` (needs hipcc, targets gfx950). "
+            "There is no CPU or PyTorch fallback for the 4-bit kernels in this package."
+        )
+
+    def __bool__(self):
+        return False
+
+
+_VOID_P = ct.c_void_p
+_I32 = ct.c_int32
+
+
+def _declare(dll: ct.CDLL) -> None:
+    def sig(names, argtypes, restype=None):
+        for n in names:
+            fn = getattr(dll, n)
+            fn.argtypes = argtypes
+            fn.restype = restype
+
+    dts = ("fp32", "bf16", "fp16")
+    qts = ("nf4", "fp4")
+    # (code, A, absmax, out, blocksize, n)
+    sig([f"cquantize_blockwise_{d}_{q}" for d in dts for q in qts] + [f"cquantize_blockwise_{d}" for d in dts],
+        [_VOID_P] * 4 + [_I32, _I32])
+    # (code, A, absmax, out, blocksize, n, stream)
+    sig([f"cdequantize_blockwise_{d}_{q}" for d in dts for q in qts] + [f"cdequantize_blockwise_{d}" for d in dts],
+        [_VOID_P] * 4 + [_I32, _I32, _VOID_P])
+    # (A, B, absmax, absmax_8bit, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type, stream)
+    sig([f"cgemm_4bit_{d}" for d in dts], [_VOID_P] * 8 + [_I32] * 5 + [_VOID_P])
+    # (m, n, k, A, B, absmax, code, out, lda, ldb, ldc, blocksize, stream)
+    sig([f"cgemm_4bit_inference_naive_{d}" for d in dts], [_I32] * 3 + [_VOID_P] * 5 + [_I32] * 4 + [_VOID_P])
+    sig(["get_context"], [], _VOID_P)
+    sig(["cget_managed_ptr"], [ct.c_size_t], _VOID_P)
+    # extensions
+    sig(["bnb_mi355x_quantize_4bit"], [_VOID_P, _I32, _VOID_P, _VOID_P, _I32, ct.c_long, _I32, _VOID_P])
+    sig(["bnb_mi355x_quantize_8bit"], [_VOID_P, _VOID_P, _I32, _VOID_P, _VOID_P, _I32, ct.c_long, _VOID_P])
+    sig(["bnb_mi355x_gemm_4bit"], [_I32, _I32] + [_VOID_P] * 9 + [_I32] * 5 + [_VOID_P])
+    sig(["bnb_mi355x_set_tuning"], [_I32] * 4)
+    sig(["bnb_mi355x_version"], [], ct.c_char_p)
+
+
+def load_native_library():
+    if not LIB_PATH.exists():
+        return MissingNativeLibrary(f"{LIB_PATH} does not exist")
+    try:
+        dll = ct.CDLL(str(LIB_PATH))
+        _declare(dll)
+    except (OSError, AttributeError) as exc:  # missing libamdhip64, missing symbol, ...
+        logger.error("bitsandbytes_amd: failed to load %s: %s", LIB_PATH, exc)
+        return MissingNativeLibrary(str(exc))
+    return dll
+
+
+lib = load_native_library()
+
+# every symbol include/bnb_mi355x.h declares; tests check that the loaded library exports all of them
+EXPORTED_SYMBOLS = tuple(
+    [f"cquantize_blockwise_{d}_{q}" for d in ("fp32", "bf16", "fp16") for q in ("nf4", "fp4")]
+    + [f"cdequantize_blockwise_{d}_{q}" for d in ("fp32", "bf16", "fp16") for q in ("nf4", "fp4")]
+    + [f"cquantize_blockwise_{d}" for d in ("fp32", "bf16", "fp16")]
+    + [f"cdequantize_blockwise_{d}" for d in ("fp32", "bf16", "fp16")]
+    + [f"cgemm_4bit_{d}" for d in ("fp32", "bf16", "fp16")]
+    + [f"cgemm_4bit_inference_naive_{d}" for d in ("fp32", "bf16", "fp16")]
+    + ["get_context", "cget_managed_ptr", "bnb_mi355x_quantize_4bit", "bnb_mi355x_quantize_8bit",
+       "bnb_mi355x_gemm_4bit", "bnb_mi355x_set_tuning", "bnb_mi355x_version"]
+)

@@ -1,0 +1,109 @@
+// bnb_common.h — shared device-side helpers for the MI355X (gfx950 / CDNA4) 4-bit kernels.
+//
+// This library is written for gfx950 only: wave64, 256 CUs, 160 KiB LDS per CU. There is no CUDA
+// path, no hipify layer and no multi-arch dispatch.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+namespace bnb {
+
+constexpr int kWave = 64;
+
+// quant_type codes on the C ABI (reference csrc/common.h:3-7)
+enum QuantType : int { kGeneral8bit = 0, kFP4 = 1, kNF4 = 2 };
+
+// ---------------------------------------------------------------------------------------------
+// Error convention of the reference ABI: the C entry points return void; a failed launch prints
+// and terminates the process (reference csrc/compat.cuh:78-85, used at csrc/ops.cu:74,93,450).
+// ---------------------------------------------------------------------------------------------
+#define BNB_HIP_CHECK(expr)                                                                        \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            fprintf(stderr, "bitsandbytes_amd: HIP error %s at %s:%d\n", hipGetErrorString(_e),    \
+                    __FILE__, __LINE__);                                                           \
+            exit(1);                                                                               \
+        }                                                                                          \
+    } while (0)
+
+#define BNB_CHECK_LAUNCH() BNB_HIP_CHECK(hipPeekAtLastError())
+
+// ---------------------------------------------------------------------------------------------
+// Element types. fp16/bf16 travel as their native clang types so that conversions lower to the
+// gfx950 hardware converts (v_cvt_f16_f32 / v_cvt_pk_bf16_f32, both round-to-nearest-even).
+// ---------------------------------------------------------------------------------------------
+using f16 = _Float16;
+using bf16 = __bf16;
+
+template <typename T> struct TypeInfo;
+template <> struct TypeInfo<float> {
+    static constexpr int bytes = 4;
+};
+template <> struct TypeInfo<f16> {
+    static constexpr int bytes = 2;
+};
+template <> struct TypeInfo<bf16> {
+    static constexpr int bytes = 2;
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return static_cast<float>(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return static_cast<T>(v); }
+
+// ---------------------------------------------------------------------------------------------
+// 4-bit code tables (reference bitsandbytes/functional.py:788-823). FP4 is the raw table divided
+// by 12 in fp32, exactly as `data.div_(data.abs().max())` does (functional.py:853); entry 8 is
+// +0.0 as in the Python table.
+// ---------------------------------------------------------------------------------------------
+#define BNB_NF4_VALUES                                                                             \
+    -1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f,                      \
+        -0.28444138169288635f, -0.18477343022823334f, -0.09105003625154495f, 0.0f,                 \
+        0.07958029955625534f, 0.16093020141124725f, 0.24611230194568634f, 0.33791524171829224f,    \
+        0.44070982933044434f, 0.5626170039176941f, 0.7229568362236023f, 1.0f
+
+#define BNB_FP4_VALUES                                                                             \
+    0.0f / 12.0f, 0.0625f / 12.0f, 8.0f / 12.0f, 12.0f / 12.0f, 4.0f / 12.0f, 6.0f / 12.0f,       \
+        2.0f / 12.0f, 3.0f / 12.0f, 0.0f / 12.0f, -0.0625f / 12.0f, -8.0f / 12.0f, -12.0f / 12.0f, \
+        -4.0f / 12.0f, -6.0f / 12.0f, -2.0f / 12.0f, -3.0f / 12.0f
+
+// Device-resident copies. Deliberately plain __device__ (global address space), not __constant__:
+// kernels select between these and a caller-supplied table pointer, and mixing address spaces would
+// turn the gather into flat_load, whose completion the compiler can only await with vmcnt(0).
+__device__ static const float kNF4Code[16] = {BNB_NF4_VALUES};
+__device__ static const float kFP4Code[16] = {BNB_FP4_VALUES};
+
+// explicit global-address-space view of a device pointer (forces global_load, which vmcnt can count)
+typedef const float __attribute__((address_space(1))) * gfloat_ptr;
+
+// ---------------------------------------------------------------------------------------------
+// wave64 reductions
+// ---------------------------------------------------------------------------------------------
+template <int WIDTH> __device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int off = 1; off < WIDTH; off <<= 1)
+        v = fmaxf(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+static inline int ilog2(int v) {
+    int s = 0;
+    while ((1 << s) < v)
+        ++s;
+    return s;
+}
+
+static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+} // namespace bnb

@@ -1,0 +1,233 @@
+// c_api.hip — the extern "C" surface of libbitsandbytes_mi355x.so (declared in include/bnb_mi355x.h).
+// Thin, un-mangled wrappers over the launchers in quantize4.hip, dequantize4.hip, blockwise8.hip,
+// gemv4.hip and gemm4_mfma.hip. Mirrors the symbol set the reference exports for this path from
+// csrc/pythonInterface.cpp:343-841 and csrc/gemm_4bit.cu:136-168.
+#include "bnb_common.h"
+
+#include "../../include/bnb_mi355x.h"
+
+namespace bnb {
+// quantize4.hip
+void quantize_4bit_f32(const float*, float*, uint8_t*, int, long, int, hipStream_t);
+void quantize_4bit_f16(const void*, float*, uint8_t*, int, long, int, hipStream_t);
+void quantize_4bit_bf16(const void*, float*, uint8_t*, int, long, int, hipStream_t);
+// dequantize4.hip
+void dequantize_4bit_f32(const uint8_t*, const float*, float*, int, long, int, hipStream_t);
+void dequantize_4bit_f16(const uint8_t*, const float*, void*, int, long, int, hipStream_t);
+void dequantize_4bit_bf16(const uint8_t*, const float*, void*, int, long, int, hipStream_t);
+// blockwise8.hip
+void quantize_8bit_f32(const float*, const float*, float*, uint8_t*, int, long, hipStream_t);
+void quantize_8bit_f16(const float*, const void*, float*, uint8_t*, int, long, hipStream_t);
+void quantize_8bit_bf16(const float*, const void*, float*, uint8_t*, int, long, hipStream_t);
+void dequantize_8bit_f32(const float*, const uint8_t*, const float*, float*, int, long, hipStream_t);
+void dequantize_8bit_f16(const float*, const uint8_t*, const float*, void*, int, long, hipStream_t);
+void dequantize_8bit_bf16(const float*, const uint8_t*, const float*, void*, int, long, hipStream_t);
+// gemv4.hip
+void gemv_4bit_dot(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
+                   const float* absmax_code, const float* absmax_offset, const float* code16, void* out,
+                   const void* bias, int M, int N, int K, int blocksize, int quant_type, hipStream_t stream);
+extern int g_dot_rpw, g_dot_segs;
+// gemm4_mfma.hip
+bool gemm_4bit_mfma_supported(int dtype, const void* A, const uint8_t* B, int M, int N, int K, int blocksize);
+void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
+                    const float* absmax_code, const float* absmax_offset, const float* code16, void* out,
+                    const void* bias, int M, int N, int K, int blocksize, int quant_type, hipStream_t stream);
+extern int g_mfma_knob0, g_mfma_knob1;
+
+namespace {
+
+// M at or below which the wave64 dot kernel is used; above it the MFMA kernel (when supported).
+// MI355X-specific replacement for the reference's per-arch heuristic
+// (bitsandbytes/backends/cuda/ops.py:814-843), calibrated on gfx950 — see DESIGN.md.
+constexpr int kDotMaxM = 4;
+
+void gemm_4bit_dispatch(int kernel, int dtype, const void* A, const uint8_t* B, const float* absmax,
+                        const uint8_t* absmax8, const float* absmax_code, const float* absmax_offset,
+                        const float* code16, void* out, const void* bias, int M, int N, int K, int blocksize,
+                        int quant_type, hipStream_t stream) {
+    if (M <= 0 || N <= 0)
+        return;
+    if (quant_type != kFP4 && quant_type != kNF4) {
+        fprintf(stderr, "bitsandbytes_amd: gemm_4bit: quant_type must be 1 (FP4) or 2 (NF4), got %d\n", quant_type);
+        exit(1);
+    }
+    bool use_mfma;
+    if (kernel == 1)
+        use_mfma = false;
+    else if (kernel == 2)
+        use_mfma = gemm_4bit_mfma_supported(dtype, A, B, M, N, K, blocksize);
+    else
+        use_mfma = (M > kDotMaxM) && gemm_4bit_mfma_supported(dtype, A, B, M, N, K, blocksize);
+    if (use_mfma)
+        gemm_4bit_mfma(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, code16, out, bias, M, N, K, blocksize,
+                       quant_type, stream);
+    else
+        gemv_4bit_dot(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, code16, out, bias, M, N, K, blocksize,
+                      quant_type, stream);
+}
+
+} // namespace
+} // namespace bnb
+
+using namespace bnb;
+
+static inline hipStream_t S(bnb_stream_t s) { return static_cast<hipStream_t>(s); }
+
+extern "C" {
+
+// ------------------------------------------------------------------ 4-bit quantize (NULL stream, like the reference)
+void cquantize_blockwise_fp32_nf4(float*, float* A, float* absmax, unsigned char* out, int bs, const int n) {
+    quantize_4bit_f32(A, absmax, out, bs, n, kNF4, nullptr);
+}
+void cquantize_blockwise_fp32_fp4(float*, float* A, float* absmax, unsigned char* out, int bs, const int n) {
+    quantize_4bit_f32(A, absmax, out, bs, n, kFP4, nullptr);
+}
+void cquantize_blockwise_fp16_nf4(float*, void* A, float* absmax, unsigned char* out, int bs, const int n) {
+    quantize_4bit_f16(A, absmax, out, bs, n, kNF4, nullptr);
+}
+void cquantize_blockwise_fp16_fp4(float*, void* A, float* absmax, unsigned char* out, int bs, const int n) {
+    quantize_4bit_f16(A, absmax, out, bs, n, kFP4, nullptr);
+}
+void cquantize_blockwise_bf16_nf4(float*, void* A, float* absmax, unsigned char* out, int bs, const int n) {
+    quantize_4bit_bf16(A, absmax, out, bs, n, kNF4, nullptr);
+}
+void cquantize_blockwise_bf16_fp4(float*, void* A, float* absmax, unsigned char* out, int bs, const int n) {
+    quantize_4bit_bf16(A, absmax, out, bs, n, kFP4, nullptr);
+}
+
+// ------------------------------------------------------------------ 4-bit dequantize
+void cdequantize_blockwise_fp32_nf4(float*, unsigned char* A, float* absmax, float* out, int bs, const int n,
+                                    bnb_stream_t s) {
+    dequantize_4bit_f32(A, absmax, out, bs, n, kNF4, S(s));
+}
+void cdequantize_blockwise_fp32_fp4(float*, unsigned char* A, float* absmax, float* out, int bs, const int n,
+                                    bnb_stream_t s) {
+    dequantize_4bit_f32(A, absmax, out, bs, n, kFP4, S(s));
+}
+void cdequantize_blockwise_fp16_nf4(float*, unsigned char* A, float* absmax, void* out, int bs, const int n,
+                                    bnb_stream_t s) {
+    dequantize_4bit_f16(A, absmax, out, bs, n, kNF4, S(s));
+}
+void cdequantize_blockwise_fp16_fp4(float*, unsigned char* A, float* absmax, void* out, int bs, const int n,
+                                    bnb_stream_t s) {
+    dequantize_4bit_f16(A, absmax, out, bs, n, kFP4, S(s));
+}
+void cdequantize_blockwise_bf16_nf4(float*, unsigned char* A, float* absmax, void* out, int bs, const int n,
+                                    bnb_stream_t s) {
+    dequantize_4bit_bf16(A, absmax, out, bs, n, kNF4, S(s));
+}
+void cdequantize_blockwise_bf16_fp4(float*, unsigned char* A, float* absmax, void* out, int bs, const int n,
+                                    bnb_stream_t s) {
+    dequantize_4bit_bf16(A, absmax, out, bs, n, kFP4, S(s));
+}
+
+// ------------------------------------------------------------------ 8-bit blockwise (double-quant helper)
+void cquantize_blockwise_fp32(float* code, float* A, float* absmax, unsigned char* out, int bs, const int n) {
+    quantize_8bit_f32(code, A, absmax, out, bs, n, nullptr);
+}
+void cquantize_blockwise_fp16(float* code, void* A, float* absmax, unsigned char* out, int bs, const int n) {
+    quantize_8bit_f16(code, A, absmax, out, bs, n, nullptr);
+}
+void cquantize_blockwise_bf16(float* code, void* A, float* absmax, unsigned char* out, int bs, const int n) {
+    quantize_8bit_bf16(code, A, absmax, out, bs, n, nullptr);
+}
+void cdequantize_blockwise_fp32(float* code, unsigned char* A, float* absmax, float* out, int bs, const int n,
+                                bnb_stream_t s) {
+    dequantize_8bit_f32(code, A, absmax, out, bs, n, S(s));
+}
+void cdequantize_blockwise_fp16(float* code, unsigned char* A, float* absmax, void* out, int bs, const int n,
+                                bnb_stream_t s) {
+    dequantize_8bit_f16(code, A, absmax, out, bs, n, S(s));
+}
+void cdequantize_blockwise_bf16(float* code, unsigned char* A, float* absmax, void* out, int bs, const int n,
+                                bnb_stream_t s) {
+    dequantize_8bit_bf16(code, A, absmax, out, bs, n, S(s));
+}
+
+// ------------------------------------------------------------------ fused dequant + GEMM
+void cgemm_4bit_bf16(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit,
+                     const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N,
+                     int K, int blocksize, int quant_type, bnb_stream_t s) {
+    gemm_4bit_dispatch(0, 2, A, B, absmax, absmax_8bit, absmax_code, absmax_offset, nullptr, out, bias, M, N, K,
+                       blocksize, quant_type, S(s));
+}
+void cgemm_4bit_fp16(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit,
+                     const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N,
+                     int K, int blocksize, int quant_type, bnb_stream_t s) {
+    gemm_4bit_dispatch(0, 1, A, B, absmax, absmax_8bit, absmax_code, absmax_offset, nullptr, out, bias, M, N, K,
+                       blocksize, quant_type, S(s));
+}
+void cgemm_4bit_fp32(const float* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit,
+                     const float* absmax_code, const float* absmax_offset, float* out, const float* bias, int M, int N,
+                     int K, int blocksize, int quant_type, bnb_stream_t s) {
+    gemm_4bit_dispatch(0, 0, A, B, absmax, absmax_8bit, absmax_code, absmax_offset, nullptr, out, bias, M, N, K,
+                       blocksize, quant_type, S(s));
+}
+
+// ------------------------------------------------------------------ legacy gemv (m = N, n = 1, k = K)
+void cgemm_4bit_inference_naive_fp16(int m, int n, int k, void* A, unsigned char* B, float* absmax, float* datatype,
+                                     void* out, int, int, int, int blocksize, bnb_stream_t s) {
+    (void)n;
+    gemv_4bit_dot(1, A, B, absmax, nullptr, nullptr, nullptr, datatype, out, nullptr, 1, m, k, blocksize, kNF4, S(s));
+}
+void cgemm_4bit_inference_naive_bf16(int m, int n, int k, void* A, unsigned char* B, float* absmax, float* datatype,
+                                     void* out, int, int, int, int blocksize, bnb_stream_t s) {
+    (void)n;
+    gemv_4bit_dot(2, A, B, absmax, nullptr, nullptr, nullptr, datatype, out, nullptr, 1, m, k, blocksize, kNF4, S(s));
+}
+void cgemm_4bit_inference_naive_fp32(int m, int n, int k, float* A, unsigned char* B, float* absmax, float* datatype,
+                                     float* out, int, int, int, int blocksize, bnb_stream_t s) {
+    (void)n;
+    gemv_4bit_dot(0, A, B, absmax, nullptr, nullptr, nullptr, datatype, out, nullptr, 1, m, k, blocksize, kNF4, S(s));
+}
+
+// ------------------------------------------------------------------ loader symbols
+void* get_context(void) {
+    static int token = 0x4d493335; // opaque: this path needs no BLAS handle
+    return &token;
+}
+void* cget_managed_ptr(size_t bytes) {
+    void* ptr = nullptr;
+    BNB_HIP_CHECK(hipMallocManaged(&ptr, bytes, hipMemAttachHost));
+    return ptr;
+}
+
+// ------------------------------------------------------------------ extensions
+void bnb_mi355x_quantize_4bit(const void* A, int dtype, float* absmax, unsigned char* out, int blocksize, long n,
+                              int quant_type, bnb_stream_t s) {
+    if (quant_type != kFP4 && quant_type != kNF4) {
+        fprintf(stderr, "bitsandbytes_amd: quantize_4bit: quant_type must be 1 (FP4) or 2 (NF4)\n");
+        exit(1);
+    }
+    if (dtype == 0)
+        quantize_4bit_f32(static_cast<const float*>(A), absmax, out, blocksize, n, quant_type, S(s));
+    else if (dtype == 1)
+        quantize_4bit_f16(A, absmax, out, blocksize, n, quant_type, S(s));
+    else
+        quantize_4bit_bf16(A, absmax, out, blocksize, n, quant_type, S(s));
+}
+void bnb_mi355x_quantize_8bit(const float* code, const void* A, int dtype, float* absmax, unsigned char* out,
+                              int blocksize, long n, bnb_stream_t s) {
+    if (dtype == 0)
+        quantize_8bit_f32(code, static_cast<const float*>(A), absmax, out, blocksize, n, S(s));
+    else if (dtype == 1)
+        quantize_8bit_f16(code, A, absmax, out, blocksize, n, S(s));
+    else
+        quantize_8bit_bf16(code, A, absmax, out, blocksize, n, S(s));
+}
+void bnb_mi355x_gemm_4bit(int kernel, int dtype, const void* A, const uint8_t* B, const float* absmax,
+                          const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset,
+                          const float* code16, void* out, const void* bias, int M, int N, int K, int blocksize,
+                          int quant_type, bnb_stream_t s) {
+    gemm_4bit_dispatch(kernel, dtype, A, B, absmax, absmax_8bit, absmax_code, absmax_offset, code16, out, bias, M, N, K,
+                       blocksize, quant_type, S(s));
+}
+void bnb_mi355x_set_tuning(int dot_rows_per_wave, int dot_segments, int mfma_knob0, int mfma_knob1) {
+    g_dot_rpw = dot_rows_per_wave;
+    g_dot_segs = dot_segments;
+    g_mfma_knob0 = mfma_knob0;
+    g_mfma_knob1 = mfma_knob1;
+}
+const char* bnb_mi355x_version(void) { return "bitsandbytes_amd 0.1.0 gfx950"; }
+
+} // extern "C"

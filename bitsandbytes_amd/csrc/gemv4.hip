@@ -1,0 +1,401 @@
+// gemv4.hip — fused 4-bit dequantize + dot-product kernel for decode-sized batches (M <= 4 rows of A
+// per pass) on gfx950.   out[m, n] = sum_k A[m, k] * code[B[n, k]] * scale[n, k / bs]  (+ bias[n])
+//
+// Replaces, on MI355X, the reference's kgemm_4bit_inference_naive (csrc/kernels.cu:1452-1567) and the
+// small-M range of gemm_4bit_simt (csrc/gemm_4bit_simt.cu:109-480). It is not a translation of
+// either: those map one logical 32-lane warp to an output column and decode nibbles with shifts and
+// an LDS/const table per nibble; this kernel is built around three CDNA4 facts:
+//
+//  * HBM-bound, so the only job is to keep ~8 MB of loads in flight. A wavefront owns RPW whole
+//    weight rows; lane l reads bytes [16 l, 16 l + 16) of each 1 KiB row segment with one
+//    global_load_dwordx4, i.e. every load instruction covers 1 KiB contiguous (eight full 128-B
+//    lines). All loads of an iteration (and of the next one) are issued before any arithmetic.
+//  * The VALU budget at 8 TB/s is ~5 lane-ops per nibble, so nibbles are never decoded one by one:
+//    a 256-entry table maps a packed BYTE straight to the pair (code[hi], code[lo]) as packed
+//    bf16x2 / f16x2, and one v_dot2c_f32_{bf16,f16} consumes the pair against two activations:
+//    2 VALU + 1 LDS read per byte.
+//  * A random 4-byte LDS gather would be ~4-way bank-conflicted. The table is therefore stored
+//    32x replicated, entry e of copy j at dword e*32 + j, and lane l only ever reads copy l%32:
+//    each lane owns its bank, so the gather is conflict-free for any data. 32 KiB of the CU's
+//    160 KiB LDS buys a 2-cycles-per-64-bytes decode. The table is built from 16 SGPR-resident
+//    code values (no vector memory traffic) while the first weight loads are in flight.
+//
+// The per-block scale multiplies the fp32 partial sum of each 32-nibble run (one run never
+// straddles a quantization block because blocksize >= 32 and K % 32 == 0), so absmax is applied in
+// full fp32. Nested (double-quantized) absmax is fused:
+//   scale = absmax_code[absmax_8bit[b]] * absmax[b >> 8] + offset   (reference autograd/_functions.py:471-485).
+#include "bnb_common.h"
+
+namespace bnb {
+
+// Tuning knobs (overridable for sweeps through bnb_mi355x_set_tuning; see c_api.hip).
+int g_dot_rpw = 0;  // rows per wavefront, 0 = heuristic
+int g_dot_segs = 0; // 2048-k segments per iteration, 0 = heuristic
+
+namespace {
+
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+template <typename T> struct Pair2;
+template <> struct Pair2<bf16> {
+    static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
+        using V = __attribute__((ext_vector_type(2))) bf16;
+        V v;
+        v[0] = static_cast<bf16>(lo);
+        v[1] = static_cast<bf16>(hi);
+        return __builtin_bit_cast(uint32_t, v);
+    }
+    static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+        using V = __attribute__((ext_vector_type(2))) bf16;
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(V, a), __builtin_bit_cast(V, b), c, false);
+    }
+};
+template <> struct Pair2<f16> {
+    static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
+        using V = __attribute__((ext_vector_type(2))) f16;
+        V v;
+        v[0] = static_cast<f16>(lo);
+        v[1] = static_cast<f16>(hi);
+        return __builtin_bit_cast(uint32_t, v);
+    }
+    static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+        using V = __attribute__((ext_vector_type(2))) f16;
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(V, a), __builtin_bit_cast(V, b), c, false);
+    }
+};
+
+struct GemvArgs {
+    const void* A;              // [M, K] activations, row-major
+    const uint8_t* B;           // packed [N, K/2]
+    const float* absmax;        // fp32 [N*K/bs]   (nested: fp32 [ceil(N*K/bs/256)])
+    const uint8_t* absmax8;     // nested only: uint8 [N*K/bs]
+    const float* absmax_code;   // nested only: fp32 [256]
+    const float* absmax_offset; // nested only: fp32 scalar
+    const float* code16;        // optional caller-supplied 16-entry code (gemv_4bit op), else NULL
+    void* out;                  // [M, N]
+    const void* bias;           // optional [N]
+    int M, N, K;
+    int bs_shift;
+    int quant_type;
+};
+
+constexpr int kSegK = 2048; // k covered by one wavefront-wide 16-byte load
+
+// T in {bf16, f16}; MB = activation rows per pass; RPW = weight rows per wavefront;
+// SEGS = 2048-k sub-segments per loop iteration; SINGLE = the whole K fits one iteration (no
+// prefetch registers are allocated then).
+template <typename T, int MB, int RPW, int SEGS, bool SINGLE, bool NESTED>
+__global__ __launch_bounds__(256) void gemv4_dot_kernel(const GemvArgs p) {
+    __shared__ uint32_t lut[256 * 32];
+    __shared__ float code2[NESTED ? 256 : 1];
+
+    const int tid = threadIdx.x;
+    // The two code values this lane needs for its table entry are the FIRST vector loads of the
+    // kernel: vmcnt retires in order, so waiting for them later never waits for the weight stream.
+    const gfloat_ptr tbl = (gfloat_ptr)(p.code16 ? p.code16 : (p.quant_type == kNF4 ? kNF4Code : kFP4Code));
+    const float code_hi = tbl[tid >> 4];
+    const float code_lo = tbl[tid & 15];
+
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int N = p.N, K = p.K;
+    const int row0 = (blockIdx.x * 4 + wave) * RPW;
+    const int m0 = blockIdx.y * MB;
+
+    const T* __restrict__ A = static_cast<const T*>(p.A);
+    const uint8_t* __restrict__ B = p.B;
+    const float* __restrict__ absmax = p.absmax;
+
+    struct Stage {
+        u32x4 w[SEGS][RPW];
+        float s[SEGS][RPW];
+        u32x4 x[SEGS][MB][4];
+    };
+
+    auto load_stage = [&](Stage& st, int it) {
+#pragma unroll
+        for (int sg = 0; sg < SEGS; ++sg) {
+            const int k0 = (it * SEGS + sg) * kSegK + lane * 32;
+            const bool act = k0 < K;
+            const int kk = act ? k0 : 0;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = (row0 + r < N) ? row0 + r : N - 1;
+                const long e = static_cast<long>(row) * K + kk;
+                // lanes past K read the row start instead (valid memory); their scale is forced to 0 below
+                st.w[sg][r] = *reinterpret_cast<const u32x4*>(B + (e >> 1));
+                const long blk = e >> p.bs_shift;
+                if constexpr (NESTED) {
+                    // scale reconstructed in compute_stage (needs the LDS code table)
+                    st.s[sg][r] = __builtin_bit_cast(float, static_cast<uint32_t>(p.absmax8[blk]));
+                } else {
+                    st.s[sg][r] = absmax[blk];
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const int mr = (m0 + m < p.M) ? m0 + m : p.M - 1;
+                const T* ap = A + static_cast<long>(mr) * K + kk;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    st.x[sg][m][q] = *reinterpret_cast<const u32x4*>(ap + q * 8);
+            }
+        }
+    };
+
+    float acc[MB][RPW];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+            acc[m][r] = 0.0f;
+
+    const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
+    float offset = 0.0f;
+
+    auto compute_stage = [&](const Stage& st, int it) {
+#pragma unroll
+        for (int sg = 0; sg < SEGS; ++sg) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                // two independent fp32 chains per output so consecutive v_dot2c do not serialise
+                float part[MB][2];
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+                    part[m][0] = part[m][1] = 0.0f;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t w = st.w[sg][r][d];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t byte = (w >> (8 * j)) & 0xFFu;
+                        const uint32_t pr = lut[(byte << 5) + lane_slot];
+#pragma unroll
+                        for (int m = 0; m < MB; ++m)
+                            part[m][j & 1] = Pair2<T>::dot2(pr, st.x[sg][m][d][j], part[m][j & 1]);
+                    }
+                }
+                const int k0 = (it * SEGS + sg) * kSegK + lane * 32;
+                float scale;
+                if constexpr (NESTED) {
+                    const int kk = (k0 < K) ? k0 : 0;
+                    const int row = (row0 + r < N) ? row0 + r : N - 1;
+                    const long blk = (static_cast<long>(row) * K + kk) >> p.bs_shift;
+                    const uint32_t q8 = __builtin_bit_cast(uint32_t, st.s[sg][r]);
+                    scale = __fadd_rn(__fmul_rn(code2[q8], absmax[blk >> 8]), offset);
+                } else {
+                    scale = st.s[sg][r];
+                }
+                scale = (k0 < K) ? scale : 0.0f; // lanes past the end of the row contribute nothing
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+                    acc[m][r] = fmaf(scale, part[m][0] + part[m][1], acc[m][r]);
+            }
+        }
+    };
+
+    const int iters = (K + SEGS * kSegK - 1) / (SEGS * kSegK);
+
+    // 1) put the first stage's loads in flight
+    Stage cur;
+    load_stage(cur, 0);
+
+    // 2) build the byte -> (code[hi], code[lo]) table while they fly.
+    {
+        const uint32_t pr = Pair2<T>::pack(code_hi, code_lo);
+        const u32x4 v = {pr, pr, pr, pr};
+        u32x4* dst = reinterpret_cast<u32x4*>(&lut[tid * 32]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            dst[j] = v;
+        if constexpr (NESTED) {
+            code2[tid] = p.absmax_code[tid];
+            offset = p.absmax_offset[0];
+        }
+    }
+    __syncthreads();
+
+    // 3) main loop: prefetch iteration it+1, consume iteration it
+    if constexpr (SINGLE) {
+        compute_stage(cur, 0);
+    } else {
+        for (int it = 0; it < iters; ++it) {
+            Stage nxt;
+            if (it + 1 < iters)
+                load_stage(nxt, it + 1);
+            compute_stage(cur, it);
+            if (it + 1 < iters)
+                cur = nxt;
+        }
+    }
+
+    // 4) wavefront reduction + epilogue (bias add in fp32, one rounding to T)
+    T* __restrict__ out = static_cast<T*>(p.out);
+    const T* __restrict__ bias = static_cast<const T*>(p.bias);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const float v = wave_sum(acc[m][r]);
+            const int row = row0 + r;
+            if (lane == 0 && row < N && m0 + m < p.M) {
+                const float b = bias ? static_cast<float>(bias[row]) : 0.0f;
+                out[static_cast<long>(m0 + m) * N + row] = static_cast<T>(v + b);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic fallback: any T (incl. fp32 activations), any K (odd, not a multiple of 32), any pointer
+// alignment. One wavefront per output row, scalar byte loads, fp32 math, 16-entry fp32 table in
+// LDS. Correctness path only; the dispatcher prefers the kernel above whenever its preconditions
+// hold (T in {bf16, f16}, K % 32 == 0, 16-byte aligned A and B).
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool NESTED> __global__ __launch_bounds__(256) void gemv4_generic_kernel(const GemvArgs p) {
+    __shared__ float code[16];
+    __shared__ float code2[NESTED ? 256 : 1];
+    const int tid = threadIdx.x;
+    if (tid < 16)
+        code[tid] = p.code16 ? p.code16[tid] : (p.quant_type == kNF4 ? kNF4Code[tid] : kFP4Code[tid]);
+    if constexpr (NESTED)
+        code2[tid] = p.absmax_code[tid];
+    __syncthreads();
+    const int lane = tid & 63;
+    const int row = blockIdx.x * 4 + (tid >> 6);
+    const int m = blockIdx.y;
+    if (row >= p.N)
+        return;
+    const T* __restrict__ A = static_cast<const T*>(p.A) + static_cast<long>(m) * p.K;
+    const long base = static_cast<long>(row) * p.K;
+    const int bs_mask = (1 << p.bs_shift) - 1;
+    float acc = 0.0f;
+    float run = 0.0f;       // partial sum inside the current quantization block
+    long run_blk = -1;
+    auto block_scale = [&](long blk) -> float {
+        if constexpr (NESTED)
+            return __fadd_rn(__fmul_rn(code2[p.absmax8[blk]], p.absmax[blk >> 8]), p.absmax_offset[0]);
+        else
+            return p.absmax[blk];
+    };
+    (void)bs_mask;
+    for (int k = lane; k < p.K; k += 64) {
+        const long e = base + k;
+        const uint8_t byte = p.B[e >> 1];
+        const int nib = (e & 1) ? (byte & 0xF) : (byte >> 4);
+        const long blk = e >> p.bs_shift;
+        if (blk != run_blk) {
+            if (run_blk >= 0)
+                acc = fmaf(block_scale(run_blk), run, acc);
+            run = 0.0f;
+            run_blk = blk;
+        }
+        run = fmaf(static_cast<float>(A[k]), code[nib], run);
+    }
+    if (run_blk >= 0)
+        acc = fmaf(block_scale(run_blk), run, acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        const float b = p.bias ? static_cast<float>(static_cast<const T*>(p.bias)[row]) : 0.0f;
+        static_cast<T*>(p.out)[static_cast<long>(m) * p.N + row] = static_cast<T>(acc + b);
+    }
+}
+
+template <typename T, int MB, int RPW, int SEGS> void launch_dot(const GemvArgs& p, hipStream_t stream) {
+    const int rows_per_block = 4 * RPW;
+    dim3 grid((p.N + rows_per_block - 1) / rows_per_block, (p.M + MB - 1) / MB);
+    const bool single = p.K <= SEGS * kSegK;
+    if (single) {
+        if (p.absmax8)
+            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, true, true>), grid, dim3(256), 0, stream, p);
+        else
+            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, true, false>), grid, dim3(256), 0, stream, p);
+    } else {
+        if (p.absmax8)
+            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, false, true>), grid, dim3(256), 0, stream, p);
+        else
+            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, false, false>), grid, dim3(256), 0, stream, p);
+    }
+}
+
+template <typename T> void launch_generic(const GemvArgs& p, hipStream_t stream) {
+    dim3 grid((p.N + 3) / 4, p.M);
+    if (p.absmax8)
+        hipLaunchKernelGGL((gemv4_generic_kernel<T, true>), grid, dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((gemv4_generic_kernel<T, false>), grid, dim3(256), 0, stream, p);
+}
+
+template <typename T> void dispatch_dot(const GemvArgs& p, hipStream_t stream) {
+    // rows per wavefront: enough workgroups to cover 256 CUs a few times, but not less than 2 rows
+    int rpw = g_dot_rpw;
+    if (rpw == 0) {
+        const long waves2 = (static_cast<long>(p.N) + 1) / 2;
+        rpw = (waves2 >= 256 * 16) ? 4 : 2;
+        if (p.N < 256 * 4 * 2)
+            rpw = 1;
+    }
+    int segs = g_dot_segs;
+    if (segs == 0)
+        segs = (p.K > kSegK) ? 2 : 1;
+    const int mb = (p.M >= 3) ? 4 : p.M;
+
+#define BNB_DOT_CASE(MBV, RPWV, SEGSV)                                                             \
+    if (mb == MBV && rpw == RPWV && segs == SEGSV) {                                               \
+        launch_dot<T, MBV, RPWV, SEGSV>(p, stream);                                                \
+        return;                                                                                    \
+    }
+    BNB_DOT_CASE(1, 1, 1) BNB_DOT_CASE(1, 1, 2) BNB_DOT_CASE(1, 2, 1) BNB_DOT_CASE(1, 2, 2)
+    BNB_DOT_CASE(1, 4, 1) BNB_DOT_CASE(1, 4, 2) BNB_DOT_CASE(1, 8, 1)
+    BNB_DOT_CASE(2, 1, 1) BNB_DOT_CASE(2, 1, 2) BNB_DOT_CASE(2, 2, 1) BNB_DOT_CASE(2, 2, 2)
+    BNB_DOT_CASE(2, 4, 1)
+    BNB_DOT_CASE(4, 1, 1) BNB_DOT_CASE(4, 1, 2) BNB_DOT_CASE(4, 2, 1)
+#undef BNB_DOT_CASE
+    // unsupported combination requested by a sweep: fall back to a safe one
+    launch_dot<T, 1, 1, 1>(p, stream);
+}
+
+} // namespace
+
+// Entry used by c_api.hip. dtype: 0 = f32, 1 = f16, 2 = bf16. Chooses the fast kernel when its
+// preconditions hold, else the generic one. M may be any value >= 1 (rows handled 4 at a time).
+void gemv_4bit_dot(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
+                   const float* absmax_code, const float* absmax_offset, const float* code16, void* out,
+                   const void* bias, int M, int N, int K, int blocksize, int quant_type, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0)
+        return;
+    GemvArgs p;
+    p.A = A;
+    p.B = B;
+    p.absmax = absmax;
+    p.absmax8 = absmax8;
+    p.absmax_code = absmax_code;
+    p.absmax_offset = absmax_offset;
+    p.code16 = code16;
+    p.out = out;
+    p.bias = bias;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.bs_shift = ilog2(blocksize);
+    p.quant_type = quant_type;
+
+    const bool fast_ok = (dtype != 0) && (K % 32 == 0) && (blocksize >= 32) && is_pow2(blocksize) &&
+                         aligned_to(A, 16) && aligned_to(B, 16);
+    if (fast_ok) {
+        if (dtype == 2)
+            dispatch_dot<bf16>(p, stream);
+        else
+            dispatch_dot<f16>(p, stream);
+    } else {
+        if (dtype == 0)
+            launch_generic<float>(p, stream);
+        else if (dtype == 1)
+            launch_generic<f16>(p, stream);
+        else
+            launch_generic<bf16>(p, stream);
+    }
+    BNB_CHECK_LAUNCH();
+}
+
+} // namespace bnb

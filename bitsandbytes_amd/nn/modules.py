@@ -1,0 +1,279 @@
+"""``Params4bit`` / ``Linear4bit`` — the module-level face of the 4-bit path
+(reference ``bitsandbytes/nn/modules.py:213-716``).
+
+Same contract as the reference: a ``Linear4bit`` holds its weight as a :class:`Params4bit`; the fp
+weight is quantised lazily the first time the parameter is moved to a (HIP) device; ``forward`` is
+``matmul_4bit(x, weight, bias, quant_state)``; the state-dict layout (``weight`` packed bytes plus
+``weight.absmax``, ``weight.quant_map``, optional ``weight.nested_*`` and the JSON blob
+``weight.quant_state.bitsandbytes__{nf4,fp4}``) is byte-compatible, so checkpoints written by either
+implementation load in the other.
+"""
+from __future__ import annotations
+
+import copy
+import logging
+from typing import Any, Optional
+
+import torch
+from torch import nn
+
+from .. import functional as F
+from ..autograd import matmul_4bit
+from ..functional import QuantState
+
+logger = logging.getLogger(__name__)
+
+# QuantState attributes re-exported on the parameter so that FSDP's dotted-FQN traversal
+# (getattr(weight, "absmax") ...) finds them. Implemented as properties, not __getattr__, which
+# keeps torch.compile from graph-breaking on tensor subclasses (reference modules.py:261-339).
+def _qs_property(attr_path: str, exported_name: str, none_ok: bool = False):
+    def getter(self):
+        obj = self.__dict__.get("quant_state")
+        if obj is not None:
+            for part in attr_path.split("."):
+                obj = getattr(obj, part, None)
+                if obj is None:
+                    break
+            if obj is not None or none_ok:
+                return obj
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{exported_name}'")
+
+    return property(getter)
+
+
+class Params4bit(torch.nn.Parameter):
+    def __new__(
+        cls,
+        data: Optional[torch.Tensor] = None,
+        requires_grad: bool = False,  # quantised weights are frozen by default
+        quant_state: Optional[QuantState] = None,
+        blocksize: Optional[int] = None,
+        compress_statistics: bool = True,
+        quant_type: str = "fp4",
+        quant_storage: torch.dtype = torch.uint8,
+        module: Optional["Linear4bit"] = None,
+        bnb_quantized: bool = False,
+        **kwargs,
+    ) -> "Params4bit":
+        if data is None:
+            data = torch.empty(0)
+        self = torch.Tensor._make_subclass(cls, data, requires_grad)
+        self.blocksize = 64 if blocksize is None else blocksize
+        self.compress_statistics = compress_statistics
+        self.quant_type = quant_type
+        self.quant_state = quant_state
+        self.quant_storage = quant_storage
+        self.bnb_quantized = bnb_quantized
+        self.data = data
+        self.module = module
+        return self
+
+    # ---- QuantState proxies (FSDP state-dict traversal)
+    absmax = _qs_property("absmax", "absmax")
+    code = _qs_property("code", "code")
+    quant_map = _qs_property("code", "quant_map")
+    offset = _qs_property("offset", "offset", none_ok=True)
+    state2 = _qs_property("state2", "state2", none_ok=True)
+    nested_absmax = _qs_property("state2.absmax", "nested_absmax")
+    nested_blocksize = _qs_property("state2.blocksize", "nested_blocksize")
+    nested_quant_map = _qs_property("state2.code", "nested_quant_map")
+    nested_dtype = _qs_property("state2.dtype", "nested_dtype")
+    nested_offset = _qs_property("offset", "nested_offset", none_ok=True)
+
+    # ---- pickling / copying
+    _STATE_FIELDS = ("blocksize", "compress_statistics", "quant_type", "quant_state", "quant_storage",
+                     "bnb_quantized", "module")
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["data"] = self.data
+        state["requires_grad"] = self.requires_grad
+        return state
+
+    def __setstate__(self, state):
+        self.requires_grad = state["requires_grad"]
+        for f in self._STATE_FIELDS:
+            setattr(self, f, state[f])
+        self.data = state["data"]
+
+    def __deepcopy__(self, memo):
+        new = type(self).__new__(type(self))
+        state = self.__getstate__()
+        new.__setstate__(state)
+        new.quant_state = copy.deepcopy(state["quant_state"])
+        new.data = copy.deepcopy(state["data"])
+        return new
+
+    def __copy__(self):
+        new = type(self).__new__(type(self))
+        new.__setstate__(self.__getstate__())
+        return new
+
+    # ---- construction from a pre-quantised checkpoint
+    @classmethod
+    def from_prequantized(cls, data: torch.Tensor, quantized_stats: dict[str, Any], requires_grad: bool = False,
+                          device="cuda", module: Optional["Linear4bit"] = None, **kwargs) -> "Params4bit":
+        self = torch.Tensor._make_subclass(cls, data.to(device))
+        self.requires_grad = requires_grad
+        self.quant_state = QuantState.from_dict(qs_dict=quantized_stats, device=device)
+        self.blocksize = self.quant_state.blocksize
+        self.compress_statistics = self.quant_state.nested
+        self.quant_type = self.quant_state.quant_type
+        self.bnb_quantized = True
+        self.quant_storage = data.dtype
+        self.module = module
+        if module is not None:
+            module.quant_state = self.quant_state
+        return self
+
+    # ---- lazy quantisation on device move
+    def _quantize(self, device):
+        w = self.data.contiguous().to(device)
+        packed, state = F.quantize_4bit(
+            w,
+            blocksize=self.blocksize,
+            compress_statistics=self.compress_statistics,
+            quant_type=self.quant_type,
+            quant_storage=self.quant_storage,
+        )
+        self.data = packed
+        self.quant_state = state
+        if self.module is not None:
+            self.module.quant_state = state
+        self.bnb_quantized = True
+        return self
+
+    def cpu(self):
+        return self.to(device="cpu")
+
+    def cuda(self, device=None, non_blocking: bool = False):
+        return self.to(device="cuda" if device is None else device, non_blocking=non_blocking)
+
+    def to(self, *args, **kwargs):
+        device, dtype, non_blocking, _ = torch._C._nn._parse_to(*args, **kwargs)
+        if device is not None and device.type != "meta" and not self.bnb_quantized:
+            return self._quantize(device)
+        if self.quant_state is not None:
+            self.quant_state.to(device)
+        return Params4bit(
+            super().to(device=device, dtype=dtype, non_blocking=non_blocking),
+            requires_grad=self.requires_grad,
+            quant_state=self.quant_state,
+            blocksize=self.blocksize,
+            compress_statistics=self.compress_statistics,
+            quant_type=self.quant_type,
+            quant_storage=self.quant_storage,
+            bnb_quantized=self.bnb_quantized,
+        )
+
+    # torch.chunk / torch.split (FSDP sharding, fused-QKV splitting) must keep the metadata
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        result = super().__torch_function__(func, types, args, kwargs)
+        if func not in (torch.chunk, torch.split):
+            return result
+        src = args[0]
+
+        def rewrap(t):
+            return cls(
+                data=t,
+                requires_grad=src.requires_grad,
+                quant_state=src.quant_state,
+                blocksize=src.blocksize,
+                compress_statistics=src.compress_statistics,
+                quant_type=src.quant_type,
+                quant_storage=src.quant_storage,
+                module=src.module,
+                bnb_quantized=src.bnb_quantized,
+            )
+
+        return tuple(rewrap(t) for t in result) if isinstance(result, tuple) else rewrap(result)
+
+
+def fix_4bit_weight_quant_state_from_module(module: "Linear4bit") -> None:
+    """FSDP and friends may replace the parameter by a plain tensor and lose ``quant_state``; the
+    module keeps a copy so it can be put back (reference modules.py:487-501)."""
+    if getattr(module.weight, "quant_state", None) is not None:
+        return
+    if getattr(module, "quant_state", None) is None:
+        logger.warning(
+            "FP4 quantization state not initialized. Please call .cuda() or .to(device) on the LinearFP4 layer first."
+        )
+    assert module.weight.shape[1] == 1
+    if not isinstance(module.weight, Params4bit):
+        module.weight = Params4bit(module.weight, quant_storage=module.quant_storage, bnb_quantized=True)
+    module.weight.quant_state = module.quant_state
+
+
+class Linear4bit(nn.Linear):
+    """QLoRA-style 4-bit linear layer (reference modules.py:504-637). Load fp weights into it, then
+    ``.to("cuda")`` quantises them on the MI355X."""
+
+    def __init__(self, input_features, output_features, bias=True, compute_dtype=None, compress_statistics=True,
+                 quant_type="fp4", quant_storage=torch.uint8, device=None):
+        super().__init__(input_features, output_features, bias, device)
+        self.weight = Params4bit(
+            self.weight.data,
+            requires_grad=False,
+            compress_statistics=compress_statistics,
+            quant_type=quant_type,
+            quant_storage=quant_storage,
+            module=self,
+        )
+        self.compute_dtype = compute_dtype
+        self.compute_type_is_set = compute_dtype is not None
+        self.quant_state = None
+        self.quant_storage = quant_storage
+
+    def set_compute_type(self, x: torch.Tensor) -> None:
+        if x.dtype in (torch.float32, torch.bfloat16):
+            # safe to compute in the input's dtype
+            self.compute_dtype = x.dtype
+        elif x.dtype == torch.float16 and self.compute_dtype in (None, torch.float32):
+            single = x.numel() == x.shape[-1]
+            logger.warning(
+                "Input type into Linear4bit is torch.float16, but bnb_4bit_compute_dtype=torch.float32 (default). "
+                + ("This will lead to slow inference." if single else "This will lead to slow inference or training speed.")
+            )
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)  # weight (packed) and bias
+        state = getattr(self.weight, "quant_state", None)
+        if state is not None:
+            for k, v in state.as_dict(packed=True).items():
+                destination[prefix + "weight." + k] = v if keep_vars else v.detach()
+
+    def forward(self, x: torch.Tensor):
+        fix_4bit_weight_quant_state_from_module(self)
+        quant_state = self.weight.quant_state
+
+        if not self.compute_type_is_set:
+            self.set_compute_type(x)
+            self.compute_type_is_set = True
+
+        inp_dtype = x.dtype
+        if self.compute_dtype is not None:
+            x = x.to(self.compute_dtype)
+
+        bias = self.bias
+        if bias is not None:
+            if bias.dtype != x.dtype:
+                bias.data = bias.data.to(x.dtype)
+            bias = bias.to(self.compute_dtype)
+
+        return matmul_4bit(x, self.weight, bias=bias, quant_state=quant_state).to(inp_dtype)
+
+
+class LinearFP4(Linear4bit):
+    def __init__(self, input_features, output_features, bias=True, compute_dtype=None, compress_statistics=True,
+                 quant_storage=torch.uint8, device=None):
+        super().__init__(input_features, output_features, bias, compute_dtype, compress_statistics, "fp4",
+                         quant_storage, device)
+
+
+class LinearNF4(Linear4bit):
+    def __init__(self, input_features, output_features, bias=True, compute_dtype=None, compress_statistics=True,
+                 quant_storage=torch.uint8, device=None):
+        super().__init__(input_features, output_features, bias, compute_dtype, compress_statistics, "nf4",
+                         quant_storage, device)

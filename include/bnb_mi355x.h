@@ -1,0 +1,119 @@
+/*
+ * bnb_mi355x.h — C ABI of libbitsandbytes_mi355x.so, the MI355X (gfx950) native backend for the
+ * bitsandbytes 4-bit quantized-linear path.
+ *
+ * The first group of entry points is exactly what the reference's ctypes layer binds for this path
+ * (reference bitsandbytes/backends/cuda/ops.py:16-66): same names, same argument order, same types,
+ * `void` return, errors reported as the reference's BNB_CHECK_RETURN does (message on stderr and
+ * exit(1), reference csrc/compat.cuh:78-85). A reference build pointed at this library (see
+ * INTEGRATION.md) runs its quantize_4bit / dequantize_4bit / gemm_4bit / gemv_4bit ops on these
+ * kernels unchanged.
+ *
+ * Conventions (reference SURVEY §8b):
+ *   - every pointer is a raw device address owned by the caller; outputs are pre-allocated; the
+ *     library allocates nothing and keeps no pointer after return;
+ *   - calls only enqueue work on `stream` (no synchronisation, no allocation): legal inside
+ *     hipGraph capture;
+ *   - packed weights: row-major flat over [N, K]; element 2i in the HIGH nibble and 2i+1 in the
+ *     low nibble of byte i; quantization block j covers flat elements [j*bs, (j+1)*bs);
+ *   - quant_type: 1 = FP4, 2 = NF4 (reference csrc/common.h:3-7);
+ *   - `bnb_stream_t` is a hipStream_t passed as void*.
+ *
+ * fp16 / bf16 buffers are declared `void*` here so the header is usable from plain C.
+ */
+#ifndef BNB_MI355X_H
+#define BNB_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* bnb_stream_t;
+
+/* ------------------------------------------------------------------------------------------------
+ * 4-bit blockwise quantize — replaces reference csrc/pythonInterface.cpp:364-426
+ * (cquantize_blockwise_<T>_{fp4,nf4}); `code` is unused (NULL). As in the reference these take NO
+ * stream and run on the NULL stream. out: (n+1)/2 bytes; absmax: ceil(n/blocksize) floats.
+ * blocksize in {32,64,...,4096}. Results are bit-identical to the reference CPU backend
+ * (bitsandbytes/backends/default/ops.py:233-259).
+ * ---------------------------------------------------------------------------------------------- */
+void cquantize_blockwise_fp32_nf4(float* code, float* A, float* absmax, unsigned char* out, int blocksize, const int n);
+void cquantize_blockwise_fp32_fp4(float* code, float* A, float* absmax, unsigned char* out, int blocksize, const int n);
+void cquantize_blockwise_fp16_nf4(float* code, void* A, float* absmax, unsigned char* out, int blocksize, const int n);
+void cquantize_blockwise_fp16_fp4(float* code, void* A, float* absmax, unsigned char* out, int blocksize, const int n);
+void cquantize_blockwise_bf16_nf4(float* code, void* A, float* absmax, unsigned char* out, int blocksize, const int n);
+void cquantize_blockwise_bf16_fp4(float* code, void* A, float* absmax, unsigned char* out, int blocksize, const int n);
+
+/* 4-bit blockwise dequantize — replaces reference csrc/pythonInterface.cpp:346-444
+ * (cdequantize_blockwise_<T>_{fp4,nf4}); n = number of OUTPUT elements. */
+void cdequantize_blockwise_fp32_nf4(float* code, unsigned char* A, float* absmax, float* out, int blocksize, const int n, bnb_stream_t stream);
+void cdequantize_blockwise_fp32_fp4(float* code, unsigned char* A, float* absmax, float* out, int blocksize, const int n, bnb_stream_t stream);
+void cdequantize_blockwise_fp16_nf4(float* code, unsigned char* A, float* absmax, void* out, int blocksize, const int n, bnb_stream_t stream);
+void cdequantize_blockwise_fp16_fp4(float* code, unsigned char* A, float* absmax, void* out, int blocksize, const int n, bnb_stream_t stream);
+void cdequantize_blockwise_bf16_nf4(float* code, unsigned char* A, float* absmax, void* out, int blocksize, const int n, bnb_stream_t stream);
+void cdequantize_blockwise_bf16_fp4(float* code, unsigned char* A, float* absmax, void* out, int blocksize, const int n, bnb_stream_t stream);
+
+/* 8-bit blockwise pair with a 256-entry fp32 `code` (General8bit) — replaces reference
+ * csrc/pythonInterface.cpp:346-444 (cquantize_blockwise_<T> / cdequantize_blockwise_<T>). On this
+ * path they only (de)compress the absmax vector for double quantization. Quantize follows the
+ * reference CPU kernel's 65536-bin rule (csrc/cpu_ops.cpp:501-665). Quantize: NULL stream. */
+void cquantize_blockwise_fp32(float* code, float* A, float* absmax, unsigned char* out, int blocksize, const int n);
+void cquantize_blockwise_fp16(float* code, void* A, float* absmax, unsigned char* out, int blocksize, const int n);
+void cquantize_blockwise_bf16(float* code, void* A, float* absmax, unsigned char* out, int blocksize, const int n);
+void cdequantize_blockwise_fp32(float* code, unsigned char* A, float* absmax, float* out, int blocksize, const int n, bnb_stream_t stream);
+void cdequantize_blockwise_fp16(float* code, unsigned char* A, float* absmax, void* out, int blocksize, const int n, bnb_stream_t stream);
+void cdequantize_blockwise_bf16(float* code, unsigned char* A, float* absmax, void* out, int blocksize, const int n, bnb_stream_t stream);
+
+/* Fused dequantize + GEMM — replaces reference csrc/gemm_4bit.cu:138-166.
+ *   out[M,N] = A[M,K] * dequant(B)[N,K]^T (+ bias[N])
+ *   scale of block b = absmax[b]                                            (absmax_8bit == NULL)
+ *                    = absmax_code[absmax_8bit[b]] * absmax[b >> 8] + *absmax_offset   (nested)
+ * K % blocksize == 0 is guaranteed by the caller (reference backends/cuda/ops.py:956-962);
+ * absmax_offset is fp32; bias has A's dtype. M is any positive value: M <= 4 runs the
+ * wave64 dot kernel, 5 <= M the MFMA kernel (bf16/fp16). */
+void cgemm_4bit_bf16(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K, int blocksize, int quant_type, bnb_stream_t stream);
+void cgemm_4bit_fp16(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K, int blocksize, int quant_type, bnb_stream_t stream);
+void cgemm_4bit_fp32(const float* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, float* out, const float* bias, int M, int N, int K, int blocksize, int quant_type, bnb_stream_t stream);
+
+/* Legacy gemv (M = 1) — replaces reference csrc/pythonInterface.cpp:594-613.
+ * m = N (output features), n = 1, k = K; `datatype` = the 16-entry fp32 code table on the device;
+ * absmax already un-nested; lda/ldb/ldc are ignored exactly as the reference kernel ignores them
+ * (it indexes B flat, reference csrc/kernels.cu:1452-1567). */
+void cgemm_4bit_inference_naive_fp16(int m, int n, int k, void* A, unsigned char* B, float* absmax, float* datatype, void* out, int lda, int ldb, int ldc, int blocksize, bnb_stream_t stream);
+void cgemm_4bit_inference_naive_bf16(int m, int n, int k, void* A, unsigned char* B, float* absmax, float* datatype, void* out, int lda, int ldb, int ldc, int blocksize, bnb_stream_t stream);
+void cgemm_4bit_inference_naive_fp32(int m, int n, int k, float* A, unsigned char* B, float* absmax, float* datatype, float* out, int lda, int ldb, int ldc, int blocksize, bnb_stream_t stream);
+
+/* Loader symbols the reference's cextension.py:109-115,371-372 probes to classify a GPU library.
+ * get_context returns an opaque non-NULL token (this path needs no BLAS handle);
+ * cget_managed_ptr returns hipMallocManaged memory (reference csrc/pythonInterface.cpp:522,557-563). */
+void* get_context(void);
+void* cget_managed_ptr(size_t bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * Extensions (not in the reference ABI). Used by bitsandbytes_amd's own host layer.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Stream-ordered 4-bit / 8-bit quantize: same kernels as the cquantize_blockwise_* family above but
+ * enqueued on `stream`. dtype: 0 = fp32, 1 = fp16, 2 = bf16. */
+void bnb_mi355x_quantize_4bit(const void* A, int dtype, float* absmax, unsigned char* out, int blocksize, long n, int quant_type, bnb_stream_t stream);
+void bnb_mi355x_quantize_8bit(const float* code, const void* A, int dtype, float* absmax, unsigned char* out, int blocksize, long n, bnb_stream_t stream);
+
+/* gemm_4bit with an explicit kernel choice, for benchmarks and parity tests:
+ * kernel = 0 auto, 1 wave64 dot kernel, 2 MFMA kernel. dtype as above; code16 may be NULL. */
+void bnb_mi355x_gemm_4bit(int kernel, int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, const float* code16, void* out, const void* bias, int M, int N, int K, int blocksize, int quant_type, bnb_stream_t stream);
+
+/* Tuning overrides for sweeps (0 = built-in heuristic): rows per wavefront and 2048-k segments per
+ * iteration of the dot kernel; reserved knobs for the MFMA kernel. Not thread-safe; bench/test use only. */
+void bnb_mi355x_set_tuning(int dot_rows_per_wave, int dot_segments, int mfma_knob0, int mfma_knob1);
+
+/* Version / build identification: returns "bitsandbytes_amd <ver> gfx950". */
+const char* bnb_mi355x_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* BNB_MI355X_H */
