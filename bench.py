@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X 4-bit path (contract in the task statement).
+
+Workload at N = 1 (BASELINE.json configs[1], the configuration the headline metric is quoted on):
+    gemv_4bit / Linear4bit forward, NF4, bf16, M = 1, N = K = 4096, blocksize 64, fp32 absmax.
+One "step" = one forward pass of one such layer on one synthetic activation row. Steps rotate over
+LAYERS = 64 distinct layers (64 x 9.45 MB = 605 MB > the 256 MiB Infinity Cache), so every step
+streams its weights from HBM; inputs are resident in HBM before the timed region.
+
+    value = algorithmic bytes per step x steps / wall time      [GB/s, whole job, all ranks]
+    algorithmic bytes per step = N*K/2 + 4*N*K/bs + 2*M*K + 2*M*N = 9 453 568   
+
+Timed region: the K steps are enqueued as replays of a hipGraph holding GRAPH_CHUNK consecutive
+steps (launch-bound inner loop -> graph, as on a real decode loop), bracketed by barrier +
+synchronize; MAX over ranks.
+
+--gpus N > 1 (weak scaling): every rank owns a full-size 4096-row shard of an N*4096-row layer
+(bitsandbytes_amd.parallel semantics: x replicated, rows sharded, no reduction). The y shards are
+re-assembled by RCCL all-gathers, bucketed GRAPH_CHUNK steps per collective and issued on a side
+stream so they overlap the next chunk's weight streaming.
+
+Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed per launch inside the
+same process) and, at N = 1 on rank 0, "cpu_baseline" (the reference's own AVX512-BF16 fused CPU
+gemv from oracle/_ref when the host supports it, else the scalar port from oracle/).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+LAYERS = 64
+GRAPH_CHUNK = 64
+
+
+def algorithmic_bytes(M, N, K, bs, elt=2):
+    return N * K // 2 + 4 * (N * K // bs) + elt * M * K + elt * M * N
+
+
+def build_layers(device, n_layers, N, K, M, blocksize, quant_type, seed):
+    import bitsandbytes_amd.functional as F
+
+    g = torch.Generator(device=device).manual_seed(seed)
+    layers = []
+    for _ in range(n_layers):
+        W = (torch.randn(N, K, device=device, generator=g) / K**0.5).to(torch.bfloat16)
+        q, st = F.quantize_4bit(W, blocksize=blocksize, quant_type=quant_type)
+        layers.append((q, st))
+        del W
+    x = torch.randn(M, K, device=device, generator=g).to(torch.bfloat16)
+    return layers, x
+
+
+def cpu_baseline(M, N, K, blocksize, quant_type):
+    """Reference CPU path timed on this host (rank 0, N = 1 only). Checker infrastructure from oracle/."""
+    from oracle import oracle as O
+
+    torch.manual_seed(0)
+    W = (torch.randn(N, K) / K**0.5).bfloat16()
+    x = torch.randn(M, K).bfloat16()
+    q, am = O.quantize_4bit(W, blocksize, quant_type)
+    nbytes = algorithmic_bytes(M, N, K, blocksize)
+    if O.ref_has_avx512bf16():
+        wp, amt = O.ref_pack_for_cpu_gemv(q, am, N, K, blocksize)
+        fn = lambda: O.ref_fused_gemv(x, wp, amt, N, K, blocksize, quant_type)  # noqa: E731
+        kind, cores = "reference", len(os.sched_getaffinity(0))
+        what = "gemv_4bit_inference_cpu_nf4_bf16 (csrc/cpu_ops.cpp:865-915, OpenMP over all host cores)"
+    else:
+        fn = lambda: O.gemv_4bit_f32acc(x, q, (N, K), am, blocksize, quant_type)  # noqa: E731
+        kind, cores = "port", 1
+        what = "oracle scalar dequant+dot (host lacks AVX512-BF16 for the reference's fused kernel)"
+    for _ in range(3):
+        fn()
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        iters += 1
+        dt = time.perf_counter() - t0
+        if (iters >= 20 and dt > 2.0) or dt > 20.0:
+            break
+    return {
+        "value": round(nbytes * iters / dt / 1e9, 3),
+        "unit": "GB/s",
+        "cores": cores,
+        "kind": kind,
+        "ms_per_step": round(dt / iters * 1e3, 4),
+        "sample": f"{iters} forward passes of the same M={M} N=K={N} workload in {dt:.1f} s; {what}",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6400)
+    ap.add_argument("--warmup", type=int, default=640)
+    ap.add_argument("--m", type=int, default=1, help="activation rows (headline: 1)")
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--k", type=int, default=4096)
+    ap.add_argument("--blocksize", type=int, default=64)
+    ap.add_argument("--quant-type", default="nf4")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue steps eagerly instead of replaying a hipGraph")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import bitsandbytes_amd as bnb
+    from bitsandbytes_amd.backends import hip
+
+    assert bnb.lib, "native HIP library missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
+
+    M, N, K, bs, qt = args.m, args.n, args.k, args.blocksize, args.quant_type
+    layers, x = build_layers(device, LAYERS, N, K, M, bs, qt, seed=1234 + rank)
+    nbytes_step = algorithmic_bytes(M, N, K, bs)
+    flops_step = 2 * M * N * K
+
+    # output buckets: GRAPH_CHUNK steps of this rank's y shard, double-buffered
+    buckets = [torch.empty(GRAPH_CHUNK, M, N, device=device, dtype=torch.bfloat16) for _ in range(2)]
+    gathered = [torch.empty(world * GRAPH_CHUNK, M, N, device=device, dtype=torch.bfloat16) for _ in range(2)] if world > 1 else None
+
+    def run_step(i, out):
+        q, st = layers[i % LAYERS]
+        hip._gemm_4bit_fused(x, q, st.shape, st.absmax, st.blocksize, st.quant_type, None, None, None, None, out=out)
+
+    def run_chunk_eager(base, bucket):
+        for j in range(GRAPH_CHUNK):
+            run_step(base + j, bucket[j])
+
+    # LAYERS == GRAPH_CHUNK, so every chunk touches the same layer sequence: one graph per bucket
+    graphs = None
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run_chunk_eager(0, buckets[0])  # warm-up outside capture
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graphs = []
+        for b in range(2):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                run_chunk_eager(0, buckets[b])
+            graphs.append(g)
+
+    comm_stream = torch.cuda.Stream() if world > 1 else None
+    pending = [None, None]
+
+    def run_steps(nsteps):
+        """Enqueue exactly nsteps steps (+ the bucketed all-gathers when world > 1)."""
+        done, c = 0, 0
+        while done < nsteps:
+            b = c & 1
+            if world > 1 and pending[b] is not None:
+                torch.cuda.current_stream().wait_event(pending[b])  # bucket b's previous gather finished
+            left = nsteps - done
+            if left >= GRAPH_CHUNK:
+                if graphs is not None:
+                    graphs[b].replay()
+                else:
+                    run_chunk_eager(done, buckets[b])
+                n_now = GRAPH_CHUNK
+            else:
+                for j in range(left):
+                    run_step(done + j, buckets[b][j])
+                n_now = left
+            if world > 1:
+                ready = torch.cuda.Event()
+                ready.record()
+                with torch.cuda.stream(comm_stream):
+                    comm_stream.wait_event(ready)
+                    dist.all_gather_into_tensor(gathered[b].view(world * GRAPH_CHUNK * M, N),
+                                                buckets[b].view(GRAPH_CHUNK * M, N))
+                    ev = torch.cuda.Event()
+                    ev.record()
+                pending[b] = ev
+            done += n_now
+            c += 1
+        if world > 1:
+            torch.cuda.current_stream().wait_stream(comm_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- warm-up
+    run_steps(args.warmup)
+    torch.cuda.synchronize()
+
+    # ---- timed region: exactly args.steps steps
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline leg: per-launch kernel time of the dominant kernel, HIP events on the launch stream
+    n_ev = min(args.steps, 512)
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
+    run_chunk_eager(0, buckets[0])
+    torch.cuda.synchronize()
+    for i in range(n_ev):
+        starts[i].record()
+        run_step(i, buckets[0][i % GRAPH_CHUNK])
+        ends[i].record()
+    torch.cuda.synchronize()
+    per_launch_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
+    # trimmed mean (drop the top 5%: host hiccups between record and launch land inside the bracket)
+    kept = per_launch_ms[: max(1, int(0.95 * n_ev))]
+    kernel_ms = sum(kept) / len(kept)
+    achieved = nbytes_step / (kernel_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        total_steps = args.steps * world
+        value = nbytes_step * total_steps / elapsed / 1e9
+        line = {
+            "metric": "NF4 Linear4bit forward GB/s (gemv_4bit M=1, N=K=4096; algorithmic bytes / time)",
+            "value": round(value, 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 6),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "tflops": round(flops_step * total_steps / elapsed / 1e12, 4),
+            "config": {
+                "workload": f"gemv_4bit {qt.upper()} bf16 M={M} N=K={N}x{K} blocksize={bs} fp32-absmax "
+                            "(BASELINE.json configs[1]); one step = one layer forward",
+                "layers_in_rotation": LAYERS,
+                "hbm_resident_bytes_rotated": LAYERS * nbytes_step,
+                "bytes_per_step": nbytes_step,
+                "launch": "eager" if graphs is None else f"hipGraph x{GRAPH_CHUNK} steps",
+                "parallelism": f"rows sharded x{world}, all-gather bucketed x{GRAPH_CHUNK}" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "gemv4_dot_kernel<bf16>",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "kernel_us": round(kernel_ms * 1e3, 3),
+                "method": f"mean of {len(kept)} per-launch HIP-event brackets (eager launches, HBM-resident rotation)",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(M, N, K, bs, qt)
+            except Exception as exc:  # baseline is informational; never lose the GPU line over it
+                line["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {exc}"}
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -220,7 +220,7 @@ def _gemm_4bit_route(dtype: torch.dtype, M: int, N: int, K: int, blocksize: int)
 
 
 def _gemm_4bit_fused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8bit, absmax_code, absmax_offset,
-                     kernel: int = 0):
+                     kernel: int = 0, out: Optional[torch.Tensor] = None):
     K = A.shape[-1]
     M = A.numel() // K
     N = int(shapeB[0])
@@ -238,7 +238,10 @@ def _gemm_4bit_fused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8
         raise RuntimeError(f"unsupported dtype {A.dtype}")
     A = A.contiguous()
     B = B.contiguous()
-    out = torch.empty((*A.shape[:-1], N), dtype=A.dtype, device=A.device)
+    if out is None:
+        out = torch.empty((*A.shape[:-1], N), dtype=A.dtype, device=A.device)
+    elif out.dtype != A.dtype or out.numel() != M * N or not out.is_contiguous():
+        raise RuntimeError("out must be a contiguous tensor of A's dtype with M*N elements")
     offset32 = absmax_offset.to(dtype=torch.float32) if absmax_offset is not None else None
     with _device_of(A):
         lib.bnb_mi355x_gemm_4bit(

@@ -41,6 +41,12 @@ def _qs_property(attr_path: str, exported_name: str, none_ok: bool = False):
     return property(getter)
 
 
+def _rebuild_params4bit(state):
+    new = Params4bit.__new__(Params4bit, data=state["data"], requires_grad=state["requires_grad"])
+    new.__setstate__(state)
+    return new
+
+
 class Params4bit(torch.nn.Parameter):
     def __new__(
         cls,
@@ -95,6 +101,10 @@ class Params4bit(torch.nn.Parameter):
         for f in self._STATE_FIELDS:
             setattr(self, f, state[f])
         self.data = state["data"]
+
+    def __reduce_ex__(self, proto):
+        # torch.nn.Parameter's default reduce rebuilds a plain Parameter; keep the subclass
+        return (_rebuild_params4bit, (self.__getstate__(),))
 
     def __deepcopy__(self, memo):
         new = type(self).__new__(type(self))

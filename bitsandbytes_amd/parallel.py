@@ -93,11 +93,12 @@ class ShardedLinear4bit(nn.Module):
         lead = y_local.shape[:-1]
         ns = y_local.shape[-1]
         y2 = y_local.reshape(-1, ns).contiguous()
-        buf = torch.empty((G, y2.shape[0], ns), dtype=y2.dtype, device=y2.device)
+        m = y2.shape[0]
+        buf = torch.empty((G * m, ns), dtype=y2.dtype, device=y2.device)  # rank-major concatenation
         dist.all_gather_into_tensor(buf, y2, group=self.group)
-        if y2.shape[0] == 1:
+        if m == 1:
             return buf.view(*lead, G * ns)  # M == 1: rank-major already is feature-major
-        return buf.permute(1, 0, 2).reshape(*lead, G * ns)
+        return buf.view(G, m, ns).permute(1, 0, 2).reshape(*lead, G * ns)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y = self.local_forward(x)

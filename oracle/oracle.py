@@ -239,3 +239,34 @@ def ref_dequantize_blockwise(A: torch.Tensor, absmax: torch.Tensor, code: torch.
     fn(_p(_cpu_contig(code).float()), _p(A), _p(_cpu_contig(absmax).float()), _p(out), ct.c_longlong(blocksize),
        ct.c_longlong(A.numel()))
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# The reference's fused CPU gemv (csrc/cpu_ops.cpp:687-915, AVX512-BF16), used as the timed CPU
+# baseline ("kind": "reference") by bench.py. It needs the weight in the reference's CPU packing,
+# produced in the reference by Python code that cannot travel to the GPU box
+# (bitsandbytes/functional.py:1676-1727, _convert_weight_packed_for_cpu); restated here.
+# --------------------------------------------------------------------------------------------------
+def ref_pack_for_cpu_gemv(packed: torch.Tensor, absmax: torch.Tensor, N: int, K: int, blocksize: int):
+    """[N*K/2] bytes (hi nibble = even element) -> the 32-row interleaved layout + bf16 absmax [K/bs, N]."""
+    q = _cpu_contig(packed).view(torch.uint8).reshape(-1)
+    nib = torch.empty(q.numel() * 2, dtype=torch.uint8)
+    nib[0::2] = q >> 4
+    nib[1::2] = q & 0xF
+    assert N % 32 == 0 and K % 2 == 0
+    w = nib.reshape(N // 32, 32, K // 2, 2).transpose(1, 2).contiguous().reshape(-1, 64)
+    out = ((w[:, 32:] << 4) | w[:, :32]).reshape(N, K // 2).contiguous()
+    am = _cpu_contig(absmax).float().reshape(N, K // blocksize).t().to(torch.bfloat16).contiguous()
+    return out, am
+
+
+def ref_fused_gemv(x: torch.Tensor, w_cpu_packed: torch.Tensor, absmax_bf16_t: torch.Tensor, N: int, K: int,
+                   blocksize: int, quant_type: str = "nf4") -> torch.Tensor:
+    """gemv_4bit_inference_cpu_{nf4,fp4}_bf16 (csrc/pythonInterface.cpp:820-833); x: [M, K] bf16."""
+    x = _cpu_contig(x).to(torch.bfloat16).reshape(-1, K)
+    M = x.shape[0]
+    out = torch.empty((M, N), dtype=torch.bfloat16)
+    fn = getattr(ref_lib(), f"gemv_4bit_inference_cpu_{quant_type}_bf16")
+    fn(ct.c_int64(M), ct.c_int64(N), ct.c_int64(K), _p(x), _p(w_cpu_packed), _p(absmax_bf16_t), _p(out),
+       ct.c_int64(blocksize), ct.c_int64(x.stride(0)), ct.c_int64(out.stride(0)))
+    return out

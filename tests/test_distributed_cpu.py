@@ -1,0 +1,77 @@
+"""CPU, world_size 2 over gloo: the N-sharded Linear4bit (bitsandbytes_amd/parallel.py) — shard
+slicing of packed weight / absmax (plain and nested), per-rank matmul, ONE all-gather, and equality
+with the unsharded layer. Arithmetic is the oracle (test-only CPU kernels)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle_cpu_backend
+
+    _oracle_cpu_backend.register()
+    import bitsandbytes_amd as bnb
+    from bitsandbytes_amd.nn import Linear4bit
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        for (N, K, dq, qt, bs, bias) in [(64, 256, False, "nf4", 64, True), (64, 512, True, "nf4", 64, False),
+                                         (48, 256, True, "fp4", 128, True), (1024, 128, True, "nf4", 64, False)]:
+            torch.manual_seed(7)  # same weights on every rank
+            layer = Linear4bit(K, N, bias=bias, quant_type=qt, compress_statistics=dq)
+            layer.weight.blocksize = bs
+            layer = layer.to("cpu")
+            sharded = bnb.shard_linear4bit(layer, rank, world)
+            assert sharded.weight.numel() == N * K // 2 // world
+            for M in (1, 5):
+                x = torch.randn(M, K)
+                y_full = layer(x)
+                y = sharded(x)
+                ok &= y.shape == (M, N) and bool(torch.equal(y, y_full))
+                # local part is this rank's column block
+                y_loc = sharded.local_forward(x)
+                ns = N // world
+                ok &= bool(torch.equal(y_loc, y_full[:, rank * ns:(rank + 1) * ns]))
+        results[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_linear4bit_two_ranks():
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    with mp.Manager() as mgr:
+        results = mgr.dict()
+        mp.spawn(_worker, args=(world, port, results), nprocs=world, join=True)
+        assert dict(results) == {0: True, 1: True}
+
+
+def test_shard_validation():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle_cpu_backend
+
+    _oracle_cpu_backend.register()
+    import bitsandbytes_amd.functional as F
+    from bitsandbytes_amd.parallel import shard_quant_state
+
+    W = torch.randn(30, 128)
+    q, st = F.quantize_4bit(W, quant_type="nf4")
+    with pytest.raises(ValueError, match="divisible"):
+        shard_quant_state(q, st, 0, 4)
+    # nested state whose shard boundary is not on a second-level block boundary -> un-nested fp32 absmax
+    W = torch.randn(64, 128).bfloat16()
+    q, st = F.quantize_4bit(W, quant_type="nf4", compress_statistics=True)
+    qs, sts = shard_quant_state(q, st, 1, 2)
+    assert not sts.nested and sts.absmax.dtype == torch.float32 and sts.shape == (32, 128)
+    full = F.dequantize_4bit(q, st)
+    assert torch.equal(F.dequantize_4bit(qs, sts), full[32:])

@@ -1,0 +1,441 @@
+"""GPU (-m gpu): parity of the HIP path against the oracle and the committed golden vectors, through
+the public Python API and straight through the C ABI. Bars (BASELINE.json north_star):
+  * quantize_4bit packed codes + absmax, 8-bit codes: BIT-EXACT
+  * dequantize: bit-exact (up to the sign of zero / bf16 denormal flush noted in conftest.py)
+  * fused dequant+matmul: relative Frobenius error <= 1e-2 vs fp32-dequantize + fp32-linear
+    (REL_TOL below; observed values are ~1e-3 for bf16, ~2e-4 for fp16)
+"""
+import ctypes as ct
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import DT, QT, from_bits, golden, gpu_ready, rel_err, same_values_ftz
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-2  # north_star tolerance for the bf16/fp16 dequant+matmul
+DEV = "cuda"
+G = golden()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu_and_native_lib():
+    assert gpu_ready(), "GPU tests selected but torch.cuda.is_available() is False"
+    import bitsandbytes_amd as bnb
+
+    assert bnb.lib, "libbitsandbytes_mi355x.so is not loaded: GPU tests must run on the native HIP path"
+    yield
+
+
+def _F():
+    import bitsandbytes_amd.functional as F
+
+    return F
+
+
+# ------------------------------------------------------------------------------------------ quantize / dequantize
+@pytest.mark.parametrize("i", range(int(G["q4/count"][0])))
+def test_quantize_dequantize_4bit_golden(i):
+    F = _F()
+    qt_c, dt_c, bs, n = (int(v) for v in G[f"q4/{i}/meta"])
+    A = from_bits(G[f"q4/{i}/A"], dt_c).to(DEV)
+    packed, st = F.quantize_4bit(A, blocksize=bs, quant_type=QT[qt_c])
+    assert np.array_equal(packed.cpu().reshape(-1).numpy(), G[f"q4/{i}/packed"]), "packed codes differ from reference"
+    assert np.array_equal(st.absmax.cpu().view(torch.int32).numpy(), G[f"q4/{i}/absmax"]), "absmax differs"
+    for oc, name in ((0, "fp32"), (2, "bf16"), (1, "fp16")):
+        d = torch.ops.bitsandbytes.dequantize_4bit.default(packed, st.absmax, bs, QT[qt_c], (n,), DT[oc])
+        assert same_values_ftz(d.cpu(), from_bits(G[f"q4/{i}/deq_{name}"], oc)), f"dequantize -> {name}"
+
+
+@pytest.mark.parametrize("quant_type", ["nf4", "fp4"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32], ids=["fp16", "bf16", "fp32"])
+@pytest.mark.parametrize("blocksize", [32, 64, 128, 256, 512, 1024, 2048, 4096])
+def test_quantize_4bit_random_vs_oracle(quant_type, dtype, blocksize):
+    F = _F()
+    for n in (blocksize * 40 + 13, 8192 * 3 + 1, 7):
+        A = (torch.randn(n) * 0.3).to(dtype)
+        A[:: 11] = 0
+        if n > 4 * blocksize:
+            A[blocksize : 2 * blocksize] = 0  # a whole zero block
+        q_o, am_o = O.quantize_4bit(A, blocksize, quant_type)
+        q, st = F.quantize_4bit(A.to(DEV), blocksize=blocksize, quant_type=quant_type)
+        assert torch.equal(q.cpu(), q_o), f"n={n}"
+        assert torch.equal(st.absmax.cpu(), am_o), f"n={n}"
+        d = F.dequantize_4bit(q, st)
+        assert same_values_ftz(d.cpu(), O.dequantize_4bit(q_o, am_o, blocksize, quant_type, A.shape, dtype))
+
+
+def test_config1_full_size_4096x4096_fp16_nf4():
+    """BASELINE config 1 at full size: every one of the 16.7M codes and 262144 absmax bit-exact."""
+    F = _F()
+    W = torch.randn(4096, 4096).half()
+    q_o, am_o = O.quantize_4bit(W, 64, "nf4")
+    q, st = F.quantize_4bit(W.to(DEV), blocksize=64, quant_type="nf4")
+    assert q.shape == (4096 * 4096 // 2, 1) and torch.equal(q.cpu(), q_o) and torch.equal(st.absmax.cpu(), am_o)
+    d = F.dequantize_4bit(q, st)
+    assert d.shape == W.shape and d.dtype == torch.float16
+    assert torch.equal(d.cpu(), O.dequantize_4bit(q_o, am_o, 64, "nf4", W.shape, torch.float16))
+    # reference envelope (tests/test_functional.py:606-651): NF4 bs64 mean-abs 0.072798 +- 7 sigma
+    assert (d.float().cpu() - W.float()).abs().mean().item() < 0.072798 + 7 * 0.000074 + 2e-4
+    # idempotence: re-quantising the dequantised weight reproduces the same codes
+    q2, st2 = F.quantize_4bit(d, blocksize=64, quant_type="nf4")
+    assert torch.equal(q2, q)
+
+
+@pytest.mark.parametrize("storage", [torch.bfloat16, torch.float16, torch.float32])
+def test_quant_storage_views(storage):
+    F = _F()
+    W = torch.randn(64, 256, device=DEV).bfloat16()
+    q8, st8 = F.quantize_4bit(W, quant_type="nf4")
+    q, st = F.quantize_4bit(W, quant_type="nf4", quant_storage=storage)
+    assert q.dtype == storage and torch.equal(q.view(torch.uint8).reshape(-1), q8.reshape(-1))
+    assert torch.equal(F.dequantize_4bit(q, st), F.dequantize_4bit(q8, st8))
+
+
+def test_noncontiguous_and_offset_inputs():
+    F = _F()
+    base = torch.randn(130, 257, device=DEV).bfloat16()
+    A = base[1:, 1:]  # non-contiguous, and (once made contiguous by the op) arbitrary values
+    q, st = F.quantize_4bit(A, quant_type="nf4")
+    q_o, am_o = O.quantize_4bit(A.cpu().contiguous(), 64, "nf4")
+    assert torch.equal(q.cpu(), q_o) and torch.equal(st.absmax.cpu(), am_o)
+    # mis-aligned input pointer (storage offset of 1 element) exercises the scalar-load path
+    flat = torch.randn(64 * 50 + 1, device=DEV).half()
+    B = flat[1:]
+    q, st = F.quantize_4bit(B, quant_type="fp4")
+    q_o, am_o = O.quantize_4bit(B.cpu(), 64, "fp4")
+    assert torch.equal(q.cpu(), q_o) and torch.equal(st.absmax.cpu(), am_o)
+    out = torch.empty(64 * 50 + 8, device=DEV, dtype=torch.half)[3 : 3 + 64 * 50]  # mis-aligned output
+    F.dequantize_4bit(q, st, out=out)
+    assert same_values_ftz(out.cpu(), O.dequantize_4bit(q_o, am_o, 64, "fp4", (64 * 50,), torch.half))
+
+
+# ------------------------------------------------------------------------------------------ 8-bit + double quant
+@pytest.mark.parametrize("i", range(int(G["q8/count"][0])))
+def test_blockwise_8bit_golden(i):
+    dt_c, bs, n = (int(v) for v in G[f"q8/{i}/meta"])
+    A = from_bits(G[f"q8/{i}/A"], dt_c).to(DEV)
+    code = from_bits(G["code/dynamic"], 0).to(DEV)
+    q, am = torch.ops.bitsandbytes.quantize_blockwise.default(A, code, bs)
+    assert np.array_equal(q.cpu().numpy(), G[f"q8/{i}/q"])
+    assert np.array_equal(am.cpu().view(torch.int32).numpy(), G[f"q8/{i}/absmax"])
+    for oc, name in ((0, "fp32"), (2, "bf16"), (1, "fp16")):
+        d = torch.ops.bitsandbytes.dequantize_blockwise.default(q, am, code, bs, DT[oc])
+        assert same_values_ftz(d.cpu(), from_bits(G[f"q8/{i}/deq_{name}"], oc))
+
+
+def test_blockwise_8bit_dense_vs_oracle():
+    """Dense sweep near zero, where the dynamic map is densest and the 65536-bin rule differs from
+    nearest-code (SURVEY §8a note 6)."""
+    F = _F()
+    code = F.create_dynamic_map()
+    A = torch.cat([torch.linspace(-1, 1, 100003), torch.linspace(-2e-3, 2e-3, 50021), torch.randn(4096) * 1e-5])
+    A[0] = 1.0
+    pad = (-A.numel()) % 256
+    A = torch.cat([A, torch.zeros(pad)])
+    A.view(-1, 256)[:, 0] = 1.0  # absmax == 1 in every block -> x/absmax == x exactly
+    q_o, am_o = O.quantize_blockwise(A, code, 256)
+    q, am = torch.ops.bitsandbytes.quantize_blockwise.default(A.to(DEV), code.to(DEV), 256)
+    assert torch.equal(q.cpu(), q_o) and torch.equal(am.cpu(), am_o)
+
+
+@pytest.mark.parametrize("quant_type,blocksize", [("nf4", 64), ("fp4", 128)])
+def test_double_quant_state_vs_oracle(quant_type, blocksize):
+    F = _F()
+    W = (torch.randn(512, 1024) * 0.02).bfloat16()
+    q, st = F.quantize_4bit(W.to(DEV), blocksize=blocksize, quant_type=quant_type, compress_statistics=True)
+    assert st.nested and st.absmax.dtype == torch.uint8 and st.state2.blocksize == 256
+    q_o, am_o = O.quantize_4bit(W, blocksize, quant_type)
+    assert torch.equal(q.cpu(), q_o)
+    # offset = absmax.mean() is a device-order reduction (SURVEY §8a note 7): take the device's own
+    # offset, then everything downstream must be bit-exact
+    offset = st.offset.cpu()
+    assert abs(offset.item() - am_o.mean().item()) <= 2e-7 * abs(am_o.mean().item()) + 1e-12
+    q8_o, am2_o = O.quantize_blockwise(am_o - offset, F.create_dynamic_map(), 256)
+    assert torch.equal(st.absmax.cpu(), q8_o) and torch.equal(st.state2.absmax.cpu(), am2_o)
+    d = F.dequantize_4bit(q, st)
+    am_rec = O.dequantize_blockwise(q8_o, am2_o, F.create_dynamic_map(), 256, torch.float32) + offset
+    assert same_values_ftz(d.cpu(), O.dequantize_4bit(q_o, am_rec, blocksize, quant_type, W.shape, torch.bfloat16))
+    # reference envelope test_4bit_compressed_stats (tests/test_functional.py:666-695)
+    err = (d.float().cpu() - W.float()).abs().mean() / W.float().abs().mean()
+    assert err < 0.28
+
+
+# ------------------------------------------------------------------------------------------ gemm / gemv
+def _oracle_y(x, q, st, bias=None):
+    """fp32-dequant + fp32-linear oracle result for a (possibly nested) QuantState living on the GPU."""
+    kw = {}
+    if st.nested:
+        absmax = st.state2.absmax
+        kw = dict(absmax_8bit=st.absmax, absmax_code=st.state2.code, absmax_offset=st.offset)
+    else:
+        absmax = st.absmax
+    return O.gemm_4bit(x, q, st.shape, absmax, st.blocksize, st.quant_type, bias, **kw)[1]
+
+
+def _run_kernel(kernel, x, q, st, bias=None):
+    """Call the fused op with an explicit kernel choice (0 auto, 1 wave64 dot, 2 MFMA)."""
+    from bitsandbytes_amd.backends import hip
+
+    if st.nested:
+        args = (x, q, st.shape, st.state2.absmax, st.blocksize, st.quant_type, bias, st.absmax, st.state2.code, st.offset)
+    else:
+        args = (x, q, st.shape, st.absmax, st.blocksize, st.quant_type, bias, None, None, None)
+    return hip._gemm_4bit_fused(*args, kernel=kernel)
+
+
+@pytest.mark.parametrize("i", range(int(G["gemm/count"][0])))
+def test_gemm_4bit_golden(i):
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    qt_c, dt_c, bs, M, N, K, dqf, has_bias = (int(v) for v in G[f"gemm/{i}/meta"])
+    x = from_bits(G[f"gemm/{i}/x"], dt_c).reshape(M, K).to(DEV)
+    packed = torch.from_numpy(G[f"gemm/{i}/packed"]).reshape(-1, 1).to(DEV)
+    bias = from_bits(G[f"gemm/{i}/bias"], dt_c).to(DEV) if has_bias else None
+    code = F.get_4bit_type(QT[qt_c], device=DEV)
+    if dqf:
+        s2 = F.QuantState(absmax=from_bits(G[f"gemm/{i}/absmax2"], 0).to(DEV), code=from_bits(G["code/dynamic"], 0).to(DEV),
+                          blocksize=256, dtype=torch.float32)
+        st = F.QuantState(absmax=torch.from_numpy(G[f"gemm/{i}/absmax8"]).to(DEV), shape=torch.Size((N, K)), code=code,
+                          blocksize=bs, quant_type=QT[qt_c], dtype=DT[dt_c],
+                          offset=from_bits(G[f"gemm/{i}/offset"], 0).reshape(()).to(DEV), state2=s2)
+    else:
+        st = F.QuantState(absmax=from_bits(G[f"gemm/{i}/absmax"], 0).to(DEV), shape=torch.Size((N, K)), code=code,
+                          blocksize=bs, quant_type=QT[qt_c], dtype=DT[dt_c])
+    y = bnb.matmul_4bit(x, packed, st, bias=bias)
+    y32_ref = from_bits(G[f"gemm/{i}/y_fp32"], 0).reshape(M, N)
+    y_ref = from_bits(G[f"gemm/{i}/y"], dt_c).reshape(M, N)
+    tol = 2e-5 if dt_c == 0 else REL_TOL
+    assert y.shape == (M, N) and y.dtype == DT[dt_c]
+    assert rel_err(y.cpu(), y32_ref) < tol
+    # and never worse than ~2x the reference CPU backend's own distance to the fp32 result
+    if dt_c != 0:
+        assert rel_err(y.cpu(), y32_ref) < max(2.5 * rel_err(y_ref, y32_ref), 3e-3)
+
+
+SHAPES = [  # (M, N, K)
+    (1, 4096, 4096),   # BASELINE config 2
+    (1, 1000, 2048), (1, 31, 96), (1, 512, 11008 // 4), (2, 256, 4096), (3, 130, 1024), (4, 4096, 1024),
+    (5, 256, 1024), (8, 4096, 4096), (16, 512, 2048), (17, 96, 512), (33, 200, 768), (64, 1024, 4096),
+    (65, 128, 512), (130, 64, 256),
+]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_gemm_4bit_shapes_both_kernels(M, N, K, dtype):
+    F = _F()
+    W = (torch.randn(N, K) / K**0.5).to(dtype)
+    x = torch.randn(M, K).to(dtype)
+    bias = torch.randn(N).to(dtype)
+    q, st = F.quantize_4bit(W.to(DEV), blocksize=64, quant_type="nf4")
+    y_ref = _oracle_y(x, q, st, bias)
+    for kernel in (1, 2, 0):
+        if kernel == 2 and K % 256:
+            continue
+        y = _run_kernel(kernel, x.to(DEV), q, st, bias.to(DEV))
+        e = rel_err(y.cpu(), y_ref)
+        assert e < REL_TOL, f"kernel={kernel} rel err {e}"
+
+
+@pytest.mark.parametrize("quant_type,blocksize,dq", [("fp4", 128, True), ("nf4", 64, True), ("fp4", 64, False),
+                                                      ("nf4", 32, False), ("nf4", 256, True), ("nf4", 4096, False)])
+@pytest.mark.parametrize("M", [1, 4, 16, 48])
+def test_gemm_4bit_quant_variants(quant_type, blocksize, dq, M):
+    """Covers BASELINE config 5 (FP4, double quant, blocksize 128, bf16, N = K = 4096 at M = 1)."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    N, K = (4096, 4096) if M == 1 else (512, 4096)
+    W = (torch.randn(N, K) / K**0.5).bfloat16()
+    x = torch.randn(M, K).bfloat16()
+    q, st = F.quantize_4bit(W.to(DEV), blocksize=blocksize, quant_type=quant_type, compress_statistics=dq)
+    y = bnb.matmul_4bit(x.to(DEV), q, st)
+    assert rel_err(y.cpu(), _oracle_y(x, q, st)) < REL_TOL
+    if blocksize >= 64:
+        y2 = _run_kernel(2, x.to(DEV), q, st)
+        assert rel_err(y2.cpu(), _oracle_y(x, q, st)) < REL_TOL
+
+
+def test_config3_m64_8192_subset_and_properties():
+    """BASELINE config 3 (M = 64, N = K = 8192) at full size: oracle on a row subset (the oracle is
+    scalar C), plus size-independent properties: linearity in x, and exact column independence."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    N = K = 8192
+    M = 64
+    W = (torch.randn(N, K, device=DEV) / K**0.5).bfloat16()
+    x = torch.randn(M, K, device=DEV).bfloat16()
+    q, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4")
+    del W
+    y = bnb.matmul_4bit(x, q, st)
+    assert y.shape == (M, N)
+    rows = torch.cat([torch.arange(0, 16), torch.arange(4000, 4016), torch.arange(8176, 8192)])
+    bpr, blk = K // 2, K // 64
+    q_sub = torch.cat([q.view(N, bpr)[r] for r in rows]).cpu().reshape(-1, 1)
+    am_sub = torch.cat([st.absmax.view(N, blk)[r] for r in rows]).cpu()
+    y_sub = O.gemm_4bit(x.cpu(), q_sub, (len(rows), K), am_sub, 64, "nf4")[1]
+    assert rel_err(y[:, rows].cpu(), y_sub) < REL_TOL
+    # linearity: (x1 + x2) W == x1 W + x2 W up to bf16 rounding of inputs/outputs
+    x2 = torch.randn(M, K, device=DEV).bfloat16()
+    lhs = bnb.matmul_4bit((x.float() + x2.float()).bfloat16(), q, st).float()
+    rhs = y.float() + bnb.matmul_4bit(x2, q, st).float()
+    assert rel_err(lhs.cpu(), rhs.cpu()) < 2e-2
+    # determinism
+    assert torch.equal(bnb.matmul_4bit(x, q, st), y)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("dq", [False, True])
+def test_gemv_4bit_legacy_api_and_eye(dtype, dq):
+    """F.gemv_4bit (reference functional.py:1300-1334) incl. the identity-weight check of the reference's
+    test_gemv_eye_4bit (tests/test_functional.py:950-977): 0 and 1 are exact NF4 codes, so y == x."""
+    F = _F()
+    dim = 256
+    eye = torch.eye(dim, device=DEV, dtype=dtype)
+    q, st = F.quantize_4bit(eye, quant_type="nf4", compress_statistics=dq)
+    x = torch.randn(1, 1, dim, device=DEV, dtype=dtype)
+    y = F.gemv_4bit(x, q, state=st)
+    tol = dict(rtol=1e-2, atol=1e-2) if dq else dict(rtol=0, atol=0)  # double quant perturbs absmax=1 slightly
+    torch.testing.assert_close(y, x, **tol)
+    W = (torch.randn(384, 512) / 512**0.5).to(dtype)
+    q, st = F.quantize_4bit(W.to(DEV), quant_type="fp4", compress_statistics=dq)
+    x = torch.randn(1, 512).to(dtype)
+    y = F.gemv_4bit(x.to(DEV), q, state=st)
+    assert rel_err(y.cpu(), _oracle_y(x, q, st)) < (2e-5 if dtype == torch.float32 else REL_TOL)
+
+
+def test_gemm_fp32_and_generic_fallbacks():
+    """fp32 activations (dot kernel's generic path for M <= 4, dequant + rocBLAS above), odd K,
+    K % blocksize != 0 (warns, unfused path like the reference backends/cuda/ops.py:956-962)."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    for (M, N, K) in [(1, 64, 256), (3, 100, 512), (9, 64, 256)]:
+        W = torch.randn(N, K) / K**0.5
+        x = torch.randn(M, K)
+        q, st = F.quantize_4bit(W.to(DEV), quant_type="nf4")
+        assert rel_err(bnb.matmul_4bit(x.to(DEV), q, st).cpu(), _oracle_y(x, q, st)) < 2e-5
+    W = (torch.randn(48, 96) / 10).bfloat16()  # K = 96 is not a multiple of blocksize 64
+    x = torch.randn(2, 96).bfloat16()
+    q, st = F.quantize_4bit(W.to(DEV), quant_type="nf4")
+    with pytest.warns(UserWarning, match="not aligned"):
+        y = bnb.matmul_4bit(x.to(DEV), q, st)
+    assert rel_err(y.cpu(), _oracle_y(x, q, st)) < REL_TOL
+    # the C-ABI kernels themselves also accept it (generic kernel): K odd, flat block indexing
+    W = (torch.randn(10, 33) / 5).half()
+    x = torch.randn(1, 33).half()
+    q, st = F.quantize_4bit(W.to(DEV), quant_type="nf4", blocksize=32)
+    y = _run_kernel(1, x.to(DEV), q, st)
+    assert rel_err(y.cpu(), _oracle_y(x, q, st)) < REL_TOL
+
+
+# ------------------------------------------------------------------------------------------ C ABI, graphs, modules
+def test_c_abi_direct_calls():
+    """Drive the reference-named symbols with raw pointers, exactly as the reference's ctypes layer
+    does (backends/cuda/ops.py:384-420, 846-901)."""
+    from bitsandbytes_amd.cextension import lib
+
+    N, K, bs = 256, 1024, 64
+    W = (torch.randn(N, K) / K**0.5).bfloat16()
+    Wd = W.to(DEV)
+    absmax = torch.empty(N * K // bs, device=DEV, dtype=torch.float32)
+    packed = torch.empty(N * K // 2, device=DEV, dtype=torch.uint8)
+    torch.cuda.synchronize()
+    lib.cquantize_blockwise_bf16_nf4(None, Wd.data_ptr(), absmax.data_ptr(), packed.data_ptr(), bs, N * K)  # NULL stream
+    torch.cuda.synchronize()
+    q_o, am_o = O.quantize_4bit(W, bs, "nf4")
+    assert torch.equal(packed.cpu(), q_o.reshape(-1)) and torch.equal(absmax.cpu(), am_o)
+    stream = torch._C._cuda_getCurrentRawStream(0)
+    out = torch.empty(N, K, device=DEV, dtype=torch.bfloat16)
+    lib.cdequantize_blockwise_bf16_nf4(None, packed.data_ptr(), absmax.data_ptr(), out.data_ptr(), bs, N * K, stream)
+    assert same_values_ftz(out.cpu(), O.dequantize_4bit(q_o, am_o, bs, "nf4", (N, K), torch.bfloat16))
+    for M in (1, 16):
+        x = torch.randn(M, K).bfloat16()
+        xd = x.to(DEV)
+        y = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        lib.cgemm_4bit_bf16(xd.data_ptr(), packed.data_ptr(), absmax.data_ptr(), None, None, None, y.data_ptr(), None,
+                            M, N, K, bs, 2, stream)
+        assert rel_err(y.cpu(), O.gemm_4bit(x, q_o, (N, K), am_o, bs, "nf4")[1]) < REL_TOL
+    code = O.get_4bit_code("nf4").to(DEV)
+    y = torch.empty(1, N, device=DEV, dtype=torch.bfloat16)
+    lib.cgemm_4bit_inference_naive_bf16(N, 1, K, xd[:1].contiguous().data_ptr(), packed.data_ptr(), absmax.data_ptr(),
+                                        code.data_ptr(), y.data_ptr(), N, K // 2, N, bs, stream)
+    assert rel_err(y.cpu(), O.gemm_4bit(x[:1], q_o, (N, K), am_o, bs, "nf4")[1]) < REL_TOL
+    assert lib.get_context() is not None
+
+
+@pytest.mark.parametrize("M", [1, 32])
+def test_hip_graph_capture(M):
+    """The fused op only enqueues kernels: it must be capturable and replayable."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    N = K = 1024
+    W = (torch.randn(N, K, device=DEV) / K**0.5).bfloat16()
+    q, st = F.quantize_4bit(W, quant_type="nf4")
+    x = torch.randn(M, K, device=DEV).bfloat16()
+    y_eager = bnb.matmul_4bit(x, q, st)  # also warms up any lazily created workspace
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            bnb.matmul_4bit(x, q, st)
+        with torch.cuda.graph(g, stream=s):
+            y_graph = bnb.matmul_4bit(x, q, st)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y_graph, y_eager)
+
+
+@pytest.mark.parametrize("double_quant", [False, True])
+@pytest.mark.parametrize("storage", [torch.uint8, torch.bfloat16])
+def test_linear4bit_module_gpu(double_quant, storage):
+    from bitsandbytes_amd.nn import Linear4bit, Params4bit
+
+    torch.manual_seed(3)
+    ref = torch.nn.Linear(1024, 768, bias=True)
+    layer = Linear4bit(1024, 768, bias=True, quant_type="nf4", compress_statistics=double_quant, quant_storage=storage,
+                       compute_dtype=torch.bfloat16)
+    layer.load_state_dict(ref.state_dict())
+    layer = layer.to(DEV)  # quantises on the GPU
+    assert layer.weight.bnb_quantized and layer.weight.dtype == storage and layer.weight.device.type == "cuda"
+    for shape in ((1, 1024), (2, 7, 1024), (64, 1024)):
+        x = torch.randn(*shape)
+        y = layer(x.to(DEV))
+        assert y.shape == (*shape[:-1], 768) and y.dtype == torch.float32
+        y_o = _oracle_y(x.bfloat16().reshape(-1, 1024), layer.weight.data, layer.weight.quant_state,
+                        layer.bias.detach().cpu().bfloat16())
+        assert rel_err(y.reshape(-1, 768).cpu(), y_o) < REL_TOL
+    # state-dict round trip -> identical outputs (reference tests/test_linear4bit.py:153-172)
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    new = Linear4bit(1024, 768, bias=True, quant_type="nf4", compress_statistics=double_quant, quant_storage=storage,
+                     compute_dtype=torch.bfloat16)
+    stats = {k[len("weight."):]: v for k, v in sd.items() if k.startswith("weight.")}
+    new.weight = Params4bit.from_prequantized(sd["weight"], stats, device=DEV, module=new)
+    new.bias.data = sd["bias"]
+    new = new.to(DEV)
+    x = torch.randn(4, 1024, device=DEV)
+    assert torch.equal(new(x), layer(x))
+
+
+def test_backward_through_matmul_4bit_gpu():
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    W = (torch.randn(256, 512, device=DEV) / 512**0.5).bfloat16()
+    q, st = F.quantize_4bit(W, quant_type="nf4")
+    x = torch.randn(8, 512, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    y = bnb.matmul_4bit(x, q, st)
+    y.float().pow(2).sum().backward()
+    Wd = F.dequantize_4bit(q, st).float()
+    g_ref = (2 * y.detach().float()) @ Wd
+    assert rel_err(x.grad.float().cpu(), g_ref.cpu()) < 2e-2

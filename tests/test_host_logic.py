@@ -1,0 +1,179 @@
+"""CPU: host-side logic of the package — op schemas/fake kernels, QuantState (de)serialisation,
+functional wrappers' validation, Linear4bit / Params4bit behaviour and state-dict round trips.
+Arithmetic on CPU tensors is provided by the ORACLE, registered as test-only CPU kernels
+(tests/_oracle_cpu_backend.py); the product itself has no CPU kernels."""
+import copy
+import io
+import pickle
+
+import pytest
+import torch
+
+import _oracle_cpu_backend
+import bitsandbytes_amd as bnb
+import bitsandbytes_amd.functional as F
+from bitsandbytes_amd.nn import Linear4bit, LinearFP4, LinearNF4, Params4bit
+from conftest import from_bits, golden, rel_err
+
+_oracle_cpu_backend.register()
+
+
+def test_code_tables_match_reference_golden():
+    G = golden()
+    assert torch.equal(F.get_4bit_type("nf4", device="cpu"), from_bits(G["code/nf4"], 0))
+    assert torch.equal(F.get_4bit_type("fp4", device="cpu"), from_bits(G["code/fp4"], 0))
+    assert torch.equal(F.create_dynamic_map().view(torch.int32), from_bits(G["code/dynamic"], 0).view(torch.int32))
+
+
+@pytest.mark.parametrize("storage", [torch.uint8, torch.bfloat16, torch.float32])
+def test_fake_kernels_shapes(storage):
+    A = torch.empty(48, 128, device="meta", dtype=torch.bfloat16)
+    q, am = torch.ops.bitsandbytes.quantize_4bit.default(A, 64, "nf4", storage)
+    assert q.shape == ((48 * 128 + 1) // (storage.itemsize * 2), 1) and q.dtype == storage
+    assert am.shape == (96,) and am.dtype == torch.float32
+    d = torch.ops.bitsandbytes.dequantize_4bit.default(q, am, 64, "nf4", (48, 128), torch.float16)
+    assert d.shape == (48, 128) and d.dtype == torch.float16
+    x = torch.empty(3, 5, 128, device="meta", dtype=torch.bfloat16)
+    y = torch.ops.bitsandbytes.gemm_4bit.default(x, q, (48, 128), am, 64, "nf4")
+    assert y.shape == (3, 5, 48)
+    with pytest.raises(RuntimeError):
+        torch.ops.bitsandbytes.quantize_4bit.default(A, 48, "nf4", storage)
+    with pytest.raises(RuntimeError):
+        torch.ops.bitsandbytes.gemm_4bit.default(x, q, (48, 128), am, 64, "int4")
+
+
+def test_functional_validation_errors():
+    A = torch.randn(64, 64)
+    with pytest.raises(ValueError, match="invalid blocksize"):
+        F.quantize_4bit(A, blocksize=48)
+    with pytest.raises(ValueError, match="quant_type"):
+        F.quantize_4bit(A, quant_type="int4")
+    with pytest.raises(ValueError, match="16/32-bit floats"):
+        F.quantize_4bit(A.to(torch.int32))
+    with pytest.raises(ValueError, match="requires both absmax and out"):
+        F.dequantize_4bit(torch.zeros(8, 1, dtype=torch.uint8))
+    with pytest.raises(ValueError, match="state cannot be None"):
+        F.gemv_4bit(A[:1], torch.zeros(8, 1, dtype=torch.uint8))
+    with pytest.raises(ValueError, match="quant_state is required"):
+        bnb.matmul_4bit(A, torch.zeros(8, 1, dtype=torch.uint8), None)
+
+
+@pytest.mark.parametrize("quant_type", ["nf4", "fp4"])
+@pytest.mark.parametrize("double_quant", [False, True])
+def test_quant_state_roundtrip(quant_type, double_quant):
+    W = torch.randn(64, 256).bfloat16()
+    q, st = F.quantize_4bit(W, blocksize=64, quant_type=quant_type, compress_statistics=double_quant)
+    assert st.nested == double_quant and st.shape == W.shape and st.dtype == torch.bfloat16
+    d = st.as_dict(packed=True)
+    assert f"quant_state.bitsandbytes__{quant_type}" in d and all(isinstance(v, torch.Tensor) for v in d.values())
+    st2 = F.QuantState.from_dict(dict(d), device="cpu")
+    assert st2 == st
+    assert torch.equal(F.dequantize_4bit(q, st2), F.dequantize_4bit(q, st))
+    # legacy list view
+    assert st[0] is st.absmax and st[3] == 64 and st[5] == quant_type
+    # error envelope of the reference's test_4bit_quant (tests/test_functional.py:606-651), blocksize 64
+    err = (F.dequantize_4bit(q, st).float() - W.float()).abs().mean().item()
+    assert err < (0.0735 if quant_type == "nf4" else 0.098) * 1.15 * (1.1 if double_quant else 1.0)
+
+
+def test_quant_storage_views_are_byte_identical():
+    W = torch.randn(32, 64).half()
+    q8, _ = F.quantize_4bit(W, quant_type="nf4", quant_storage=torch.uint8)
+    for st_dtype in (torch.bfloat16, torch.float16, torch.float32):
+        q, state = F.quantize_4bit(W, quant_type="nf4", quant_storage=st_dtype)
+        assert q.dtype == st_dtype and q.shape == (32 * 64 // (2 * st_dtype.itemsize), 1)
+        assert torch.equal(q.view(torch.uint8).reshape(-1), q8.reshape(-1))
+        assert torch.equal(F.dequantize_4bit(q, state), F.dequantize_4bit(q8, state))
+
+
+def _make_layer(cls=Linear4bit, bias=True, **kw):
+    torch.manual_seed(1)
+    ref = torch.nn.Linear(128, 48, bias=bias)
+    layer = cls(128, 48, bias=bias, **kw)
+    layer.load_state_dict(ref.state_dict())
+    return ref, layer.to("cpu")  # first .to(device) quantises (lazy quantisation contract)
+
+
+@pytest.mark.parametrize("cls,kw", [(LinearNF4, {}), (LinearFP4, {}), (Linear4bit, {"quant_type": "nf4", "compress_statistics": False})])
+def test_linear4bit_forward_close_to_fp(cls, kw):
+    ref, layer = _make_layer(cls, **kw)
+    assert layer.weight.bnb_quantized and layer.weight.dtype == torch.uint8 and layer.weight.shape == (128 * 48 // 2, 1)
+    x = torch.randn(5, 128)
+    y = layer(x)
+    assert y.shape == (5, 48) and y.dtype == x.dtype
+    assert rel_err(y, ref(x)) < 0.2
+    # weight orientation: B and B.t() must give identical results (reference test_functional.py:1016-1034)
+    st = layer.weight.quant_state
+    assert torch.equal(bnb.matmul_4bit(x, layer.weight.data, st), bnb.matmul_4bit(x, layer.weight.data.t(), st))
+
+
+@pytest.mark.parametrize("double_quant", [False, True])
+@pytest.mark.parametrize("storage", [torch.uint8, torch.bfloat16])
+def test_linear4bit_state_dict_roundtrip(double_quant, storage):
+    _, layer = _make_layer(Linear4bit, quant_type="nf4", compress_statistics=double_quant, quant_storage=storage)
+    sd = layer.state_dict()
+    keys = set(sd)
+    assert {"weight", "bias", "weight.absmax", "weight.quant_map", "weight.quant_state.bitsandbytes__nf4"} <= keys
+    assert ("weight.nested_absmax" in keys) == double_quant
+    buf = io.BytesIO()
+    torch.save(sd, buf)
+    buf.seek(0)
+    sd2 = torch.load(buf)
+    # rebuild the way HF loaders do: Params4bit.from_prequantized(weight, {the other weight.* items})
+    new = Linear4bit(128, 48, quant_type="nf4", compress_statistics=double_quant, quant_storage=storage)
+    stats = {k[len("weight."):]: v for k, v in sd2.items() if k.startswith("weight.")}
+    new.weight = Params4bit.from_prequantized(sd2["weight"], stats, device="cpu", module=new)
+    new.bias.data = sd2["bias"]
+    x = torch.randn(3, 128)
+    assert torch.equal(new(x), layer(x))
+    assert new.weight.quant_state == layer.weight.quant_state
+
+
+def test_params4bit_copy_pickle_chunk():
+    _, layer = _make_layer(Linear4bit, quant_type="nf4")
+    w = layer.weight
+    for clone in (copy.copy(w), copy.deepcopy(w), pickle.loads(pickle.dumps(w))):
+        assert isinstance(clone, Params4bit) and clone.quant_type == "nf4" and clone.bnb_quantized
+        assert torch.equal(clone.data, w.data) and clone.quant_state == w.quant_state
+    parts = torch.chunk(w, 2, dim=0)
+    assert all(isinstance(p, Params4bit) and p.quant_state is w.quant_state and p.blocksize == w.blocksize for p in parts)
+    assert torch.equal(torch.cat([p.data for p in parts]), w.data)
+    # FSDP-style attribute proxies
+    assert w.absmax is w.quant_state.absmax and w.quant_map is w.quant_state.code
+    assert w.nested_absmax is w.quant_state.state2.absmax
+
+
+def test_quant_state_recovered_after_param_replacement():
+    """FSDP replaces the parameter by a plain tensor; forward must restore quant_state from the module."""
+    _, layer = _make_layer(Linear4bit, quant_type="nf4")
+    x = torch.randn(2, 128)
+    y0 = layer(x)
+    layer.weight = torch.nn.Parameter(layer.weight.data.clone(), requires_grad=False)
+    assert torch.equal(layer(x), y0) and isinstance(layer.weight, Params4bit)
+
+
+def test_matmul_4bit_backward_matches_dequant_linear():
+    _, layer = _make_layer(Linear4bit, quant_type="nf4", compress_statistics=False, bias=True)
+    st = layer.weight.quant_state
+    x = torch.randn(4, 128, requires_grad=True)
+    bias = layer.bias.detach().clone().requires_grad_(True)
+    y = bnb.matmul_4bit(x, layer.weight, st, bias=bias)
+    y.sum().backward()
+    W = F.dequantize_4bit(layer.weight.data, st).float()
+    assert torch.allclose(x.grad, torch.ones(4, 48) @ W, atol=1e-5)
+    assert torch.allclose(bias.grad, torch.full((48,), 4.0))
+
+
+def test_legacy_kn_orientation_warns_and_works():
+    W = torch.randn(128, 48)  # [K, N]
+    q, st = F.quantize_4bit(W, quant_type="nf4")
+    x = torch.randn(2, 128)
+    with pytest.warns(DeprecationWarning):
+        y = bnb.matmul_4bit(x, q, st)
+    assert y.shape == (2, 48)
+
+
+def test_empty_input():
+    _, layer = _make_layer(Linear4bit, quant_type="nf4")
+    y = bnb.matmul_4bit(torch.empty(0, 128), layer.weight, layer.weight.quant_state)
+    assert y.shape == (0, 48)
