@@ -1,0 +1,125 @@
+"""(Run through tests/test_oracle_pinning.py, in its own process: the reference package and
+bitsandbytes_amd both define the ``bitsandbytes::`` operator schemas, and the reference must be the
+first to do so.)
+
+CPU, authoring container only: the oracle against the LIVE reference (Python package imported from
+/root/reference + its own libbitsandbytes_cpu.so from oracle/build_ref.sh) on fresh random inputs,
+and against that library's C ABI directly. Skipped where the reference checkout is absent."""
+import pytest
+import torch
+
+from conftest import same_values, same_values_ftz
+from oracle import oracle as O
+from oracle.ref_import import reference_available
+
+pytestmark = pytest.mark.skipif(not reference_available(), reason="needs /root/reference and oracle/_ref (build_ref.sh)")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle.ref_import import import_reference
+
+    bnb = import_reference()
+    import bitsandbytes.functional as F
+
+    return bnb, F
+
+
+@pytest.mark.parametrize("quant_type", ["nf4", "fp4"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16], ids=["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("blocksize", [32, 64, 256, 4096])
+def test_quantize_4bit_live(ref, quant_type, dtype, blocksize):
+    _, F = ref
+    for n in (blocksize * 6, blocksize * 2 + 11, 4097):
+        A = (torch.randn(n) * 0.7).to(dtype)
+        A[::13] = 0
+        q_ref, st = F.quantize_4bit(A, blocksize=blocksize, quant_type=quant_type)
+        q, am = O.quantize_4bit(A, blocksize, quant_type)
+        assert torch.equal(q, q_ref) and torch.equal(am, st.absmax)
+        for odt in (torch.float32, torch.float16, torch.bfloat16):
+            d_ref = torch.ops.bitsandbytes.dequantize_4bit.default(q_ref, st.absmax, blocksize, quant_type, (n,), odt)
+            d = O.dequantize_4bit(q, am, blocksize, quant_type, (n,), odt)
+            assert same_values_ftz(d, d_ref.reshape(-1))
+
+
+def test_quantize_4bit_c1_full_size(ref):
+    """BASELINE config 1: NF4 bs=64 on a 4096x4096 fp16 weight — all 16.7M codes and 262144 absmax."""
+    _, F = ref
+    W = torch.randn(4096, 4096).half()
+    q_ref, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4")
+    q, am = O.quantize_4bit(W, 64, "nf4")
+    assert torch.equal(q, q_ref) and torch.equal(am, st.absmax)
+    d = O.dequantize_4bit(q, am, 64, "nf4", W.shape, torch.float16)
+    assert same_values(d, F.dequantize_4bit(q_ref, st))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16], ids=["fp32", "fp16", "bf16"])
+def test_blockwise_8bit_live_and_c_abi(ref, dtype):
+    _, F = ref
+    code = F.create_dynamic_map().float()
+    A = torch.randn(256 * 37 + 5).to(dtype)
+    A[256:512] = 0
+    q_ref, am_ref = torch.ops.bitsandbytes.quantize_blockwise.default(A, code, 256)
+    q, am = O.quantize_blockwise(A, code, 256)
+    assert torch.equal(q, q_ref) and torch.equal(am, am_ref)
+    # the reference library called straight through its C ABI (what bench.py's cpu_baseline uses)
+    q_c, am_c = O.ref_quantize_blockwise(A, code, 256)
+    assert torch.equal(q, q_c) and torch.equal(am, am_c)
+    d = O.dequantize_blockwise(q, am, code, 256, torch.float32)
+    assert torch.equal(d, O.ref_dequantize_blockwise(q, am, code, 256, torch.float32))
+
+
+def test_ref_c_abi_dequantize_4bit(ref):
+    A = torch.randn(64, 256).bfloat16()
+    q, am = O.quantize_4bit(A, 64, "nf4")
+    for odt in (torch.float32, torch.bfloat16, torch.float16):
+        assert same_values_ftz(O.ref_dequantize_4bit(q, am, 64, "nf4", (64, 256), odt),
+                               O.dequantize_4bit(q, am, 64, "nf4", (64, 256), odt))
+
+
+def test_dynamic_map_and_code_tables_match_reference(ref):
+    _, F = ref
+    import bitsandbytes_amd.functional as MF
+
+    assert torch.equal(MF.create_dynamic_map().view(torch.int32), F.create_dynamic_map().float().view(torch.int32))
+    for qt in ("nf4", "fp4"):
+        assert torch.equal(MF.get_4bit_type(qt, device="cpu").view(torch.int32),
+                           F.get_4bit_type(qt, device="cpu").view(torch.int32))
+
+
+def test_quant_state_dict_format_matches_reference(ref):
+    """Packed state-dict blob written by our QuantState is byte-identical to the reference's."""
+    _, F = ref
+    import bitsandbytes_amd.functional as MF
+
+    W = torch.randn(32, 128).bfloat16()
+    for dq in (False, True):
+        q, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4", compress_statistics=dq)
+        ref_dict = st.as_dict(packed=True)
+        mine = MF.QuantState.from_dict({k: v.clone() if isinstance(v, torch.Tensor) else v
+                                        for k, v in st.as_dict(packed=True).items()}, device="cpu")
+        my_dict = mine.as_dict(packed=True)
+        assert set(ref_dict) == set(my_dict)
+        for k in ref_dict:
+            assert torch.equal(ref_dict[k], my_dict[k]), k
+
+
+def test_ref_fused_cpu_gemv_baseline_path(ref):
+    """The CPU-baseline path bench.py times (reference AVX512-BF16 fused gemv through its C ABI with
+    our restatement of the reference's weight repack) computes the right thing."""
+    if not O.ref_has_avx512bf16():
+        pytest.skip("host lacks AVX512-BF16")
+    bnb, F = ref
+    N, K = 256, 512
+    W = (torch.randn(N, K) / K**0.5).bfloat16()
+    q, am = O.quantize_4bit(W, 64, "nf4")
+    wp, amt = O.ref_pack_for_cpu_gemv(q, am, N, K, 64)
+    # same packing as the reference's own Python repack
+    q_ref, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4")
+    wp_ref, st_ref = F._convert_weight_packed_for_cpu(q_ref.clone(), st)
+    assert torch.equal(wp, wp_ref) and torch.equal(amt, st_ref.absmax)
+    for M in (1, 8):
+        x = torch.randn(M, K).bfloat16()
+        y = O.ref_fused_gemv(x, wp, amt, N, K, 64, "nf4")
+        y32 = O.gemm_4bit(x, q, (N, K), am, 64, "nf4")[1]
+        assert (y.float() - y32).norm() / y32.norm() < 1e-2
