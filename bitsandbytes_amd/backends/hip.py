@@ -243,12 +243,18 @@ def _gemm_4bit_fused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8
     elif out.dtype != A.dtype or out.numel() != M * N or not out.is_contiguous():
         raise RuntimeError("out must be a contiguous tensor of A's dtype with M*N elements")
     offset32 = absmax_offset.to(dtype=torch.float32) if absmax_offset is not None else None
+    # split-K scratch for the MFMA kernel comes from torch's caching allocator: stream-ordered and
+    # legal under hipGraph capture (the library never has to allocate)
+    ws = None
+    ws_bytes = lib.bnb_mi355x_gemm_4bit_workspace_bytes(kernel, _DT_CODE[A.dtype], M, N, K, blocksize)
+    if ws_bytes:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device)
     with _device_of(A):
         lib.bnb_mi355x_gemm_4bit(
             kernel, _DT_CODE[A.dtype], A.data_ptr(), B.data_ptr(), absmax.contiguous().data_ptr(),
             _ptr(absmax_8bit if absmax_8bit is None else absmax_8bit.contiguous()),
             _ptr(absmax_code if absmax_code is None else absmax_code.contiguous()), _ptr(offset32), None,
-            out.data_ptr(), _ptr(bias), M, N, K, blocksize, _QT_CODE[quant_type], _stream(A),
+            out.data_ptr(), _ptr(bias), M, N, K, blocksize, _QT_CODE[quant_type], _ptr(ws), ws_bytes, _stream(A),
         )
     return out
 

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void dequantize8_kernel(const float* __restric
     __syncthreads();
     const long stride = static_cast<long>(gridDim.x) * 256;
     for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride)
-        out[i] = static_cast<T>(lut[A[i]] * absmax[i >> bs_shift]);
+        out[i] = static_cast<T>(rounded_f32(lut[A[i]] * absmax[i >> bs_shift]));
 }
 
 template <typename T>

@@ -78,6 +78,15 @@ __device__ static const float kFP4Code[16] = {BNB_FP4_VALUES};
 // explicit global-address-space view of a device pointer (forces global_load, which vmcnt can count)
 typedef const float __attribute__((address_space(1))) * gfloat_ptr;
 
+// The reference rounds `code * absmax` to fp32 first and to T second (csrc/cpu_ops.cpp:419-431).
+// hipcc would otherwise fuse the multiply and the fp16 convert into v_fma_mix{lo,hi}_f16, which
+// rounds once and differs from the two-step result in rare double-rounding cases. An empty asm
+// makes the fp32 product an opaque register value: no instruction is emitted, the fusion is blocked.
+__device__ __forceinline__ float rounded_f32(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave64 reductions
 // ---------------------------------------------------------------------------------------------

@@ -26,12 +26,14 @@ void dequantize_8bit_bf16(const float*, const uint8_t*, const float*, void*, int
 void gemv_4bit_dot(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                    const float* absmax_code, const float* absmax_offset, const float* code16, void* out,
                    const void* bias, int M, int N, int K, int blocksize, int quant_type, hipStream_t stream);
-extern int g_dot_rpw, g_dot_segs;
+extern int g_dot_rpw, g_dot_segs, g_dot_ablate, g_dot_flags;
 // gemm4_mfma.hip
 bool gemm_4bit_mfma_supported(int dtype, const void* A, const uint8_t* B, int M, int N, int K, int blocksize);
 void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                     const float* absmax_code, const float* absmax_offset, const float* code16, void* out,
-                    const void* bias, int M, int N, int K, int blocksize, int quant_type, hipStream_t stream);
+                    const void* bias, int M, int N, int K, int blocksize, int quant_type, void* workspace,
+                    size_t workspace_bytes, hipStream_t stream);
+size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K);
 extern int g_mfma_knob0, g_mfma_knob1;
 
 namespace {
@@ -41,26 +43,27 @@ namespace {
 // (bitsandbytes/backends/cuda/ops.py:814-843), calibrated on gfx950 — see DESIGN.md.
 constexpr int kDotMaxM = 4;
 
+bool route_to_mfma(int kernel, int dtype, const void* A, const uint8_t* B, int M, int N, int K, int blocksize) {
+    if (kernel == 1)
+        return false;
+    if (kernel == 2)
+        return gemm_4bit_mfma_supported(dtype, A, B, M, N, K, blocksize);
+    return (M > kDotMaxM) && gemm_4bit_mfma_supported(dtype, A, B, M, N, K, blocksize);
+}
+
 void gemm_4bit_dispatch(int kernel, int dtype, const void* A, const uint8_t* B, const float* absmax,
                         const uint8_t* absmax8, const float* absmax_code, const float* absmax_offset,
                         const float* code16, void* out, const void* bias, int M, int N, int K, int blocksize,
-                        int quant_type, hipStream_t stream) {
+                        int quant_type, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (M <= 0 || N <= 0)
         return;
     if (quant_type != kFP4 && quant_type != kNF4) {
         fprintf(stderr, "bitsandbytes_amd: gemm_4bit: quant_type must be 1 (FP4) or 2 (NF4), got %d\n", quant_type);
         exit(1);
     }
-    bool use_mfma;
-    if (kernel == 1)
-        use_mfma = false;
-    else if (kernel == 2)
-        use_mfma = gemm_4bit_mfma_supported(dtype, A, B, M, N, K, blocksize);
-    else
-        use_mfma = (M > kDotMaxM) && gemm_4bit_mfma_supported(dtype, A, B, M, N, K, blocksize);
-    if (use_mfma)
+    if (route_to_mfma(kernel, dtype, A, B, M, N, K, blocksize))
         gemm_4bit_mfma(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, code16, out, bias, M, N, K, blocksize,
-                       quant_type, stream);
+                       quant_type, workspace, workspace_bytes, stream);
     else
         gemv_4bit_dot(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, code16, out, bias, M, N, K, blocksize,
                       quant_type, stream);
@@ -149,19 +152,19 @@ void cgemm_4bit_bf16(const void* A, const uint8_t* B, const float* absmax, const
                      const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N,
                      int K, int blocksize, int quant_type, bnb_stream_t s) {
     gemm_4bit_dispatch(0, 2, A, B, absmax, absmax_8bit, absmax_code, absmax_offset, nullptr, out, bias, M, N, K,
-                       blocksize, quant_type, S(s));
+                       blocksize, quant_type, nullptr, 0, S(s));
 }
 void cgemm_4bit_fp16(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit,
                      const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N,
                      int K, int blocksize, int quant_type, bnb_stream_t s) {
     gemm_4bit_dispatch(0, 1, A, B, absmax, absmax_8bit, absmax_code, absmax_offset, nullptr, out, bias, M, N, K,
-                       blocksize, quant_type, S(s));
+                       blocksize, quant_type, nullptr, 0, S(s));
 }
 void cgemm_4bit_fp32(const float* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit,
                      const float* absmax_code, const float* absmax_offset, float* out, const float* bias, int M, int N,
                      int K, int blocksize, int quant_type, bnb_stream_t s) {
     gemm_4bit_dispatch(0, 0, A, B, absmax, absmax_8bit, absmax_code, absmax_offset, nullptr, out, bias, M, N, K,
-                       blocksize, quant_type, S(s));
+                       blocksize, quant_type, nullptr, 0, S(s));
 }
 
 // ------------------------------------------------------------------ legacy gemv (m = N, n = 1, k = K)
@@ -218,15 +221,27 @@ void bnb_mi355x_quantize_8bit(const float* code, const void* A, int dtype, float
 void bnb_mi355x_gemm_4bit(int kernel, int dtype, const void* A, const uint8_t* B, const float* absmax,
                           const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset,
                           const float* code16, void* out, const void* bias, int M, int N, int K, int blocksize,
-                          int quant_type, bnb_stream_t s) {
+                          int quant_type, void* workspace, size_t workspace_bytes, bnb_stream_t s) {
     gemm_4bit_dispatch(kernel, dtype, A, B, absmax, absmax_8bit, absmax_code, absmax_offset, code16, out, bias, M, N, K,
-                       blocksize, quant_type, S(s));
+                       blocksize, quant_type, workspace, workspace_bytes, S(s));
+}
+size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N, int K, int blocksize) {
+    // alignment of A/B is unknown here; assume the aligned (fast) case, an unused workspace is harmless
+    static const int dummy_aligned[4] __attribute__((aligned(16))) = {0, 0, 0, 0};
+    const void* a = dummy_aligned;
+    if (!route_to_mfma(kernel, dtype, a, reinterpret_cast<const uint8_t*>(a), M, N, K, blocksize))
+        return 0;
+    return gemm_4bit_mfma_workspace_bytes(M, N, K);
 }
 void bnb_mi355x_set_tuning(int dot_rows_per_wave, int dot_segments, int mfma_knob0, int mfma_knob1) {
     g_dot_rpw = dot_rows_per_wave;
     g_dot_segs = dot_segments;
     g_mfma_knob0 = mfma_knob0;
     g_mfma_knob1 = mfma_knob1;
+}
+void bnb_mi355x_set_debug(int dot_ablation, int dot_flags) {
+    g_dot_ablate = dot_ablation;
+    g_dot_flags = dot_flags;
 }
 const char* bnb_mi355x_version(void) { return "bitsandbytes_amd 0.1.0 gfx950"; }
 

@@ -72,8 +72,8 @@ __global__ __launch_bounds__(kDqThreads) void dequantize4_kernel(const uint8_t* 
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const uint32_t byte = (w[u] >> (8 * b)) & 0xFFu;
-                v[2 * b] = code[byte >> 4] * s[u];
-                v[2 * b + 1] = code[byte & 0xF] * s[u];
+                v[2 * b] = rounded_f32(code[byte >> 4] * s[u]);
+                v[2 * b + 1] = rounded_f32(code[byte & 0xF] * s[u]);
             }
             store8<T>(out, base, v);
         }
@@ -89,9 +89,9 @@ __global__ __launch_bounds__(kDqThreads) void dequantize4_kernel(const uint8_t* 
                 if (e >= n)
                     break;
                 const uint32_t byte = A[e >> 1];
-                out[e] = static_cast<T>(code[byte >> 4] * absmax[e >> bs_shift]);
+                out[e] = static_cast<T>(rounded_f32(code[byte >> 4] * absmax[e >> bs_shift]));
                 if (e + 1 < n)
-                    out[e + 1] = static_cast<T>(code[byte & 0xF] * absmax[(e + 1) >> bs_shift]);
+                    out[e + 1] = static_cast<T>(rounded_f32(code[byte & 0xF] * absmax[(e + 1) >> bs_shift]));
             }
         }
     }

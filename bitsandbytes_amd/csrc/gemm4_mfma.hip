@@ -22,8 +22,10 @@
 //    one XOR-swizzled LDS image of A[MT*16, 256] (16-byte chunk index ^ (row & 15) => conflict-free
 //    ds_read_b128 fragment reads), double-buffered, written by all 256 lanes with full-line loads.
 //  * Work decomposition = (column group of 64*NT columns) x (K slice). K slices exist only to put
-//    >= 256 workgroups on the chip when N is small; their fp32 partials are combined with global
-//    atomics into a self-cleaning fp32 workspace and a tiny finalize kernel (bias, rounding).
+//    >= 256 workgroups on the chip when N is small. Each slice writes its fp32 partial tile to its own
+//    slab of a workspace with plain stores; a small finalize kernel adds the slabs in slice order,
+//    adds the bias and rounds once. No atomics: results are bit-reproducible run to run (the
+//    reference's test_matmul_4bit_weight_orientation demands exact equality between calls).
 #include "bnb_common.h"
 
 #include <mutex>
@@ -80,7 +82,7 @@ struct GemmArgs {
     const float* code16;
     void* out;
     const void* bias;
-    float* ws; // fp32 [M, N] partial-sum workspace (all zero between calls) when kslices > 1
+    float* ws; // fp32 [kslices, M, N] partial-sum slabs when kslices > 1
     int M, N, K;
     int bs_shift;
     int quant_type;
@@ -291,23 +293,28 @@ __global__ __launch_bounds__(256) void gemm4_mfma_kernel(const GemmArgs p) {
                 const long o = static_cast<long>(m) * N + col;
                 if (p.kslices == 1)
                     out[o] = static_cast<T>(acc[mt][t][r] + b);
-                else if (nst > 0)
-                    atomicAdd(p.ws + o, acc[mt][t][r]);
+                else
+                    p.ws[static_cast<long>(blockIdx.y) * M * N + o] = acc[mt][t][r];
             }
         }
     }
 }
 
-// out = T(ws + bias); ws = 0  (keeps the workspace all-zero for the next call)
+// out = T(sum_s ws[s] + bias), slabs added in slice order (deterministic)
 template <typename T>
-__global__ __launch_bounds__(256) void gemm4_finalize_kernel(float* __restrict__ ws, const T* __restrict__ bias,
-                                                             T* __restrict__ out, long total, int N) {
+__global__ __launch_bounds__(256) void gemm4_finalize_kernel(const float* __restrict__ ws, const T* __restrict__ bias,
+                                                             T* __restrict__ out, long total, int N, int kslices) {
     const long i = (static_cast<long>(blockIdx.x) * 256 + threadIdx.x) * 4;
     if (i >= total)
         return;
-    if (i + 4 <= total && (N % 4) == 0) {
-        f32x4 v = *reinterpret_cast<f32x4*>(ws + i);
-        *reinterpret_cast<f32x4*>(ws + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i + 4 <= total && (total % 4) == 0 && (N % 4) == 0) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(ws + i);
+        for (int s = 1; s < kslices; ++s) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(ws + static_cast<long>(s) * total + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v[j] += w[j];
+        }
         const int col = static_cast<int>(i % N);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -316,17 +323,20 @@ __global__ __launch_bounds__(256) void gemm4_finalize_kernel(float* __restrict__
         }
     } else {
         for (long e = i; e < i + 4 && e < total; ++e) {
+            float v = ws[e];
+            for (int s = 1; s < kslices; ++s)
+                v += ws[static_cast<long>(s) * total + e];
             const float b = bias ? static_cast<float>(bias[e % N]) : 0.0f;
-            out[e] = static_cast<T>(ws[e] + b);
-            ws[e] = 0.0f;
+            out[e] = static_cast<T>(v + b);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// fp32 split-K workspace: one buffer per (device, stream), created on first use, zero-filled once on
-// that stream, kept all-zero by the finalize kernel. Stream-private so that concurrent streams never
-// share partial sums. Buffers are never freed (a handful of MiB per stream used).
+// Library-owned split-K workspace, used only when the caller passes none (the reference ABI has no
+// workspace argument): one buffer per (device, stream) so concurrent streams never share slabs;
+// created on first use; never created while the stream is being captured (hipMalloc would
+// invalidate the capture) - in that case the call simply runs with a single K slice. Never freed.
 // ---------------------------------------------------------------------------------------------
 struct WsKey {
     int dev;
@@ -345,23 +355,59 @@ struct WsBuf {
 std::mutex g_ws_mu;
 std::unordered_map<WsKey, WsBuf, WsKeyHash> g_ws;
 
-float* get_workspace(size_t bytes, hipStream_t stream) {
+float* get_internal_workspace(size_t bytes, hipStream_t stream) {
     int dev = 0;
     BNB_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_ws_mu);
     WsBuf& b = g_ws[WsKey{dev, stream}];
     if (b.bytes < bytes) {
-        size_t want = bytes < (size_t(8) << 20) ? (size_t(8) << 20) : bytes;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        size_t want = bytes < (size_t(16) << 20) ? (size_t(16) << 20) : bytes;
         float* np = nullptr;
         if (hipMalloc(reinterpret_cast<void**>(&np), want) != hipSuccess) {
             (void)hipGetLastError();
-            return nullptr; // caller falls back to a single K slice
+            return nullptr;
         }
-        BNB_HIP_CHECK(hipMemsetAsync(np, 0, want, stream));
         b.p = np; // an older, smaller buffer stays allocated: kernels already enqueued may still use it
         b.bytes = want;
     }
     return b.p;
+}
+
+struct Plan {
+    int mt, nt, ks;
+};
+
+// Tile shape and K-slice count for a problem: a pure function of (M, N, K) and the tuning knobs,
+// shared by the launch and by the workspace-size query.
+Plan make_plan(int M, int N, int K) {
+    Plan pl;
+    pl.mt = (M > 48) ? 4 : (M > 32) ? 3 : (M > 16) ? 2 : 1;
+    int nt = g_mfma_knob0;
+    if (nt == 0)
+        nt = (pl.mt >= 3) ? 2 : 1;
+    if (nt != 1 && nt != 2 && nt != 4)
+        nt = 1;
+    if ((pl.mt >= 3 && nt == 4))
+        nt = 2;
+    pl.nt = nt;
+    const int steps = K / kKC;
+    const int gx = (N + 64 * nt - 1) / (64 * nt);
+    const int gz = (M + pl.mt * 16 - 1) / (pl.mt * 16);
+    int ks = g_mfma_knob1;
+    if (ks == 0)
+        ks = (512 + gx * gz - 1) / (gx * gz); // aim for ~2 workgroups per CU
+    if (ks > steps)
+        ks = steps;
+    if (ks < 1)
+        ks = 1;
+    const int per = (steps + ks - 1) / ks;
+    pl.ks = (steps + per - 1) / per; // every slice non-empty
+    return pl;
 }
 
 template <typename T, int MT, int NT> void launch_mfma(GemmArgs& p, hipStream_t stream) {
@@ -380,30 +426,26 @@ template <typename T, int MT, int NT> void launch_mfma(GemmArgs& p, hipStream_t 
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
 }
 
-template <typename T> void dispatch_mfma(GemmArgs& p, hipStream_t stream) {
-    const int mt = (p.M > 48) ? 4 : (p.M > 32) ? 3 : (p.M > 16) ? 2 : 1;
-    int nt = g_mfma_knob0;
-    if (nt == 0)
-        nt = (mt >= 3) ? 2 : 1;
-    if (nt != 1 && nt != 2 && nt != 4)
-        nt = 1;
-    const int gx = (p.N + 64 * nt - 1) / (64 * nt);
-    const int gz = (p.M + mt * 16 - 1) / (mt * 16);
-    int ks = g_mfma_knob1;
-    if (ks == 0) {
-        // aim for ~2 workgroups per CU
-        ks = (512 + gx * gz - 1) / (gx * gz);
+template <typename T> void dispatch_mfma(GemmArgs& p, float* ws, size_t ws_bytes, hipStream_t stream) {
+    Plan pl = make_plan(p.M, p.N, p.K);
+    const size_t slab = static_cast<size_t>(p.M) * p.N * sizeof(float);
+    if (pl.ks > 1) {
+        if (ws == nullptr) {
+            ws = get_internal_workspace(slab * pl.ks, stream);
+            ws_bytes = ws ? slab * pl.ks : 0;
+        }
+        if (ws_bytes < slab * pl.ks) {
+            // not enough room for all slabs: use as many slices as fit (>= 2), else none
+            const int fit = static_cast<int>(ws_bytes / slab);
+            const int steps = p.steps_total;
+            int ks = fit >= 2 ? fit : 1;
+            const int per = (steps + ks - 1) / ks;
+            pl.ks = (steps + per - 1) / per;
+        }
     }
-    if (ks > p.steps_total)
-        ks = p.steps_total;
-    if (ks < 1)
-        ks = 1;
-    if (ks > 1) {
-        p.ws = get_workspace(static_cast<size_t>(p.M) * p.N * sizeof(float), stream);
-        if (!p.ws)
-            ks = 1;
-    }
-    p.kslices = ks;
+    p.ws = ws;
+    p.kslices = pl.ks;
+    const int mt = pl.mt, nt = pl.nt;
 
 #define BNB_MFMA_CASE(MTV, NTV)                                                                    \
     if (mt == MTV && nt == NTV) {                                                                  \
@@ -416,11 +458,11 @@ template <typename T> void dispatch_mfma(GemmArgs& p, hipStream_t stream) {
 #undef BNB_MFMA_CASE
     BNB_CHECK_LAUNCH();
 
-    if (ks > 1) {
+    if (pl.ks > 1) {
         const long total = static_cast<long>(p.M) * p.N;
         const long threads = (total + 3) / 4;
         hipLaunchKernelGGL((gemm4_finalize_kernel<T>), dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0,
-                           stream, p.ws, static_cast<const T*>(p.bias), static_cast<T*>(p.out), total, p.N);
+                           stream, p.ws, static_cast<const T*>(p.bias), static_cast<T*>(p.out), total, p.N, pl.ks);
         BNB_CHECK_LAUNCH();
     }
 }
@@ -434,9 +476,18 @@ bool gemm_4bit_mfma_supported(int dtype, const void* A, const uint8_t* B, int M,
            aligned_to(A, 16) && aligned_to(B, 8);
 }
 
+// Bytes of fp32 slab workspace the launch heuristics would like for this problem (0 = none needed).
+size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K) {
+    if (M < 1 || N < 1 || K < kKC)
+        return 0;
+    const Plan pl = make_plan(M, N, K);
+    return pl.ks > 1 ? static_cast<size_t>(pl.ks) * M * N * sizeof(float) : 0;
+}
+
 void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                     const float* absmax_code, const float* absmax_offset, const float* code16, void* out,
-                    const void* bias, int M, int N, int K, int blocksize, int quant_type, hipStream_t stream) {
+                    const void* bias, int M, int N, int K, int blocksize, int quant_type, void* workspace,
+                    size_t workspace_bytes, hipStream_t stream) {
     GemmArgs p;
     p.A = A;
     p.B = B;
@@ -456,9 +507,9 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
     p.kslices = 1;
     p.steps_total = K / kKC;
     if (dtype == 2)
-        dispatch_mfma<bf16>(p, stream);
+        dispatch_mfma<bf16>(p, static_cast<float*>(workspace), workspace_bytes, stream);
     else
-        dispatch_mfma<f16>(p, stream);
+        dispatch_mfma<f16>(p, static_cast<float*>(workspace), workspace_bytes, stream);
 }
 
 } // namespace bnb

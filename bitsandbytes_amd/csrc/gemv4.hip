@@ -28,6 +28,9 @@
 
 namespace bnb {
 
+int g_dot_ablate = 0; // profiling only: see the ablation bits of DotFlags
+int g_dot_flags = 0;  // kWaves8 | kNT | kXLds selection (0 = default)
+
 // Tuning knobs (overridable for sweeps through bnb_mi355x_set_tuning; see c_api.hip).
 int g_dot_rpw = 0;  // rows per wavefront, 0 = heuristic
 int g_dot_segs = 0; // 2048-k segments per iteration, 0 = heuristic
@@ -81,35 +84,66 @@ struct GemvArgs {
 
 constexpr int kSegK = 2048; // k covered by one wavefront-wide 16-byte load
 
+// Compile-time switches of the dot kernel, packed into one template int.
+enum DotFlags : int {
+    kSingle = 1,  // the whole K fits one iteration: no prefetch registers are allocated
+    kNested = 2,  // double-quantised absmax reconstructed in-kernel
+    kWaves8 = 4,  // 512-thread workgroups (8 wavefronts share one table build) instead of 256
+    kNT = 8,      // non-temporal weight / absmax loads (streamed once, keep them out of the way of x)
+    kXLds = 16,   // activations staged once per workgroup in LDS instead of per-wave global loads (kSingle only)
+    // bits 8..: ablation for profiling builds (results are wrong): 1 = stream + reduce raw words, no decode;
+    // 2 = no table build; 3 = no weight loads; 4 = weights only (no x / absmax traffic); 5 = empty kernel
+};
+
+template <typename T> __device__ __forceinline__ T ld_stream(const T* p, bool nt) {
+    return nt ? __builtin_nontemporal_load(p) : *p;
+}
+
 // T in {bf16, f16}; MB = activation rows per pass; RPW = weight rows per wavefront;
-// SEGS = 2048-k sub-segments per loop iteration; SINGLE = the whole K fits one iteration (no
-// prefetch registers are allocated then).
-template <typename T, int MB, int RPW, int SEGS, bool SINGLE, bool NESTED>
-__global__ __launch_bounds__(256) void gemv4_dot_kernel(const GemvArgs p) {
-    __shared__ uint32_t lut[256 * 32];
+// SEGS = 2048-k sub-segments per loop iteration.
+template <typename T, int MB, int RPW, int SEGS, int FLAGS>
+__global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kernel(const GemvArgs p) {
+    constexpr bool SINGLE = FLAGS & kSingle, NESTED = FLAGS & kNested, NTL = FLAGS & kNT;
+    constexpr bool XLDS = (FLAGS & kXLds) && SINGLE;
+    constexpr int WAVES = (FLAGS & kWaves8) ? 8 : 4;
+    constexpr int THREADS = WAVES * 64;
+    constexpr int ABL = FLAGS >> 8;
+    constexpr int kXBytes = XLDS ? MB * SEGS * kSegK * 2 : 16;
+
+    __shared__ __attribute__((aligned(16))) uint32_t lut[256 * 32];
+    __shared__ __attribute__((aligned(16))) unsigned char xs[kXBytes];
     __shared__ float code2[NESTED ? 256 : 1];
 
     const int tid = threadIdx.x;
     // The two code values this lane needs for its table entry are the FIRST vector loads of the
     // kernel: vmcnt retires in order, so waiting for them later never waits for the weight stream.
     const gfloat_ptr tbl = (gfloat_ptr)(p.code16 ? p.code16 : (p.quant_type == kNF4 ? kNF4Code : kFP4Code));
-    const float code_hi = tbl[tid >> 4];
-    const float code_lo = tbl[tid & 15];
+    float code_hi = 0.f, code_lo = 0.f;
+    if (THREADS == 256 || tid < 256) {
+        code_hi = tbl[(tid >> 4) & 15];
+        code_lo = tbl[tid & 15];
+    }
 
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int N = p.N, K = p.K;
-    const int row0 = (blockIdx.x * 4 + wave) * RPW;
+    const int row0 = (blockIdx.x * WAVES + wave) * RPW;
     const int m0 = blockIdx.y * MB;
 
     const T* __restrict__ A = static_cast<const T*>(p.A);
     const uint8_t* __restrict__ B = p.B;
     const float* __restrict__ absmax = p.absmax;
 
+    if constexpr (ABL == 5) {
+        if (lane == 0 && row0 < N)
+            static_cast<T*>(p.out)[row0] = static_cast<T>(code_hi);
+        return;
+    }
+
     struct Stage {
         u32x4 w[SEGS][RPW];
         float s[SEGS][RPW];
-        u32x4 x[SEGS][MB][4];
+        u32x4 x[XLDS ? 1 : SEGS][XLDS ? 1 : MB][4];
     };
 
     auto load_stage = [&](Stage& st, int it) {
@@ -123,22 +157,29 @@ __global__ __launch_bounds__(256) void gemv4_dot_kernel(const GemvArgs p) {
                 const int row = (row0 + r < N) ? row0 + r : N - 1;
                 const long e = static_cast<long>(row) * K + kk;
                 // lanes past K read the row start instead (valid memory); their scale is forced to 0 below
-                st.w[sg][r] = *reinterpret_cast<const u32x4*>(B + (e >> 1));
+                if constexpr (ABL == 3)
+                    st.w[sg][r] = u32x4{static_cast<uint32_t>(lane), 0x12345678u, static_cast<uint32_t>(row), 0x9abcdef0u};
+                else
+                    st.w[sg][r] = ld_stream(reinterpret_cast<const u32x4*>(B + (e >> 1)), NTL);
                 const long blk = e >> p.bs_shift;
-                if constexpr (NESTED) {
+                if constexpr (ABL == 4) {
+                    st.s[sg][r] = 1.0f;
+                } else if constexpr (NESTED) {
                     // scale reconstructed in compute_stage (needs the LDS code table)
-                    st.s[sg][r] = __builtin_bit_cast(float, static_cast<uint32_t>(p.absmax8[blk]));
+                    st.s[sg][r] = __builtin_bit_cast(float, static_cast<uint32_t>(ld_stream(p.absmax8 + blk, NTL)));
                 } else {
-                    st.s[sg][r] = absmax[blk];
+                    st.s[sg][r] = ld_stream(absmax + blk, NTL);
                 }
             }
+            if constexpr (!XLDS && ABL != 4) {
 #pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                const int mr = (m0 + m < p.M) ? m0 + m : p.M - 1;
-                const T* ap = A + static_cast<long>(mr) * K + kk;
+                for (int m = 0; m < MB; ++m) {
+                    const int mr = (m0 + m < p.M) ? m0 + m : p.M - 1;
+                    const T* ap = A + static_cast<long>(mr) * K + kk;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    st.x[sg][m][q] = *reinterpret_cast<const u32x4*>(ap + q * 8);
+                    for (int q = 0; q < 4; ++q)
+                        st.x[sg][m][q] = *reinterpret_cast<const u32x4*>(ap + q * 8);
+                }
             }
         }
     };
@@ -153,11 +194,36 @@ __global__ __launch_bounds__(256) void gemv4_dot_kernel(const GemvArgs p) {
     const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
     float offset = 0.0f;
 
+    // x fragment (4 x 16 B = this lane's 32 activations of segment sg, row m)
+    auto x_frag = [&](const Stage& st, int sg, int m, int q) -> u32x4 {
+        if constexpr (ABL == 4) {
+            return u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        } else if constexpr (XLDS) {
+            // LDS image: chunk (lane*4 + q) of segment sg sits at slot q*64 + lane -> conflict-free b128 reads
+            return *reinterpret_cast<const u32x4*>(xs + ((m * SEGS + sg) * 256 + q * 64 + lane) * 16);
+        } else {
+            return st.x[sg][m][q];
+        }
+    };
+
     auto compute_stage = [&](const Stage& st, int it) {
 #pragma unroll
         for (int sg = 0; sg < SEGS; ++sg) {
+            u32x4 xf[MB][4];
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    xf[m][q] = x_frag(st, sg, m, q);
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
+                if constexpr (ABL == 1 || ABL == 4) {
+                    const u32x4 w = st.w[sg][r];
+                    const uint32_t x0 = xf[0][0][0] ^ xf[0][1][1] ^ xf[0][2][2] ^ xf[0][3][3];
+                    acc[0][r] += __builtin_bit_cast(float, ((w[0] ^ w[1] ^ w[2] ^ w[3] ^ x0) & 0x007fffffu) | 0x3f800000u) *
+                                 st.s[sg][r];
+                    continue;
+                }
                 // two independent fp32 chains per output so consecutive v_dot2c do not serialise
                 float part[MB][2];
 #pragma unroll
@@ -172,7 +238,7 @@ __global__ __launch_bounds__(256) void gemv4_dot_kernel(const GemvArgs p) {
                         const uint32_t pr = lut[(byte << 5) + lane_slot];
 #pragma unroll
                         for (int m = 0; m < MB; ++m)
-                            part[m][j & 1] = Pair2<T>::dot2(pr, st.x[sg][m][d][j], part[m][j & 1]);
+                            part[m][j & 1] = Pair2<T>::dot2(pr, xf[m][d][j], part[m][j & 1]);
                     }
                 }
                 const int k0 = (it * SEGS + sg) * kSegK + lane * 32;
@@ -200,19 +266,43 @@ __global__ __launch_bounds__(256) void gemv4_dot_kernel(const GemvArgs p) {
     Stage cur;
     load_stage(cur, 0);
 
-    // 2) build the byte -> (code[hi], code[lo]) table while they fly.
-    {
-        const uint32_t pr = Pair2<T>::pack(code_hi, code_lo);
-        const u32x4 v = {pr, pr, pr, pr};
-        u32x4* dst = reinterpret_cast<u32x4*>(&lut[tid * 32]);
+    // 1b) activations: one cooperative, fully coalesced copy per workgroup into the LDS image
+    if constexpr (XLDS) {
+        constexpr int kChunks = MB * SEGS * 256; // 16-byte chunks
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            dst[j] = v;
-        if constexpr (NESTED) {
-            code2[tid] = p.absmax_code[tid];
-            offset = p.absmax_offset[0];
+        for (int c0 = 0; c0 < kChunks; c0 += THREADS) {
+            const int c = c0 + tid;
+            if (kChunks % THREADS == 0 || c < kChunks) {
+                const int m = c / (SEGS * 256), rem = c % (SEGS * 256);
+                const int sg = rem >> 8, g = rem & 255; // g = lane*4 + q within the segment
+                const int k = sg * kSegK + g * 8;
+                const int mr = (m0 + m < p.M) ? m0 + m : p.M - 1;
+                u32x4 v = u32x4{0, 0, 0, 0};
+                if (k < K)
+                    v = *reinterpret_cast<const u32x4*>(A + static_cast<long>(mr) * K + k);
+                *reinterpret_cast<u32x4*>(xs + ((m * SEGS + sg) * 256 + (g & 3) * 64 + (g >> 2)) * 16) = v;
+            }
         }
     }
+
+    // 2) build the byte -> (code[hi], code[lo]) table while the weights fly.
+    if constexpr (ABL == 0 || ABL == 3) {
+        if (THREADS == 256 || tid < 256) {
+            const uint32_t pr = Pair2<T>::pack(code_hi, code_lo);
+            const u32x4 v = {pr, pr, pr, pr};
+            u32x4* dst = reinterpret_cast<u32x4*>(&lut[tid * 32]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                dst[j] = v;
+            if constexpr (NESTED) {
+                code2[tid] = p.absmax_code[tid];
+            }
+        }
+        if constexpr (NESTED)
+            offset = p.absmax_offset[0];
+    }
+    if constexpr (ABL == 1 || ABL == 2 || ABL == 4)
+        asm volatile("" ::"v"(code_hi), "v"(code_lo));
     __syncthreads();
 
     // 3) main loop: prefetch iteration it+1, consume iteration it
@@ -301,20 +391,24 @@ template <typename T, bool NESTED> __global__ __launch_bounds__(256) void gemv4_
     }
 }
 
-template <typename T, int MB, int RPW, int SEGS> void launch_dot(const GemvArgs& p, hipStream_t stream) {
-    const int rows_per_block = 4 * RPW;
+// runtime knob bits -> the FLAGS template argument (only a curated set of combinations is instantiated)
+template <typename T, int MB, int RPW, int SEGS, int EXTRA> void launch_dot(const GemvArgs& p, hipStream_t stream) {
+    constexpr int waves = (EXTRA & kWaves8) ? 8 : 4;
+    const int rows_per_block = waves * RPW;
     dim3 grid((p.N + rows_per_block - 1) / rows_per_block, (p.M + MB - 1) / MB);
+    dim3 block(waves * 64);
     const bool single = p.K <= SEGS * kSegK;
     if (single) {
         if (p.absmax8)
-            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, true, true>), grid, dim3(256), 0, stream, p);
+            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, EXTRA | kSingle | kNested>), grid, block, 0, stream, p);
         else
-            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, true, false>), grid, dim3(256), 0, stream, p);
+            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, EXTRA | kSingle>), grid, block, 0, stream, p);
     } else {
+        constexpr int E2 = EXTRA & ~kXLds;
         if (p.absmax8)
-            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, false, true>), grid, dim3(256), 0, stream, p);
+            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, E2 | kNested>), grid, block, 0, stream, p);
         else
-            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, false, false>), grid, dim3(256), 0, stream, p);
+            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, E2>), grid, block, 0, stream, p);
     }
 }
 
@@ -327,6 +421,18 @@ template <typename T> void launch_generic(const GemvArgs& p, hipStream_t stream)
 }
 
 template <typename T> void dispatch_dot(const GemvArgs& p, hipStream_t stream) {
+    // profiling-only ablations of the M = 1, K <= 4096 configuration
+    if (g_dot_ablate != 0 && p.M == 1 && !p.absmax8 && p.K <= 2 * kSegK) {
+        dim3 grid((p.N + 7) / 8, 1);
+#define BNB_ABL(A)                                                                                 \
+    if (g_dot_ablate == A) {                                                                       \
+        hipLaunchKernelGGL((gemv4_dot_kernel<T, 1, 2, 2, kSingle | (A << 8)>), grid, dim3(256), 0, stream, p); \
+        return;                                                                                    \
+    }
+        BNB_ABL(1) BNB_ABL(2) BNB_ABL(3) BNB_ABL(4) BNB_ABL(5)
+#undef BNB_ABL
+    }
+
     // rows per wavefront: enough workgroups to cover 256 CUs a few times, but not less than 2 rows
     int rpw = g_dot_rpw;
     if (rpw == 0) {
@@ -339,20 +445,26 @@ template <typename T> void dispatch_dot(const GemvArgs& p, hipStream_t stream) {
     if (segs == 0)
         segs = (p.K > kSegK) ? 2 : 1;
     const int mb = (p.M >= 3) ? 4 : p.M;
+    const int extra = g_dot_flags & (kWaves8 | kNT | kXLds);
 
-#define BNB_DOT_CASE(MBV, RPWV, SEGSV)                                                             \
-    if (mb == MBV && rpw == RPWV && segs == SEGSV) {                                               \
-        launch_dot<T, MBV, RPWV, SEGSV>(p, stream);                                                \
+#define BNB_DOT_CASE(MBV, RPWV, SEGSV, EX)                                                         \
+    if (mb == MBV && rpw == RPWV && segs == SEGSV && extra == (EX)) {                              \
+        launch_dot<T, MBV, RPWV, SEGSV, (EX)>(p, stream);                                          \
         return;                                                                                    \
     }
-    BNB_DOT_CASE(1, 1, 1) BNB_DOT_CASE(1, 1, 2) BNB_DOT_CASE(1, 2, 1) BNB_DOT_CASE(1, 2, 2)
-    BNB_DOT_CASE(1, 4, 1) BNB_DOT_CASE(1, 4, 2) BNB_DOT_CASE(1, 8, 1)
-    BNB_DOT_CASE(2, 1, 1) BNB_DOT_CASE(2, 1, 2) BNB_DOT_CASE(2, 2, 1) BNB_DOT_CASE(2, 2, 2)
-    BNB_DOT_CASE(2, 4, 1)
-    BNB_DOT_CASE(4, 1, 1) BNB_DOT_CASE(4, 1, 2) BNB_DOT_CASE(4, 2, 1)
+#define BNB_DOT_ALLX(MBV, RPWV, SEGSV)                                                             \
+    BNB_DOT_CASE(MBV, RPWV, SEGSV, 0) BNB_DOT_CASE(MBV, RPWV, SEGSV, kWaves8)                      \
+    BNB_DOT_CASE(MBV, RPWV, SEGSV, kNT) BNB_DOT_CASE(MBV, RPWV, SEGSV, kXLds)                      \
+    BNB_DOT_CASE(MBV, RPWV, SEGSV, kWaves8 | kNT) BNB_DOT_CASE(MBV, RPWV, SEGSV, kWaves8 | kXLds)  \
+    BNB_DOT_CASE(MBV, RPWV, SEGSV, kNT | kXLds) BNB_DOT_CASE(MBV, RPWV, SEGSV, kWaves8 | kNT | kXLds)
+    BNB_DOT_ALLX(1, 2, 2) BNB_DOT_ALLX(1, 1, 2) BNB_DOT_ALLX(1, 4, 2) BNB_DOT_ALLX(2, 2, 2) BNB_DOT_ALLX(4, 1, 2)
+    BNB_DOT_CASE(1, 1, 1, 0) BNB_DOT_CASE(1, 2, 1, 0) BNB_DOT_CASE(1, 4, 1, 0) BNB_DOT_CASE(1, 8, 1, 0)
+    BNB_DOT_CASE(2, 1, 1, 0) BNB_DOT_CASE(2, 1, 2, 0) BNB_DOT_CASE(2, 2, 1, 0) BNB_DOT_CASE(2, 4, 1, 0)
+    BNB_DOT_CASE(4, 1, 1, 0) BNB_DOT_CASE(4, 2, 1, 0)
+#undef BNB_DOT_ALLX
 #undef BNB_DOT_CASE
     // unsupported combination requested by a sweep: fall back to a safe one
-    launch_dot<T, 1, 1, 1>(p, stream);
+    launch_dot<T, 1, 1, 1, 0>(p, stream);
 }
 
 } // namespace

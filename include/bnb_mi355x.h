@@ -101,13 +101,23 @@ void* cget_managed_ptr(size_t bytes);
 void bnb_mi355x_quantize_4bit(const void* A, int dtype, float* absmax, unsigned char* out, int blocksize, long n, int quant_type, bnb_stream_t stream);
 void bnb_mi355x_quantize_8bit(const float* code, const void* A, int dtype, float* absmax, unsigned char* out, int blocksize, long n, bnb_stream_t stream);
 
-/* gemm_4bit with an explicit kernel choice, for benchmarks and parity tests:
- * kernel = 0 auto, 1 wave64 dot kernel, 2 MFMA kernel. dtype as above; code16 may be NULL. */
-void bnb_mi355x_gemm_4bit(int kernel, int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, const float* code16, void* out, const void* bias, int M, int N, int K, int blocksize, int quant_type, bnb_stream_t stream);
+/* gemm_4bit with an explicit kernel choice and a caller-owned split-K workspace:
+ * kernel = 0 auto, 1 wave64 dot kernel, 2 MFMA kernel. dtype as above; code16 may be NULL.
+ * workspace: device buffer of bnb_mi355x_gemm_4bit_workspace_bytes(...) bytes (may be NULL / smaller:
+ * the MFMA kernel then uses fewer K slices, or a library-owned per-stream buffer when NULL and the
+ * stream is not being captured). Its contents are scratch; no initialisation is required. */
+void bnb_mi355x_gemm_4bit(int kernel, int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, const float* code16, void* out, const void* bias, int M, int N, int K, int blocksize, int quant_type, void* workspace, size_t workspace_bytes, bnb_stream_t stream);
+size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N, int K, int blocksize);
 
 /* Tuning overrides for sweeps (0 = built-in heuristic): rows per wavefront and 2048-k segments per
  * iteration of the dot kernel; reserved knobs for the MFMA kernel. Not thread-safe; bench/test use only. */
 void bnb_mi355x_set_tuning(int dot_rows_per_wave, int dot_segments, int mfma_knob0, int mfma_knob1);
+
+/* Profiling only. dot_ablation: 0 = normal; 1..5 run ablated variants of the dot kernel (stream only /
+ * no table build / no weight loads / weights only / empty) whose RESULTS ARE WRONG. dot_flags selects
+ * structural variants of the dot kernel (4 = 512-thread workgroups, 8 = non-temporal weight loads,
+ * 16 = activations staged in LDS); results stay correct. Never set outside tools/sweep.py. */
+void bnb_mi355x_set_debug(int dot_ablation, int dot_flags);
 
 /* Version / build identification: returns "bitsandbytes_amd <ver> gfx950". */
 const char* bnb_mi355x_version(void);

@@ -10,7 +10,7 @@ from conftest import ROOT
 def _header_symbols():
     text = open(os.path.join(ROOT, "include", "bnb_mi355x.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+)?(?:void\*?|void|int|const char\*)\s+\*?([A-Za-z_][A-Za-z0-9_]*)\s*\(", text, flags=re.M)
+    names = re.findall(r"^\s*(?:const\s+)?(?:void\*?|void|int|size_t|const char\*)\s+\*?([A-Za-z_][A-Za-z0-9_]*)\s*\(", text, flags=re.M)
     return sorted(set(names))
 
 

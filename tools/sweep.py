@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--k", type=int, default=4096)
     ap.add_argument("--bs", type=int, default=64)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--dot-only", action="store_true")
     a = ap.parse_args()
     N, K, bs = a.n, a.k, a.bs
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -81,19 +82,42 @@ def main():
         del W
     print(f"# N={N} K={K} bs={bs} layers={L} ({L * bytes_alg(1, N, K, bs) / 1e6:.0f} MB rotated)")
     print(f"{'kernel':8s} {'M':>3s} {'knobs':>12s} {'graph_us':>9s} {'evpair_us':>9s} {'GB/s(graph)':>11s} {'TFLOP/s':>8s}")
-    dot_cfgs = [(1, 1), (1, 2), (2, 1), (2, 2), (4, 1), (4, 2), (8, 1)]
-    Ms_dot = [1] if a.quick else [1, 2, 4]
-    for M in Ms_dot:
+    FL = {0: "base", 4: "w8", 8: "nt", 16: "xlds", 12: "w8+nt", 20: "w8+xlds", 24: "nt+xlds", 28: "w8+nt+xlds"}
+    x1 = torch.randn(1, K, device="cuda", generator=g).bfloat16()
+    # correctness reference for the structural variants (they must not change results beyond rounding)
+    bnb.lib.bnb_mi355x_set_debug(0, 0)
+    q0, st0 = layers[0]
+
+    def run1(xx):
+        return hip._gemm_4bit_fused(xx, q0, st0.shape, st0.absmax, st0.blocksize, st0.quant_type, None, None, None, None, kernel=1).float()
+
+    y_ref = run1(x1)
+    for rpw in (1, 2, 4):
+        for fl, name in FL.items():
+            bnb.lib.bnb_mi355x_set_tuning(rpw, 2, 0, 0)
+            bnb.lib.bnb_mi355x_set_debug(0, fl)
+            err = float((run1(x1) - y_ref).norm() / y_ref.norm())
+            tg, te = measure(layers, x1, 1)
+            print(f"{'dot':8s} {1:3d} {f'rpw{rpw} {name}':>16s} {tg:9.2f} {te:9.2f} {bytes_alg(1, N, K, bs) / tg / 1e3:11.1f} {2 * N * K / tg / 1e6:8.2f}  relerr_vs_base={err:.1e}")
+    bnb.lib.bnb_mi355x_set_debug(0, 0)
+    for abl, name in ((5, "empty"), (4, "weights-only"), (1, "stream-only"), (3, "no-weight-loads"), (0, "full rpw2 seg2")):
+        bnb.lib.bnb_mi355x_set_debug(abl, 0)
+        bnb.lib.bnb_mi355x_set_tuning(2, 2, 0, 0)
+        tg, te = measure(layers, x1, 1)
+        print(f"{'dot-abl':8s} {1:3d} {name:>16s} {tg:9.2f} {te:9.2f} {bytes_alg(1, N, K, bs) / tg / 1e3:11.1f}")
+    bnb.lib.bnb_mi355x_set_debug(0, 0)
+    for M in (() if a.quick else (2, 4)):
         x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
-        for rpw, segs in dot_cfgs:
-            if M == 4 and (rpw, segs) not in ((1, 1), (1, 2), (2, 1)):
-                continue
-            if M == 2 and (rpw, segs) in ((4, 2), (8, 1)):
-                continue
-            bnb.lib.bnb_mi355x_set_tuning(rpw, segs, 0, 0)
-            tg, te = measure(layers, x, 1)
-            print(f"{'dot':8s} {M:3d} {f'rpw{rpw} seg{segs}':>12s} {tg:9.2f} {te:9.2f} {bytes_alg(M, N, K, bs) / tg / 1e3:11.1f} {2 * M * N * K / tg / 1e6:8.2f}")
+        for rpw in ((2,) if M == 2 else (1,)):
+            for fl, name in FL.items():
+                bnb.lib.bnb_mi355x_set_tuning(rpw, 2, 0, 0)
+                bnb.lib.bnb_mi355x_set_debug(0, fl)
+                tg, te = measure(layers, x, 1)
+                print(f"{'dot':8s} {M:3d} {f'rpw{rpw} {name}':>16s} {tg:9.2f} {te:9.2f} {bytes_alg(M, N, K, bs) / tg / 1e3:11.1f} {2 * M * N * K / tg / 1e6:8.2f}")
+    bnb.lib.bnb_mi355x_set_debug(0, 0)
     bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+    if a.dot_only:
+        return
     Ms = [1, 8, 16, 64] if a.quick else [1, 2, 4, 5, 8, 16, 32, 48, 64]
     for M in Ms:
         x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
