@@ -220,7 +220,7 @@ def _gemm_4bit_route(dtype: torch.dtype, M: int, N: int, K: int, blocksize: int)
 
 
 def _gemm_4bit_fused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8bit, absmax_code, absmax_offset,
-                     kernel: int = 0, out: Optional[torch.Tensor] = None):
+                     kernel: int = 0, out: Optional[torch.Tensor] = None, code16: Optional[torch.Tensor] = None):
     K = A.shape[-1]
     M = A.numel() // K
     N = int(shapeB[0])
@@ -253,7 +253,7 @@ def _gemm_4bit_fused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8
         lib.bnb_mi355x_gemm_4bit(
             kernel, _DT_CODE[A.dtype], A.data_ptr(), B.data_ptr(), absmax.contiguous().data_ptr(),
             _ptr(absmax_8bit if absmax_8bit is None else absmax_8bit.contiguous()),
-            _ptr(absmax_code if absmax_code is None else absmax_code.contiguous()), _ptr(offset32), None,
+            _ptr(absmax_code if absmax_code is None else absmax_code.contiguous()), _ptr(offset32), _ptr(code16),
             out.data_ptr(), _ptr(bias), M, N, K, blocksize, _QT_CODE[quant_type], _ptr(ws), ws_bytes, _stream(A),
         )
     return out

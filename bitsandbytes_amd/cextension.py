@@ -72,6 +72,7 @@ def _declare(dll: ct.CDLL) -> None:
     sig(["bnb_mi355x_gemm_4bit_workspace_bytes"], [_I32] * 6, ct.c_size_t)
     sig(["bnb_mi355x_set_tuning"], [_I32] * 4)
     sig(["bnb_mi355x_set_debug"], [_I32, _I32])
+    sig(["bnb_mi355x_set_stamp_buffer"], [_VOID_P])
     sig(["bnb_mi355x_version"], [], ct.c_char_p)
 
 
@@ -98,5 +99,5 @@ EXPORTED_SYMBOLS = tuple(
     + [f"cgemm_4bit_{d}" for d in ("fp32", "bf16", "fp16")]
     + [f"cgemm_4bit_inference_naive_{d}" for d in ("fp32", "bf16", "fp16")]
     + ["get_context", "cget_managed_ptr", "bnb_mi355x_quantize_4bit", "bnb_mi355x_quantize_8bit",
-       "bnb_mi355x_gemm_4bit", "bnb_mi355x_gemm_4bit_workspace_bytes", "bnb_mi355x_set_tuning", "bnb_mi355x_set_debug", "bnb_mi355x_version"]
+       "bnb_mi355x_gemm_4bit", "bnb_mi355x_gemm_4bit_workspace_bytes", "bnb_mi355x_set_tuning", "bnb_mi355x_set_debug", "bnb_mi355x_set_stamp_buffer", "bnb_mi355x_version"]
 )

@@ -87,6 +87,17 @@ __device__ __forceinline__ float rounded_f32(float v) {
     return v;
 }
 
+// A zero the compiler cannot see through, materialised at the point of the call. Adding it to the
+// shift amounts of the nibble/byte extraction ties the whole decode to program order *after* this
+// point: without it LLVM hoists the first v_bfe_u32 of the decode above the workgroup barrier and
+// into the middle of the load-issue sequence, where its s_waitcnt vmcnt stalls the wavefront for a
+// full HBM round trip before the rest of its loads are even issued (seen in the ISA and as +1 us).
+__device__ __forceinline__ int opaque_zero() {
+    int z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return z;
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave64 reductions
 // ---------------------------------------------------------------------------------------------
@@ -97,11 +108,26 @@ template <int WIDTH> __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
+// Sum over the 64 lanes, result valid in every lane. All cross-lane traffic stays in the VALU (DPP
+// modifiers + v_readlane): no ds_bpermute round trips through the LDS pipe, which measured ~0.5 us
+// for the two reductions at the end of the M = 1 gemv (s_memtime timeline, profiles/).
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    // v + (v moved by DPP control CTRL); all rows/banks enabled, bound_ctrl irrelevant (full wave active)
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+    return v + __builtin_bit_cast(float, moved);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
-        v += __shfl_xor(v, off, kWave);
-    return v;
+    v = dpp_add<0xB1>(v);  // quad_perm [1,0,3,2]  : lane ^ 1
+    v = dpp_add<0x4E>(v);  // quad_perm [2,3,0,1]  : lane ^ 2
+    v = dpp_add<0x141>(v); // row_half_mirror      : the other quad of each 8
+    v = dpp_add<0x140>(v); // row_mirror           : the other half of each 16-lane row
+    // every lane of a row now holds its row sum; combine the four rows through SGPRs
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 static inline int ilog2(int v) {

@@ -27,6 +27,7 @@ void gemv_4bit_dot(int dtype, const void* A, const uint8_t* B, const float* absm
                    const float* absmax_code, const float* absmax_offset, const float* code16, void* out,
                    const void* bias, int M, int N, int K, int blocksize, int quant_type, hipStream_t stream);
 extern int g_dot_rpw, g_dot_segs, g_dot_ablate, g_dot_flags;
+extern unsigned long long* g_dbg_buf;
 // gemm4_mfma.hip
 bool gemm_4bit_mfma_supported(int dtype, const void* A, const uint8_t* B, int M, int N, int K, int blocksize);
 void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
@@ -242,6 +243,9 @@ void bnb_mi355x_set_tuning(int dot_rows_per_wave, int dot_segments, int mfma_kno
 void bnb_mi355x_set_debug(int dot_ablation, int dot_flags) {
     g_dot_ablate = dot_ablation;
     g_dot_flags = dot_flags;
+}
+void bnb_mi355x_set_stamp_buffer(void* device_u64_buffer) {
+    g_dbg_buf = static_cast<unsigned long long*>(device_u64_buffer);
 }
 const char* bnb_mi355x_version(void) { return "bitsandbytes_amd 0.1.0 gfx950"; }
 

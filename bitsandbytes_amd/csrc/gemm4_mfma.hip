@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256) void gemm4_mfma_kernel(const GemmArgs p) {
     if (nst > 0)
         store_a(a_cur, 0);
     __syncthreads();
+    const int zsh = opaque_zero();
 
     for (int it = 0; it < nst; ++it) {
         const int st = st_begin + it;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void gemm4_mfma_kernel(const GemmArgs p) {
                     const uint32_t w = b_cur.w[u][t][j];
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        bf[j][q] = lut[(((w >> (8 * q)) & 0xFFu) << 5) + lane_slot];
+                        bf[j][q] = lut[(((w >> (8 * q + zsh)) & 0xFFu) << 5) + lane_slot];
                 }
                 float scale;
                 if constexpr (NESTED) {

@@ -30,6 +30,7 @@ namespace bnb {
 
 int g_dot_ablate = 0; // profiling only: see the ablation bits of DotFlags
 int g_dot_flags = 0;  // kWaves8 | kNT | kXLds selection (0 = default)
+unsigned long long* g_dbg_buf = nullptr; // profiling only: device buffer for s_memtime stamps
 
 // Tuning knobs (overridable for sweeps through bnb_mi355x_set_tuning; see c_api.hip).
 int g_dot_rpw = 0;  // rows per wavefront, 0 = heuristic
@@ -80,6 +81,8 @@ struct GemvArgs {
     int M, N, K;
     int bs_shift;
     int quant_type;
+    float code[16];             // the 16 code values by value (kernarg -> SGPRs) when code16 == NULL
+    unsigned long long* dbg;    // profiling builds only: per-wavefront s_memtime stamps (8 per wave), else NULL
 };
 
 constexpr int kSegK = 2048; // k covered by one wavefront-wide 16-byte load
@@ -91,6 +94,8 @@ enum DotFlags : int {
     kWaves8 = 4,  // 512-thread workgroups (8 wavefronts share one table build) instead of 256
     kNT = 8,      // non-temporal weight / absmax loads (streamed once, keep them out of the way of x)
     kXLds = 16,   // activations staged once per workgroup in LDS instead of per-wave global loads (kSingle only)
+    kCodePtr = 32, // code table read from a table pointer (device-resident built-in table or the caller's)
+    kWaves16 = 64, // 1024-thread workgroups: one table build per CU shared by 16 wavefronts
     // bits 8..: ablation for profiling builds (results are wrong): 1 = stream + reduce raw words, no decode;
     // 2 = no table build; 3 = no weight loads; 4 = weights only (no x / absmax traffic); 5 = empty kernel
 };
@@ -102,11 +107,12 @@ template <typename T> __device__ __forceinline__ T ld_stream(const T* p, bool nt
 // T in {bf16, f16}; MB = activation rows per pass; RPW = weight rows per wavefront;
 // SEGS = 2048-k sub-segments per loop iteration.
 template <typename T, int MB, int RPW, int SEGS, int FLAGS>
-__global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kernel(const GemvArgs p) {
-    constexpr bool SINGLE = FLAGS & kSingle, NESTED = FLAGS & kNested, NTL = FLAGS & kNT;
+__global__ __launch_bounds__((FLAGS & kWaves16) ? 1024 : (FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kernel(const GemvArgs p) {
+    constexpr bool SINGLE = FLAGS & kSingle, NESTED = FLAGS & kNested, NTL = FLAGS & kNT, CODEPTR = FLAGS & kCodePtr;
     constexpr bool XLDS = (FLAGS & kXLds) && SINGLE;
-    constexpr int WAVES = (FLAGS & kWaves8) ? 8 : 4;
+    constexpr int WAVES = (FLAGS & kWaves16) ? 16 : (FLAGS & kWaves8) ? 8 : 4;
     constexpr int THREADS = WAVES * 64;
+    constexpr int TPE = THREADS / 256; // threads cooperating on one table entry
     constexpr int ABL = FLAGS >> 8;
     constexpr int kXBytes = XLDS ? MB * SEGS * kSegK * 2 : 16;
 
@@ -117,11 +123,13 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
     const int tid = threadIdx.x;
     // The two code values this lane needs for its table entry are the FIRST vector loads of the
     // kernel: vmcnt retires in order, so waiting for them later never waits for the weight stream.
-    const gfloat_ptr tbl = (gfloat_ptr)(p.code16 ? p.code16 : (p.quant_type == kNF4 ? kNF4Code : kFP4Code));
+    // (caller-supplied table pointer only; the built-in tables travel by value in the kernel arguments)
     float code_hi = 0.f, code_lo = 0.f;
-    if (THREADS == 256 || tid < 256) {
-        code_hi = tbl[(tid >> 4) & 15];
-        code_lo = tbl[tid & 15];
+    const int entry = tid / TPE; // table entry this lane (co-)writes
+    if constexpr (CODEPTR) {
+        const gfloat_ptr tbl = (gfloat_ptr)p.code16;
+        code_hi = tbl[entry >> 4];
+        code_lo = tbl[entry & 15];
     }
 
     const int lane = tid & 63;
@@ -193,6 +201,7 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
 
     const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
     float offset = 0.0f;
+    int zsh = 0; // opaque zero, set after the barrier (see opaque_zero())
 
     // x fragment (4 x 16 B = this lane's 32 activations of segment sg, row m)
     auto x_frag = [&](const Stage& st, int sg, int m, int q) -> u32x4 {
@@ -234,7 +243,7 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
                     const uint32_t w = st.w[sg][r][d];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const uint32_t byte = (w >> (8 * j)) & 0xFFu;
+                        const uint32_t byte = (w >> (8 * j + zsh)) & 0xFFu;
                         const uint32_t pr = lut[(byte << 5) + lane_slot];
 #pragma unroll
                         for (int m = 0; m < MB; ++m)
@@ -287,23 +296,33 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
 
     // 2) build the byte -> (code[hi], code[lo]) table while the weights fly.
     if constexpr (ABL == 0 || ABL == 3) {
-        if (THREADS == 256 || tid < 256) {
-            const uint32_t pr = Pair2<T>::pack(code_hi, code_lo);
-            const u32x4 v = {pr, pr, pr, pr};
-            u32x4* dst = reinterpret_cast<u32x4*>(&lut[tid * 32]);
+        if constexpr (!CODEPTR) { // SGPR values picked by a v_cndmask chain, no memory
+            const int hi = entry >> 4, lo = entry & 15;
+            code_hi = p.code[0];
+            code_lo = p.code[0];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                dst[j] = v;
-            if constexpr (NESTED) {
-                code2[tid] = p.absmax_code[tid];
+            for (int j = 1; j < 16; ++j) {
+                code_hi = (hi == j) ? p.code[j] : code_hi;
+                code_lo = (lo == j) ? p.code[j] : code_lo;
             }
         }
-        if constexpr (NESTED)
+        const uint32_t pr = Pair2<T>::pack(code_hi, code_lo);
+        const u32x4 v = {pr, pr, pr, pr};
+        // entry `entry` = 8 x 16 B; TPE lanes share it
+        u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * 32]) + (tid % TPE) * (8 / TPE);
+#pragma unroll
+        for (int j = 0; j < 8 / TPE; ++j)
+            dst[j] = v;
+        if constexpr (NESTED) {
+            if (tid < 256)
+                code2[tid] = p.absmax_code[tid];
             offset = p.absmax_offset[0];
+        }
     }
     if constexpr (ABL == 1 || ABL == 2 || ABL == 4)
         asm volatile("" ::"v"(code_hi), "v"(code_lo));
     __syncthreads();
+    zsh = opaque_zero();
 
     // 3) main loop: prefetch iteration it+1, consume iteration it
     if constexpr (SINGLE) {
@@ -335,6 +354,236 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// gemv4_dotx_kernel — the production dot kernel. Same decode scheme as gemv4_dot_kernel above
+// (kept as the fallback for activations too large for LDS), restructured after on-device ablation
+// (profiles/): at M = 1, N = K = 4096 the weight stream alone costs ~2.2 us on top of a 1.8 us
+// launch-to-launch floor, and what was slowing the full kernel down was everything *around* it:
+//   * the 16 code values now arrive by value in the kernel arguments (SGPRs) and the table entry of
+//     a lane is picked with a v_cndmask chain - the table build needs no memory round trip and
+//     starts at cycle 0 (it used to wait ~1 us for a 64-byte gather);
+//   * activations are staged ONCE per workgroup into LDS (fully coalesced, issued BEFORE the weight
+//     loads so that their vmcnt wait does not drain the weight stream) instead of 8 KiB of
+//     per-wavefront global loads - that was 2x the weight bytes in L1/TA traffic; the LDS image is
+//     laid out so the per-lane 16-byte fragment reads are conflict-free (chunk lane*4+q at slot
+//     q*64+lane of each 2048-k segment);
+//   * up to 8 activation rows share one pass over the weights (the decode is shared, only the
+//     v_dot2c count grows), which covers M <= 8 without the matrix pipe.
+// XCH = 16-byte activation chunks staged per lane (compile time so they can sit in registers while
+// the weight loads are issued).
+// ---------------------------------------------------------------------------------------------
+enum DotxFlags : int { kxNested = 1, kxCodePtr = 2, kxDebug = 4 };
+
+#define BNB_STAMP(i)                                                                               \
+    if constexpr (DBG) {                                                                           \
+        if (lane == 0)                                                                             \
+            p.dbg[(static_cast<long>(blockIdx.x) * WAVES + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    }
+
+template <typename T, int MB, int RPW, int XCH, int FLAGS>
+__global__ __launch_bounds__(256) void gemv4_dotx_kernel(const GemvArgs p) {
+    constexpr bool NESTED = FLAGS & kxNested, CODEPTR = FLAGS & kxCodePtr, DBG = FLAGS & kxDebug;
+    constexpr int THREADS = 256, WAVES = 4, SEGS = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* lut = reinterpret_cast<uint32_t*>(smem); // 32 KiB pair table
+    unsigned char* xs = smem + 256 * 32 * 4;           // MB * nseg * 4 KiB activation image
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int N = p.N, K = p.K;
+    const int nseg = (K + kSegK - 1) / kSegK;
+    float* code2 = reinterpret_cast<float*>(xs + MB * nseg * 4096);
+    const int row0 = (blockIdx.x * WAVES + wave) * RPW;
+    const int m0 = blockIdx.y * MB;
+
+    const T* __restrict__ A = static_cast<const T*>(p.A);
+    const uint8_t* __restrict__ B = p.B;
+    const float* __restrict__ absmax = p.absmax;
+
+    BNB_STAMP(0)
+    // ---- 1) activations -> registers (first vector loads of the kernel)
+    float code_hi = 0.f, code_lo = 0.f;
+    if constexpr (CODEPTR) {
+        const gfloat_ptr tbl = (gfloat_ptr)p.code16;
+        code_hi = tbl[tid >> 4];
+        code_lo = tbl[tid & 15];
+    }
+    const int total_chunks = MB * nseg * 256;
+    u32x4 xr[XCH];
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+        const int c = tid + i * THREADS;
+        const int m = c / (nseg * 256), rem = c - m * (nseg * 256);
+        const int k = rem * 8; // chunk rem of the row covers k .. k+8
+        const int mr = (m0 + m < p.M) ? m0 + m : p.M - 1;
+        xr[i] = u32x4{0, 0, 0, 0};
+        if (c < total_chunks && k < K)
+            xr[i] = *reinterpret_cast<const u32x4*>(A + static_cast<long>(mr) * K + k);
+    }
+
+    // ---- 2) weights + scales of the first iteration
+    struct Stage {
+        u32x4 w[SEGS][RPW];
+        float s[SEGS][RPW];
+    };
+    auto load_stage = [&](Stage& st, int it) {
+#pragma unroll
+        for (int sg = 0; sg < SEGS; ++sg) {
+            const int k0 = (it * SEGS + sg) * kSegK + lane * 32;
+            const int kk = (k0 < K) ? k0 : 0;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = (row0 + r < N) ? row0 + r : N - 1;
+                const long e = static_cast<long>(row) * K + kk;
+                st.w[sg][r] = *reinterpret_cast<const u32x4*>(B + (e >> 1));
+                const long blk = e >> p.bs_shift;
+                if constexpr (NESTED)
+                    st.s[sg][r] = __builtin_bit_cast(float, static_cast<uint32_t>(p.absmax8[blk]));
+                else
+                    st.s[sg][r] = absmax[blk];
+            }
+        }
+    };
+    Stage cur;
+    load_stage(cur, 0);
+
+    // ---- 3) table build (no memory traffic unless the caller handed a code pointer)
+    {
+        if constexpr (!CODEPTR) {
+            const int hi = tid >> 4, lo = tid & 15;
+            code_hi = p.code[0];
+            code_lo = p.code[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) {
+                code_hi = (hi == j) ? p.code[j] : code_hi;
+                code_lo = (lo == j) ? p.code[j] : code_lo;
+            }
+        }
+        const uint32_t pr = Pair2<T>::pack(code_hi, code_lo);
+        const u32x4 v = {pr, pr, pr, pr};
+        u32x4* dst = reinterpret_cast<u32x4*>(&lut[tid * 32]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            dst[j] = v;
+    }
+    float offset = 0.0f;
+    if constexpr (NESTED) {
+        code2[tid] = p.absmax_code[tid];
+        offset = p.absmax_offset[0];
+    }
+
+    // ---- 4) activation image: chunk g = lane'*4 + q of segment sg -> slot q*64 + lane'
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+        const int c = tid + i * THREADS;
+        if (c < total_chunks) {
+            const int m = c / (nseg * 256), rem = c - m * (nseg * 256);
+            const int sg = rem >> 8, g = rem & 255;
+            *reinterpret_cast<u32x4*>(xs + ((m * nseg + sg) * 256 + (g & 3) * 64 + (g >> 2)) * 16) = xr[i];
+        }
+    }
+    BNB_STAMP(1)
+    __syncthreads();
+    const int zsh = opaque_zero();
+    BNB_STAMP(2)
+    if constexpr (DBG) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BNB_STAMP(3)
+    }
+
+    float acc[MB][RPW];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+            acc[m][r] = 0.0f;
+    const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
+
+    auto compute_stage = [&](const Stage& st, int it) {
+#pragma unroll
+        for (int sg = 0; sg < SEGS; ++sg) {
+            const int seg = it * SEGS + sg;
+            if (seg >= nseg)
+                break;
+            float part[RPW][MB][2];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+                    part[r][m][0] = part[r][m][1] = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                u32x4 xf[MB];
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+                    xf[m] = *reinterpret_cast<const u32x4*>(xs + ((m * nseg + seg) * 256 + d * 64 + lane) * 16);
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    const uint32_t w = st.w[sg][r][d];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t byte = (w >> (8 * j + zsh)) & 0xFFu;
+                        const uint32_t pr = lut[(byte << 5) + lane_slot];
+#pragma unroll
+                        for (int m = 0; m < MB; ++m)
+                            part[r][m][j & 1] = Pair2<T>::dot2(pr, xf[m][j], part[r][m][j & 1]);
+                    }
+                }
+            }
+            const int k0 = seg * kSegK + lane * 32;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                float scale;
+                if constexpr (NESTED) {
+                    const int kk = (k0 < K) ? k0 : 0;
+                    const int row = (row0 + r < N) ? row0 + r : N - 1;
+                    const long blk = (static_cast<long>(row) * K + kk) >> p.bs_shift;
+                    const uint32_t q8 = __builtin_bit_cast(uint32_t, st.s[sg][r]);
+                    scale = __fadd_rn(__fmul_rn(code2[q8], absmax[blk >> 8]), offset);
+                } else {
+                    scale = st.s[sg][r];
+                }
+                scale = (k0 < K) ? scale : 0.0f; // lanes past the end of the row contribute nothing
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+                    acc[m][r] = fmaf(scale, part[r][m][0] + part[r][m][1], acc[m][r]);
+            }
+        }
+    };
+
+    const int iters = (nseg + SEGS - 1) / SEGS;
+    for (int it = 0; it < iters; ++it) {
+        Stage nxt;
+        const bool more = it + 1 < iters;
+        if (more)
+            load_stage(nxt, it + 1);
+        compute_stage(cur, it);
+        if (more)
+            cur = nxt;
+    }
+
+    if constexpr (DBG) {
+        asm volatile("" ::"v"(acc[0][0]), "v"(acc[MB - 1][RPW - 1]));
+        BNB_STAMP(4)
+    }
+    T* __restrict__ out = static_cast<T*>(p.out);
+    const T* __restrict__ bias = static_cast<const T*>(p.bias);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const float v = wave_sum(acc[m][r]);
+            const int row = row0 + r;
+            if (lane == 0 && row < N && m0 + m < p.M) {
+                const float b = bias ? static_cast<float>(bias[row]) : 0.0f;
+                out[static_cast<long>(m0 + m) * N + row] = static_cast<T>(v + b);
+            }
+        }
+    }
+    BNB_STAMP(5)
+}
+#undef BNB_STAMP
 
 // ---------------------------------------------------------------------------------------------
 // Generic fallback: any T (incl. fp32 activations), any K (odd, not a multiple of 32), any pointer
@@ -393,11 +642,18 @@ template <typename T, bool NESTED> __global__ __launch_bounds__(256) void gemv4_
 
 // runtime knob bits -> the FLAGS template argument (only a curated set of combinations is instantiated)
 template <typename T, int MB, int RPW, int SEGS, int EXTRA> void launch_dot(const GemvArgs& p, hipStream_t stream) {
-    constexpr int waves = (EXTRA & kWaves8) ? 8 : 4;
+    constexpr int waves = (EXTRA & kWaves16) ? 16 : (EXTRA & kWaves8) ? 8 : 4;
     const int rows_per_block = waves * RPW;
     dim3 grid((p.N + rows_per_block - 1) / rows_per_block, (p.M + MB - 1) / MB);
     dim3 block(waves * 64);
     const bool single = p.K <= SEGS * kSegK;
+    if (p.code16) { // legacy gemv op: caller-supplied table, never nested
+        if (single)
+            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, (EXTRA & (kWaves8 | kWaves16)) | kSingle | kCodePtr>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, (EXTRA & (kWaves8 | kWaves16)) | kCodePtr>), grid, block, 0, stream, p);
+        return;
+    }
     if (single) {
         if (p.absmax8)
             hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, EXTRA | kSingle | kNested>), grid, block, 0, stream, p);
@@ -420,7 +676,72 @@ template <typename T> void launch_generic(const GemvArgs& p, hipStream_t stream)
         hipLaunchKernelGGL((gemv4_generic_kernel<T, false>), grid, dim3(256), 0, stream, p);
 }
 
+template <typename T, int MB, int XCH> bool launch_dotx(const GemvArgs& p, hipStream_t stream) {
+    constexpr int RPW = 2;
+    const int nseg = (p.K + kSegK - 1) / kSegK;
+    const size_t smem = 256 * 32 * 4 + static_cast<size_t>(MB) * nseg * 4096 + 1024;
+    dim3 grid((p.N + 4 * RPW - 1) / (4 * RPW), (p.M + MB - 1) / MB);
+    const int flags = (p.absmax8 ? kxNested : 0) | (p.code16 ? kxCodePtr : 0);
+    if constexpr ((MB == 1 && XCH == 2) || (MB == 8 && XCH == 16)) {
+        if (g_dbg_buf && flags == 0) {
+            GemvArgs q = p;
+            q.dbg = g_dbg_buf;
+            auto kern = gemv4_dotx_kernel<T, MB, RPW, XCH, kxDebug>;
+            static bool attr_dbg = false;
+            if (!attr_dbg) {
+                BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_dbg = true;
+            }
+            hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, q);
+            return true;
+        }
+    }
+#define BNB_DOTX_LAUNCH(F)                                                                         \
+    if (flags == (F)) {                                                                            \
+        auto kern = gemv4_dotx_kernel<T, MB, RPW, XCH, (F)>;                                       \
+        static bool attr_done = false;                                                             \
+        if (!attr_done) {                                                                          \
+            BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                 \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_done = true;                                                                      \
+        }                                                                                          \
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);                                \
+        return true;                                                                               \
+    }
+    BNB_DOTX_LAUNCH(0) BNB_DOTX_LAUNCH(kxNested) BNB_DOTX_LAUNCH(kxCodePtr)
+#undef BNB_DOTX_LAUNCH
+    return false; // nested + caller code pointer never occurs (the gemv op un-nests on the host)
+}
+
+// x-in-LDS dot kernel: MB rows per pass (1, 2, 4, 8), XCH = MB * nseg chunks per lane rounded up to a
+// power of two <= 16. Returns false when the activations do not fit (caller falls back).
+template <typename T> bool dispatch_dotx(const GemvArgs& p, hipStream_t stream) {
+    const int nseg = (p.K + kSegK - 1) / kSegK;
+    const int mb = p.M >= 5 ? 8 : p.M >= 3 ? 4 : p.M;
+    int need = mb * nseg;
+    int mbsel = mb;
+    while (need > 16 && mbsel > 1) { // too much activation per pass: fewer rows per pass, more passes
+        mbsel >>= 1;
+        need = mbsel * nseg;
+    }
+    if (need > 16)
+        return false;
+    const int xch = need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16;
+#define BNB_DOTX_CASE(MBV, XV)                                                                     \
+    if (mbsel == MBV && xch == XV)                                                                 \
+        return launch_dotx<T, MBV, XV>(p, stream);
+    BNB_DOTX_CASE(1, 2) BNB_DOTX_CASE(1, 4) BNB_DOTX_CASE(1, 8) BNB_DOTX_CASE(1, 16)
+    BNB_DOTX_CASE(2, 2) BNB_DOTX_CASE(2, 4) BNB_DOTX_CASE(2, 8) BNB_DOTX_CASE(2, 16)
+    BNB_DOTX_CASE(4, 4) BNB_DOTX_CASE(4, 8) BNB_DOTX_CASE(4, 16)
+    BNB_DOTX_CASE(8, 8) BNB_DOTX_CASE(8, 16)
+#undef BNB_DOTX_CASE
+    return false;
+}
+
 template <typename T> void dispatch_dot(const GemvArgs& p, hipStream_t stream) {
+    if (g_dot_ablate == 0 && (g_dot_flags & 32) && dispatch_dotx<T>(p, stream))
+        return;
     // profiling-only ablations of the M = 1, K <= 4096 configuration
     if (g_dot_ablate != 0 && p.M == 1 && !p.absmax8 && p.K <= 2 * kSegK) {
         dim3 grid((p.N + 7) / 8, 1);
@@ -445,7 +766,7 @@ template <typename T> void dispatch_dot(const GemvArgs& p, hipStream_t stream) {
     if (segs == 0)
         segs = (p.K > kSegK) ? 2 : 1;
     const int mb = (p.M >= 3) ? 4 : p.M;
-    const int extra = g_dot_flags & (kWaves8 | kNT | kXLds);
+    const int extra = g_dot_flags & (kWaves8 | kWaves16);
 
 #define BNB_DOT_CASE(MBV, RPWV, SEGSV, EX)                                                         \
     if (mb == MBV && rpw == RPWV && segs == SEGSV && extra == (EX)) {                              \
@@ -453,10 +774,7 @@ template <typename T> void dispatch_dot(const GemvArgs& p, hipStream_t stream) {
         return;                                                                                    \
     }
 #define BNB_DOT_ALLX(MBV, RPWV, SEGSV)                                                             \
-    BNB_DOT_CASE(MBV, RPWV, SEGSV, 0) BNB_DOT_CASE(MBV, RPWV, SEGSV, kWaves8)                      \
-    BNB_DOT_CASE(MBV, RPWV, SEGSV, kNT) BNB_DOT_CASE(MBV, RPWV, SEGSV, kXLds)                      \
-    BNB_DOT_CASE(MBV, RPWV, SEGSV, kWaves8 | kNT) BNB_DOT_CASE(MBV, RPWV, SEGSV, kWaves8 | kXLds)  \
-    BNB_DOT_CASE(MBV, RPWV, SEGSV, kNT | kXLds) BNB_DOT_CASE(MBV, RPWV, SEGSV, kWaves8 | kNT | kXLds)
+    BNB_DOT_CASE(MBV, RPWV, SEGSV, 0) BNB_DOT_CASE(MBV, RPWV, SEGSV, kWaves8) BNB_DOT_CASE(MBV, RPWV, SEGSV, kWaves16)
     BNB_DOT_ALLX(1, 2, 2) BNB_DOT_ALLX(1, 1, 2) BNB_DOT_ALLX(1, 4, 2) BNB_DOT_ALLX(2, 2, 2) BNB_DOT_ALLX(4, 1, 2)
     BNB_DOT_CASE(1, 1, 1, 0) BNB_DOT_CASE(1, 2, 1, 0) BNB_DOT_CASE(1, 4, 1, 0) BNB_DOT_CASE(1, 8, 1, 0)
     BNB_DOT_CASE(2, 1, 1, 0) BNB_DOT_CASE(2, 1, 2, 0) BNB_DOT_CASE(2, 2, 1, 0) BNB_DOT_CASE(2, 4, 1, 0)
@@ -491,6 +809,13 @@ void gemv_4bit_dot(int dtype, const void* A, const uint8_t* B, const float* absm
     p.K = K;
     p.bs_shift = ilog2(blocksize);
     p.quant_type = quant_type;
+    p.dbg = nullptr;
+    {
+        static const float nf4[16] = {BNB_NF4_VALUES};
+        static const float fp4[16] = {BNB_FP4_VALUES};
+        for (int i = 0; i < 16; ++i)
+            p.code[i] = (quant_type == kNF4) ? nf4[i] : fp4[i];
+    }
 
     const bool fast_ok = (dtype != 0) && (K % 32 == 0) && (blocksize >= 32) && is_pow2(blocksize) &&
                          aligned_to(A, 16) && aligned_to(B, 16);

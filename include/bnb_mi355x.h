@@ -119,6 +119,10 @@ void bnb_mi355x_set_tuning(int dot_rows_per_wave, int dot_segments, int mfma_kno
  * 16 = activations staged in LDS); results stay correct. Never set outside tools/sweep.py. */
 void bnb_mi355x_set_debug(int dot_ablation, int dot_flags);
 
+/* Profiling only: when non-NULL, the M = 1 and M = 8 instances of the dot kernel write 8 s_memtime
+ * stamps per wavefront (u64) into this device buffer (N/2 wavefronts). NULL switches it off. */
+void bnb_mi355x_set_stamp_buffer(void* device_u64_buffer);
+
 /* Version / build identification: returns "bitsandbytes_amd <ver> gfx950". */
 const char* bnb_mi355x_version(void);
 

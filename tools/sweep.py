@@ -22,6 +22,9 @@ def bytes_alg(M, N, K, bs):
     return N * K // 2 + 4 * N * K // bs + 2 * M * K + 2 * M * N
 
 
+CODE16 = None
+
+
 def measure(layers, x, kernel, reps=10):
     M = x.shape[0]
     N = layers[0][1].shape[0]
@@ -30,7 +33,7 @@ def measure(layers, x, kernel, reps=10):
     def step(i):
         q, st = layers[i % L]
         hip._gemm_4bit_fused(x, q, st.shape, st.absmax, st.blocksize, st.quant_type, None, None, None, None,
-                             kernel=kernel, out=outs[i % L])
+                             kernel=kernel, out=outs[i % L], code16=CODE16)
 
     for i in range(L):
         step(i)
@@ -82,7 +85,7 @@ def main():
         del W
     print(f"# N={N} K={K} bs={bs} layers={L} ({L * bytes_alg(1, N, K, bs) / 1e6:.0f} MB rotated)")
     print(f"{'kernel':8s} {'M':>3s} {'knobs':>12s} {'graph_us':>9s} {'evpair_us':>9s} {'GB/s(graph)':>11s} {'TFLOP/s':>8s}")
-    FL = {0: "base", 4: "w8", 8: "nt", 16: "xlds", 12: "w8+nt", 20: "w8+xlds", 24: "nt+xlds", 28: "w8+nt+xlds"}
+    FL = {0: "base", 4: "w8", 64: "w16"}
     x1 = torch.randn(1, K, device="cuda", generator=g).bfloat16()
     # correctness reference for the structural variants (they must not change results beyond rounding)
     bnb.lib.bnb_mi355x_set_debug(0, 0)
@@ -92,6 +95,12 @@ def main():
         return hip._gemm_4bit_fused(xx, q0, st0.shape, st0.absmax, st0.blocksize, st0.quant_type, None, None, None, None, kernel=1).float()
 
     y_ref = run1(x1)
+    for M in (1, 2, 3, 4, 5, 8):
+        x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+        bnb.lib.bnb_mi355x_set_debug(0, 32)
+        tg, te = measure(layers, x, 1)
+        bnb.lib.bnb_mi355x_set_debug(0, 0)
+        print(f"{'dotx':8s} {M:3d} {'default':>16s} {tg:9.2f} {te:9.2f} {bytes_alg(M, N, K, bs) / tg / 1e3:11.1f} {2 * M * N * K / tg / 1e6:8.2f}")
     for rpw in (1, 2, 4):
         for fl, name in FL.items():
             bnb.lib.bnb_mi355x_set_tuning(rpw, 2, 0, 0)
@@ -99,6 +108,15 @@ def main():
             err = float((run1(x1) - y_ref).norm() / y_ref.norm())
             tg, te = measure(layers, x1, 1)
             print(f"{'dot':8s} {1:3d} {f'rpw{rpw} {name}':>16s} {tg:9.2f} {te:9.2f} {bytes_alg(1, N, K, bs) / tg / 1e3:11.1f} {2 * N * K / tg / 1e6:8.2f}  relerr_vs_base={err:.1e}")
+    global CODE16
+    CODE16 = F.get_4bit_type("nf4", device="cuda")
+    for rpw in (1, 2, 4):
+        for fl, name in FL.items():
+            bnb.lib.bnb_mi355x_set_tuning(rpw, 2, 0, 0)
+            bnb.lib.bnb_mi355x_set_debug(0, fl)
+            tg, te = measure(layers, x1, 1)
+            print(f"{'dot-ptr':8s} {1:3d} {f'rpw{rpw} {name}':>16s} {tg:9.2f} {te:9.2f} {bytes_alg(1, N, K, bs) / tg / 1e3:11.1f} {2 * N * K / tg / 1e6:8.2f}")
+    CODE16 = None
     bnb.lib.bnb_mi355x_set_debug(0, 0)
     for abl, name in ((5, "empty"), (4, "weights-only"), (1, "stream-only"), (3, "no-weight-loads"), (0, "full rpw2 seg2")):
         bnb.lib.bnb_mi355x_set_debug(abl, 0)
