@@ -18,11 +18,11 @@
 //    accumulator (4 v_fma per tile), so the scale is applied exactly, in fp32, after the MFMA — the
 //    same idea as the reference's CDNA SIMT path (csrc/gemm_4bit_simt.cu:436-444), but on the
 //    matrix pipe.
-//  * Activations are the re-used operand: the workgroup's four wavefronts share one k-range and
-//    one XOR-swizzled LDS image of A[MT*16, 256] (16-byte chunk index ^ (row & 15) => conflict-free
-//    ds_read_b128 fragment reads), double-buffered, written by all 256 lanes with full-line loads.
-//  * Work decomposition = (column group of 64*NT columns) x (K slice). K slices exist only to put
-//    >= 256 workgroups on the chip when N is small. Each slice writes its fp32 partial tile to its own
+//  * Activations come straight from L2 as MFMA fragments (no LDS staging, no barriers in the loop);
+//    a 4-block register ring per wavefront keeps one full 128-B line of every row in flight.
+//  * Work decomposition = (column group of 16*NT columns) x (K range split over the workgroup's 4
+//    wavefronts, combined through LDS) x (optional cross-workgroup K slice). Cross-workgroup slices
+//    exist only to put >= 256 workgroups on the chip when N is small. Each such slice writes its fp32 partial tile to its own
 //    slab of a workspace with plain stores; a small finalize kernel adds the slabs in slice order,
 //    adds the bias and rounds once. No atomics: results are bit-reproducible run to run (the
 //    reference's test_matmul_4bit_weight_orientation demands exact equality between calls).
@@ -33,6 +33,7 @@
 
 namespace bnb {
 
+extern unsigned long long* g_dbg_buf; // gemv4.hip (profiling only)
 int g_mfma_knob0 = 0; // NT override (0 = heuristic)
 int g_mfma_knob1 = 0; // K-slice count override (0 = heuristic)
 
@@ -86,101 +87,111 @@ struct GemmArgs {
     int M, N, K;
     int bs_shift;
     int quant_type;
+    unsigned long long* dbg; // profiling only: s_memtime stamps, 8 per wavefront (NULL in production)
     int kslices;     // number of K slices (grid.y)
     int steps_total; // K / 256
 };
 
-constexpr int kKC = 256;       // k per pipeline stage (4 quantization blocks of 64)
-constexpr int kSteps = kKC / 64;
+constexpr int kKC = 256;   // K granularity of the kernel: one pipeline group = 4 quantization blocks of 64
+// Workgroup geometry is a template parameter pair: WAVES wavefronts split the workgroup's K range,
+// each keeps DEPTH 64-k blocks in flight (4 blocks x 32 B = one full 128-B line of every weight row).
+// Bytes in flight per CU = WAVES * DEPTH * 512 B * NT: (16, 4) and (8, 8) reach the ~32 KiB that the
+// dot kernel needs to cover HBM latency; (4, 4) is kept for register-heavy tiles.
 
-// LDS image of the A tile for one stage: [rows][256 k] of T, 512 B per row, 16-byte chunks XOR-swizzled by row.
-__device__ __forceinline__ int a_lds_off(int row, int chunk) { return row * 512 + ((chunk ^ (row & 15)) << 4); }
-
-template <typename T, int MT, int NT, bool NESTED>
-__global__ __launch_bounds__(256) void gemm4_mfma_kernel(const GemmArgs p) {
-    // one LDS array: [0, 32K) pair table; then 2 x A stage buffers; then nested code table
+// gemm4_mfma_kernel (v2, "wave-independent streaming"). What on-device profiling of v1 taught
+// (profiles/): at these sizes a launch is bound by per-wavefront serial instruction latency and
+// fixed costs, not by throughput. So: no workgroup barriers in the main loop, no LDS staging of the
+// activations, small code, and every workgroup small enough that N/16 of them fill the chip
+// without a second (finalize) launch whenever M <= 16.
+//   * A workgroup owns NT*16 output columns; its 4 wavefronts split the K range and combine through
+//     LDS at the end. Cross-workgroup K slices (grid.y) are only used when N/(16 NT) < ~256.
+//   * Per 64-k block a lane loads 8 packed bytes of its column (global_load_dwordx2), its fp32
+//     absmax, and - straight from L2, fragment-shaped, full 128-B lines per row over a 4-block group -
+//     the two 16-byte A fragments per M-tile. Rows >= M simply re-read row M-1: MFMA rows are
+//     independent and those rows are never stored, so no masking instructions are needed.
+//   * Four blocks are kept in flight per wavefront in a register ring (static indices: the loop is
+//     unrolled by the ring depth); waits are the compiler's counted vmcnt in issue order.
+template <typename T, int MT, int NT, bool NESTED, int kWaves, int kDepth>
+__global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_kernel(const GemmArgs p) {
     constexpr int kLutBytes = 256 * 32 * 4;
-    constexpr int kABytes = MT * 16 * 512;
+    constexpr int kThreads = kWaves * 64;
+    constexpr int TPE = kThreads / 256; // lanes cooperating on one table entry
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
-    unsigned char* abuf = smem + kLutBytes;
-    float* code2 = reinterpret_cast<float*>(smem + kLutBytes + 2 * kABytes);
+    float* red = reinterpret_cast<float*>(smem + kLutBytes); // [kWaves-1][MT][NT][64][4]
+    float* code2 = red + (kWaves - 1) * MT * NT * 256;       // nested: [256]
 
     const int tid = threadIdx.x;
+#define MFMA_STAMP(i)                                                                              \
+    if (p.dbg && (tid & 63) == 0)                                                                  \
+        p.dbg[((static_cast<long>(blockIdx.x) * gridDim.y + blockIdx.y) * kWaves + (tid >> 6)) * 8 + (i)] =          \
+            __builtin_amdgcn_s_memtime();
+    MFMA_STAMP(0)
     // first vector loads of the kernel (vmcnt retires in order): this lane's two code values
     const gfloat_ptr tbl = (gfloat_ptr)(p.code16 ? p.code16 : (p.quant_type == kNF4 ? kNF4Code : kFP4Code));
-    const float code_hi = tbl[tid >> 4];
-    const float code_lo = tbl[tid & 15];
+    const int entry = tid / TPE;
+    const float code_hi = tbl[entry >> 4];
+    const float code_lo = tbl[entry & 15];
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int ln = lane & 15; // column within an n-tile (B operand / accumulator), row within an m-tile (A operand)
     const int lg = lane >> 4; // k group
     const int N = p.N, K = p.K, M = p.M;
     const int m_base = blockIdx.z * (MT * 16);
+    const int col0 = blockIdx.x * (NT * 16);
 
-    // this wavefront's columns
-    const int col0 = (blockIdx.x * 4 + wave) * (NT * 16);
-    // this workgroup's K slice, in stages of 256 k
-    const int per = (p.steps_total + p.kslices - 1) / p.kslices;
-    const int st_begin = blockIdx.y * per;
-    const int st_end = (st_begin + per < p.steps_total) ? st_begin + per : p.steps_total;
-    const int nst = st_end - st_begin;
+    // K range of this wavefront, in blocks of 64: slice of the workgroup (grid.y), then split over the waves
+    const int blocks_total = K >> 6;
+    // (K is a multiple of 256, so every range below is a whole number of 4-block groups; ranges that
+    //  are not a multiple of kDepth end with a partly filled ring, handled by the per-block guards)
+    const int per_wg = ((blocks_total / 4 + p.kslices - 1) / p.kslices) * 4;
+    const int wg_begin = blockIdx.y * per_wg;
+    const int wg_end = (wg_begin + per_wg < blocks_total) ? wg_begin + per_wg : blocks_total;
+    const int wg_blocks = (wg_end > wg_begin) ? wg_end - wg_begin : 0;
+    const int per_wave = ((wg_blocks / 4 + kWaves - 1) / kWaves) * 4;
+    const int b_begin = wg_begin + wave * per_wave;
+    const int b_end = (b_begin + per_wave < wg_end) ? b_begin + per_wave : wg_end;
+    const int nb = (b_end > b_begin) ? b_end - b_begin : 0; // multiple of 4
 
-    const T* __restrict__ A = static_cast<const T*>(p.A);
     const uint8_t* __restrict__ B = p.B;
+    const T* __restrict__ A = static_cast<const T*>(p.A);
 
-    long rowoff[NT]; // element offset of this lane's weight row, per n-tile
+    long rowoff[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         int row = col0 + t * 16 + ln;
         row = (row < N) ? row : N - 1;
         rowoff[t] = static_cast<long>(row) * K;
     }
+    const T* arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = m_base + mt * 16 + ln;
+        m = (m < M) ? m : M - 1;
+        arow[mt] = A + static_cast<long>(m) * K + lg * 16;
+    }
 
-    struct BStage {
-        u32x2 w[kSteps][NT];
-        float s[kSteps][NT];
+    struct Stage {
+        u32x2 w[NT];
+        float s[NT];
+        u32x4 a[MT][2];
     };
-    auto load_b = [&](BStage& bs, int st) {
-        const int k0 = st * kKC;
+    auto load_block = [&](Stage& st, int blk) {
+        const int kb = blk << 6;
 #pragma unroll
-        for (int u = 0; u < kSteps; ++u) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const long e = rowoff[t] + k0 + u * 64;
-                bs.w[u][t] = *reinterpret_cast<const u32x2*>(B + ((e + lg * 16) >> 1));
-                const long blk = e >> p.bs_shift;
-                if constexpr (NESTED)
-                    bs.s[u][t] = __builtin_bit_cast(float, static_cast<uint32_t>(p.absmax8[blk]));
-                else
-                    bs.s[u][t] = p.absmax[blk];
-            }
+        for (int t = 0; t < NT; ++t) {
+            const long e = rowoff[t] + kb;
+            st.w[t] = *reinterpret_cast<const u32x2*>(B + ((e + lg * 16) >> 1));
+            const long q = e >> p.bs_shift;
+            if constexpr (NESTED)
+                st.s[t] = __builtin_bit_cast(float, static_cast<uint32_t>(p.absmax8[q]));
+            else
+                st.s[t] = p.absmax[q];
         }
-    };
-
-    // A staging: the tile is MT*16 rows x 32 chunks of 16 B; 256 lanes move MT*2 chunks each.
-    constexpr int kAChunks = MT * 2;
-    struct AStage {
-        u32x4 v[kAChunks];
-    };
-    auto load_a = [&](AStage& as, int st) {
-        const int k0 = st * kKC;
 #pragma unroll
-        for (int i = 0; i < kAChunks; ++i) {
-            const int c = tid + 256 * i;
-            const int row = c >> 5, chunk = c & 31;
-            const int m = m_base + row;
-            const T* src = A + static_cast<long>(m < M ? m : M - 1) * K + k0 + chunk * 8;
-            u32x4 v = *reinterpret_cast<const u32x4*>(src);
-            as.v[i] = (m < M) ? v : u32x4{0, 0, 0, 0};
-        }
-    };
-    auto store_a = [&](const AStage& as, int buf) {
-#pragma unroll
-        for (int i = 0; i < kAChunks; ++i) {
-            const int c = tid + 256 * i;
-            const int row = c >> 5, chunk = c & 31;
-            *reinterpret_cast<u32x4*>(abuf + buf * kABytes + a_lds_off(row, chunk)) = as.v[i];
+        for (int mt = 0; mt < MT; ++mt) {
+            st.a[mt][0] = *reinterpret_cast<const u32x4*>(arow[mt] + kb);
+            st.a[mt][1] = *reinterpret_cast<const u32x4*>(arow[mt] + kb + 8);
         }
     };
 
@@ -191,91 +202,103 @@ __global__ __launch_bounds__(256) void gemm4_mfma_kernel(const GemmArgs p) {
         for (int t = 0; t < NT; ++t)
             acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float offset = 0.0f;
-    const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
-
-    // ---- prologue: first stage in flight, then build the table under its latency
-    AStage a_cur;
-    BStage b_cur;
-    if (nst > 0) {
-        load_a(a_cur, st_begin);
-        load_b(b_cur, st_begin);
-    }
+    // ---- prologue: first ring of blocks in flight, then the table build under their latency
+    Stage ring[kDepth];
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d)
+        if (d < nb)
+            load_block(ring[d], b_begin + d);
     {
         const uint32_t pr = Mma<T>::pack(code_hi, code_lo);
         const u32x4 v = {pr, pr, pr, pr};
-        u32x4* dst = reinterpret_cast<u32x4*>(&lut[tid * 32]);
+        u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * 32]) + (tid % TPE) * (8 / TPE);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 8 / TPE; ++j)
             dst[j] = v;
-        if constexpr (NESTED) {
-            code2[tid] = p.absmax_code[tid];
-            offset = p.absmax_offset[0];
-        }
     }
-    if (nst > 0)
-        store_a(a_cur, 0);
+    float offset = 0.0f;
+    if constexpr (NESTED) {
+        if (tid < 256)
+            code2[tid] = p.absmax_code[tid];
+        offset = p.absmax_offset[0];
+    }
+    MFMA_STAMP(1)
     __syncthreads();
     const int zsh = opaque_zero();
+    MFMA_STAMP(2)
+    const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
 
-    for (int it = 0; it < nst; ++it) {
-        const int st = st_begin + it;
-        const int buf = it & 1;
-        AStage a_nxt;
-        BStage b_nxt;
-        const bool more = (it + 1 < nst);
-        if (more) {
-            load_a(a_nxt, st + 1); // issued before the B loads so that its wait leaves them in flight
-            load_b(b_nxt, st + 1);
-        }
-
-        const unsigned char* ab = abuf + buf * kABytes;
+    auto consume = [&](const Stage& st, int blk) {
 #pragma unroll
-        for (int u = 0; u < kSteps; ++u) {
-            // A fragments of this 64-k block: chunk = u*8 + g*2 + j
-            u32x4 af[MT][2];
+        for (int t = 0; t < NT; ++t) {
+            u32x4 bf[2];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t w = st.w[t][j];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    af[mt][j] = *reinterpret_cast<const u32x4*>(ab + a_lds_off(mt * 16 + ln, u * 8 + lg * 2 + j));
+                for (int q = 0; q < 4; ++q)
+                    bf[j][q] = lut[(((w >> (8 * q + zsh)) & 0xFFu) << 5) + lane_slot];
+            }
+            float scale;
+            if constexpr (NESTED) {
+                const long q = (rowoff[t] + (static_cast<long>(blk) << 6)) >> p.bs_shift;
+                const uint32_t q8 = __builtin_bit_cast(uint32_t, st.s[t]);
+                scale = __fadd_rn(__fmul_rn(code2[q8], p.absmax[q >> 8]), offset);
+            } else {
+                scale = st.s[t];
+            }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                u32x4 bf[2];
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 part = Mma<T>::run(st.a[mt][0], bf[0], f32x4{0.f, 0.f, 0.f, 0.f});
+                part = Mma<T>::run(st.a[mt][1], bf[1], part);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const uint32_t w = b_cur.w[u][t][j];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        bf[j][q] = lut[(((w >> (8 * q + zsh)) & 0xFFu) << 5) + lane_slot];
-                }
-                float scale;
-                if constexpr (NESTED) {
-                    const long blk = (rowoff[t] + static_cast<long>(st) * kKC + u * 64) >> p.bs_shift;
-                    const uint32_t q8 = __builtin_bit_cast(uint32_t, b_cur.s[u][t]);
-                    scale = __fadd_rn(__fmul_rn(code2[q8], p.absmax[blk >> 8]), offset);
-                } else {
-                    scale = b_cur.s[u][t];
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    f32x4 part = Mma<T>::run(af[mt][0], bf[0], f32x4{0.f, 0.f, 0.f, 0.f});
-                    part = Mma<T>::run(af[mt][1], bf[1], part);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        acc[mt][t][r] = fmaf(scale, part[r], acc[mt][t][r]);
-                }
+                for (int r = 0; r < 4; ++r)
+                    acc[mt][t][r] = fmaf(scale, part[r], acc[mt][t][r]);
             }
         }
+    };
 
-        if (more) {
-            store_a(a_nxt, buf ^ 1);
-            b_cur = b_nxt;
+    // ---- main loop over groups of kDepth blocks (ring indices are compile-time)
+    for (int g = 0; g < nb; g += kDepth) {
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) {
+            if (g + d < nb) {
+                consume(ring[d], b_begin + g + d);
+                if (g + kDepth + d < nb)
+                    load_block(ring[d], b_begin + g + kDepth + d);
+            }
         }
-        __syncthreads();
     }
 
-    // ---- epilogue. accumulator layout: column = lane&15, row = 4*(lane>>4) + r
+    if (p.dbg) {
+        asm volatile("" ::"v"(acc[0][0]));
+        MFMA_STAMP(3)
+    }
+    // ---- combine the wavefronts' K partials through LDS, then bias + store (or slab store)
+    if (wave > 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                *reinterpret_cast<f32x4*>(red + ((((wave - 1) * MT + mt) * NT + t) * 64 + lane) * 4) = acc[mt][t];
+    }
+    MFMA_STAMP(4)
+    __syncthreads();
+    MFMA_STAMP(5)
+    if (wave != 0)
+        return;
+#pragma unroll
+    for (int w = 0; w < kWaves - 1; ++w)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 o = *reinterpret_cast<const f32x4*>(red + (((w * MT + mt) * NT + t) * 64 + lane) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[mt][t][r] += o[r];
+            }
+
     T* __restrict__ out = static_cast<T*>(p.out);
     const T* __restrict__ bias = static_cast<const T*>(p.bias);
 #pragma unroll
@@ -299,6 +322,8 @@ __global__ __launch_bounds__(256) void gemm4_mfma_kernel(const GemmArgs p) {
             }
         }
     }
+    MFMA_STAMP(6)
+#undef MFMA_STAMP
 }
 
 // out = T(sum_s ws[s] + bias), slabs added in slice order (deterministic)
@@ -381,7 +406,10 @@ float* get_internal_workspace(size_t bytes, hipStream_t stream) {
 
 struct Plan {
     int mt, nt, ks;
+    int cfg; // 0: 4 waves x 4 blocks, 1: 8 x 8, 2: 16 x 4, 3: 8 x 4, 4: 4 x 8
 };
+
+constexpr int kCfgWaves[5] = {4, 8, 16, 8, 4};
 
 // Tile shape and K-slice count for a problem: a pure function of (M, N, K) and the tuning knobs,
 // shared by the launch and by the workspace-size query.
@@ -393,38 +421,65 @@ Plan make_plan(int M, int N, int K) {
         nt = (pl.mt >= 3) ? 2 : 1;
     if (nt != 1 && nt != 2 && nt != 4)
         nt = 1;
-    if ((pl.mt >= 3 && nt == 4))
+    if (pl.mt >= 3 && nt == 4)
         nt = 2;
     pl.nt = nt;
-    const int steps = K / kKC;
-    const int gx = (N + 64 * nt - 1) / (64 * nt);
+    const int groups = K / kKC; // units of 4 blocks
+    const int gx = (N + 16 * nt - 1) / (16 * nt);
     const int gz = (M + pl.mt * 16 - 1) / (pl.mt * 16);
-    int ks = g_mfma_knob1;
+    int ks = g_mfma_knob1 % 100;
+    int cfg = g_mfma_knob1 / 100;
+    if (g_mfma_knob1 == 0)
+        cfg = (pl.mt == 1 && nt <= 2) ? 2 : 0;
+    if (cfg < 0 || cfg > 4)
+        cfg = 0;
+    if (cfg == 2 && !(pl.mt == 1 && nt <= 2))
+        cfg = 0; // 1024-thread workgroups only fit the register budget of the smallest tiles
+    if ((cfg == 1 || cfg == 4) && pl.mt * nt > 4)
+        cfg = (cfg == 1) ? 3 : 0;
+    pl.cfg = cfg;
+    const int kWaves = kCfgWaves[cfg];
     if (ks == 0)
-        ks = (512 + gx * gz - 1) / (gx * gz); // aim for ~2 workgroups per CU
-    if (ks > steps)
-        ks = steps;
+        ks = (gx * gz >= 192) ? 1 : (256 + gx * gz - 1) / (gx * gz); // fill the 256 CUs once
+    const int max_ks = groups / kWaves > 0 ? groups / kWaves : 1;   // keep >= 1 group per wavefront
+    if (ks > max_ks)
+        ks = max_ks;
     if (ks < 1)
         ks = 1;
-    const int per = (steps + ks - 1) / ks;
-    pl.ks = (steps + per - 1) / per; // every slice non-empty
+    const int per = (groups + ks - 1) / ks;
+    pl.ks = (groups + per - 1) / per; // every slice non-empty
     return pl;
 }
 
-template <typename T, int MT, int NT> void launch_mfma(GemmArgs& p, hipStream_t stream) {
-    const int cols_per_wg = 64 * NT;
-    const int gx = (p.N + cols_per_wg - 1) / cols_per_wg;
+template <typename T, int MT, int NT, int WAVES, int DEPTH> void launch_mfma_cfg(GemmArgs& p, hipStream_t stream) {
+    const int gx = (p.N + 16 * NT - 1) / (16 * NT);
     const int gz = (p.M + MT * 16 - 1) / (MT * 16);
-    size_t smem = 256 * 32 * 4 + 2 * (MT * 16 * 512) + 1024;
+    const size_t smem = 256 * 32 * 4 + static_cast<size_t>(WAVES - 1) * MT * NT * 256 * 4 + 1024;
     dim3 grid(gx, p.kslices, gz);
-    auto kern = p.absmax8 ? gemm4_mfma_kernel<T, MT, NT, true> : gemm4_mfma_kernel<T, MT, NT, false>;
+    auto kern = p.absmax8 ? gemm4_mfma_kernel<T, MT, NT, true, WAVES, DEPTH> : gemm4_mfma_kernel<T, MT, NT, false, WAVES, DEPTH>;
     static bool attr_set[2] = {false, false};
     if (smem > 64 * 1024 && !attr_set[p.absmax8 ? 1 : 0]) {
         BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
         attr_set[p.absmax8 ? 1 : 0] = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p);
+}
+
+template <typename T, int MT, int NT> void launch_mfma(GemmArgs& p, int cfg, hipStream_t stream) {
+    if constexpr (MT == 1 && NT <= 2) {
+        if (cfg == 2)
+            return launch_mfma_cfg<T, MT, NT, 16, 4>(p, stream);
+    }
+    if constexpr (MT * NT <= 4) {
+        if (cfg == 1)
+            return launch_mfma_cfg<T, MT, NT, 8, 8>(p, stream);
+        if (cfg == 4)
+            return launch_mfma_cfg<T, MT, NT, 4, 8>(p, stream);
+    }
+    if (cfg == 3)
+        return launch_mfma_cfg<T, MT, NT, 8, 4>(p, stream);
+    return launch_mfma_cfg<T, MT, NT, 4, 4>(p, stream);
 }
 
 template <typename T> void dispatch_mfma(GemmArgs& p, float* ws, size_t ws_bytes, hipStream_t stream) {
@@ -450,11 +505,11 @@ template <typename T> void dispatch_mfma(GemmArgs& p, float* ws, size_t ws_bytes
 
 #define BNB_MFMA_CASE(MTV, NTV)                                                                    \
     if (mt == MTV && nt == NTV) {                                                                  \
-        launch_mfma<T, MTV, NTV>(p, stream);                                                       \
+        launch_mfma<T, MTV, NTV>(p, pl.cfg, stream);                                               \
     } else
     BNB_MFMA_CASE(1, 1) BNB_MFMA_CASE(1, 2) BNB_MFMA_CASE(1, 4) BNB_MFMA_CASE(2, 1) BNB_MFMA_CASE(2, 2)
     BNB_MFMA_CASE(2, 4) BNB_MFMA_CASE(3, 1) BNB_MFMA_CASE(3, 2) BNB_MFMA_CASE(4, 1) BNB_MFMA_CASE(4, 2) {
-        launch_mfma<T, 1, 1>(p, stream);
+        launch_mfma<T, 1, 1>(p, pl.cfg, stream);
     }
 #undef BNB_MFMA_CASE
     BNB_CHECK_LAUNCH();
@@ -500,6 +555,7 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
     p.out = out;
     p.bias = bias;
     p.ws = nullptr;
+    p.dbg = g_dbg_buf;
     p.M = M;
     p.N = N;
     p.K = K;

@@ -15,7 +15,7 @@ if [[ "$WHAT" == *" bench "* ]]; then
   echo "=== bench"; timeout 600 python bench.py --steps 1280 --warmup 128 2>&1 | grep -v amdgpu.ids | tail -2 | tee $OUT/bench_n1.json
 fi
 if [[ "$WHAT" == *" sweep "* ]]; then
-  echo "=== sweep"; timeout 1200 python tools/sweep.py > $OUT/sweep.txt 2>&1; grep -v amdgpu.ids $OUT/sweep.txt | tail -120
+  echo "=== sweep"; timeout 1200 python tools/sweep.py --mfma-only > $OUT/sweep.txt 2>&1; grep -v amdgpu.ids $OUT/sweep.txt | tail -120
 fi
 if [[ "$WHAT" == *" sweepquick "* ]]; then
   echo "=== sweep quick"; timeout 900 python tools/sweep.py --quick --dot-only > $OUT/sweep.txt 2>&1; grep -v amdgpu.ids $OUT/sweep.txt | tail -80

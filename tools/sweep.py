@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--bs", type=int, default=64)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--dot-only", action="store_true")
+    ap.add_argument("--mfma-only", action="store_true")
     a = ap.parse_args()
     N, K, bs = a.n, a.k, a.bs
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -86,6 +87,8 @@ def main():
     print(f"# N={N} K={K} bs={bs} layers={L} ({L * bytes_alg(1, N, K, bs) / 1e6:.0f} MB rotated)")
     print(f"{'kernel':8s} {'M':>3s} {'knobs':>12s} {'graph_us':>9s} {'evpair_us':>9s} {'GB/s(graph)':>11s} {'TFLOP/s':>8s}")
     FL = {0: "base", 4: "w8", 64: "w16"}
+    if a.mfma_only:
+        FL = {}
     x1 = torch.randn(1, K, device="cuda", generator=g).bfloat16()
     # correctness reference for the structural variants (they must not change results beyond rounding)
     bnb.lib.bnb_mi355x_set_debug(0, 0)
@@ -95,7 +98,7 @@ def main():
         return hip._gemm_4bit_fused(xx, q0, st0.shape, st0.absmax, st0.blocksize, st0.quant_type, None, None, None, None, kernel=1).float()
 
     y_ref = run1(x1)
-    for M in (1, 2, 3, 4, 5, 8):
+    for M in (() if a.mfma_only else (1, 2, 3, 4, 5, 8)):
         x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
         bnb.lib.bnb_mi355x_set_debug(0, 32)
         tg, te = measure(layers, x, 1)
@@ -118,7 +121,7 @@ def main():
             print(f"{'dot-ptr':8s} {1:3d} {f'rpw{rpw} {name}':>16s} {tg:9.2f} {te:9.2f} {bytes_alg(1, N, K, bs) / tg / 1e3:11.1f} {2 * N * K / tg / 1e6:8.2f}")
     CODE16 = None
     bnb.lib.bnb_mi355x_set_debug(0, 0)
-    for abl, name in ((5, "empty"), (4, "weights-only"), (1, "stream-only"), (3, "no-weight-loads"), (0, "full rpw2 seg2")):
+    for abl, name in (() if a.mfma_only else ((5, "empty"), (4, "weights-only"), (1, "stream-only"), (3, "no-weight-loads"), (0, "full rpw2 seg2"))):
         bnb.lib.bnb_mi355x_set_debug(abl, 0)
         bnb.lib.bnb_mi355x_set_tuning(2, 2, 0, 0)
         tg, te = measure(layers, x1, 1)
@@ -136,19 +139,30 @@ def main():
     bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
     if a.dot_only:
         return
-    Ms = [1, 8, 16, 64] if a.quick else [1, 2, 4, 5, 8, 16, 32, 48, 64]
+    Ms = [1, 8, 16, 64] if a.quick else [1, 4, 8, 16, 32, 64]
+    CFG = {0: "w4d4", 1: "w8d8", 2: "w16d4", 3: "w8d4", 4: "w4d8"}
     for M in Ms:
         x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+        mt = (M + 15) // 16
+        bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+        tg, te = measure(layers, x, 2)
+        print(f"{'mfma':8s} {M:3d} {'auto':>14s} {tg:9.2f} {te:9.2f} {bytes_alg(M, N, K, bs) / tg / 1e3:11.1f} {2 * M * N * K / tg / 1e6:8.2f}")
+        if a.quick:
+            continue
         for nt in (1, 2, 4):
-            mt = (M + 15) // 16
-            if (mt, nt) in ((3, 4), (4, 4)):
+            if mt >= 3 and nt == 4:
                 continue
-            for ks in ((0,) if a.quick else (0, 1, 2, 4, 8, 16)):
-                if ks > K // 256:
+            for cfg, cname in CFG.items():
+                if cfg == 2 and not (mt == 1 and nt <= 2):
                     continue
-                bnb.lib.bnb_mi355x_set_tuning(0, 0, nt, ks)
-                tg, te = measure(layers, x, 2)
-                print(f"{'mfma':8s} {M:3d} {f'nt{nt} ks{ks}':>12s} {tg:9.2f} {te:9.2f} {bytes_alg(M, N, K, bs) / tg / 1e3:11.1f} {2 * M * N * K / tg / 1e6:8.2f}")
+                if cfg in (1, 4) and mt * nt > 4:
+                    continue
+                for ks in (1, 2):
+                    if ks == 2 and (N // (16 * nt)) >= 192:
+                        continue
+                    bnb.lib.bnb_mi355x_set_tuning(0, 0, nt, cfg * 100 + ks)
+                    tg, te = measure(layers, x, 2)
+                    print(f"{'mfma':8s} {M:3d} {f'nt{nt} {cname} ks{ks}':>14s} {tg:9.2f} {te:9.2f} {bytes_alg(M, N, K, bs) / tg / 1e3:11.1f} {2 * M * N * K / tg / 1e6:8.2f}")
     bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
     # standalone quantize / dequantize streams (C1 shapes)
     W = (torch.randn(4096, 4096, device="cuda") ).half()

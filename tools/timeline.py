@@ -19,14 +19,23 @@ for _ in range(L):
     W = (torch.randn(N, K, device="cuda", generator=g) / K**0.5).bfloat16()
     layers.append(F.quantize_4bit(W, quant_type="nf4"))
     del W
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--kernel", type=int, default=1)
+ap.add_argument("--nt", type=int, default=0)
+ap.add_argument("--cfgks", type=int, default=0)
+args = ap.parse_args()
+bnb.lib.bnb_mi355x_set_tuning(0, 0, args.nt, args.cfgks)
+if args.kernel == 1:
+    bnb.lib.bnb_mi355x_set_debug(0, 32)
 for M in (1, 8):
     x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
-    nw = N // 2
+    nw = N // 2 if args.kernel == 1 else 4096 * 4
     buf = torch.zeros(nw * 8, dtype=torch.int64, device="cuda")
 
     def step(i):
         q, st = layers[i % L]
-        return hip._gemm_4bit_fused(x, q, st.shape, st.absmax, st.blocksize, st.quant_type, None, None, None, None, kernel=1)
+        return hip._gemm_4bit_fused(x, q, st.shape, st.absmax, st.blocksize, st.quant_type, None, None, None, None, kernel=args.kernel)
 
     for i in range(L):
         step(i)
@@ -37,6 +46,15 @@ for M in (1, 8):
     torch.cuda.synchronize()
     bnb.lib.bnb_mi355x_set_stamp_buffer(None)
     t = buf.view(nw, 8).cpu().double()
+    t = t[t[:, 0] > 0]
+    nw = t.shape[0]
+    if args.kernel == 2:
+        names = ["start", "loads issued+lut", "after barrier", "loop done", "partials written", "after 2nd barrier", "end(wave0)"]
+        d = t[:, 1:6] - t[:, 0:5]
+        print(f"M={M} mfma: per-wave deltas median (ticks) over {nw} wavefronts: " + ", ".join(f"{names[i + 1]}: {d[:, i].median().item():.0f}" for i in range(5)))
+        w0 = t[t[:, 6] > 0]
+        print(f"   wave0 total start->end median {(w0[:, 6] - w0[:, 0]).median().item():.0f}, max {(w0[:, 6] - w0[:, 0]).max().item():.0f}; any-wave start->partials max {(t[:, 4] - t[:, 0]).max().item():.0f}")
+        continue
     t0 = t[:, 0].min()
     rel = t[:, :6] - t0
     names = ["start", "lut+x written", "after barrier", "all loads landed", "compute done", "end"]
