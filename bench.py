@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--quant-type", default="nf4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue steps eagerly instead of replaying a hipGraph")
+    ap.add_argument("--sweep", action="store_true", help="also time M = 1..64 at N = K = 4096 (headline sweep)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -218,22 +219,63 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline leg: per-launch kernel time of the dominant kernel, HIP events on the launch stream
-    n_ev = min(args.steps, 512)
+    # ---- roofline leg: launch-to-launch time of the dominant kernel, HIP events on the launch stream.
+    # Primary figure: events bracket whole hipGraph replays of GRAPH_CHUNK back-to-back launches
+    # (HBM-resident rotation), divided by the launch count - i.e. what one launch costs in a dependent
+    # stream, boundary included. Secondary: per-launch event brackets around eager launches (these
+    # also include the event-record commands, so they over-state the kernel by ~3 us).
+    def per_launch_us(m_rows, reps=10):
+        xm = x if m_rows == M else torch.randn(m_rows, K, device=device).to(torch.bfloat16)
+        outs = torch.empty(GRAPH_CHUNK, m_rows, N, device=device, dtype=torch.bfloat16)
+
+        def chunk():
+            for j in range(GRAPH_CHUNK):
+                q, st = layers[j % LAYERS]
+                hip._gemm_4bit_fused(xm, q, st.shape, st.absmax, st.blocksize, st.quant_type, None, None, None, None,
+                                     out=outs[j])
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            chunk()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            chunk()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (reps * GRAPH_CHUNK) * 1e3
+
+    kernel_us = per_launch_us(M)
+    achieved = nbytes_step / (kernel_us * 1e-6) / 1e9
+
+    n_ev = min(args.steps, 256)
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
-    run_chunk_eager(0, buckets[0])
-    torch.cuda.synchronize()
     for i in range(n_ev):
         starts[i].record()
         run_step(i, buckets[0][i % GRAPH_CHUNK])
         ends[i].record()
     torch.cuda.synchronize()
     per_launch_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
-    # trimmed mean (drop the top 5%: host hiccups between record and launch land inside the bracket)
-    kept = per_launch_ms[: max(1, int(0.95 * n_ev))]
-    kernel_ms = sum(kept) / len(kept)
-    achieved = nbytes_step / (kernel_ms * 1e-3) / 1e9
+    kept = per_launch_ms[: max(1, int(0.9 * n_ev))]
+    kernel_us_events = sum(kept) / len(kept) * 1e3
+
+    sweep = None
+    if args.sweep and rank == 0:
+        sweep = []
+        for m_rows in (1, 2, 4, 8, 16, 32, 64):
+            t_us = per_launch_us(m_rows, reps=5)
+            sweep.append({"M": m_rows, "us_per_launch": round(t_us, 2),
+                          "GBps": round(algorithmic_bytes(m_rows, N, K, bs) / t_us / 1e3, 1),
+                          "TFLOPs": round(2 * m_rows * N * K / t_us / 1e6, 2)})
 
     if rank == 0:
         total_steps = args.steps * world
@@ -269,10 +311,14 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None,
-                "kernel_us": round(kernel_ms * 1e3, 3),
-                "method": f"mean of {len(kept)} per-launch HIP-event brackets (eager launches, HBM-resident rotation)",
+                "kernel_us": round(kernel_us, 3),
+                "kernel_us_event_brackets": round(kernel_us_events, 3),
+                "method": f"HIP events around 10 hipGraph replays of {GRAPH_CHUNK} back-to-back launches over "
+                          f"{LAYERS} distinct HBM-resident layers, divided by the launch count",
             },
         }
+        if sweep is not None:
+            line["headline_sweep_N4096_K4096"] = sweep
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(M, N, K, bs, qt)

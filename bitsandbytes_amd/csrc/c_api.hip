@@ -42,7 +42,7 @@ namespace {
 // M at or below which the wave64 dot kernel is used; above it the MFMA kernel (when supported).
 // MI355X-specific replacement for the reference's per-arch heuristic
 // (bitsandbytes/backends/cuda/ops.py:814-843), calibrated on gfx950 — see DESIGN.md.
-constexpr int kDotMaxM = 4;
+constexpr int kDotMaxM = 2;
 
 bool route_to_mfma(int kernel, int dtype, const void* A, const uint8_t* B, int M, int N, int K, int blocksize) {
     if (kernel == 1)

@@ -34,6 +34,7 @@
 namespace bnb {
 
 extern unsigned long long* g_dbg_buf; // gemv4.hip (profiling only)
+extern int g_dot_ablate;               // gemv4.hip (profiling only): 11 / 12 select the MFMA ablations
 int g_mfma_knob0 = 0; // NT override (0 = heuristic)
 int g_mfma_knob1 = 0; // K-slice count override (0 = heuristic)
 
@@ -88,6 +89,7 @@ struct GemmArgs {
     int bs_shift;
     int quant_type;
     unsigned long long* dbg; // profiling only: s_memtime stamps, 8 per wavefront (NULL in production)
+    int ablate;              // profiling only: 1 = skip decode + MFMA (stream only), 2 = also skip the A loads
     int kslices;     // number of K slices (grid.y)
     int steps_total; // K / 256
 };
@@ -188,6 +190,8 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_kernel(const GemmArgs 
             else
                 st.s[t] = p.absmax[q];
         }
+        if (p.ablate == 2)
+            return;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             st.a[mt][0] = *reinterpret_cast<const u32x4*>(arow[mt] + kb);
@@ -229,6 +233,16 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_kernel(const GemmArgs 
     const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
 
     auto consume = [&](const Stage& st, int blk) {
+        if (p.ablate != 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                uint32_t v = st.w[t][0] ^ st.w[t][1];
+                if (p.ablate == 1)
+                    v ^= st.a[0][0][0] ^ st.a[0][1][3];
+                acc[0][t][0] += __builtin_bit_cast(float, (v & 0x007fffffu) | 0x3f800000u) * st.s[t];
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             u32x4 bf[2];
@@ -326,6 +340,232 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_kernel(const GemmArgs 
 #undef MFMA_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm4_mfma_dma_kernel (v3): same decomposition as v2 for NT = 1, but the weights travel
+// HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) in FULL 128-byte lines: on-device ablation of v2
+// (profiles/) showed that fetching a row's line in four 32-byte pieces (what the MFMA B-fragment
+// layout asks for) streams the same bytes ~2x slower than the dot kernel's 1-KiB-per-instruction
+// pattern. Here one DMA instruction moves 8 rows x 128 B; two of them bring the wavefront's whole
+// 256-k chunk of its 16 columns. The image is lane-linear in LDS (hardware constraint), so the
+// bank swizzle is applied on the SOURCE side: lane (r, s) fetches 16-byte chunk s ^ r of row r, which
+// permutes within one 128-B line (coalescing untouched) and makes the per-block 8-byte fragment
+// reads (ds_read_b64 at chunk (2b + g/2) ^ (n & 7)) conflict-free. The four fp32 absmax of a chunk
+// are one 16-byte load per lane; A fragments still come straight from L2.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* dma_src_t;
+typedef __attribute__((address_space(3))) void* dma_dst_t;
+
+template <typename T, int MT, bool NESTED, int kWaves>
+__global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmArgs p) {
+    constexpr int kLutBytes = 256 * 32 * 4;
+    constexpr int kThreads = kWaves * 64;
+    constexpr int TPE = kThreads / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
+    unsigned char* wring = smem + kLutBytes;                                          // [kWaves][2048]
+    float* red = reinterpret_cast<float*>(smem + kLutBytes + kWaves * 2048);           // [kWaves-1][MT][64][4]
+    float* code2 = red + (kWaves - 1) * MT * 256;                                      // nested: [256]
+
+    const int tid = threadIdx.x;
+    const gfloat_ptr tbl = (gfloat_ptr)(p.code16 ? p.code16 : (p.quant_type == kNF4 ? kNF4Code : kFP4Code));
+    const int entry = tid / TPE;
+    const float code_hi = tbl[entry >> 4];
+    const float code_lo = tbl[entry & 15];
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, lg = lane >> 4;
+    const int N = p.N, K = p.K, M = p.M;
+    const int m_base = blockIdx.z * (MT * 16);
+    const int col0 = blockIdx.x * 16;
+
+    // chunk (256 k) range of this wavefront
+    const int chunks_total = K >> 8;
+    const int per_wg = (chunks_total + p.kslices - 1) / p.kslices;
+    const int wg_begin = blockIdx.y * per_wg;
+    const int wg_end = (wg_begin + per_wg < chunks_total) ? wg_begin + per_wg : chunks_total;
+    const int wg_chunks = (wg_end > wg_begin) ? wg_end - wg_begin : 0;
+    const int per_wave = (wg_chunks + kWaves - 1) / kWaves;
+    const int c_begin = wg_begin + wave * per_wave;
+    const int c_end = (c_begin + per_wave < wg_end) ? c_begin + per_wave : wg_end;
+
+    // DMA source: lane (r8, s8) of instruction h fetches chunk s8 ^ r8 of row col0 + 8h + r8
+    const int r8 = lane >> 3, s8 = lane & 7;
+    const uint8_t* dsrc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int row = col0 + h * 8 + r8;
+        row = (row < N) ? row : N - 1;
+        dsrc[h] = p.B + static_cast<long>(row) * (K >> 1) + ((s8 ^ r8) << 4);
+    }
+    unsigned char* wbuf = wring + wave * 2048;
+    // fragment read offsets inside the wavefront's 2 KiB image (block b adds its own chunk index)
+    const int rd_row = (ln >> 3) * 1024 + (ln & 7) * 128;
+    const int rd_sw = ln & 7;
+
+    int rown = col0 + ln;
+    rown = (rown < N) ? rown : N - 1;
+    const long rowk = static_cast<long>(rown) * K;
+    const T* __restrict__ A = static_cast<const T*>(p.A);
+    const T* arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = m_base + mt * 16 + ln;
+        m = (m < M) ? m : M - 1;
+        arow[mt] = A + static_cast<long>(m) * K + lg * 16;
+    }
+
+    struct Stage {
+        float s[4];
+        u32x4 a[4][MT][2];
+    };
+    auto issue_chunk = [&](Stage& st, int c) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            __builtin_amdgcn_global_load_lds((dma_src_t)(dsrc[h] + static_cast<long>(c) * 128), (dma_dst_t)(wbuf + h * 1024),
+                                             16, 0, 0);
+        const long e = rowk + (static_cast<long>(c) << 8);
+        if (p.bs_shift == 6) {
+            if constexpr (NESTED) {
+                const uint32_t q4 = *reinterpret_cast<const uint32_t*>(p.absmax8 + (e >> 6));
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    st.s[b] = __builtin_bit_cast(float, (q4 >> (8 * b)) & 0xFFu);
+            } else {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.absmax + (e >> 6));
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    st.s[b] = s4[b];
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const long q = (e + b * 64) >> p.bs_shift;
+                if constexpr (NESTED)
+                    st.s[b] = __builtin_bit_cast(float, static_cast<uint32_t>(p.absmax8[q]));
+                else
+                    st.s[b] = p.absmax[q];
+            }
+        }
+        const int kb = c << 8;
+        // A rows >= M are never stored and MFMA rows are independent, so those lanes skip the load
+        // altogether (exec-masked): the fragment loads then cost M/16 of a full tile in L1/TA time.
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (m_base + mt * 16 + ln < M) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    st.a[b][mt][0] = *reinterpret_cast<const u32x4*>(arow[mt] + kb + b * 64);
+                    st.a[b][mt][1] = *reinterpret_cast<const u32x4*>(arow[mt] + kb + b * 64 + 8);
+                }
+            }
+        }
+    };
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Stage st;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            st.a[b][mt][0] = st.a[b][mt][1] = u32x4{0, 0, 0, 0}; // rows >= M stay zero (finite) in the skipped lanes
+    if (c_begin < c_end)
+        issue_chunk(st, c_begin);
+    {
+        const uint32_t pr = Mma<T>::pack(code_hi, code_lo);
+        const u32x4 v = {pr, pr, pr, pr};
+        u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * 32]) + (tid % TPE) * (8 / TPE);
+#pragma unroll
+        for (int j = 0; j < 8 / TPE; ++j)
+            dst[j] = v;
+    }
+    float offset = 0.0f;
+    if constexpr (NESTED) {
+        if (tid < 256)
+            code2[tid] = p.absmax_code[tid];
+        offset = p.absmax_offset[0];
+    }
+    __syncthreads();
+    const int zsh = opaque_zero();
+    const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
+
+    for (int c = c_begin; c < c_end; ++c) {
+        if (c > c_begin)
+            issue_chunk(st, c);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA'd image and this chunk's register loads
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int cidx = (2 * b + (lg >> 1)) ^ rd_sw;
+            const u32x2 w2 = *reinterpret_cast<const u32x2*>(wbuf + rd_row + (cidx << 4) + (lg & 1) * 8);
+            u32x4 bf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t w = w2[j];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    bf[j][q] = lut[(((w >> (8 * q + zsh)) & 0xFFu) << 5) + lane_slot];
+            }
+            float scale;
+            if constexpr (NESTED) {
+                const long q = (rowk + (static_cast<long>(c) << 8) + b * 64) >> p.bs_shift;
+                const uint32_t q8 = __builtin_bit_cast(uint32_t, st.s[b]);
+                scale = __fadd_rn(__fmul_rn(code2[q8], p.absmax[q >> 8]), offset);
+            } else {
+                scale = st.s[b];
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 part = Mma<T>::run(st.a[b][mt][0], bf[0], f32x4{0.f, 0.f, 0.f, 0.f});
+                part = Mma<T>::run(st.a[b][mt][1], bf[1], part);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[mt][r] = fmaf(scale, part[r], acc[mt][r]);
+            }
+        }
+    }
+
+    if (wave > 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            *reinterpret_cast<f32x4*>(red + (((wave - 1) * MT + mt) * 64 + lane) * 4) = acc[mt];
+    }
+    __syncthreads();
+    if (wave != 0)
+        return;
+#pragma unroll
+    for (int w = 0; w < kWaves - 1; ++w)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(red + ((w * MT + mt) * 64 + lane) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[mt][r] += o[r];
+        }
+    T* __restrict__ out = static_cast<T*>(p.out);
+    const T* __restrict__ bias = static_cast<const T*>(p.bias);
+    const int col = col0 + ln;
+    if (col >= N)
+        return;
+    const float bv = (bias && p.kslices == 1) ? static_cast<float>(bias[col]) : 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m_base + mt * 16 + lg * 4 + r;
+            if (m >= M)
+                continue;
+            const long o = static_cast<long>(m) * N + col;
+            if (p.kslices == 1)
+                out[o] = static_cast<T>(acc[mt][r] + bv);
+            else
+                p.ws[static_cast<long>(blockIdx.y) * M * N + o] = acc[mt][r];
+        }
+    }
+}
+
 // out = T(sum_s ws[s] + bias), slabs added in slice order (deterministic)
 template <typename T>
 __global__ __launch_bounds__(256) void gemm4_finalize_kernel(const float* __restrict__ ws, const T* __restrict__ bias,
@@ -406,10 +646,11 @@ float* get_internal_workspace(size_t bytes, hipStream_t stream) {
 
 struct Plan {
     int mt, nt, ks;
-    int cfg; // 0: 4 waves x 4 blocks, 1: 8 x 8, 2: 16 x 4, 3: 8 x 4, 4: 4 x 8
+    int cfg; // v2 register-ring kernel: 0: 4 waves x 4 blocks, 1: 8 x 8, 2: 16 x 4, 3: 8 x 4, 4: 4 x 8
+             // v3 LDS-DMA kernel (NT = 1): 5: 16 waves, 6: 8 waves
 };
 
-constexpr int kCfgWaves[5] = {4, 8, 16, 8, 4};
+constexpr int kCfgWaves[7] = {4, 8, 16, 8, 4, 16, 8};
 
 // Tile shape and K-slice count for a problem: a pure function of (M, N, K) and the tuning knobs,
 // shared by the launch and by the workspace-size query.
@@ -430,9 +671,13 @@ Plan make_plan(int M, int N, int K) {
     int ks = g_mfma_knob1 % 100;
     int cfg = g_mfma_knob1 / 100;
     if (g_mfma_knob1 == 0)
-        cfg = (pl.mt == 1 && nt <= 2) ? 2 : 0;
-    if (cfg < 0 || cfg > 4)
+        cfg = (nt == 1 && pl.mt == 1) ? 5 : (nt == 1 && pl.mt == 2) ? 6 : 0;
+    if (cfg < 0 || cfg > 6)
         cfg = 0;
+    if (cfg >= 5 && (nt != 1 || pl.mt > 2))
+        cfg = 0;
+    if (cfg == 5 && pl.mt != 1)
+        cfg = 6;
     if (cfg == 2 && !(pl.mt == 1 && nt <= 2))
         cfg = 0; // 1024-thread workgroups only fit the register budget of the smallest tiles
     if ((cfg == 1 || cfg == 4) && pl.mt * nt > 4)
@@ -466,7 +711,30 @@ template <typename T, int MT, int NT, int WAVES, int DEPTH> void launch_mfma_cfg
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p);
 }
 
+template <typename T, int MT, int WAVES> void launch_mfma_dma(GemmArgs& p, hipStream_t stream) {
+    const int gx = (p.N + 15) / 16;
+    const int gz = (p.M + MT * 16 - 1) / (MT * 16);
+    const size_t smem = 256 * 32 * 4 + static_cast<size_t>(WAVES) * 2048 + static_cast<size_t>(WAVES - 1) * MT * 1024 + 1024;
+    dim3 grid(gx, p.kslices, gz);
+    auto kern = p.absmax8 ? gemm4_mfma_dma_kernel<T, MT, true, WAVES> : gemm4_mfma_dma_kernel<T, MT, false, WAVES>;
+    static bool attr_set[2] = {false, false};
+    if (smem > 64 * 1024 && !attr_set[p.absmax8 ? 1 : 0]) {
+        BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
+        attr_set[p.absmax8 ? 1 : 0] = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p);
+}
+
 template <typename T, int MT, int NT> void launch_mfma(GemmArgs& p, int cfg, hipStream_t stream) {
+    if constexpr (NT == 1 && MT <= 2) {
+        if constexpr (MT == 1) {
+            if (cfg == 5)
+                return launch_mfma_dma<T, MT, 16>(p, stream);
+        }
+        if (cfg == 5 || cfg == 6)
+            return launch_mfma_dma<T, MT, 8>(p, stream);
+    }
     if constexpr (MT == 1 && NT <= 2) {
         if (cfg == 2)
             return launch_mfma_cfg<T, MT, NT, 16, 4>(p, stream);
@@ -556,6 +824,7 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
     p.bias = bias;
     p.ws = nullptr;
     p.dbg = g_dbg_buf;
+    p.ablate = g_dot_ablate >= 10 ? g_dot_ablate - 10 : 0;
     p.M = M;
     p.N = N;
     p.K = K;

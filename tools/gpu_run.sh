@@ -12,13 +12,13 @@ if [[ "$WHAT" == *" tests "* ]]; then
   echo "=== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; tail -12 $OUT/pytest_gpu.log
 fi
 if [[ "$WHAT" == *" bench "* ]]; then
-  echo "=== bench"; timeout 600 python bench.py --steps 1280 --warmup 128 2>&1 | grep -v amdgpu.ids | tail -2 | tee $OUT/bench_n1.json
+  echo "=== bench"; timeout 600 python bench.py --steps 6400 --warmup 640 --sweep 2>&1 | grep -v amdgpu.ids | tail -2 | tee $OUT/bench_n1.json
 fi
 if [[ "$WHAT" == *" sweep "* ]]; then
   echo "=== sweep"; timeout 1200 python tools/sweep.py --mfma-only > $OUT/sweep.txt 2>&1; grep -v amdgpu.ids $OUT/sweep.txt | tail -120
 fi
 if [[ "$WHAT" == *" sweepquick "* ]]; then
-  echo "=== sweep quick"; timeout 900 python tools/sweep.py --quick --dot-only > $OUT/sweep.txt 2>&1; grep -v amdgpu.ids $OUT/sweep.txt | tail -80
+  echo "=== sweep quick"; timeout 900 python tools/sweep.py --quick --mfma-only > $OUT/sweep.txt 2>&1; grep -v amdgpu.ids $OUT/sweep.txt | tail -80
 fi
 if [[ "$WHAT" == *" prof "* ]]; then
   echo "=== rocprof"; R=$PWD; cd /tmp

@@ -139,8 +139,16 @@ def main():
     bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
     if a.dot_only:
         return
+    for abl, name in ((11, "stream+A"), (12, "stream only"), (0, "full")):
+        x = torch.randn(8, K, device="cuda", generator=g).bfloat16()
+        for cfgks in (501, 601, 201):
+            bnb.lib.bnb_mi355x_set_debug(abl, 0)
+            bnb.lib.bnb_mi355x_set_tuning(0, 0, 1, cfgks)
+            tg, te = measure(layers, x, 2)
+            print(f"{'mfma-abl':8s} {8:3d} {f'{name} cfg{cfgks}':>20s} {tg:9.2f} {te:9.2f} {bytes_alg(8, N, K, bs) / tg / 1e3:11.1f}")
+    bnb.lib.bnb_mi355x_set_debug(0, 0)
     Ms = [1, 8, 16, 64] if a.quick else [1, 4, 8, 16, 32, 64]
-    CFG = {0: "w4d4", 1: "w8d8", 2: "w16d4", 3: "w8d4", 4: "w4d8"}
+    CFG = {0: "w4d4", 2: "w16d4", 3: "w8d4", 5: "dma16", 6: "dma8"}
     for M in Ms:
         x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
         mt = (M + 15) // 16
@@ -149,13 +157,15 @@ def main():
         print(f"{'mfma':8s} {M:3d} {'auto':>14s} {tg:9.2f} {te:9.2f} {bytes_alg(M, N, K, bs) / tg / 1e3:11.1f} {2 * M * N * K / tg / 1e6:8.2f}")
         if a.quick:
             continue
-        for nt in (1, 2, 4):
+        for nt in (1, 2):
             if mt >= 3 and nt == 4:
                 continue
             for cfg, cname in CFG.items():
                 if cfg == 2 and not (mt == 1 and nt <= 2):
                     continue
                 if cfg in (1, 4) and mt * nt > 4:
+                    continue
+                if cfg >= 5 and (nt != 1 or mt > 2 or (cfg == 5 and mt != 1)):
                     continue
                 for ks in (1, 2):
                     if ks == 2 and (N // (16 * nt)) >= 192:
