@@ -566,6 +566,238 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmA
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm4_mfma_tile_kernel (v4): the tiled kernel for the larger batches (M up to 64 per pass).
+// Workgroup tile = (MT*16 rows of A) x (128 weight columns): 4 wavefronts x 2 n-tiles. Per 256-k
+// chunk everything arrives by LDS-DMA in full lines and is double-buffered:
+//   * the A tile [MT*16][256] is fetched ONCE per workgroup (source-side XOR swizzle by row & 15 ->
+//     conflict-free ds_read_b128 fragment reads) and shared by the 4 wavefronts - this is what
+//     v2/v3 lack: there every 16 columns re-read all of A from L2;
+//   * every wavefront DMAs the 32 weight rows it owns (4 instructions of 8 rows x 128 B).
+// A raw s_barrier pair per chunk publishes / retires a buffer; waits are counted (vmcnt(N) leaves
+// the next chunk's DMAs in flight across the barrier). Scales: one 16-byte load per lane per n-tile.
+// The K range can be sliced across workgroups (grid.y) to fill the chip; slices meet in the
+// deterministic slab finalize.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MT, bool NESTED>
+__global__ __launch_bounds__(256) void gemm4_mfma_tile_kernel(const GemmArgs p) {
+    constexpr int NTW = 2;                       // n-tiles per wavefront
+    constexpr int kLutBytes = 256 * 32 * 4;
+    constexpr int XB = MT * 16 * 512;            // bytes of one A stage
+    constexpr int WB = NTW * 2048;               // bytes of one weight stage of one wavefront
+    constexpr int XI = MT * 8;                   // DMA instructions per A stage (2 rows each)
+    constexpr int XIW = XI / 4;                  // ... per wavefront
+    constexpr int kLoadsPerChunk = NTW * 2 + XIW + NTW; // vm ops one wavefront issues per chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
+    unsigned char* xring = smem + kLutBytes;                 // [2][XB]
+    unsigned char* wring = xring + 2 * XB;                   // [4 waves][2][WB]
+    float* code2 = reinterpret_cast<float*>(wring + 4 * 2 * WB);
+
+    const int tid = threadIdx.x;
+    const gfloat_ptr tbl = (gfloat_ptr)(p.code16 ? p.code16 : (p.quant_type == kNF4 ? kNF4Code : kFP4Code));
+    const float code_hi = tbl[tid >> 4];
+    const float code_lo = tbl[tid & 15];
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, lg = lane >> 4;
+    const int N = p.N, K = p.K, M = p.M;
+    const int m_base = blockIdx.z * (MT * 16);
+    const int colw = blockIdx.x * 128 + wave * (NTW * 16); // first column of this wavefront
+
+    const int chunks_total = K >> 8;
+    const int per_wg = (chunks_total + p.kslices - 1) / p.kslices;
+    const int c_begin = blockIdx.y * per_wg;
+    const int c_end = (c_begin + per_wg < chunks_total) ? c_begin + per_wg : chunks_total;
+
+    // ---- DMA sources
+    const int r8 = lane >> 3, s8 = lane & 7;
+    const uint8_t* wsrc[NTW][2];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int row = colw + t * 16 + h * 8 + r8;
+            row = (row < N) ? row : N - 1;
+            wsrc[t][h] = p.B + static_cast<long>(row) * (K >> 1) + ((s8 ^ r8) << 4);
+        }
+    const T* __restrict__ A = static_cast<const T*>(p.A);
+    const T* xsrc[XIW];
+    const int r2 = lane >> 5, s32 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < XIW; ++i) {
+        const int row = 2 * (wave + 4 * i) + r2; // row of the A tile this lane fetches in instruction i
+        int m = m_base + row;
+        m = (m < M) ? m : M - 1;
+        xsrc[i] = A + static_cast<long>(m) * K + ((s32 ^ (row & 15)) << 3);
+    }
+    unsigned char* wbase = wring + wave * (2 * WB);
+
+    long rowk[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        int row = colw + t * 16 + ln;
+        row = (row < N) ? row : N - 1;
+        rowk[t] = static_cast<long>(row) * K;
+    }
+    const int rd_row = (ln >> 3) * 1024 + (ln & 7) * 128;
+    const int rd_sw = ln & 7;
+
+    struct Scales {
+        float s[NTW][4];
+    };
+    auto issue_chunk = [&](Scales& sc, int c, int buf) {
+#pragma unroll
+        for (int i = 0; i < XIW; ++i)
+            __builtin_amdgcn_global_load_lds((dma_src_t)(xsrc[i] + (static_cast<long>(c) << 8)),
+                                             (dma_dst_t)(xring + buf * XB + (wave + 4 * i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                __builtin_amdgcn_global_load_lds((dma_src_t)(wsrc[t][h] + static_cast<long>(c) * 128),
+                                                 (dma_dst_t)(wbase + buf * WB + (t * 2 + h) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const long e = rowk[t] + (static_cast<long>(c) << 8);
+            if (p.bs_shift == 6 && !NESTED) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.absmax + (e >> 6));
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    sc.s[t][b] = s4[b];
+            } else if (p.bs_shift == 6) {
+                const uint32_t q4 = *reinterpret_cast<const uint32_t*>(p.absmax8 + (e >> 6));
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    sc.s[t][b] = __builtin_bit_cast(float, (q4 >> (8 * b)) & 0xFFu);
+            } else {
+                // blocksize >= 128: one scale per 2, 4 or more 64-k blocks; a single (uniform-shape) load
+                // per block index keeps the vm-op count per chunk equal to kLoadsPerChunk only for
+                // blocksize 64, so larger blocksizes use the conservative wait below
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const long q = (e + b * 64) >> p.bs_shift;
+                    if constexpr (NESTED)
+                        sc.s[t][b] = __builtin_bit_cast(float, static_cast<uint32_t>(p.absmax8[q]));
+                    else
+                        sc.s[t][b] = p.absmax[q];
+                }
+            }
+        }
+    };
+
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+            acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Scales sc_cur, sc_nxt;
+    if (c_begin < c_end)
+        issue_chunk(sc_cur, c_begin, 0);
+    {
+        const uint32_t pr = Mma<T>::pack(code_hi, code_lo);
+        const u32x4 v = {pr, pr, pr, pr};
+        u32x4* dst = reinterpret_cast<u32x4*>(&lut[tid * 32]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            dst[j] = v;
+    }
+    float offset = 0.0f;
+    if constexpr (NESTED) {
+        code2[tid] = p.absmax_code[tid];
+        offset = p.absmax_offset[0];
+    }
+    const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
+    const bool fixed_count = (p.bs_shift == 6);
+
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        const bool more = c + 1 < c_end;
+        if (more)
+            issue_chunk(sc_nxt, c + 1, buf ^ 1);
+        // chunk c (DMAs and scale loads of this wavefront) has landed; chunk c+1 may stay in flight
+        if (more && fixed_count)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoadsPerChunk) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier(); // every wavefront's part of the A tile (and the table, first time) is in LDS
+        const int zsh = opaque_zero();
+
+        const unsigned char* xb = xring + buf * XB;
+        const unsigned char* wb = wbase + buf * WB;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            u32x4 af[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int idx = (b * 8 + lg * 2 + j) ^ ln;
+                    af[mt][j] = *reinterpret_cast<const u32x4*>(xb + (mt * 16 + ln) * 512 + (idx << 4));
+                }
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int cidx = (2 * b + (lg >> 1)) ^ rd_sw;
+                const u32x2 w2 = *reinterpret_cast<const u32x2*>(wb + t * 2048 + rd_row + (cidx << 4) + (lg & 1) * 8);
+                u32x4 bf[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const uint32_t w = w2[j];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        bf[j][q] = lut[(((w >> (8 * q + zsh)) & 0xFFu) << 5) + lane_slot];
+                }
+                float scale;
+                if constexpr (NESTED) {
+                    const long q = (rowk[t] + (static_cast<long>(c) << 8) + b * 64) >> p.bs_shift;
+                    const uint32_t q8 = __builtin_bit_cast(uint32_t, sc_cur.s[t][b]);
+                    scale = __fadd_rn(__fmul_rn(code2[q8], p.absmax[q >> 8]), offset);
+                } else {
+                    scale = sc_cur.s[t][b];
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    f32x4 part = Mma<T>::run(af[mt][0], bf[0], f32x4{0.f, 0.f, 0.f, 0.f});
+                    part = Mma<T>::run(af[mt][1], bf[1], part);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[mt][t][r] = fmaf(scale, part[r], acc[mt][t][r]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier(); // everybody is done reading stage `buf`: it may be refilled next iteration
+        sc_cur = sc_nxt;
+    }
+
+    T* __restrict__ out = static_cast<T*>(p.out);
+    const T* __restrict__ bias = static_cast<const T*>(p.bias);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int col = colw + t * 16 + ln;
+        if (col >= N)
+            continue;
+        const float bv = (bias && p.kslices == 1) ? static_cast<float>(bias[col]) : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m_base + mt * 16 + lg * 4 + r;
+                if (m >= M)
+                    continue;
+                const long o = static_cast<long>(m) * N + col;
+                if (p.kslices == 1)
+                    out[o] = static_cast<T>(acc[mt][t][r] + bv);
+                else
+                    p.ws[static_cast<long>(blockIdx.y) * M * N + o] = acc[mt][t][r];
+            }
+        }
+    }
+}
+
 // out = T(sum_s ws[s] + bias), slabs added in slice order (deterministic)
 template <typename T>
 __global__ __launch_bounds__(256) void gemm4_finalize_kernel(const float* __restrict__ ws, const T* __restrict__ bias,
@@ -647,10 +879,10 @@ float* get_internal_workspace(size_t bytes, hipStream_t stream) {
 struct Plan {
     int mt, nt, ks;
     int cfg; // v2 register-ring kernel: 0: 4 waves x 4 blocks, 1: 8 x 8, 2: 16 x 4, 3: 8 x 4, 4: 4 x 8
-             // v3 LDS-DMA kernel (NT = 1): 5: 16 waves, 6: 8 waves
+             // v3 LDS-DMA kernel (NT = 1): 5: 16 waves, 6: 8 waves;  v4 tiled LDS-DMA kernel (128 columns): 7
 };
 
-constexpr int kCfgWaves[7] = {4, 8, 16, 8, 4, 16, 8};
+constexpr int kCfgWaves[8] = {4, 8, 16, 8, 4, 16, 8, 1};
 
 // Tile shape and K-slice count for a problem: a pure function of (M, N, K) and the tuning knobs,
 // shared by the launch and by the workspace-size query.
@@ -666,15 +898,28 @@ Plan make_plan(int M, int N, int K) {
         nt = 2;
     pl.nt = nt;
     const int groups = K / kKC; // units of 4 blocks
-    const int gx = (N + 16 * nt - 1) / (16 * nt);
+    int gx = (N + 16 * nt - 1) / (16 * nt);
     const int gz = (M + pl.mt * 16 - 1) / (pl.mt * 16);
     int ks = g_mfma_knob1 % 100;
     int cfg = g_mfma_knob1 / 100;
-    if (g_mfma_knob1 == 0)
-        cfg = (nt == 1 && pl.mt == 1) ? 5 : (nt == 1 && pl.mt == 2) ? 6 : 0;
-    if (cfg < 0 || cfg > 6)
+    if (g_mfma_knob1 == 0) {
+        // Calibrated on MI355X (profiles/r1_sweep_mfma_variants.txt): the tiled kernel (A shared through
+        // LDS by 128 columns) wins once the A tile is big (M > 32) or the weight matrix is large; the
+        // 16-column LDS-DMA kernel wins for small batches on small matrices, where a second (finalize)
+        // launch would cost more than it saves.
+        const bool big = static_cast<long>(N) * K >= (32L << 20) && N >= 1024;
+        if (pl.mt >= 3 || big) {
+            cfg = 7;
+            pl.nt = nt = 1;
+        } else {
+            cfg = (pl.mt == 1) ? 5 : 6;
+            pl.nt = nt = 1;
+            gx = (N + 15) / 16;
+        }
+    }
+    if (cfg < 0 || cfg > 7)
         cfg = 0;
-    if (cfg >= 5 && (nt != 1 || pl.mt > 2))
+    if ((cfg == 5 || cfg == 6) && (nt != 1 || pl.mt > 2))
         cfg = 0;
     if (cfg == 5 && pl.mt != 1)
         cfg = 6;
@@ -684,9 +929,17 @@ Plan make_plan(int M, int N, int K) {
         cfg = (cfg == 1) ? 3 : 0;
     pl.cfg = cfg;
     const int kWaves = kCfgWaves[cfg];
-    if (ks == 0)
-        ks = (gx * gz >= 192) ? 1 : (256 + gx * gz - 1) / (gx * gz); // fill the 256 CUs once
-    const int max_ks = groups / kWaves > 0 ? groups / kWaves : 1;   // keep >= 1 group per wavefront
+    if (cfg == 7)
+        gx = (N + 127) / 128;
+    if (ks == 0) {
+        if (cfg == 7)
+            ks = (256 + gx * gz / 2) / (gx * gz); // ~256 workgroups
+        else
+            ks = (gx * gz >= 192) ? 1 : (256 + gx * gz - 1) / (gx * gz); // fill the 256 CUs once
+    }
+    int max_ks = groups / kWaves > 0 ? groups / kWaves : 1; // keep >= 1 group per wavefront
+    if (cfg == 7)
+        max_ks = groups / 2 > 0 ? groups / 2 : 1;           // >= 2 chunks per workgroup so the ring has something to overlap
     if (ks > max_ks)
         ks = max_ks;
     if (ks < 1)
@@ -726,7 +979,24 @@ template <typename T, int MT, int WAVES> void launch_mfma_dma(GemmArgs& p, hipSt
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p);
 }
 
+template <typename T, int MT> void launch_mfma_tile(GemmArgs& p, hipStream_t stream) {
+    const int gx = (p.N + 127) / 128;
+    const int gz = (p.M + MT * 16 - 1) / (MT * 16);
+    const size_t smem = 256 * 32 * 4 + 2 * static_cast<size_t>(MT) * 16 * 512 + 4 * 2 * 2 * 2048 + 1024;
+    dim3 grid(gx, p.kslices, gz);
+    auto kern = p.absmax8 ? gemm4_mfma_tile_kernel<T, MT, true> : gemm4_mfma_tile_kernel<T, MT, false>;
+    static bool attr_set[2] = {false, false};
+    if (smem > 64 * 1024 && !attr_set[p.absmax8 ? 1 : 0]) {
+        BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
+        attr_set[p.absmax8 ? 1 : 0] = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
+}
+
 template <typename T, int MT, int NT> void launch_mfma(GemmArgs& p, int cfg, hipStream_t stream) {
+    if (cfg == 7)
+        return launch_mfma_tile<T, MT>(p, stream);
     if constexpr (NT == 1 && MT <= 2) {
         if constexpr (MT == 1) {
             if (cfg == 5)

@@ -439,3 +439,28 @@ def test_backward_through_matmul_4bit_gpu():
     Wd = F.dequantize_4bit(q, st).float()
     g_ref = (2 * y.detach().float()) @ Wd
     assert rel_err(x.grad.float().cpu(), g_ref.cpu()) < 2e-2
+
+
+@pytest.mark.parametrize("cfg", [0, 2, 3, 5, 6, 7])
+@pytest.mark.parametrize("M,N,K,ks", [(5, 256, 1024, 1), (16, 200, 2048, 2), (33, 384, 1024, 1), (64, 512, 4096, 4),
+                                      (64, 1000, 2816, 1), (100, 128, 512, 2)])
+def test_mfma_kernel_variants(cfg, M, N, K, ks):
+    """Every geometry of the MFMA kernels (register-ring v2, LDS-DMA v3, tiled v4), incl. cross-workgroup
+    K slices and ragged N / M, against the oracle; results must also be bit-reproducible run to run."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    W = (torch.randn(N, K) / K**0.5).bfloat16()
+    x = torch.randn(M, K).bfloat16()
+    bias = torch.randn(N).bfloat16()
+    for dq in (False, True):
+        q, st = F.quantize_4bit(W.to(DEV), blocksize=64, quant_type="nf4", compress_statistics=dq)
+        y_ref = _oracle_y(x, q, st, bias)
+        try:
+            bnb.lib.bnb_mi355x_set_tuning(0, 0, 1, cfg * 100 + ks)
+            y1 = _run_kernel(2, x.to(DEV), q, st, bias.to(DEV))
+            y2 = _run_kernel(2, x.to(DEV), q, st, bias.to(DEV))
+        finally:
+            bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+        assert rel_err(y1.cpu(), y_ref) < REL_TOL
+        assert torch.equal(y1, y2)
