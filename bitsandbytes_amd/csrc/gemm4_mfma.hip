@@ -579,31 +579,34 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmA
 // The K range can be sliced across workgroups (grid.y) to fill the chip; slices meet in the
 // deterministic slab finalize.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int MT, bool NESTED>
-__global__ __launch_bounds__(256) void gemm4_mfma_tile_kernel(const GemmArgs p) {
-    constexpr int NTW = 2;                       // n-tiles per wavefront
+template <typename T, int MT, bool NESTED, int WAVES, int NTW>
+__global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_tile_kernel(const GemmArgs p) {
+    // WAVES wavefronts x NTW n-tiles each = WAVES*NTW*16 columns per workgroup
     constexpr int kLutBytes = 256 * 32 * 4;
     constexpr int XB = MT * 16 * 512;            // bytes of one A stage
     constexpr int WB = NTW * 2048;               // bytes of one weight stage of one wavefront
     constexpr int XI = MT * 8;                   // DMA instructions per A stage (2 rows each)
-    constexpr int XIW = XI / 4;                  // ... per wavefront
+    constexpr int XIW = XI / WAVES;              // ... per wavefront
+    static_assert(XI % WAVES == 0, "A-tile DMA instructions must divide evenly over the wavefronts");
     constexpr int kLoadsPerChunk = NTW * 2 + XIW + NTW; // vm ops one wavefront issues per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
     unsigned char* xring = smem + kLutBytes;                 // [2][XB]
-    unsigned char* wring = xring + 2 * XB;                   // [4 waves][2][WB]
-    float* code2 = reinterpret_cast<float*>(wring + 4 * 2 * WB);
+    unsigned char* wring = xring + 2 * XB;                   // [WAVES][2][WB]
+    float* code2 = reinterpret_cast<float*>(wring + WAVES * 2 * WB);
 
     const int tid = threadIdx.x;
     const gfloat_ptr tbl = (gfloat_ptr)(p.code16 ? p.code16 : (p.quant_type == kNF4 ? kNF4Code : kFP4Code));
-    const float code_hi = tbl[tid >> 4];
-    const float code_lo = tbl[tid & 15];
+    constexpr int TPE = WAVES / 4; // lanes cooperating on one table entry
+    const int entry = tid / TPE;
+    const float code_hi = tbl[entry >> 4];
+    const float code_lo = tbl[entry & 15];
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane & 15, lg = lane >> 4;
     const int N = p.N, K = p.K, M = p.M;
     const int m_base = blockIdx.z * (MT * 16);
-    const int colw = blockIdx.x * 128 + wave * (NTW * 16); // first column of this wavefront
+    const int colw = blockIdx.x * (WAVES * NTW * 16) + wave * (NTW * 16); // first column of this wavefront
 
     const int chunks_total = K >> 8;
     const int per_wg = (chunks_total + p.kslices - 1) / p.kslices;
@@ -626,7 +629,7 @@ __global__ __launch_bounds__(256) void gemm4_mfma_tile_kernel(const GemmArgs p) 
     const int r2 = lane >> 5, s32 = lane & 31;
 #pragma unroll
     for (int i = 0; i < XIW; ++i) {
-        const int row = 2 * (wave + 4 * i) + r2; // row of the A tile this lane fetches in instruction i
+        const int row = 2 * (wave + WAVES * i) + r2; // row of the A tile this lane fetches in instruction i
         int m = m_base + row;
         m = (m < M) ? m : M - 1;
         xsrc[i] = A + static_cast<long>(m) * K + ((s32 ^ (row & 15)) << 3);
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(256) void gemm4_mfma_tile_kernel(const GemmArgs p) 
 #pragma unroll
         for (int i = 0; i < XIW; ++i)
             __builtin_amdgcn_global_load_lds((dma_src_t)(xsrc[i] + (static_cast<long>(c) << 8)),
-                                             (dma_dst_t)(xring + buf * XB + (wave + 4 * i) * 1024), 16, 0, 0);
+                                             (dma_dst_t)(xring + buf * XB + (wave + WAVES * i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
 #pragma unroll
@@ -699,14 +702,15 @@ __global__ __launch_bounds__(256) void gemm4_mfma_tile_kernel(const GemmArgs p) 
     {
         const uint32_t pr = Mma<T>::pack(code_hi, code_lo);
         const u32x4 v = {pr, pr, pr, pr};
-        u32x4* dst = reinterpret_cast<u32x4*>(&lut[tid * 32]);
+        u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * 32]) + (tid % TPE) * (8 / TPE);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 8 / TPE; ++j)
             dst[j] = v;
     }
     float offset = 0.0f;
     if constexpr (NESTED) {
-        code2[tid] = p.absmax_code[tid];
+        if (tid < 256)
+            code2[tid] = p.absmax_code[tid];
         offset = p.absmax_offset[0];
     }
     const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
@@ -771,6 +775,238 @@ __global__ __launch_bounds__(256) void gemm4_mfma_tile_kernel(const GemmArgs p) 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier(); // everybody is done reading stage `buf`: it may be refilled next iteration
         sc_cur = sc_nxt;
+    }
+
+    T* __restrict__ out = static_cast<T*>(p.out);
+    const T* __restrict__ bias = static_cast<const T*>(p.bias);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int col = colw + t * 16 + ln;
+        if (col >= N)
+            continue;
+        const float bv = (bias && p.kslices == 1) ? static_cast<float>(bias[col]) : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m_base + mt * 16 + lg * 4 + r;
+                if (m >= M)
+                    continue;
+                const long o = static_cast<long>(m) * N + col;
+                if (p.kslices == 1)
+                    out[o] = static_cast<T>(acc[mt][t][r] + bv);
+                else
+                    p.ws[static_cast<long>(blockIdx.y) * M * N + o] = acc[mt][t][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm4_mfma_ring_kernel (v4b): v4 with a D-deep LDS ring of 128-k chunks and ONE barrier per chunk.
+// v4's two-stage double buffer exposes a full DMA latency per chunk (measured ~3 us per 256-k chunk at
+// M = 64); here D-1 chunks are in flight while one is consumed. Per 128-k chunk and wavefront:
+// MT A-tile DMAs (4 rows x 256 B each), 2 weight DMAs (16 rows x 64 B each, one per n-tile) and one
+// scale load per n-tile (two for nested absmax) - a fixed count, so the consumer waits with a counted
+// vmcnt that leaves the younger chunks in flight across the barrier. Source-side swizzles:
+// A chunk s ^ (row & 15) (256-B rows), weight chunk s ^ ((row >> 2) & 3) (64-B rows); both make the
+// fragment reads conflict-free.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MT, bool NESTED, int D>
+__global__ __launch_bounds__(256) void gemm4_mfma_ring_kernel(const GemmArgs p) {
+    constexpr int NTW = 2;
+    constexpr int kLutBytes = 256 * 32 * 4;
+    constexpr int XB = MT * 16 * 256;  // bytes of one A stage (128 k)
+    constexpr int WB = NTW * 1024;     // bytes of one weight stage of one wavefront
+    constexpr int kL = MT + NTW + NTW * (NESTED ? 2 : 1); // vm ops per wavefront per chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
+    unsigned char* xring = smem + kLutBytes;    // [D][XB]
+    unsigned char* wring = xring + D * XB;      // [4 waves][D][WB]
+    float* code2 = reinterpret_cast<float*>(wring + 4 * D * WB);
+
+    const int tid = threadIdx.x;
+    const gfloat_ptr tbl = (gfloat_ptr)(p.code16 ? p.code16 : (p.quant_type == kNF4 ? kNF4Code : kFP4Code));
+    const float code_hi = tbl[tid >> 4];
+    const float code_lo = tbl[tid & 15];
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, lg = lane >> 4;
+    const int N = p.N, K = p.K, M = p.M;
+    const int m_base = blockIdx.z * (MT * 16);
+    const int colw = blockIdx.x * 128 + wave * (NTW * 16);
+
+    // chunk = 128 k; K slices are handed out in units of 256 k (two chunks)
+    const int groups = K >> 8;
+    const int per_wg = (groups + p.kslices - 1) / p.kslices;
+    const int c_begin = blockIdx.y * per_wg * 2;
+    const int c_last = (blockIdx.y + 1) * per_wg * 2;
+    const int c_end = (c_last < 2 * groups) ? c_last : 2 * groups;
+
+    // ---- DMA sources
+    const T* __restrict__ A = static_cast<const T*>(p.A);
+    const T* xsrc[MT];
+    {
+        const int r4 = lane >> 4, s16 = lane & 15;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = 4 * (wave + 4 * i) + r4;
+            int m = m_base + row;
+            m = (m < M) ? m : M - 1;
+            xsrc[i] = A + static_cast<long>(m) * K + ((s16 ^ (row & 15)) << 3);
+        }
+    }
+    const uint8_t* wsrc[NTW];
+    {
+        const int r16 = lane >> 2, s4 = lane & 3;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            int row = colw + t * 16 + r16;
+            row = (row < N) ? row : N - 1;
+            wsrc[t] = p.B + static_cast<long>(row) * (K >> 1) + ((s4 ^ ((r16 >> 2) & 3)) << 4);
+        }
+    }
+    unsigned char* wbase = wring + wave * (D * WB);
+    long rowk[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        int row = colw + t * 16 + ln;
+        row = (row < N) ? row : N - 1;
+        rowk[t] = static_cast<long>(row) * K;
+    }
+    const int w_rd = ln * 64 + (lg & 1) * 8;
+    const int w_sw = (ln >> 2) & 3;
+    const bool bs64 = (p.bs_shift == 6);
+
+    struct Scales {
+        float s[NTW][2];
+        float s2[NTW]; // nested: second-level absmax of this chunk
+    };
+    auto issue_chunk = [&](Scales& sc, int c, int buf) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            __builtin_amdgcn_global_load_lds((dma_src_t)(xsrc[i] + (static_cast<long>(c) << 7)),
+                                             (dma_dst_t)(xring + buf * XB + (wave + 4 * i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+            __builtin_amdgcn_global_load_lds((dma_src_t)(wsrc[t] + static_cast<long>(c) * 64),
+                                             (dma_dst_t)(wbase + buf * WB + t * 1024), 16, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const long e = rowk[t] + (static_cast<long>(c) << 7);
+            const long q = e >> p.bs_shift;
+            if constexpr (NESTED) {
+                if (bs64) {
+                    const uint32_t q2 = *reinterpret_cast<const uint16_t*>(p.absmax8 + q);
+                    sc.s[t][0] = __builtin_bit_cast(float, q2 & 0xFFu);
+                    sc.s[t][1] = __builtin_bit_cast(float, q2 >> 8);
+                } else {
+                    const uint32_t q1 = p.absmax8[q];
+                    sc.s[t][0] = sc.s[t][1] = __builtin_bit_cast(float, q1);
+                }
+                sc.s2[t] = p.absmax[q >> 8];
+            } else {
+                if (bs64) {
+                    using f32x2 = __attribute__((ext_vector_type(2))) float;
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(p.absmax + q);
+                    sc.s[t][0] = v[0];
+                    sc.s[t][1] = v[1];
+                } else {
+                    sc.s[t][0] = sc.s[t][1] = p.absmax[q];
+                }
+            }
+        }
+    };
+
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+            acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Scales sc[D];
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+        if (c_begin + d < c_end)
+            issue_chunk(sc[d], c_begin + d, d);
+    {
+        const uint32_t pr = Mma<T>::pack(code_hi, code_lo);
+        const u32x4 v = {pr, pr, pr, pr};
+        u32x4* dst = reinterpret_cast<u32x4*>(&lut[tid * 32]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            dst[j] = v;
+    }
+    float offset = 0.0f;
+    if constexpr (NESTED) {
+        code2[tid] = p.absmax_code[tid];
+        offset = p.absmax_offset[0];
+    }
+    const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
+
+    for (int c0 = c_begin; c0 < c_end; c0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int c = c0 + d;
+            if (c >= c_end)
+                break;
+            // chunk c of this wavefront has landed; up to D-2 younger chunks stay in flight
+            const int younger = (c_end - 1 - c < D - 2) ? c_end - 1 - c : D - 2;
+            if (younger >= 2)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kL) : "memory");
+            else if (younger == 1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kL) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // chunk c complete for everybody; everybody done with chunk c-1
+            if (c + D - 1 < c_end)
+                issue_chunk(sc[(d + D - 1) % D], c + D - 1, (d + D - 1) % D);
+            const int zsh = opaque_zero();
+
+            const unsigned char* xb = xring + d * XB;
+            const unsigned char* wb = wbase + d * WB;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                u32x4 af[MT][2];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int idx = (b * 8 + lg * 2 + j) ^ ln;
+                        af[mt][j] = *reinterpret_cast<const u32x4*>(xb + (mt * 16 + ln) * 256 + (idx << 4));
+                    }
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    const int cidx = (2 * b + (lg >> 1)) ^ w_sw;
+                    const u32x2 w2 = *reinterpret_cast<const u32x2*>(wb + t * 1024 + w_rd + (cidx << 4));
+                    u32x4 bf[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const uint32_t w = w2[j];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            bf[j][q] = lut[(((w >> (8 * q + zsh)) & 0xFFu) << 5) + lane_slot];
+                    }
+                    float scale;
+                    if constexpr (NESTED) {
+                        const uint32_t q8 = __builtin_bit_cast(uint32_t, sc[d].s[t][b]);
+                        scale = __fadd_rn(__fmul_rn(code2[q8], sc[d].s2[t]), offset);
+                    } else {
+                        scale = sc[d].s[t][b];
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        f32x4 part = Mma<T>::run(af[mt][0], bf[0], f32x4{0.f, 0.f, 0.f, 0.f});
+                        part = Mma<T>::run(af[mt][1], bf[1], part);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[mt][t][r] = fmaf(scale, part[r], acc[mt][t][r]);
+                    }
+                }
+            }
+        }
     }
 
     T* __restrict__ out = static_cast<T*>(p.out);
@@ -879,10 +1115,13 @@ float* get_internal_workspace(size_t bytes, hipStream_t stream) {
 struct Plan {
     int mt, nt, ks;
     int cfg; // v2 register-ring kernel: 0: 4 waves x 4 blocks, 1: 8 x 8, 2: 16 x 4, 3: 8 x 4, 4: 4 x 8
-             // v3 LDS-DMA kernel (NT = 1): 5: 16 waves, 6: 8 waves;  v4 tiled LDS-DMA kernel (128 columns): 7
+             // v3 LDS-DMA kernel (NT = 1): 5: 16 waves, 6: 8 waves;  v4 tiled LDS-DMA kernel (128 columns): 7;
+             // v4b ring kernel (128 columns, 128-k chunks, 4-deep ring): 8
+             // v4 with 8 wavefronts: 9: 8 x 1 n-tile (128 columns), 10: 8 x 2 n-tiles (256 columns)
 };
 
-constexpr int kCfgWaves[8] = {4, 8, 16, 8, 4, 16, 8, 1};
+constexpr int kCfgWaves[11] = {4, 8, 16, 8, 4, 16, 8, 1, 1, 1, 1};
+constexpr int kCfgCols[11] = {0, 0, 0, 0, 0, 16, 16, 128, 128, 128, 256};
 
 // Tile shape and K-slice count for a problem: a pure function of (M, N, K) and the tuning knobs,
 // shared by the launch and by the workspace-size query.
@@ -908,8 +1147,8 @@ Plan make_plan(int M, int N, int K) {
         // 16-column LDS-DMA kernel wins for small batches on small matrices, where a second (finalize)
         // launch would cost more than it saves.
         const bool big = static_cast<long>(N) * K >= (32L << 20) && N >= 1024;
-        if (pl.mt >= 3 || big) {
-            cfg = 7;
+        if (pl.mt >= 2 || big) {
+            cfg = 9; // 8 wavefronts x 16 columns share one A tile
             pl.nt = nt = 1;
         } else {
             cfg = (pl.mt == 1) ? 5 : 6;
@@ -917,7 +1156,7 @@ Plan make_plan(int M, int N, int K) {
             gx = (N + 15) / 16;
         }
     }
-    if (cfg < 0 || cfg > 7)
+    if (cfg < 0 || cfg > 10)
         cfg = 0;
     if ((cfg == 5 || cfg == 6) && (nt != 1 || pl.mt > 2))
         cfg = 0;
@@ -929,16 +1168,16 @@ Plan make_plan(int M, int N, int K) {
         cfg = (cfg == 1) ? 3 : 0;
     pl.cfg = cfg;
     const int kWaves = kCfgWaves[cfg];
-    if (cfg == 7)
-        gx = (N + 127) / 128;
+    if (cfg >= 7)
+        gx = (N + kCfgCols[cfg] - 1) / kCfgCols[cfg];
     if (ks == 0) {
-        if (cfg == 7)
+        if (cfg >= 7)
             ks = (256 + gx * gz / 2) / (gx * gz); // ~256 workgroups
         else
             ks = (gx * gz >= 192) ? 1 : (256 + gx * gz - 1) / (gx * gz); // fill the 256 CUs once
     }
     int max_ks = groups / kWaves > 0 ? groups / kWaves : 1; // keep >= 1 group per wavefront
-    if (cfg == 7)
+    if (cfg >= 7)
         max_ks = groups / 2 > 0 ? groups / 2 : 1;           // >= 2 chunks per workgroup so the ring has something to overlap
     if (ks > max_ks)
         ks = max_ks;
@@ -979,12 +1218,29 @@ template <typename T, int MT, int WAVES> void launch_mfma_dma(GemmArgs& p, hipSt
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p);
 }
 
-template <typename T, int MT> void launch_mfma_tile(GemmArgs& p, hipStream_t stream) {
+template <typename T, int MT, int WAVES, int NTW> void launch_mfma_tile(GemmArgs& p, hipStream_t stream) {
+    constexpr int BN = WAVES * NTW * 16;
+    const int gx = (p.N + BN - 1) / BN;
+    const int gz = (p.M + MT * 16 - 1) / (MT * 16);
+    const size_t smem = 256 * 32 * 4 + 2 * static_cast<size_t>(MT) * 16 * 512 + static_cast<size_t>(WAVES) * 2 * NTW * 2048 + 1024;
+    dim3 grid(gx, p.kslices, gz);
+    auto kern = p.absmax8 ? gemm4_mfma_tile_kernel<T, MT, true, WAVES, NTW> : gemm4_mfma_tile_kernel<T, MT, false, WAVES, NTW>;
+    static bool attr_set[2] = {false, false};
+    if (smem > 64 * 1024 && !attr_set[p.absmax8 ? 1 : 0]) {
+        BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
+        attr_set[p.absmax8 ? 1 : 0] = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p);
+}
+
+template <typename T, int MT> void launch_mfma_ring(GemmArgs& p, hipStream_t stream) {
+    constexpr int D = 4;
     const int gx = (p.N + 127) / 128;
     const int gz = (p.M + MT * 16 - 1) / (MT * 16);
-    const size_t smem = 256 * 32 * 4 + 2 * static_cast<size_t>(MT) * 16 * 512 + 4 * 2 * 2 * 2048 + 1024;
+    const size_t smem = 256 * 32 * 4 + static_cast<size_t>(D) * MT * 16 * 256 + 4 * D * 2048 + 1024;
     dim3 grid(gx, p.kslices, gz);
-    auto kern = p.absmax8 ? gemm4_mfma_tile_kernel<T, MT, true> : gemm4_mfma_tile_kernel<T, MT, false>;
+    auto kern = p.absmax8 ? gemm4_mfma_ring_kernel<T, MT, true, D> : gemm4_mfma_ring_kernel<T, MT, false, D>;
     static bool attr_set[2] = {false, false};
     if (smem > 64 * 1024 && !attr_set[p.absmax8 ? 1 : 0]) {
         BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -995,8 +1251,14 @@ template <typename T, int MT> void launch_mfma_tile(GemmArgs& p, hipStream_t str
 }
 
 template <typename T, int MT, int NT> void launch_mfma(GemmArgs& p, int cfg, hipStream_t stream) {
+    if (cfg == 8)
+        return launch_mfma_ring<T, MT>(p, stream);
     if (cfg == 7)
-        return launch_mfma_tile<T, MT>(p, stream);
+        return launch_mfma_tile<T, MT, 4, 2>(p, stream);
+    if (cfg == 9)
+        return launch_mfma_tile<T, MT, 8, 1>(p, stream);
+    if (cfg == 10)
+        return launch_mfma_tile<T, MT, 8, 2>(p, stream);
     if constexpr (NT == 1 && MT <= 2) {
         if constexpr (MT == 1) {
             if (cfg == 5)

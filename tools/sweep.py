@@ -148,7 +148,7 @@ def main():
             print(f"{'mfma-abl':8s} {8:3d} {f'{name} cfg{cfgks}':>20s} {tg:9.2f} {te:9.2f} {bytes_alg(8, N, K, bs) / tg / 1e3:11.1f}")
     bnb.lib.bnb_mi355x_set_debug(0, 0)
     Ms = [1, 8, 16, 64] if a.quick else [1, 4, 8, 16, 32, 64]
-    CFG = {0: "w4d4", 5: "dma16", 6: "dma8", 7: "tile"}
+    CFG = {7: "tile", 9: "t8x1", 10: "t8x2"}
     for M in Ms:
         x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
         mt = (M + 15) // 16
@@ -167,10 +167,10 @@ def main():
                     continue
                 if cfg in (5, 6) and (nt != 1 or mt > 2 or (cfg == 5 and mt != 1)):
                     continue
-                for ks in ((2, 3, 4, 6, 8) if cfg == 7 else (1, 2)):
-                    if cfg == 7 and nt != 1:
+                for ks in ((2, 4, 8, 16) if cfg >= 7 else (1, 2)):
+                    if cfg >= 7 and nt != 1:
                         continue
-                    if cfg != 7 and ks == 2 and (N // (16 * nt)) >= 192:
+                    if cfg < 7 and ks == 2 and (N // (16 * nt)) >= 192:
                         continue
                     bnb.lib.bnb_mi355x_set_tuning(0, 0, nt, cfg * 100 + ks)
                     tg, te = measure(layers, x, 2)
