@@ -1162,6 +1162,8 @@ Plan make_plan(int M, int N, int K) {
         cfg = 0;
     if (cfg == 5 && pl.mt != 1)
         cfg = 6;
+    if (cfg == 10 && pl.mt == 4)
+        cfg = 9; // 8 x 2 tiles with a 64-row A tile would need 161 KiB of LDS
     if (cfg == 2 && !(pl.mt == 1 && nt <= 2))
         cfg = 0; // 1024-thread workgroups only fit the register budget of the smallest tiles
     if ((cfg == 1 || cfg == 4) && pl.mt * nt > 4)
@@ -1257,8 +1259,12 @@ template <typename T, int MT, int NT> void launch_mfma(GemmArgs& p, int cfg, hip
         return launch_mfma_tile<T, MT, 4, 2>(p, stream);
     if (cfg == 9)
         return launch_mfma_tile<T, MT, 8, 1>(p, stream);
+    if constexpr (MT <= 3) { // 8 x 2 tiles with a 64-row A tile would need 161 KiB of LDS
+        if (cfg == 10)
+            return launch_mfma_tile<T, MT, 8, 2>(p, stream);
+    }
     if (cfg == 10)
-        return launch_mfma_tile<T, MT, 8, 2>(p, stream);
+        return launch_mfma_tile<T, MT, 8, 1>(p, stream);
     if constexpr (NT == 1 && MT <= 2) {
         if constexpr (MT == 1) {
             if (cfg == 5)
