@@ -11,12 +11,26 @@
 // (The reference's CUDA kernels use hand-typed FP4 thresholds and send 0*inf to code 0,
 //  reference csrc/kernels.cu:64-153; the CPU oracle rule above is the parity target.)
 //
-// Mapping to the machine: the op is a pure HBM stream (reads n*sizeof(T), writes n/2 + 4n/bs).
-// One 256-thread workgroup owns a contiguous tile of max(2048, bs) elements; every lane pulls 8
-// consecutive elements with one 16-byte (16-bit types) or two 16-byte (fp32) loads, so a wavefront
-// reads 1-2 KiB contiguous per instruction; the per-block max is a DPP/shuffle reduction over
-// bs/8 lanes (plus one LDS hop when a block spans waves); each lane then emits one packed dword
-// (a wavefront writes 256 B contiguous).
+// Mapping to the machine: the op is a pure HBM stream (reads n*sizeof(T), writes n/2 + 4n/bs), so the
+// job of the kernel is to keep the per-element VALU cost far below the stream time (a wave64 VALU op
+// costs 4 cycles on a 16-lane SIMD; a compare tree is ~25 ops/element and was the measured bound).
+//   * one 256-thread workgroup owns a tile of CH x 2048 contiguous elements; every lane pulls 8
+//     consecutive elements per chunk with one (16-bit types) or two (fp32) 16-byte loads, all CH chunks
+//     in flight before the first use, so a wavefront reads 1-2 KiB contiguous per instruction;
+//   * the block max is taken on the raw |bit patterns| (unsigned max: packed 16-bit for fp16/bf16),
+//     which orders like the float max AND carries NaN/inf upwards, so one compare per block tells the
+//     common finite case from the special one; lanes of a block combine by xor-shuffles (+ one LDS
+//     hop when a block spans wavefronts);
+//   * finite case: the code of s = x * (1/absmax) comes from a *cell table* in LDS instead of a
+//     compare tree. [-1, 1] is cut into 2*S+1 uniform cells (S = 16 for NF4, 512 for FP4, chosen so that
+//     no cell holds two decision bounds); cell(s) = round(s*S + S) falls out of ONE fma against the
+//     2^23 magic constant (exact, single rounding), the cell stores (bound inside it or +inf, code
+//     below | code above << 16), and the code is `below + (s > bound)`: fma, shift-add, ds_read_b64,
+//     compare, add - 5 VALU ops + 1 LDS read per element, bit-identical to counting the 15 bounds
+//     (cell() of s and of every bound use the same exactly-rounded expression, see make_cells);
+//   * special case (inf/NaN in the block) and the division of the ragged tail block keep the plain
+//     compare tree - they are wave-uniform branches that normal data never takes;
+//   * each lane emits one packed dword per chunk (a wavefront writes 256 B contiguous).
 #include "bnb_common.h"
 
 namespace bnb {
@@ -47,47 +61,118 @@ constexpr float kFP4Sorted[16] = {
 constexpr Bounds kNF4Bounds = make_bounds(kNF4Sorted);
 constexpr Bounds kFP4Bounds = make_bounds(kFP4Sorted);
 
-constexpr uint64_t make_order_word() {
-    uint64_t w = 0;
-    for (int i = 0; i < 16; ++i)
-        w |= static_cast<uint64_t>(kFP4Order[i]) << (4 * i);
-    return w;
-}
-constexpr uint64_t kFP4OrderWord = make_order_word();
+constexpr int nibble_of(int qt, int pos) { return qt == kNF4 ? pos : kFP4Order[pos]; }
 
-// #{bounds < s}: a 4-level binary descent on compile-time constants (v_cmp + v_cndmask on literals).
+// ---- cell table -----------------------------------------------------------------------------------
+struct QCell {
+    float bound;   // the decision bound lying in this cell, +inf if none
+    uint32_t code; // nibble for s <= bound | nibble for s > bound << 16
+};
+
+template <int QT> struct CellGrid {
+    static constexpr int S = (QT == kNF4) ? 16 : 512; // cells per unit; power of two => s*S exact
+    static constexpr int N = 2 * S + 1;
+};
+
+// round-half-even of b*S + S, evaluated exactly (b is an fp32 value, S a power of two: the sum is exact
+// in double). This is what the device computes with fmaf(s, S, S + 2^23): one rounding of the exact sum
+// to a float whose ulp is 1.
+constexpr int cell_of(float b, int S) {
+    const double t = static_cast<double>(b) * S + S;
+    const long fl = static_cast<long>(t);
+    const double fr = t - static_cast<double>(fl);
+    if (fr > 0.5)
+        return static_cast<int>(fl + 1);
+    if (fr < 0.5)
+        return static_cast<int>(fl);
+    return static_cast<int>((fl & 1) ? fl + 1 : fl);
+}
+
+template <int QT> struct CellTable {
+    QCell c[CellGrid<QT>::N];
+};
+
+// Cell i holds at most one bound (checked below). For s in cell i every bound of a lower cell is < s and
+// every bound of a higher cell is >= s (s == bound would put both in the same cell, since both go
+// through the same exactly-rounded expression), so #{bounds < s} = #{bounds in lower cells} + (s > bound_i).
+template <int QT> constexpr CellTable<QT> make_cells() {
+    constexpr int S = CellGrid<QT>::S;
+    constexpr int N = CellGrid<QT>::N;
+    const Bounds B = (QT == kNF4) ? kNF4Bounds : kFP4Bounds;
+    CellTable<QT> t{};
+    int next = 0; // bounds are ascending: index of the first bound not yet below the current cell
+    for (int i = 0; i < N; ++i) {
+        t.c[i].bound = __builtin_huge_valf();
+        t.c[i].code = static_cast<uint32_t>(nibble_of(QT, next)) | (static_cast<uint32_t>(nibble_of(QT, next)) << 16);
+        if (next < 15 && cell_of(B.b[next], S) == i) {
+            t.c[i].bound = B.b[next];
+            t.c[i].code = static_cast<uint32_t>(nibble_of(QT, next)) |
+                          (static_cast<uint32_t>(nibble_of(QT, next + 1)) << 16);
+            ++next;
+        }
+    }
+    return t;
+}
+
+template <int QT> constexpr bool cells_are_valid() {
+    constexpr int S = CellGrid<QT>::S;
+    const Bounds B = (QT == kNF4) ? kNF4Bounds : kFP4Bounds;
+    for (int i = 0; i < 15; ++i) {
+        const int c = cell_of(B.b[i], S);
+        if (c < 0 || c >= CellGrid<QT>::N)
+            return false;
+        if (i > 0 && c <= cell_of(B.b[i - 1], S)) // two bounds in one cell, or not ascending
+            return false;
+    }
+    return true;
+}
+static_assert(cells_are_valid<kNF4>(), "NF4 cell grid too coarse");
+static_assert(cells_are_valid<kFP4>(), "FP4 cell grid too coarse");
+
+__device__ static const CellTable<kNF4> kNF4Cells = make_cells<kNF4>();
+__device__ static const CellTable<kFP4> kFP4Cells = make_cells<kFP4>();
+
+// finite s in [-1 - ulp, 1 + ulp]
+template <int QT> __device__ __forceinline__ uint32_t encode_cell(float s, const QCell* cells) {
+    constexpr float S = static_cast<float>(CellGrid<QT>::S);
+    constexpr uint32_t kMagicBits = 0x4B000000u; // 2^23
+    const float t = __fmaf_rn(s, S, S + 8388608.0f);
+    const uint32_t off = (__float_as_uint(t) << 3) - (kMagicBits << 3); // cell index * sizeof(QCell)
+    const uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(cells) + off);
+    const bool above = s > __uint_as_float(e.x);
+    if constexpr (QT == kNF4)
+        return (e.y & 0xFFFFu) + (above ? 1u : 0u); // sorted table: the code above is the code below + 1
+    else
+        return above ? (e.y >> 16) : (e.y & 0xFFFFu);
+}
+
+// #{bounds < s} by a 4-level compare tree; used for the inf/NaN and tail-division paths only.
 template <int QT> __device__ __forceinline__ int encode4(float s) {
     constexpr Bounds B = (QT == kNF4) ? kNF4Bounds : kFP4Bounds;
-    int pos;
-    if (s > B.b[7]) {
-        if (s > B.b[11]) {
-            if (s > B.b[13])
-                pos = (s > B.b[14]) ? 15 : 14;
-            else
-                pos = (s > B.b[12]) ? 13 : 12;
-        } else {
-            if (s > B.b[9])
-                pos = (s > B.b[10]) ? 11 : 10;
-            else
-                pos = (s > B.b[8]) ? 9 : 8;
-        }
-    } else {
-        if (s > B.b[3]) {
-            if (s > B.b[5])
-                pos = (s > B.b[6]) ? 7 : 6;
-            else
-                pos = (s > B.b[4]) ? 5 : 4;
-        } else {
-            if (s > B.b[1])
-                pos = (s > B.b[2]) ? 3 : 2;
-            else
-                pos = (s > B.b[0]) ? 1 : 0;
-        }
+    int pos = (s > B.b[7]) ? 8 : 0;
+    pos += (s > ((pos == 8) ? B.b[11] : B.b[3])) ? 4 : 0;
+    {
+        const float lo = (pos & 4) ? B.b[5] : B.b[1];
+        const float hi = (pos & 4) ? B.b[13] : B.b[9];
+        pos += (s > ((pos & 8) ? hi : lo)) ? 2 : 0;
+    }
+    {
+        float t = B.b[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j)
+            t = (pos == 2 * j) ? B.b[2 * j] : t;
+        pos += (s > t) ? 1 : 0;
     }
     pos = (s != s) ? 15 : pos; // bucketize sorts NaN last
     if (QT == kNF4)
         return pos;
-    return static_cast<int>((kFP4OrderWord >> (4 * pos)) & 0xF);
+    constexpr uint64_t order = [] {
+        uint64_t w = 0;
+        for (int i = 0; i < 16; ++i)
+            w |= static_cast<uint64_t>(kFP4Order[i]) << (4 * i);
+        return w;
+    }();
+    return static_cast<int>((order >> (4 * pos)) & 0xF);
 }
 
 __device__ __forceinline__ float clamp_pm1(float v) {
@@ -97,76 +182,165 @@ __device__ __forceinline__ float clamp_pm1(float v) {
     return v;
 }
 
-template <typename T> struct Vec8 {
-    float v[8];
-};
+// ---- 8 consecutive elements as raw bits -------------------------------------------------------------
+template <typename T> struct Raw8 {
+    static constexpr int W = sizeof(T) == 2 ? 4 : 8;
+    uint32_t w[W];
 
-template <typename T>
-__device__ __forceinline__ void load8(const T* __restrict__ A, long base, long n, bool vec_ok, float (&x)[8]) {
-    if (vec_ok && base + 8 <= n) {
-        if constexpr (sizeof(T) == 2) {
-            using V = __attribute__((ext_vector_type(8))) T;
-            V r = *reinterpret_cast<const V*>(A + base);
+    __device__ __forceinline__ float elem(int i) const {
+        if constexpr (sizeof(T) == 4) {
+            return __uint_as_float(w[i]);
+        } else {
+            const uint16_t h = static_cast<uint16_t>(w[i >> 1] >> (16 * (i & 1)));
+            return static_cast<float>(__builtin_bit_cast(T, h));
+        }
+    }
+    // max over the 8 elements of the |x| bit pattern, widened to the fp32 pattern domain's ordering:
+    // returned in the element type's own pattern space (16-bit patterns for fp16/bf16)
+    __device__ __forceinline__ uint32_t abs_bits_max() const {
+        if constexpr (sizeof(T) == 4) {
+            uint32_t m = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                x[i] = static_cast<float>(r[i]);
+                m = max(m, w[i] & 0x7FFFFFFFu);
+            return m;
         } else {
-            using V = __attribute__((ext_vector_type(4))) float;
-            V r0 = *reinterpret_cast<const V*>(A + base);
-            V r1 = *reinterpret_cast<const V*>(A + base + 4);
+            typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+            u16x2 m = {0, 0};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                x[i] = r0[i];
-                x[4 + i] = r1[i];
-            }
+            for (int i = 0; i < 4; ++i)
+                m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, w[i] & 0x7FFF7FFFu));
+            return max(static_cast<uint32_t>(m.x), static_cast<uint32_t>(m.y));
+        }
+    }
+};
+
+// |x| pattern in T's space -> fp32 value (NaN stays NaN, inf stays inf)
+template <typename T> __device__ __forceinline__ float abs_pattern_to_f32(uint32_t p) {
+    if constexpr (sizeof(T) == 4)
+        return __uint_as_float(p);
+    else
+        return static_cast<float>(__builtin_bit_cast(T, static_cast<uint16_t>(p)));
+}
+template <typename T> __device__ __forceinline__ bool abs_pattern_is_special(uint32_t p) {
+    if constexpr (sizeof(T) == 4)
+        return p >= 0x7F800000u;
+    else if constexpr (__is_same(T, bf16))
+        return p >= 0x7F80u;
+    else
+        return p >= 0x7C00u;
+}
+
+template <typename T>
+__device__ __forceinline__ void load8(const T* __restrict__ A, long base, long n, bool vec_ok, Raw8<T>& r) {
+    if (vec_ok) { // caller guarantees base + 8 <= n
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* p = reinterpret_cast<const u32x4*>(A + base);
+        const u32x4 a = p[0];
+        r.w[0] = a.x, r.w[1] = a.y, r.w[2] = a.z, r.w[3] = a.w;
+        if constexpr (sizeof(T) == 4) {
+            const u32x4 b = p[1];
+            r.w[4] = b.x, r.w[5] = b.y, r.w[6] = b.z, r.w[7] = b.w;
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            x[i] = (base + i < n) ? static_cast<float>(A[base + i]) : 0.0f;
+        for (int i = 0; i < Raw8<T>::W; ++i)
+            r.w[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (base + i < n) {
+                if constexpr (sizeof(T) == 4)
+                    r.w[i] = __float_as_uint(A[base + i]);
+                else
+                    r.w[i >> 1] |= static_cast<uint32_t>(__builtin_bit_cast(uint16_t, A[base + i])) << (16 * (i & 1));
+            }
+        }
     }
 }
 
-// One workgroup = 256 threads = TILE elements, TILE = max(2048, BS); CH = TILE/2048 chunks per lane.
-template <typename T, int BS, int QT>
+// max over aligned groups of WIDTH lanes, result in every lane of the group. Steps 1,2,4,8 are DPP
+// operand modifiers of the v_max itself (lane^1, lane^2, mirror within 8, mirror within 16 - once the
+// smaller group is uniform a mirror is as good as an xor); 16 and 32 cross rows through ds_bpermute.
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xF, 0xF, true);
+    return max(v, static_cast<uint32_t>(moved));
+}
+template <int WIDTH> __device__ __forceinline__ uint32_t group_max_u32(uint32_t v) {
+    if constexpr (WIDTH >= 2)
+        v = dpp_max_u32<0xB1>(v);
+    if constexpr (WIDTH >= 4)
+        v = dpp_max_u32<0x4E>(v);
+    if constexpr (WIDTH >= 8)
+        v = dpp_max_u32<0x141>(v);
+    if constexpr (WIDTH >= 16)
+        v = dpp_max_u32<0x140>(v);
+    if constexpr (WIDTH >= 32) {
+        const int lane = static_cast<int>(threadIdx.x) & 63;
+        v = max(v, static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, static_cast<int>(v))));
+        if constexpr (WIDTH >= 64)
+            v = max(v, static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, static_cast<int>(v))));
+    }
+    return v;
+}
+
+// One workgroup = 256 threads = CH chunks of 2048 elements. BS <= 2048: a chunk holds 2048/BS blocks;
+// BS = 4096: a block is two chunks (CH even).
+template <typename T, int BS, int QT, int CH>
 __global__ __launch_bounds__(256) void quantize4_kernel(const T* __restrict__ A, float* __restrict__ absmax,
                                                         uint8_t* __restrict__ out, long n, int vec_ok) {
-    constexpr int TILE = BS > 2048 ? BS : 2048;
-    constexpr int CH = TILE / 2048;
-    constexpr int GROUP = (BS < 2048 ? BS : 2048) / 8; // lanes sharing one quant block within a chunk
-    __shared__ float wave_max[4];
+    constexpr int TILE = 2048 * CH;
+    constexpr int CPB = BS > 2048 ? BS / 2048 : 1;             // chunks per block
+    constexpr int NB = CH / CPB;                               // blocks (or block groups) per tile along chunks
+    constexpr int GROUP = (BS < 2048 ? BS : 2048) / 8;         // lanes sharing one quant block within a chunk
+    static_assert(CH % CPB == 0, "tile must hold whole blocks");
+    constexpr int NCELL = CellGrid<QT>::N;
+    __shared__ QCell cells[NCELL];
+    __shared__ uint32_t wave_max[NB][4];
 
     const int tid = threadIdx.x;
     const long tile_base = static_cast<long>(blockIdx.x) * TILE;
 
-    float x[CH][8];
-    float m = 0.0f;
+    Raw8<T> x[CH];
+    if (vec_ok != 0 && tile_base + TILE <= n) { // whole tile in range: CH back-to-back vector loads
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const long base = tile_base + c * 2048 + tid * 8;
-        load8<T>(A, base, n, vec_ok != 0, x[c]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            m = fmaxf(m, fabsf(x[c][i]));
-    }
-
-    // block-wide |x| max
-    if constexpr (GROUP <= 64) {
-        m = group_max<GROUP>(m);
+        for (int c = 0; c < CH; ++c)
+            load8<T>(A, tile_base + c * 2048 + static_cast<long>(tid) * 8, n, true, x[c]);
     } else {
-        m = group_max<64>(m);
-        if ((tid & 63) == 0)
-            wave_max[tid >> 6] = m;
-        __syncthreads();
-        if constexpr (GROUP == 128)
-            m = fmaxf(wave_max[(tid >> 7) * 2], wave_max[(tid >> 7) * 2 + 1]);
-        else
-            m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            load8<T>(A, tile_base + c * 2048 + static_cast<long>(tid) * 8, n, false, x[c]);
     }
 
-    const long first = tile_base + static_cast<long>(tid) * 8; // chunk 0 position of this lane
-    if (first >= n && CH == 1)
-        return;
+    {
+        const QCell* src = (QT == kNF4) ? kNF4Cells.c : kFP4Cells.c;
+        for (int i = tid; i < NCELL; i += 256)
+            cells[i] = src[i];
+    }
+
+    // block-wide max of the |x| patterns
+    uint32_t mb[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int j = 0; j < CPB; ++j)
+            m = max(m, x[b * CPB + j].abs_bits_max());
+        mb[b] = group_max_u32<(GROUP < 64 ? GROUP : 64)>(m);
+        if constexpr (GROUP > 64) {
+            if ((tid & 63) == 0)
+                wave_max[b][tid >> 6] = mb[b];
+        }
+    }
+    __syncthreads(); // cell table (and wave_max) visible
+    if constexpr (GROUP > 64) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if constexpr (GROUP == 128)
+                mb[b] = max(wave_max[b][(tid >> 7) * 2], wave_max[b][(tid >> 7) * 2 + 1]);
+            else
+                mb[b] = max(max(wave_max[b][0], wave_max[b][1]), max(wave_max[b][2], wave_max[b][3]));
+        }
+    }
 
     const long nblocks = (n + BS - 1) / BS;
     const long rem = n % BS;
@@ -179,38 +353,45 @@ __global__ __launch_bounds__(256) void quantize4_kernel(const T* __restrict__ A,
             break;
         const long blk = base / BS;
         const bool tail = (rem != 0) && (blk == nblocks - 1);
-        float am = m;
+        const uint32_t pat = mb[c / CPB];
+        float am = abs_pattern_to_f32<T>(pat);
         if (tail)
-            am = fmaxf(am, tiny);
-        if (c == 0 && (base % BS) == 0)
+            am = (am != am) ? am : fmaxf(am, tiny); // torch.clamp(min=) keeps NaN
+        if ((c % CPB) == 0 && (base % BS) == 0)
             absmax[blk] = am;
 
-        int q[8];
-        if (!tail) {
+        uint32_t wq = 0; // packed byte i = (q[2i] << 4) | q[2i+1]
+        uint32_t q[8];
+        if (!tail && !abs_pattern_is_special<T>(pat)) {
             const float inv = 1.0f / fmaxf(am, tiny);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                q[i] = encode4<QT>(clamp_pm1(x[c][i] * inv));
+                q[i] = encode_cell<QT>(x[c].elem(i) * inv, cells);
+        } else if (!tail) {
+            const float inv = 1.0f / fmaxf(am, tiny); // fmaxf drops NaN here exactly as the oracle's clamp does not:
+            const float inv_nan = (am != am) ? am : inv; // keep NaN so every code of the block becomes 15
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                q[i] = encode4<QT>(clamp_pm1(x[c].elem(i) * inv_nan));
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                q[i] = encode4<QT>(clamp_pm1(x[c][i] / am));
+                q[i] = encode4<QT>(clamp_pm1(x[c].elem(i) / am));
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            wq |= ((q[2 * i] << 4) | q[2 * i + 1]) << (8 * i);
 
         if (base + 8 <= n) {
-            uint32_t w = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                w |= static_cast<uint32_t>((q[2 * i] << 4) | q[2 * i + 1]) << (8 * i);
-            *reinterpret_cast<uint32_t*>(out + (base >> 1)) = w;
+            *reinterpret_cast<uint32_t*>(out + (base >> 1)) = wq;
         } else {
             // ragged end: byte stores; an odd n pads the last low nibble with the code of s = 0
-            const int pad = encode4<QT>(0.0f);
+            const uint32_t pad = encode4<QT>(0.0f);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const long e = base + 2 * i;
                 if (e < n) {
-                    const int lo = (e + 1 < n) ? q[2 * i + 1] : pad;
+                    const uint32_t lo = (e + 1 < n) ? q[2 * i + 1] : pad;
                     out[e >> 1] = static_cast<uint8_t>((q[2 * i] << 4) | lo);
                 }
             }
@@ -223,12 +404,23 @@ template <typename T, int QT> void launch_quantize4(const T* A, float* absmax, u
     if (n <= 0)
         return;
     const int vec_ok = aligned_to(A, 16) && aligned_to(out, 4);
+    // 4 chunks per workgroup once that still leaves >= 4 workgroups per CU (amortises the cell-table fill
+    // and puts 4 loads per lane in flight); small inputs keep the smallest tile to spread over the CUs.
+    const bool wide = n >= 4L * 256 * 8192;
+#define BNB_Q4_LAUNCH(BS, CH)                                                                      \
+    {                                                                                              \
+        constexpr long TILE = 2048L * CH;                                                          \
+        const long grid = (n + TILE - 1) / TILE;                                                   \
+        hipLaunchKernelGGL((quantize4_kernel<T, BS, QT, CH>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, \
+                           stream, A, absmax, out, n, vec_ok);                                     \
+    }
 #define BNB_Q4_CASE(BS)                                                                            \
     case BS: {                                                                                     \
-        constexpr long TILE = BS > 2048 ? BS : 2048;                                               \
-        const long grid = (n + TILE - 1) / TILE;                                                   \
-        hipLaunchKernelGGL((quantize4_kernel<T, BS, QT>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, \
-                           A, absmax, out, n, vec_ok);                                             \
+        constexpr int MINCH = BS > 2048 ? BS / 2048 : 1;                                           \
+        if (wide)                                                                                  \
+            BNB_Q4_LAUNCH(BS, 4)                                                                   \
+        else                                                                                       \
+            BNB_Q4_LAUNCH(BS, MINCH)                                                               \
         break;                                                                                     \
     }
     switch (blocksize) {
@@ -245,6 +437,7 @@ template <typename T, int QT> void launch_quantize4(const T* A, float* absmax, u
         exit(1);
     }
 #undef BNB_Q4_CASE
+#undef BNB_Q4_LAUNCH
     BNB_CHECK_LAUNCH();
 }
 

@@ -69,6 +69,92 @@ def test_quantize_4bit_random_vs_oracle(quant_type, dtype, blocksize):
         assert same_values_ftz(d.cpu(), O.dequantize_4bit(q_o, am_o, blocksize, quant_type, A.shape, dtype))
 
 
+@pytest.mark.parametrize("quant_type", ["nf4", "fp4"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32], ids=["fp16", "bf16", "fp32"])
+@pytest.mark.parametrize("blocksize", [32, 64, 512, 2048, 4096])
+def test_quantize_4bit_wide_tiles(quant_type, dtype, blocksize):
+    """n large enough for the 4-chunk (8192-element) workgroup tiles, with a ragged tail."""
+    F = _F()
+    n = 4 * 256 * 8192 + 2048 * 3 + 5
+    A = (torch.randn(n) * 0.3).to(dtype)
+    A[::13] = 0
+    q_o, am_o = O.quantize_4bit(A, blocksize, quant_type)
+    q, st = F.quantize_4bit(A.to(DEV), blocksize=blocksize, quant_type=quant_type)
+    assert torch.equal(q.cpu(), q_o)
+    assert torch.equal(st.absmax.cpu(), am_o)
+
+
+def _bound_windows(quant_type, half_width):
+    """fp32 values in (-1, 1]: every ulp within +-half_width ulps of each decision bound and of a sample
+    of the kernel's cell edges, plus exact code values, +-0 and denormals."""
+    import numpy as np
+
+    code = F_code(quant_type)
+    srt = np.sort(code.astype(np.float32))
+    bounds = ((srt[:-1] + srt[1:]) / np.float32(2)).astype(np.float32)
+    S = 16 if quant_type == "nf4" else 512
+    edges = ((np.arange(0, 2 * S + 1, dtype=np.float64) - S + 0.5) / S).astype(np.float32)
+    edges = edges[np.abs(edges) < 1][:: max(1, len(edges) // 64)]
+    centres = np.concatenate([bounds, edges, srt, np.float32([0.0, 1e-40, -1e-40, 1.17549435e-38])])
+    offs = np.arange(-half_width, half_width + 1, dtype=np.int64)
+    out = []
+    for c in centres:
+        bits = np.float32(c).view(np.int32).astype(np.int64)
+        # walk ulps in sign-magnitude space
+        key = np.where(bits < 0, -(bits & 0x7FFFFFFF), bits) + offs
+        b = np.where(key < 0, (-key) | 0x80000000, key).astype(np.uint32)
+        out.append(b.view(np.float32))
+    v = np.concatenate(out + [np.float32([0.0, -0.0])])
+    v = v[np.isfinite(v) & (np.abs(v) <= 1)]
+    return torch.from_numpy(v.copy())
+
+
+def F_code(quant_type):
+    return O.get_4bit_code(quant_type).numpy()
+
+
+@pytest.mark.parametrize("quant_type", ["nf4", "fp4"])
+def test_quantize_4bit_every_ulp_around_bounds(quant_type):
+    """The cell-table encoder must agree with the 15-bound count on every float next to a decision bound or
+    a cell edge. Blocks are pinned to absmax = 1 (first element 1.0) so that s = x exactly."""
+    F = _F()
+    bs = 64
+    v = _bound_windows(quant_type, 2048)
+    pad = (-len(v)) % (bs - 1)
+    v = torch.cat([v, torch.zeros(pad)])
+    A = torch.cat([torch.ones(len(v) // (bs - 1), 1), v.view(-1, bs - 1)], dim=1).reshape(-1).contiguous()
+    # scaled copies exercise x * (1/absmax) with a non-trivial reciprocal
+    for scale in (1.0, 3.0, 0.37, 1e-30, 6e4):
+        As = (A * scale).float()
+        q_o, am_o = O.quantize_4bit(As, bs, quant_type)
+        q, st = F.quantize_4bit(As.to(DEV), blocksize=bs, quant_type=quant_type)
+        assert torch.equal(st.absmax.cpu(), am_o)
+        bad = (q.cpu() != q_o).nonzero()
+        assert bad.numel() == 0, f"scale={scale}: {bad.numel()} bytes differ, first at {bad[0].item()}"
+
+
+@pytest.mark.parametrize("quant_type", ["nf4", "fp4"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32], ids=["fp16", "bf16", "fp32"])
+def test_quantize_4bit_inf_nan_blocks(quant_type, dtype):
+    """inf / NaN inputs follow the torch semantics of the reference CPU backend: NaN anywhere in a block ->
+    absmax NaN and every code of the block = the last sorted position; inf -> absmax inf, inf*0 = NaN."""
+    F = _F()
+    for bs, n in ((64, 64 * 70 + 9), (256, 256 * 40), (4096, 4096 * 3 + 100)):
+        A = (torch.randn(n) * 0.5).to(dtype)
+        A[5] = float("inf")
+        A[bs + 3] = float("-inf")
+        A[2 * bs + 7] = float("nan")
+        A[3 * bs] = float("nan")
+        A[3 * bs + 1] = float("inf")
+        A[n - 2] = float("nan")  # in the tail block when there is one
+        q_o, am_o = O.quantize_4bit(A, bs, quant_type)
+        q, st = F.quantize_4bit(A.to(DEV), blocksize=bs, quant_type=quant_type)
+        am = st.absmax.cpu()
+        assert torch.equal(torch.isnan(am), torch.isnan(am_o))
+        assert torch.equal(torch.nan_to_num(am, nan=-1.0), torch.nan_to_num(am_o, nan=-1.0))
+        assert torch.equal(q.cpu(), q_o), f"bs={bs}"
+
+
 def test_config1_full_size_4096x4096_fp16_nf4():
     """BASELINE config 1 at full size: every one of the 16.7M codes and 262144 absmax bit-exact."""
     F = _F()

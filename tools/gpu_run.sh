@@ -25,3 +25,9 @@ if [[ "$WHAT" == *" prof "* ]]; then
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bench -o bench -- python $R/bench.py --steps 640 --warmup 64 --no-cpu-baseline > $R/$OUT/rocprof_bench.log 2>&1
   cd $R; f=$(find $OUT/prof_bench -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f" | cut -c1-220
 fi
+if [[ "$WHAT" == *" stream "* ]]; then
+  echo "=== stream bench"; timeout 600 python tools/stream_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/stream_bench.txt
+fi
+if [[ "$WHAT" == *" exhaustive "* ]]; then
+  echo "=== exhaustive encoder check"; timeout 1500 python tools/exhaustive_quantize.py 2>&1 | grep -v amdgpu.ids | tee $OUT/exhaustive_quantize.txt
+fi
