@@ -239,3 +239,22 @@ if _define(
 
 
 __all__ = ["register_kernel", "register_fake", "prod"]
+
+
+# ---------------------------------------------------------------------------------------------- dequantize_4bit_rows
+# Not a reference op: the fused "gather rows, then dequantize" that Embedding4bit needs (the reference
+# composes two F.embedding calls and dequantize_4bit, nn/modules.py:921-951). Lives in this package's own
+# namespace so it can never collide with an operator the reference defines later.
+torch.library.define(
+    "bitsandbytes_amd::dequantize_4bit_rows",
+    "(Tensor A, Tensor absmax, Tensor indices, int row_len, int blocksize, str quant_type, ScalarType dtype) -> Tensor",
+)
+
+
+@register_fake("bitsandbytes_amd::dequantize_4bit_rows")
+def _(A, absmax, indices, row_len: int, blocksize: int, quant_type: str, dtype: torch.dtype):
+    _check_4bit_common(blocksize, quant_type)
+    torch._check(dtype in _FLOAT_DTYPES, lambda: f"dtype must be a 16/32-bit float, got {dtype}")
+    torch._check(indices.dtype in (torch.int32, torch.int64), lambda: f"indices must be int32/int64, got {indices.dtype}")
+    torch._check(row_len % blocksize == 0 and row_len % 8 == 0, lambda: "row_len must be a multiple of blocksize and of 8")
+    return torch.empty((*indices.shape, row_len), dtype=dtype, device=A.device)

@@ -116,6 +116,31 @@ def _(A, absmax, blocksize: int, quant_type: str, shape: Sequence[int], dtype: t
     _dequantize_4bit_impl(A, absmax, blocksize, quant_type, dtype, out)
 
 
+@register_kernel("bitsandbytes_amd::dequantize_4bit_rows", "cuda")
+def _(A, absmax, indices, row_len: int, blocksize: int, quant_type: str, dtype: torch.dtype) -> torch.Tensor:
+    if dtype not in _DT_CODE:
+        raise ValueError(f"Blockwise 4bit dequantization only supports 16/32-bit floats, but got {dtype}")
+    if quant_type not in _QT_CODE:
+        raise ValueError(f"quant_type must be 'nf4' or 'fp4', got {quant_type!r}")
+    if absmax.dtype != torch.float32:
+        raise ValueError(f"absmax must be float32, got {absmax.dtype}")
+    if indices.dtype not in (torch.int32, torch.int64):
+        raise ValueError(f"indices must be int32 or int64, got {indices.dtype}")
+    if row_len % blocksize != 0 or row_len % 8 != 0:
+        raise ValueError(f"row_len ({row_len}) must be a multiple of blocksize ({blocksize}) and of 8")
+    A = A.contiguous()
+    absmax = absmax.contiguous()
+    indices = indices.contiguous()
+    num_rows = (A.numel() * A.element_size() * 2) // row_len
+    out = torch.empty((*indices.shape, row_len), dtype=dtype, device=A.device)
+    with _device_of(A):
+        lib.bnb_mi355x_dequantize_4bit_rows(
+            _DT_CODE[dtype], A.data_ptr(), absmax.data_ptr(), indices.data_ptr(), indices.element_size(), out.data_ptr(),
+            indices.numel(), num_rows, row_len, blocksize, _QT_CODE[quant_type], _stream(A),
+        )
+    return out
+
+
 # ------------------------------------------------------------------------------------------ 8-bit blockwise
 @register_kernel("bitsandbytes::quantize_blockwise", "cuda")
 def _(A: torch.Tensor, code: torch.Tensor, blocksize: int):

@@ -13,6 +13,7 @@ void quantize_4bit_f16(const void*, float*, uint8_t*, int, long, int, hipStream_
 void quantize_4bit_bf16(const void*, float*, uint8_t*, int, long, int, hipStream_t);
 // dequantize4.hip
 void dequantize_4bit_f32(const uint8_t*, const float*, float*, int, long, int, hipStream_t);
+void dequantize_4bit_rows(int, const uint8_t*, const float*, const void*, int, void*, long, long, int, int, int, hipStream_t);
 void dequantize_4bit_f16(const uint8_t*, const float*, void*, int, long, int, hipStream_t);
 void dequantize_4bit_bf16(const uint8_t*, const float*, void*, int, long, int, hipStream_t);
 // blockwise8.hip
@@ -209,6 +210,12 @@ void bnb_mi355x_quantize_4bit(const void* A, int dtype, float* absmax, unsigned 
         quantize_4bit_f16(A, absmax, out, blocksize, n, quant_type, S(s));
     else
         quantize_4bit_bf16(A, absmax, out, blocksize, n, quant_type, S(s));
+}
+void bnb_mi355x_dequantize_4bit_rows(int dtype, const unsigned char* A, const float* absmax, const void* indices,
+                                     int index_bytes, void* out, long rows_out, long num_rows, int row_len,
+                                     int blocksize, int quant_type, bnb_stream_t s) {
+    dequantize_4bit_rows(dtype, A, absmax, indices, index_bytes, out, rows_out, num_rows, row_len, blocksize,
+                         quant_type, S(s));
 }
 void bnb_mi355x_quantize_8bit(const float* code, const void* A, int dtype, float* absmax, unsigned char* out,
                               int blocksize, long n, bnb_stream_t s) {

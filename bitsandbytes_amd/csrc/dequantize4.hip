@@ -113,6 +113,77 @@ void launch_dequantize4(const uint8_t* A, const float* absmax, T* out, int block
     BNB_CHECK_LAUNCH();
 }
 
+// Row gather + dequantize in one pass (the Embedding4bit lookup, reference nn/modules.py:921-951, which
+// runs two F.embedding gathers and a dequantize): out[t, :] = T(code[nib] * absmax) of weight row idx[t].
+// Requires row_len % 8 == 0 and row_len % blocksize == 0, so a row is a whole number of packed dwords and
+// of quantization blocks. grid = (ceil(row_len / 2048), rows_out); a lane owns 8 outputs exactly as above,
+// so results are bit-identical to dequantize4_kernel on the gathered bytes. An index outside
+// [0, num_rows) yields a row of zeros (F.embedding would raise a device-side assert instead).
+template <typename T, typename IdxT>
+__global__ __launch_bounds__(kDqThreads) void dequantize4_rows_kernel(const uint8_t* __restrict__ A,
+                                                                      const float* __restrict__ absmax,
+                                                                      const IdxT* __restrict__ idx,
+                                                                      T* __restrict__ out, long num_rows, int row_len,
+                                                                      int bs_shift, int quant_type) {
+    __shared__ float code[16];
+    const int tid = threadIdx.x;
+    if (tid < 16)
+        code[tid] = (quant_type == kNF4) ? kNF4Code[tid] : kFP4Code[tid];
+    const long t = blockIdx.y;
+    const long row = static_cast<long>(idx[t]);
+    const int col = (static_cast<int>(blockIdx.x) * kDqThreads + tid) * 8;
+    const bool live = col < row_len;
+    const bool valid = row >= 0 && row < num_rows;
+    uint32_t w = 0;
+    float s = 0.0f;
+    if (live && valid) {
+        const long e = row * row_len + col;
+        w = *reinterpret_cast<const uint32_t*>(A + (e >> 1));
+        s = absmax[e >> bs_shift];
+    }
+    __syncthreads();
+    if (!live)
+        return;
+    float v[8];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t byte = (w >> (8 * b)) & 0xFFu;
+        v[2 * b] = valid ? rounded_f32(code[byte >> 4] * s) : 0.0f;
+        v[2 * b + 1] = valid ? rounded_f32(code[byte & 0xF] * s) : 0.0f;
+    }
+    store8<T>(out, t * row_len + col, v);
+}
+
+template <typename T>
+void launch_dequantize4_rows(const uint8_t* A, const float* absmax, const void* idx, int index_bytes, T* out,
+                             long rows_out, long num_rows, int row_len, int blocksize, int quant_type,
+                             hipStream_t stream) {
+    if (rows_out <= 0 || row_len <= 0)
+        return;
+    if (!is_pow2(blocksize) || blocksize < 8 || row_len % 8 != 0 || row_len % blocksize != 0 ||
+        (index_bytes != 4 && index_bytes != 8) || !aligned_to(A, 4) || !aligned_to(out, 16) || rows_out > 0x7FFFFFFFL) {
+        fprintf(stderr,
+                "bitsandbytes_amd: dequantize_4bit_rows: need row_len %% 8 == 0, row_len %% blocksize == 0, "
+                "int32/int64 indices, 4-byte aligned weights and 16-byte aligned output (row_len %d, blocksize %d)\n",
+                row_len, blocksize);
+        exit(1);
+    }
+    const dim3 grid(static_cast<unsigned>((row_len + kDqThreads * 8 - 1) / (kDqThreads * 8)), 1, 1);
+    // grid.y is limited to 65535: launch in slabs of rows
+    for (long r0 = 0; r0 < rows_out; r0 += 65535) {
+        const unsigned ny = static_cast<unsigned>(rows_out - r0 < 65535 ? rows_out - r0 : 65535);
+        if (index_bytes == 8)
+            hipLaunchKernelGGL((dequantize4_rows_kernel<T, int64_t>), dim3(grid.x, ny), dim3(kDqThreads), 0, stream, A,
+                               absmax, static_cast<const int64_t*>(idx) + r0, out + r0 * row_len, num_rows, row_len,
+                               ilog2(blocksize), quant_type);
+        else
+            hipLaunchKernelGGL((dequantize4_rows_kernel<T, int32_t>), dim3(grid.x, ny), dim3(kDqThreads), 0, stream, A,
+                               absmax, static_cast<const int32_t*>(idx) + r0, out + r0 * row_len, num_rows, row_len,
+                               ilog2(blocksize), quant_type);
+    }
+    BNB_CHECK_LAUNCH();
+}
+
 } // namespace
 
 void dequantize_4bit_f32(const uint8_t* A, const float* absmax, float* out, int blocksize, long n, int qt,
@@ -126,6 +197,19 @@ void dequantize_4bit_f16(const uint8_t* A, const float* absmax, void* out, int b
 void dequantize_4bit_bf16(const uint8_t* A, const float* absmax, void* out, int blocksize, long n, int qt,
                           hipStream_t s) {
     launch_dequantize4<bf16>(A, absmax, static_cast<bf16*>(out), blocksize, n, qt, s);
+}
+
+void dequantize_4bit_rows(int dtype, const uint8_t* A, const float* absmax, const void* idx, int index_bytes, void* out,
+                          long rows_out, long num_rows, int row_len, int blocksize, int qt, hipStream_t s) {
+    if (dtype == 0)
+        launch_dequantize4_rows<float>(A, absmax, idx, index_bytes, static_cast<float*>(out), rows_out, num_rows,
+                                       row_len, blocksize, qt, s);
+    else if (dtype == 1)
+        launch_dequantize4_rows<f16>(A, absmax, idx, index_bytes, static_cast<f16*>(out), rows_out, num_rows, row_len,
+                                     blocksize, qt, s);
+    else
+        launch_dequantize4_rows<bf16>(A, absmax, idx, index_bytes, static_cast<bf16*>(out), rows_out, num_rows,
+                                      row_len, blocksize, qt, s);
 }
 
 } // namespace bnb

@@ -1,3 +1,13 @@
-from .modules import Linear4bit, LinearFP4, LinearNF4, Params4bit
+from . import parametrize
+from .modules import (
+    Embedding4bit,
+    EmbeddingFP4,
+    EmbeddingNF4,
+    Linear4bit,
+    LinearFP4,
+    LinearNF4,
+    Params4bit,
+)
 
-__all__ = ["Linear4bit", "LinearFP4", "LinearNF4", "Params4bit"]
+__all__ = ["Linear4bit", "LinearFP4", "LinearNF4", "Params4bit", "Embedding4bit", "EmbeddingFP4", "EmbeddingNF4",
+           "parametrize"]

@@ -287,3 +287,78 @@ class LinearNF4(Linear4bit):
                  quant_storage=torch.uint8, device=None):
         super().__init__(input_features, output_features, bias, compute_dtype, compress_statistics, "nf4",
                          quant_storage, device)
+
+
+class Embedding4bit(nn.Embedding):
+    """4-bit embedding table (reference modules.py:880-978): load fp rows, ``.to("cuda")`` quantises them.
+
+    Each row is a whole number of quantization blocks when ``embedding_dim % blocksize == 0``; the lookup is
+    then ONE fused launch (gather the packed row + its scales, dequantize) instead of the reference's two
+    ``F.embedding`` gathers plus ``dequantize_4bit`` - same values bit for bit. Otherwise the whole table is
+    dequantized and indexed, as in the reference (slow path, warned about at construction)."""
+
+    def __init__(self, num_embeddings, embedding_dim, dtype=None, quant_type="fp4", quant_storage=torch.uint8,
+                 device=None):
+        super().__init__(num_embeddings, embedding_dim, device=device, dtype=dtype)
+        self.dtype = self.weight.data.dtype
+        self.weight = Params4bit(
+            self.weight.data,
+            requires_grad=False,
+            compress_statistics=None,
+            quant_type=quant_type,
+            quant_storage=quant_storage,
+            module=self,
+        )
+        self.quant_state = None
+        self.quant_storage = quant_storage
+        if embedding_dim % self.weight.blocksize != 0:
+            logger.warning(
+                f"Embedding size {embedding_dim} is not divisible by block size {self.weight.blocksize}. "
+                "This will lead to slow inference."
+            )
+
+    def _forward_with_partial_dequantize(self, input: torch.Tensor) -> torch.Tensor:
+        state = self.weight.quant_state
+        assert self.embedding_dim % state.blocksize == 0
+        absmax = state.absmax
+        if state.nested:  # un-nest the scales once per call; the row kernel takes plain fp32 absmax
+            absmax = F.dequantize_blockwise(state.absmax, state.state2) + state.offset
+            if absmax.dtype != torch.float32:
+                absmax = absmax.float()
+        if self.embedding_dim % 8 != 0 or input.dtype not in (torch.int32, torch.int64):
+            # rows that are not whole packed dwords: compose the lookup from gathers like the reference
+            packed = self.weight.data.view(torch.uint8).view(self.num_embeddings, self.embedding_dim // 2)
+            rows = torch.nn.functional.embedding(input, packed).reshape(-1, 1)
+            scales = torch.nn.functional.embedding(
+                input, absmax.view(self.num_embeddings, self.embedding_dim // state.blocksize)
+            ).reshape(-1)
+            out = torch.ops.bitsandbytes.dequantize_4bit.default(
+                rows, scales, state.blocksize, state.quant_type, (*input.shape, self.embedding_dim), state.dtype
+            )
+            return out.to(self.dtype)
+        out = torch.ops.bitsandbytes_amd.dequantize_4bit_rows.default(
+            self.weight.data, absmax, input, self.embedding_dim, state.blocksize, state.quant_type, state.dtype
+        )
+        return out.to(self.dtype)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        raise NotImplementedError("Saving Embedding4bit module is not implemented")
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        fix_4bit_weight_quant_state_from_module(self)
+        if self.embedding_dim % self.weight.quant_state.blocksize == 0:
+            return self._forward_with_partial_dequantize(input)
+        table = F.dequantize_4bit(self.weight.data, self.weight.quant_state)
+        return torch.nn.functional.embedding(input, table).to(self.dtype)
+
+
+class EmbeddingFP4(Embedding4bit):
+    def __init__(self, num_embeddings, embedding_dim, dtype=None, quant_storage=torch.uint8, device=None):
+        super().__init__(num_embeddings, embedding_dim, dtype=dtype, quant_type="fp4", quant_storage=quant_storage,
+                         device=device)
+
+
+class EmbeddingNF4(Embedding4bit):
+    def __init__(self, num_embeddings, embedding_dim, dtype=None, quant_storage=torch.uint8, device=None):
+        super().__init__(num_embeddings, embedding_dim, dtype=dtype, quant_type="nf4", quant_storage=quant_storage,
+                         device=device)

@@ -72,8 +72,9 @@ void cdequantize_blockwise_bf16(float* code, unsigned char* A, float* absmax, vo
  *   scale of block b = absmax[b]                                            (absmax_8bit == NULL)
  *                    = absmax_code[absmax_8bit[b]] * absmax[b >> 8] + *absmax_offset   (nested)
  * K % blocksize == 0 is guaranteed by the caller (reference backends/cuda/ops.py:956-962);
- * absmax_offset is fp32; bias has A's dtype. M is any positive value: M <= 4 runs the
- * wave64 dot kernel, 5 <= M the MFMA kernel (bf16/fp16). */
+ * absmax_offset is fp32; bias has A's dtype. M is any positive value: M <= 2 runs the
+ * wave64 dot kernel, larger M the MFMA kernels (bf16/fp16, K % 256 == 0, blocksize >= 64; otherwise
+ * the dot kernel loops over M). */
 void cgemm_4bit_bf16(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K, int blocksize, int quant_type, bnb_stream_t stream);
 void cgemm_4bit_fp16(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K, int blocksize, int quant_type, bnb_stream_t stream);
 void cgemm_4bit_fp32(const float* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, float* out, const float* bias, int M, int N, int K, int blocksize, int quant_type, bnb_stream_t stream);
@@ -100,6 +101,14 @@ void* cget_managed_ptr(size_t bytes);
  * enqueued on `stream`. dtype: 0 = fp32, 1 = fp16, 2 = bf16. */
 void bnb_mi355x_quantize_4bit(const void* A, int dtype, float* absmax, unsigned char* out, int blocksize, long n, int quant_type, bnb_stream_t stream);
 void bnb_mi355x_quantize_8bit(const float* code, const void* A, int dtype, float* absmax, unsigned char* out, int blocksize, long n, bnb_stream_t stream);
+
+/* Row gather + 4-bit dequantize in one launch: out[t, 0:row_len] = dequantize(row indices[t]) for
+ * t < rows_out. The fused form of the Embedding4bit lookup (reference bitsandbytes/nn/modules.py:921-951:
+ * F.embedding on the packed bytes, F.embedding on absmax, dequantize_4bit). A is the packed
+ * [num_rows, row_len] table, absmax its fp32 scales (un-nested); row_len % 8 == 0 and
+ * row_len % blocksize == 0; indices are int32 (index_bytes 4) or int64 (8). Values are bit-identical to
+ * cdequantize_blockwise_* applied to the gathered rows. An index outside [0, num_rows) gives a zero row. */
+void bnb_mi355x_dequantize_4bit_rows(int dtype, const unsigned char* A, const float* absmax, const void* indices, int index_bytes, void* out, long rows_out, long num_rows, int row_len, int blocksize, int quant_type, bnb_stream_t stream);
 
 /* gemm_4bit with an explicit kernel choice and a caller-owned split-K workspace:
  * kernel = 0 auto, 1 wave64 dot kernel, 2 MFMA kernel. dtype as above; code16 may be NULL.

@@ -45,3 +45,11 @@ def register():
     def _(A, B, shapeB, absmax, code, blocksize):
         qt = "fp4" if float(code[1]) > 0 else "nf4"
         return O.gemm_4bit(A, B, shapeB, absmax, blocksize, qt)[0]
+
+    @rk("bitsandbytes_amd::dequantize_4bit_rows", "cpu")
+    def _(A, absmax, indices, row_len, blocksize, quant_type, dtype):
+        num_rows = A.numel() * A.element_size() * 2 // row_len
+        packed = A.contiguous().view(torch.uint8).view(num_rows, row_len // 2)
+        rows = packed[indices.reshape(-1).long()].reshape(-1, 1)
+        scales = absmax.view(num_rows, row_len // blocksize)[indices.reshape(-1).long()].reshape(-1)
+        return O.dequantize_4bit(rows, scales, blocksize, quant_type, (*indices.shape, row_len), dtype)

@@ -550,3 +550,131 @@ def test_mfma_kernel_variants(cfg, M, N, K, ks):
             bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
         assert rel_err(y1.cpu(), y_ref) < REL_TOL
         assert torch.equal(y1, y2)
+
+
+# ------------------------------------------------------------------------------------------ callers of dequantize_4bit
+@pytest.mark.parametrize("quant_type", ["nf4", "fp4"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32], ids=["fp16", "bf16", "fp32"])
+@pytest.mark.parametrize("dim,blocksize", [(64, 64), (4096, 64), (2560, 128), (192, 32), (8192, 4096)])
+def test_dequantize_4bit_rows_matches_gathered_dequantize(quant_type, dtype, dim, blocksize):
+    """The fused row-gather kernel is bit-identical to dequantizing the table and indexing it, for int32 and
+    int64 indices, repeated indices and any index shape."""
+    F = _F()
+    rows = 300
+    W = (torch.randn(rows, dim) * 0.2).to(dtype)
+    q, st = F.quantize_4bit(W.to(DEV), blocksize=blocksize, quant_type=quant_type)
+    table = O.dequantize_4bit(q.cpu(), st.absmax.cpu(), blocksize, quant_type, (rows, dim), dtype)
+    for idx in (torch.tensor([0, rows - 1, 5, 5, 17]), torch.randint(0, rows, (3, 7)), torch.randint(0, rows, (1,))):
+        for it in (torch.int64, torch.int32):
+            out = torch.ops.bitsandbytes_amd.dequantize_4bit_rows.default(
+                q, st.absmax, idx.to(DEV).to(it), dim, blocksize, quant_type, dtype)
+            assert out.shape == (*idx.shape, dim) and out.dtype == dtype
+            assert same_values_ftz(out.cpu(), table[idx])
+    # out-of-range rows are zero rows (documented), never an out-of-bounds read
+    bad = torch.tensor([rows, -1, 2], device=DEV)
+    out = torch.ops.bitsandbytes_amd.dequantize_4bit_rows.default(q, st.absmax, bad, dim, blocksize, quant_type, dtype)
+    assert torch.all(out[:2] == 0) and same_values_ftz(out[2].cpu(), table[2])
+
+
+@pytest.mark.parametrize("cls_name,dim", [("EmbeddingNF4", 1024), ("EmbeddingFP4", 1024), ("EmbeddingNF4", 72),
+                                          ("EmbeddingNF4", 96)])
+def test_embedding4bit_gpu(cls_name, dim):
+    """reference tests/test_modules.py::test_embedding_lossless-style check: lookups equal rows of the
+    dequantized table (bit for bit) and are close to the fp table."""
+    import bitsandbytes_amd.nn as bnn
+
+    F = _F()
+    torch.manual_seed(2)
+    fp = torch.nn.Embedding(500, dim, dtype=torch.bfloat16)
+    emb = getattr(bnn, cls_name)(500, dim, dtype=torch.bfloat16)
+    emb.load_state_dict(fp.state_dict())
+    emb = emb.to(DEV)
+    assert emb.weight.dtype == torch.uint8 and emb.weight.bnb_quantized
+    idx = torch.randint(0, 500, (4, 33), device=DEV)
+    out = emb(idx)
+    table = F.dequantize_4bit(emb.weight.data, emb.weight.quant_state)
+    assert out.dtype == torch.bfloat16 and torch.equal(out, table[idx])
+    assert rel_err(out.float().cpu(), fp(idx.cpu()).float()) < 0.25
+
+
+def test_replace_parameter_4bit_gpu():
+    import bitsandbytes_amd.nn.parametrize as bp
+
+    F = _F()
+
+    class Experts(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.randn(8, 256, 512, dtype=torch.bfloat16) * 0.05)
+
+        def forward(self, x):
+            return torch.einsum("bi,eoi->beo", x, self.w)
+
+    m = Experts().to(DEV)
+    w_fp = m.w.detach().clone()
+    bp.replace_parameter_4bit(m, "w", compress_statistics=True, quant_type="nf4")
+    q_o, am_o = O.quantize_4bit(w_fp.cpu(), 64, "nf4")
+    assert torch.equal(m.parametrizations.w.original.cpu(), q_o)
+    assert m.w.shape == w_fp.shape and m.w.dtype == torch.bfloat16
+    assert rel_err(m.w.float().cpu(), w_fp.float().cpu()) < 0.12
+    x = torch.randn(5, 512, device=DEV, dtype=torch.bfloat16)
+    y = m(x)
+    assert rel_err(y.float().cpu(), torch.einsum("bi,eoi->beo", x, w_fp).float().cpu()) < 0.12
+    sd = m.state_dict()
+    assert sd["w"].dtype == torch.uint8 and "w.quant_state.bitsandbytes__nf4" in sd and "w.nested_absmax" in sd
+
+
+# ------------------------------------------------------------------------------------------ torch.library conformance
+def _op_samples():
+    F = _F()
+    W = (torch.randn(64, 256, device=DEV) / 16).bfloat16()
+    q, st = F.quantize_4bit(W, quant_type="nf4")
+    qd, std = F.quantize_4bit(W, quant_type="fp4", blocksize=128, compress_statistics=True)
+    x1 = torch.randn(1, 256, device=DEV, dtype=torch.bfloat16)
+    x9 = torch.randn(9, 256, device=DEV, dtype=torch.bfloat16)
+    bias = torch.randn(64, device=DEV, dtype=torch.bfloat16)
+    code = F.create_dynamic_map().to(DEV)
+    A8 = torch.randn(1024, device=DEV)
+    q8, am8 = torch.ops.bitsandbytes.quantize_blockwise.default(A8, code, 256)
+    ops = torch.ops.bitsandbytes
+    return [
+        (ops.quantize_4bit.default, (W, 64, "nf4", torch.uint8), {}),
+        (ops.quantize_4bit.default, (W.float(), 128, "fp4", torch.bfloat16), {}),
+        (ops.dequantize_4bit.default, (q, st.absmax, 64, "nf4", (64, 256), torch.bfloat16), {}),
+        (ops.gemm_4bit.default, (x1, q, (64, 256), st.absmax, 64, "nf4"), {}),
+        (ops.gemm_4bit.default, (x9, q, (64, 256), st.absmax, 64, "nf4", bias), {}),
+        (ops.gemm_4bit.default, (x9, qd, (64, 256), std.state2.absmax, 128, "fp4", None, std.absmax, std.state2.code,
+                                 std.offset), {}),
+        (ops.gemv_4bit.default, (x1, q, (64, 256), st.absmax, st.code, 64), {}),
+        (ops.quantize_blockwise.default, (A8, code, 256), {}),
+        (ops.dequantize_blockwise.default, (q8, am8, code, 256, torch.float32), {}),
+        (torch.ops.bitsandbytes_amd.dequantize_4bit_rows.default,
+         (q, st.absmax, torch.tensor([3, 1, 3], device=DEV), 256, 64, "nf4", torch.bfloat16), {}),
+    ]
+
+
+def test_opcheck_schema_and_fake_kernels():
+    """torch.library.opcheck on every op of the path (reference tests/test_ops.py:150-232 does the same):
+    schema correctness and fake-kernel/real-kernel agreement (shapes, dtypes, strides, devices)."""
+    for op, args, kwargs in _op_samples():
+        torch.library.opcheck(op, args, kwargs, test_utils=("test_schema", "test_faketensor"))
+
+
+def test_linear4bit_under_torch_compile_aot_eager():
+    """Fake kernels are sufficient to trace Linear4bit without graph breaks (reference
+    tests/test_linear4bit.py:359-420 compiles with inductor; aot_eager needs no host C++ toolchain)."""
+    import bitsandbytes_amd.nn as bnn
+
+    torch.manual_seed(4)
+    torch._dynamo.reset()
+    net = torch.nn.Sequential(
+        bnn.LinearNF4(256, 512, compute_dtype=torch.bfloat16), torch.nn.GELU(), bnn.LinearNF4(512, 256, compute_dtype=torch.bfloat16)
+    ).to(DEV)
+    x = torch.randn(3, 256, device=DEV, dtype=torch.bfloat16)
+    want = net(x)
+    compiled = torch.compile(net, backend="aot_eager", fullgraph=True)
+    with torch.no_grad():
+        got = compiled(x)
+        got1 = compiled(x[:1])
+    assert torch.equal(got, want)
+    assert torch.equal(got1, net(x[:1]))

@@ -12,7 +12,8 @@ import torch
 import _oracle_cpu_backend
 import bitsandbytes_amd as bnb
 import bitsandbytes_amd.functional as F
-from bitsandbytes_amd.nn import Linear4bit, LinearFP4, LinearNF4, Params4bit
+from bitsandbytes_amd.nn import Embedding4bit, EmbeddingFP4, EmbeddingNF4, Linear4bit, LinearFP4, LinearNF4, Params4bit
+from bitsandbytes_amd.nn import parametrize as bnb_parametrize
 from conftest import from_bits, golden, rel_err
 
 _oracle_cpu_backend.register()
@@ -177,3 +178,120 @@ def test_empty_input():
     _, layer = _make_layer(Linear4bit, quant_type="nf4")
     y = bnb.matmul_4bit(torch.empty(0, 128), layer.weight, layer.weight.quant_state)
     assert y.shape == (0, 48)
+
+
+# ------------------------------------------------------------------------------------------ Embedding4bit / parametrize
+@pytest.mark.parametrize("cls,qt", [(EmbeddingNF4, "nf4"), (EmbeddingFP4, "fp4")])
+@pytest.mark.parametrize("dim", [64, 192, 72])  # 72: not a multiple of the blocksize -> whole-table path
+def test_embedding4bit_matches_dequantized_table(cls, qt, dim):
+    """reference tests/test_modules.py (embedding lookups): the lookup equals indexing the dequantized table."""
+    torch.manual_seed(3)
+    fp = torch.nn.Embedding(50, dim)
+    emb = cls(50, dim)
+    emb.load_state_dict(fp.state_dict())
+    emb = emb.to("cpu")
+    assert emb.weight.bnb_quantized and emb.weight.quant_state.quant_type == qt and not emb.weight.quant_state.nested
+    idx = torch.tensor([[0, 49, 7], [7, 7, 23]])
+    out = emb(idx)
+    table = F.dequantize_4bit(emb.weight.data, emb.weight.quant_state)
+    assert out.shape == (2, 3, dim) and out.dtype == fp.weight.dtype
+    assert torch.equal(out, table[idx])
+    assert rel_err(out, fp(idx)) < 0.25
+    assert torch.equal(emb(idx.int()), out)
+    with pytest.raises(NotImplementedError):
+        emb.state_dict()
+
+
+def test_embedding4bit_recovers_quant_state_from_module():
+    emb = EmbeddingNF4(16, 64).to("cpu")
+    idx = torch.arange(16)
+    want = emb(idx)
+    emb.quant_state = emb.weight.quant_state
+    emb.weight = torch.nn.Parameter(emb.weight.data.clone(), requires_grad=False)  # what FSDP-style wrappers do
+    assert torch.equal(emb(idx), want)
+
+
+@pytest.mark.parametrize("quant_type", ["nf4", "fp4"])
+@pytest.mark.parametrize("compress_statistics", [False, True])
+def test_replace_parameter_4bit_roundtrip(quant_type, compress_statistics):
+    """reference tests/test_parametrize.py: attribute reads give the dequantized tensor; the state dict has
+    the Linear4bit key layout and reloads through replace_parameter_4bit_prequantized."""
+
+    class Experts(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.randn(4, 32, 64) * 0.1)
+            self.reads = 0
+
+        def forward(self, x):
+            a = self.w  # two reads inside one forward: the second one must come from the cache
+            b = self.w
+            assert a is b
+            return torch.einsum("bi,eoi->beo", x, a)
+
+    torch.manual_seed(5)
+    m = Experts()
+    w_fp = m.w.detach().clone()
+    q_want, st_want = F.quantize_4bit(w_fp, quant_type=quant_type, compress_statistics=compress_statistics)
+    bnb_parametrize.replace_parameter_4bit(m, "w", compress_statistics=compress_statistics, quant_type=quant_type)
+    assert m.w.shape == w_fp.shape and m.w.dtype == w_fp.dtype
+    assert torch.equal(m.w, F.dequantize_4bit(q_want, st_want))
+    assert rel_err(m.w, w_fp) < 0.2
+    assert m.parametrizations.w.original.dtype == torch.uint8
+    y = m(torch.randn(3, 64))
+    assert y.shape == (3, 4, 32)
+    import torch.nn.utils.parametrize as P
+
+    assert P._cache_enabled == 0 and not P._cache  # cache released after the forward
+
+    sd = m.state_dict()
+    assert "w" in sd and sd["w"].dtype == torch.uint8 and "parametrizations.w.original" not in sd
+    assert f"w.quant_state.bitsandbytes__{quant_type}" in sd and "w.absmax" in sd
+    assert ("w.nested_absmax" in sd) == compress_statistics
+
+    # reload into a fresh module holding the packed bytes
+    m2 = Experts()
+    m2.w = torch.nn.Parameter(sd["w"].clone(), requires_grad=False)
+    qs = {k[len("w."):]: v for k, v in sd.items() if k.startswith("w.")}
+    bnb_parametrize.replace_parameter_4bit_prequantized(m2, "w", qs, device=torch.device("cpu"))
+    assert torch.equal(m2.w, m.w)
+
+    with pytest.raises(AttributeError):
+        bnb_parametrize.replace_parameter_4bit(m, "nope")
+    m.buf = torch.zeros(3)
+    with pytest.raises(TypeError):
+        bnb_parametrize.replace_parameter_4bit(m, "buf")
+
+
+def test_parametrize_cache_counter_survives_failing_forward():
+    import torch.nn.utils.parametrize as P
+
+    class Boom(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.randn(64, 64))
+
+        def forward(self, x):
+            _ = self.w
+            raise RuntimeError("boom")
+
+    m = Boom()
+    bnb_parametrize.replace_parameter_4bit(m, "w")
+    for _ in range(3):
+        with pytest.raises(RuntimeError):
+            m(torch.zeros(1))
+    assert P._cache_enabled == 0 and not P._cache
+
+
+def test_linear4bit_traces_under_torch_compile():
+    """The fake kernels are enough for dynamo/AOT to trace Linear4bit with no graph break (the arithmetic in
+    this CPU test is the oracle's; the GPU suite repeats it on the HIP kernels)."""
+    torch.manual_seed(4)
+    torch._dynamo.reset()
+    net = torch.nn.Sequential(LinearNF4(128, 64, compute_dtype=torch.bfloat16), torch.nn.GELU(),
+                              LinearNF4(64, 128, compute_dtype=torch.bfloat16)).to("cpu")
+    x = torch.randn(3, 128, dtype=torch.bfloat16)
+    want = net(x)
+    compiled = torch.compile(net, backend="aot_eager", fullgraph=True)
+    with torch.no_grad():
+        assert torch.equal(compiled(x), want)

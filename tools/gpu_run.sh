@@ -31,3 +31,6 @@ fi
 if [[ "$WHAT" == *" exhaustive "* ]]; then
   echo "=== exhaustive encoder check"; timeout 1500 python tools/exhaustive_quantize.py 2>&1 | grep -v amdgpu.ids | tee $OUT/exhaustive_quantize.txt
 fi
+if [[ "$WHAT" == *" configs "* ]]; then
+  echo "=== configs bench"; timeout 900 python tools/configs_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/configs_bench.txt
+fi
