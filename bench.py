@@ -94,6 +94,58 @@ def cpu_baseline(M, N, K, blocksize, quant_type):
     }
 
 
+def pmc_traffic(extra_args, kernel_substr="gemv4_dot_kernel", timeout_s=240):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC counters, collected the way
+    /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE
+    passes (they do not fit one TCC pass), no tracing domains besides the kernel trace; both counters are
+    reported in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes,
+    so it is doubled. WRITE_SIZE is uncalibrated on gfx950 (guide) and is only ~0.1 % of this kernel's
+    traffic. Each pass re-runs this script with --pmc-child (two eager sweeps over the 64-layer rotation).
+    Returns (bytes_per_launch or None, detail dict)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, {"error": "rocprofv3 not on PATH"}
+    detail = {}
+    vals = {}
+    here = os.path.abspath(__file__)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix="bnb_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o", "pmc", "--",
+               sys.executable, here, "--pmc-child", "--no-cpu-baseline"] + list(extra_args)
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=timeout_s, check=True)
+            rows = []
+            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                with open(f, newline="") as fh:
+                    for r in csv.DictReader(fh):
+                        if kernel_substr in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                            rows.append(float(r["Counter_Value"]))
+            if not rows:
+                raise RuntimeError("no counter rows for the kernel")
+            rows = rows[len(rows) // 2:]  # second sweep over the rotation
+            vals[counter] = sum(rows) / len(rows)
+            detail[counter + "_KiB_per_launch_raw"] = round(vals[counter], 1)
+            detail[counter + "_dispatches"] = len(rows)
+        except Exception as exc:  # informational: never lose the bench line over the profiler
+            detail["error"] = f"{counter}: {type(exc).__name__}: {exc}"[:300]
+            return None, detail
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    traffic = 2.0 * vals["FETCH_SIZE"] * 1024.0 + vals["WRITE_SIZE"] * 1024.0
+    detail["correction"] = "bytes = 2 x FETCH_SIZE[KiB] x 1024 (gfx950 64-B tally of 128-B requests) + WRITE_SIZE[KiB] x 1024"
+    return traffic, detail
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +159,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue steps eagerly instead of replaying a hipGraph")
     ap.add_argument("--sweep", action="store_true", help="also time M = 1..64 at N = K = 4096 (headline sweep)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # workload run under rocprofv3 --pmc
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -145,6 +199,13 @@ def main():
     def run_chunk_eager(base, bucket):
         for j in range(GRAPH_CHUNK):
             run_step(base + j, bucket[j])
+
+    if args.pmc_child:
+        # two eager passes over the HBM-resident rotation; rocprofv3 --pmc serialises and counts every dispatch
+        for base in (0, GRAPH_CHUNK):
+            run_chunk_eager(base, buckets[0])
+        torch.cuda.synchronize()
+        return
 
     # LAYERS == GRAPH_CHUNK, so every chunk touches the same layer sequence: one graph per bucket
     graphs = None
@@ -317,6 +378,11 @@ def main():
                           f"{LAYERS} distinct HBM-resident layers, divided by the launch count",
             },
         }
+        if world == 1 and not args.no_pmc:
+            extra = ["--m", str(M), "--n", str(N), "--k", str(K), "--blocksize", str(bs), "--quant-type", qt]
+            traffic, detail = pmc_traffic(extra)
+            line["roofline"]["traffic"] = None if traffic is None else round(traffic)
+            line["roofline"]["traffic_detail"] = detail
         if sweep is not None:
             line["headline_sweep_N4096_K4096"] = sweep
         if world == 1 and not args.no_cpu_baseline:

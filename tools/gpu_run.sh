@@ -22,7 +22,7 @@ if [[ "$WHAT" == *" sweepquick "* ]]; then
 fi
 if [[ "$WHAT" == *" prof "* ]]; then
   echo "=== rocprof"; R=$PWD; cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bench -o bench -- python $R/bench.py --steps 640 --warmup 64 --no-cpu-baseline > $R/$OUT/rocprof_bench.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bench -o bench -- python $R/bench.py --steps 640 --warmup 64 --no-cpu-baseline --no-pmc > $R/$OUT/rocprof_bench.log 2>&1
   cd $R; f=$(find $OUT/prof_bench -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f" | cut -c1-220
 fi
 if [[ "$WHAT" == *" stream "* ]]; then
