@@ -1034,6 +1034,343 @@ __global__ __launch_bounds__(256) void gemm4_mfma_ring_kernel(const GemmArgs p) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm4_mfma_pc_kernel (v5, "producer / consumers"). What v4 gets wrong (measured ~3 us per 256-k chunk
+// at M = 64 against ~1.3 us of LDS traffic): its two-stage double buffer keeps ONE chunk (16 KiB per CU)
+// of weights in flight, so every chunk eats most of an HBM round trip, and because vmcnt retires in
+// order, the short-distance A prefetch of a wavefront forces all of its older weight DMAs to complete.
+// Here the two streams are decoupled by giving them to different wavefronts (vmcnt is per wavefront):
+//   * CW consumer wavefronts each own NTW*16 weight columns and a PRIVATE D-deep LDS ring of 256-k
+//     chunks filled by LDS-DMA in full 128-B lines (+ the chunk's scales, also by DMA, so a consumer's
+//     vector-memory queue holds DMAs only and its waits are exact counted vmcnt). A ring slot is refilled
+//     right after the wavefront has consumed it: no barrier is involved in the weight stream at all and
+//     D-1 chunks per wavefront stay in flight across everything else.
+//   * one producer wavefront streams the shared A tile [MT*16][256] into a two-stage buffer (source-side
+//     XOR swizzle, conflict-free ds_read_b128 fragment reads as in v4) and is the only one that waits
+//     for it. ONE s_barrier per chunk: arriving at barrier k the producer guarantees A(k) has landed and
+//     the consumers guarantee they are done with A(k-1), whose stage the producer refills right after.
+//   * an A fragment is read once per (m-tile, k-step) and used for the wavefront's NTW n-tiles.
+// K slices across workgroups / slab finalize exactly as v4.
+// ---------------------------------------------------------------------------------------------
+template <int kCount> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kCount) : "memory");
+}
+
+// kPcProducers wavefronts share the A-tile DMA issue: one LDS-DMA instruction costs its issuing wavefront
+// ~100-180 cycles while the CU is busy, so a single producer needs > 3000 cycles for the 32 pieces of a
+// 64-row stage - longer than the consumers need for a chunk (measured with the s_memtime stamps below).
+// 8 + 4 wavefronts = 3 per SIMD, the same register budget (168) as 8 + 1.
+constexpr int kPcProducers = 4;
+
+template <typename T, int MT, bool NESTED, int CW, int NTW, int D>
+__global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel(const GemmArgs p) {
+    constexpr int kLutBytes = 256 * 32 * 4;
+    constexpr int XB = MT * 16 * 512;                          // bytes of one A stage
+    constexpr int SB = NTW * 256 * (NESTED ? 2 : 1);           // scale bytes of one slot
+    constexpr int WB = NTW * 2048 + SB;                        // bytes of one ring slot of one consumer
+    constexpr int XI = MT * 8;                                 // DMA instructions per A stage (2 rows each)
+    constexpr int NP = kPcProducers;
+    constexpr int XIP = XI / NP;                               // ... per producer wavefront
+    static_assert(XI % NP == 0, "A-stage DMAs must divide over the producers");
+    constexpr int LPC = NTW * (3 + (NESTED ? 1 : 0));          // consumer vm ops per chunk
+    static_assert(XI < 64 && (D - 1) * LPC < 64, "vmcnt immediates");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
+    unsigned char* xring = smem + kLutBytes;                   // [2][XB]
+    unsigned char* wring = xring + 2 * XB;                     // [CW][D][WB]
+    float* code2 = reinterpret_cast<float*>(wring + CW * D * WB);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = p.N, K = p.K, M = p.M;
+    const int m_base = blockIdx.z * (MT * 16);
+
+    const int chunks_total = K >> 8;
+    const int per_wg = (chunks_total + p.kslices - 1) / p.kslices;
+    const int c_begin = blockIdx.y * per_wg;
+    const int c_end = (c_begin + per_wg < chunks_total) ? c_begin + per_wg : chunks_total;
+    const int n = (c_end > c_begin) ? c_end - c_begin : 0;
+    // profiling only (bnb_mi355x_set_stamp_buffer): 16 s_memtime stamps per wavefront
+#define BNB_PC_STAMP(i)                                                                            \
+    if (p.dbg && lane == 0)                                                                        \
+        p.dbg[((((static_cast<long>(blockIdx.x) * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (CW + kPcProducers)) + wave) * 16 + (i)] = \
+            __builtin_amdgcn_s_memtime();
+    BNB_PC_STAMP(0)
+
+    if (wave >= CW) {
+        // ---------------- producers: the A tile, instruction i of a stage belongs to producer i % NP
+        const int pw = wave - CW;
+        const T* __restrict__ A = static_cast<const T*>(p.A);
+        const int r2 = lane >> 5, s32 = lane & 31;
+        auto issue_a = [&](int c, int stage) {
+#pragma unroll
+            for (int ii = 0; ii < XIP; ++ii) {
+                const int i = ii * NP + pw;
+                const int row = 2 * i + r2;
+                int m = m_base + row;
+                m = (m < M) ? m : M - 1;
+                const T* src = A + static_cast<long>(m) * K + (static_cast<long>(c) << 8) + ((s32 ^ (row & 15)) << 3);
+                __builtin_amdgcn_global_load_lds((dma_src_t)src, (dma_dst_t)(xring + stage * XB + i * 1024), 16, 0, 0);
+            }
+        };
+        // The 4 producers (256 threads) also build the byte -> pair table, one entry per thread, while the
+        // consumers go straight to their weight stream. The two code values are loaded before the DMAs are
+        // issued so that their counted wait leaves the DMAs in flight.
+        static_assert(NP * 64 == 256, "one table entry per producer thread");
+        const int e = tid - CW * 64;
+        const gfloat_ptr tbl = (gfloat_ptr)(p.code16 ? p.code16 : (p.quant_type == kNF4 ? kNF4Code : kFP4Code));
+        const float code_hi = tbl[e >> 4];
+        const float code_lo = tbl[e & 15];
+        float code2_v = 0.0f;
+        if constexpr (NESTED)
+            code2_v = p.absmax_code[e];
+        if (n > 0)
+            issue_a(c_begin, 0);
+        if (n > 1)
+            issue_a(c_begin + 1, 1);
+        {
+            const uint32_t pr = Mma<T>::pack(code_hi, code_lo);
+            const u32x4 v = {pr, pr, pr, pr};
+            u32x4* dst = reinterpret_cast<u32x4*>(&lut[e * 32]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                dst[j] = v;
+            if constexpr (NESTED)
+                code2[e] = code2_v;
+        }
+        for (int k = 0; k < n; ++k) {
+            if (k == 0 && n > 1)
+                wait_vmcnt<XIP>(); // this producer's part of A(0) landed, A(1) may still be in flight
+            else
+                wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // table written (first time)
+            __builtin_amdgcn_s_barrier(); // #k
+            if (k >= 1 && k + 1 < n)
+                issue_a(c_begin + k + 1, (k + 1) & 1); // stage of A(k-1): every consumer is past it
+        }
+        return;
+    }
+
+    // ---------------- consumers
+    const int ln = lane & 15, lg = lane >> 4;
+    const int colw = blockIdx.x * (CW * NTW * 16) + wave * (NTW * 16); // first column of this wavefront
+    const int r8 = lane >> 3, s8 = lane & 7;
+    const uint8_t* wsrc[NTW][2];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int row = colw + t * 16 + h * 8 + r8;
+            row = (row < N) ? row : N - 1;
+            wsrc[t][h] = p.B + static_cast<long>(row) * (K >> 1) + ((s8 ^ r8) << 4);
+        }
+    // scale DMA: lane L fetches the scale of (row L >> 2, 64-k block L & 3) -> LDS offset 4 L, i.e. the four
+    // scales of a row are 16 contiguous bytes
+    long srow[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        int row = colw + t * 16 + (lane >> 2);
+        row = (row < N) ? row : N - 1;
+        srow[t] = static_cast<long>(row) * K + (lane & 3) * 64;
+    }
+    unsigned char* wbase = wring + wave * (D * WB);
+
+    auto issue_w = [&](int c, int slot) {
+        unsigned char* dst = wbase + slot * WB;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                __builtin_amdgcn_global_load_lds((dma_src_t)(wsrc[t][h] + static_cast<long>(c) * 128),
+                                                 (dma_dst_t)(dst + (t * 2 + h) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const long q = (srow[t] + (static_cast<long>(c) << 8)) >> p.bs_shift;
+            if constexpr (NESTED) {
+                __builtin_amdgcn_global_load_lds((dma_src_t)(p.absmax8 + q), (dma_dst_t)(dst + NTW * 2048 + t * 256), 1, 0, 0);
+                __builtin_amdgcn_global_load_lds((dma_src_t)(p.absmax + (q >> 8)),
+                                                 (dma_dst_t)(dst + NTW * 2048 + NTW * 256 + t * 256), 4, 0, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds((dma_src_t)(p.absmax + q), (dma_dst_t)(dst + NTW * 2048 + t * 256), 4, 0, 0);
+            }
+        }
+    };
+
+    float offset = 0.0f;
+    if constexpr (NESTED)
+        offset = p.absmax_offset[0]; // scalar load
+
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+        if (j < n)
+            issue_w(c_begin + j, j);
+
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+            acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    BNB_PC_STAMP(1)
+
+    // LDS byte addresses, split into a per-lane part computed once and compile-time parts that reach the
+    // instruction as an XOR constant or an immediate offset (the sums below have disjoint bits, so + is ^):
+    //   A fragment (mt, b, jj): row (mt*16 + ln) * 512 + (((b*8 + lg*2 + jj) ^ ln) << 4)
+    //   packed weights (t, b) : t*2048 + (ln>>3)*1024 + (ln&7)*128 + (((2b + (lg>>1)) ^ (ln&7)) << 4) + (lg&1)*8
+    //   table look-up         : (byte << 7) + (lane & 31) * 4
+    const uint32_t a_lane = static_cast<uint32_t>(ln * 512 + (((lg * 2) ^ ln) << 4));
+    const uint32_t w_lane = static_cast<uint32_t>((ln >> 3) * 1024 + (ln & 7) * 128 + (((lg >> 1) ^ (ln & 7)) << 4) + (lg & 1) * 8);
+    const uint32_t lut_lane = static_cast<uint32_t>((lane & 31) * 4) +
+                              static_cast<uint32_t>(reinterpret_cast<uintptr_t>((dma_dst_t)lut));
+
+    for (int k0 = 0; k0 < n; k0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int k = k0 + j;
+            if (k >= n)
+                break;
+            // chunk k of this wavefront has landed; the min(D-1, n-1-k) younger ones stay in flight
+            const int younger = (n - 1 - k < D - 1) ? n - 1 - k : D - 1;
+            if (younger <= 0)
+                wait_vmcnt<0>();
+            else if (younger == 1)
+                wait_vmcnt<1 * LPC>();
+            else if (younger == 2)
+                wait_vmcnt<(D > 2 ? 2 : 1) * LPC>();
+            else if (younger == 3)
+                wait_vmcnt<(D > 3 ? 3 : 1) * LPC>();
+            else
+                wait_vmcnt<(D > 4 ? 4 : 1) * LPC>();
+            if (k < 4)
+                BNB_PC_STAMP(2 + 3 * k)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // #k: A(k) is in LDS (and, the first time, the tables)
+            if (k < 4)
+                BNB_PC_STAMP(3 + 3 * k)
+            const int zsh = opaque_zero();
+
+            const unsigned char* xb = xring + (k & 1) * XB;
+            const unsigned char* wb = wbase + j * WB;
+            // chunk-level reads first: the packed weights of all four 64-k blocks (one ds_read_b64 each) and
+            // the scales; then a two-stage software pipeline over the blocks: the LDS reads of block b+1
+            // (A fragments, table look-ups) are issued before the MFMAs of block b, so the matrix pipe does
+            // not sit behind two dependent LDS round trips per block
+            u32x2 w2[NTW][4];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    w2[t][b] = *reinterpret_cast<const u32x2*>(wb + t * 2048 + (w_lane ^ static_cast<uint32_t>(b << 5)));
+            f32x4 sc4[NTW];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                if constexpr (NESTED) {
+                    const u32x4 q8 = *reinterpret_cast<const u32x4*>(wb + NTW * 2048 + t * 256 + ln * 16);
+                    const f32x4 a2 = *reinterpret_cast<const f32x4*>(wb + NTW * 2048 + NTW * 256 + t * 256 + ln * 16);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        sc4[t][b] = __fadd_rn(__fmul_rn(code2[q8[b] & 0xFFu], a2[b]), offset);
+                } else {
+                    sc4[t] = *reinterpret_cast<const f32x4*>(wb + NTW * 2048 + t * 256 + ln * 16);
+                }
+            }
+            u32x4 af[MT][2];
+            u32x4 bf[2][NTW][2];
+            auto fetch_a = [&](int b) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+                        af[mt][jj] = *reinterpret_cast<const u32x4*>(xb + mt * 8192 + (a_lane ^ static_cast<uint32_t>((b * 8 + jj) << 4)));
+            };
+            auto fetch_lut = [&](int b, int st) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const uint32_t w = w2[t][b][jj];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            // two VALU ops per byte, spelled out: the compiler's own canonical form is four
+                            const uint32_t byte = __builtin_amdgcn_ubfe(w, static_cast<uint32_t>(8 * q + zsh), 8u);
+                            const uint32_t addr = (byte << 7) + lut_lane; // lut_lane includes the table's LDS base
+                            bf[st][t][jj][q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(addr);
+                        }
+                    }
+            };
+            fetch_lut(0, 0);
+            fetch_a(0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int st = b & 1;
+                // (1) table look-ups of block b+1 (the second of two dependent LDS round trips) go out first
+                if (b + 1 < 4)
+                    fetch_lut(b + 1, st ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                // (2) all MFMAs of block b
+                f32x4 part[MT][NTW];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        part[mt][t] = Mma<T>::run(af[mt][0], bf[st][t][0], f32x4{0.f, 0.f, 0.f, 0.f});
+                        part[mt][t] = Mma<T>::run(af[mt][1], bf[st][t][1], part[mt][t]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                // (3) the A fragments of block b+1 are read while the matrix pipe drains block b
+                if (b + 1 < 4)
+                    fetch_a(b + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                // (4) fp32 scale of the 64-k partial tiles
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    const float scale = sc4[t][b];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[mt][t][r] = fmaf(scale, part[mt][t][r], acc[mt][t][r]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (k < 4)
+                BNB_PC_STAMP(4 + 3 * k)
+            if (k + D < n) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wavefront's reads of the slot are done
+                issue_w(c_begin + k + D, j);
+            }
+        }
+    }
+
+    BNB_PC_STAMP(14)
+    T* __restrict__ out = static_cast<T*>(p.out);
+    const T* __restrict__ bias = static_cast<const T*>(p.bias);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int col = colw + t * 16 + ln;
+        if (col >= N)
+            continue;
+        const float bv = (bias && p.kslices == 1) ? static_cast<float>(bias[col]) : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m_base + mt * 16 + lg * 4 + r;
+                if (m >= M)
+                    continue;
+                const long o = static_cast<long>(m) * N + col;
+                if (p.kslices == 1)
+                    out[o] = static_cast<T>(acc[mt][t][r] + bv);
+                else
+                    p.ws[static_cast<long>(blockIdx.y) * M * N + o] = acc[mt][t][r];
+            }
+        }
+    }
+    BNB_PC_STAMP(15)
+#undef BNB_PC_STAMP
+}
+
 // out = T(sum_s ws[s] + bias), slabs added in slice order (deterministic)
 template <typename T>
 __global__ __launch_bounds__(256) void gemm4_finalize_kernel(const float* __restrict__ ws, const T* __restrict__ bias,
@@ -1118,10 +1455,11 @@ struct Plan {
              // v3 LDS-DMA kernel (NT = 1): 5: 16 waves, 6: 8 waves;  v4 tiled LDS-DMA kernel (128 columns): 7;
              // v4b ring kernel (128 columns, 128-k chunks, 4-deep ring): 8
              // v4 with 8 wavefronts: 9: 8 x 1 n-tile (128 columns), 10: 8 x 2 n-tiles (256 columns)
+             // v5 producer/consumer kernel: 11: 8 consumers x 1 n-tile (128 columns), 12: 4 x 2 (128), 13: 8 x 2 (256)
 };
 
-constexpr int kCfgWaves[11] = {4, 8, 16, 8, 4, 16, 8, 1, 1, 1, 1};
-constexpr int kCfgCols[11] = {0, 0, 0, 0, 0, 16, 16, 128, 128, 128, 256};
+constexpr int kCfgWaves[14] = {4, 8, 16, 8, 4, 16, 8, 1, 1, 1, 1, 1, 1, 1};
+constexpr int kCfgCols[14] = {0, 0, 0, 0, 0, 16, 16, 128, 128, 128, 256, 128, 128, 256};
 
 // Tile shape and K-slice count for a problem: a pure function of (M, N, K) and the tuning knobs,
 // shared by the launch and by the workspace-size query.
@@ -1148,7 +1486,7 @@ Plan make_plan(int M, int N, int K) {
         // launch would cost more than it saves.
         const bool big = static_cast<long>(N) * K >= (32L << 20) && N >= 1024;
         if (pl.mt >= 2 || big) {
-            cfg = 9; // 8 wavefronts x 16 columns share one A tile
+            cfg = 11; // producer/consumer kernel: 8 consumer wavefronts x 16 columns share one A tile
             pl.nt = nt = 1;
         } else {
             cfg = (pl.mt == 1) ? 5 : 6;
@@ -1156,8 +1494,10 @@ Plan make_plan(int M, int N, int K) {
             gx = (N + 15) / 16;
         }
     }
-    if (cfg < 0 || cfg > 10)
+    if (cfg < 0 || cfg > 13)
         cfg = 0;
+    if (cfg == 13 && pl.mt > 2)
+        cfg = 11; // 8 x 2 consumers with a > 32-row A tile do not fit the 160 KiB of LDS
     if ((cfg == 5 || cfg == 6) && (nt != 1 || pl.mt > 2))
         cfg = 0;
     if (cfg == 5 && pl.mt != 1)
@@ -1252,7 +1592,57 @@ template <typename T, int MT> void launch_mfma_ring(GemmArgs& p, hipStream_t str
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
 }
 
+constexpr size_t pc_smem_bytes(int MT, int CW, int NTW, int D, bool nested) {
+    return 256 * 32 * 4 + 2 * static_cast<size_t>(MT) * 16 * 512 +
+           static_cast<size_t>(CW) * D * (static_cast<size_t>(NTW) * 2048 + static_cast<size_t>(NTW) * 256 * (nested ? 2 : 1)) + 1024;
+}
+// 151 KiB of dynamic LDS launches, 157 KiB is refused (hipFuncSetAttribute: invalid argument) - stay below
+constexpr size_t kPcSmemCap = 155 * 1024;
+
+template <typename T, int MT, bool NESTED, int CW, int NTW, int D> void launch_mfma_pc_one(GemmArgs& p, hipStream_t stream) {
+    constexpr size_t smem = pc_smem_bytes(MT, CW, NTW, D, NESTED);
+    static_assert(smem <= kPcSmemCap, "ring depth does not fit the LDS");
+    constexpr int BN = CW * NTW * 16;
+    const int gx = (p.N + BN - 1) / BN;
+    const int gz = (p.M + MT * 16 - 1) / (MT * 16);
+    dim3 grid(gx, p.kslices, gz);
+    auto kern = gemm4_mfma_pc_kernel<T, MT, NESTED, CW, NTW, D>;
+    static bool attr_set = false;
+    if (smem > 64 * 1024 && !attr_set) {
+        BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3((CW + kPcProducers) * 64), smem, stream, p);
+}
+
+// deepest ring (<= 4 chunks) that fits
+constexpr int pc_depth(int MT, int CW, int NTW, bool nested) {
+    for (int d = 4; d >= 2; --d)
+        if (pc_smem_bytes(MT, CW, NTW, d, nested) <= kPcSmemCap)
+            return d;
+    return 0;
+}
+
+template <typename T, int MT, int CW, int NTW> void launch_mfma_pc(GemmArgs& p, hipStream_t stream) {
+    if (p.absmax8 != nullptr)
+        launch_mfma_pc_one<T, MT, true, CW, NTW, pc_depth(MT, CW, NTW, true)>(p, stream);
+    else
+        launch_mfma_pc_one<T, MT, false, CW, NTW, pc_depth(MT, CW, NTW, false)>(p, stream);
+}
+
 template <typename T, int MT, int NT> void launch_mfma(GemmArgs& p, int cfg, hipStream_t stream) {
+    // v5 producer/consumer geometries. LDS: 32 KiB table + 2 x MT*8 KiB A stages + CW*D ring slots.
+    if (cfg == 11)
+        return launch_mfma_pc<T, MT, 8, 1>(p, stream);
+    if (cfg == 12)
+        return launch_mfma_pc<T, MT, 4, 2>(p, stream);
+    if (cfg == 13) {
+        if constexpr (pc_depth(MT, 8, 2, true) >= 2)
+            return launch_mfma_pc<T, MT, 8, 2>(p, stream);
+        else
+            return launch_mfma_pc<T, MT, 8, 1>(p, stream);
+    }
     if (cfg == 8)
         return launch_mfma_ring<T, MT>(p, stream);
     if (cfg == 7)

@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--dot-only", action="store_true")
     ap.add_argument("--mfma-only", action="store_true")
+    ap.add_argument("--cfgs", default="9,11,12,13", help="MFMA tile-kernel geometries to sweep (cfg codes)")
+    ap.add_argument("--ms", default="", help="comma list of M values for the MFMA sweep")
+    ap.add_argument("--kss", default="2,4,8,16", help="K-slice counts to sweep")
     a = ap.parse_args()
     N, K, bs = a.n, a.k, a.bs
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -148,7 +151,11 @@ def main():
             print(f"{'mfma-abl':8s} {8:3d} {f'{name} cfg{cfgks}':>20s} {tg:9.2f} {te:9.2f} {bytes_alg(8, N, K, bs) / tg / 1e3:11.1f}")
     bnb.lib.bnb_mi355x_set_debug(0, 0)
     Ms = [1, 8, 16, 64] if a.quick else [1, 4, 8, 16, 32, 64]
-    CFG = {7: "tile", 9: "t8x1", 10: "t8x2"}
+    if a.ms:
+        Ms = [int(v) for v in a.ms.split(",")]
+    names = {7: "tile", 8: "ring", 9: "t8x1", 10: "t8x2", 11: "pc8x1", 12: "pc4x2", 13: "pc8x2"}
+    CFG = {int(c): names.get(int(c), f"cfg{c}") for c in a.cfgs.split(",")}
+    KSS = tuple(int(v) for v in a.kss.split(","))
     for M in Ms:
         x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
         mt = (M + 15) // 16
@@ -167,7 +174,7 @@ def main():
                     continue
                 if cfg in (5, 6) and (nt != 1 or mt > 2 or (cfg == 5 and mt != 1)):
                     continue
-                for ks in ((2, 4, 8, 16) if cfg >= 7 else (1, 2)):
+                for ks in (KSS if cfg >= 7 else (1, 2)):
                     if cfg >= 7 and nt != 1:
                         continue
                     if cfg < 7 and ks == 2 and (N // (16 * nt)) >= 192:
