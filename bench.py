@@ -94,7 +94,7 @@ def cpu_baseline(M, N, K, blocksize, quant_type):
     }
 
 
-def pmc_traffic(extra_args, kernel_substr="gemv4_dot_kernel", timeout_s=240):
+def pmc_traffic(extra_args, kernel_substr="gemv4_dot_kernel", timeout_s=90):
     """HBM bytes per launch of the dominant kernel from rocprofv3 PMC counters, collected the way
     /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE
     passes (they do not fit one TCC pass), no tracing domains besides the kernel trace; both counters are
