@@ -109,19 +109,50 @@ template <typename T> __device__ __forceinline__ T ld_stream(const T* p, bool nt
 template <typename T, int MB, int RPW, int SEGS, int FLAGS>
 __global__ __launch_bounds__((FLAGS & kWaves16) ? 1024 : (FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kernel(const GemvArgs p) {
     constexpr bool SINGLE = FLAGS & kSingle, NESTED = FLAGS & kNested, NTL = FLAGS & kNT, CODEPTR = FLAGS & kCodePtr;
-    constexpr bool XLDS = (FLAGS & kXLds) && SINGLE;
+    constexpr bool XLDS = FLAGS & kXLds;
     constexpr int WAVES = (FLAGS & kWaves16) ? 16 : (FLAGS & kWaves8) ? 8 : 4;
     constexpr int THREADS = WAVES * 64;
     constexpr int TPE = THREADS / 256; // threads cooperating on one table entry
     constexpr int ABL = FLAGS >> 8;
-    constexpr int kXBytes = XLDS ? MB * SEGS * kSegK * 2 : 16;
 
     __shared__ __attribute__((aligned(16))) uint32_t lut[256 * 32];
-    __shared__ __attribute__((aligned(16))) unsigned char xs[kXBytes];
+    extern __shared__ __attribute__((aligned(16))) unsigned char xs[]; // XLDS: MB * ceil(K/2048) * 4 KiB activation image
+    // segments of 2048 k in the activation image: a compile-time constant when the whole K fits one iteration
+    const int nseg = SINGLE ? SEGS : (p.K + kSegK - 1) / kSegK;
     __shared__ float code2[NESTED ? 256 : 1];
 
     const int tid = threadIdx.x;
-    // The two code values this lane needs for its table entry are the FIRST vector loads of the
+    // 0) activations: ONE copy per workgroup, by LDS-DMA, issued before anything else. Without it every
+    // wavefront pulls the whole activation row through L1 itself (8 KiB per wavefront at K = 4096: twice
+    // the bytes of the two weight rows it owns). The image is lane-linear per 1-KiB piece (hardware), so
+    // the bank swizzle is applied on the source side: slot s of a row holds the 16-byte chunk
+    // s ^ ((s >> 4) & 3) - a permutation inside 64-byte groups, so the copy stays fully coalesced - and
+    // lane l finds its q-th chunk (4 l + q) at slot 4 l + (q ^ ((l >> 2) & 3)): conflict-free ds_read_b128.
+    // Being the oldest vector-memory ops of the wavefront, the DMAs have landed whenever any later load
+    // has (vmcnt retires in order); the explicit counted wait before the barrier below spells that out.
+    if constexpr (XLDS) {
+        const int pieces = MB * nseg * 4; // 1-KiB pieces
+        const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int ln0 = tid & 63;
+        for (int piece = w0; piece < pieces; piece += WAVES) {
+            const int m = (MB == 1) ? 0 : piece / (nseg * 4);
+            const int sr = (piece - m * nseg * 4) * 64 + ln0; // slot within the row
+            const int k = (sr ^ ((sr >> 4) & 3)) * 8;
+            const int mr = (blockIdx.y * MB + m < p.M) ? blockIdx.y * MB + m : p.M - 1;
+            const T* src = static_cast<const T*>(p.A) + static_cast<long>(mr) * p.K + ((k < p.K) ? k : 0);
+            // Spelled in asm on purpose: with the builtin the compiler sees LDS-DMA and ordinary loads
+            // pending on the same counter, treats vmcnt as out-of-order and turns every later wait for a
+            // loaded register into vmcnt(0) - draining the weight stream before the table build. Being
+            // the oldest vector-memory ops, untracked DMAs leave all of its counted waits valid.
+            const uint32_t dst = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+                                     (__attribute__((address_space(3))) void*)xs)) + piece * 1024;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                         :
+                         : "v"(src), "s"(dst)
+                         : "memory", "m0");
+        }
+    }
+    // The two code values this lane needs for its table entry are the next vector loads of the
     // kernel: vmcnt retires in order, so waiting for them later never waits for the weight stream.
     // (caller-supplied table pointer only; the built-in tables travel by value in the kernel arguments)
     float code_hi = 0.f, code_lo = 0.f;
@@ -204,12 +235,11 @@ __global__ __launch_bounds__((FLAGS & kWaves16) ? 1024 : (FLAGS & kWaves8) ? 512
     int zsh = 0; // opaque zero, set after the barrier (see opaque_zero())
 
     // x fragment (4 x 16 B = this lane's 32 activations of segment sg, row m)
-    auto x_frag = [&](const Stage& st, int sg, int m, int q) -> u32x4 {
+    auto x_frag = [&](const Stage& st, int it, int sg, int m, int q) -> u32x4 {
         if constexpr (ABL == 4) {
             return u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
         } else if constexpr (XLDS) {
-            // LDS image: chunk (lane*4 + q) of segment sg sits at slot q*64 + lane -> conflict-free b128 reads
-            return *reinterpret_cast<const u32x4*>(xs + ((m * SEGS + sg) * 256 + q * 64 + lane) * 16);
+            return *reinterpret_cast<const u32x4*>(xs + ((m * nseg + it * SEGS + sg) * 256 + lane * 4 + (q ^ ((lane >> 2) & 3))) * 16);
         } else {
             return st.x[sg][m][q];
         }
@@ -223,7 +253,7 @@ __global__ __launch_bounds__((FLAGS & kWaves16) ? 1024 : (FLAGS & kWaves8) ? 512
             for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    xf[m][q] = x_frag(st, sg, m, q);
+                    xf[m][q] = x_frag(st, it, sg, m, q);
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 if constexpr (ABL == 1 || ABL == 4) {
@@ -275,25 +305,6 @@ __global__ __launch_bounds__((FLAGS & kWaves16) ? 1024 : (FLAGS & kWaves8) ? 512
     Stage cur;
     load_stage(cur, 0);
 
-    // 1b) activations: one cooperative, fully coalesced copy per workgroup into the LDS image
-    if constexpr (XLDS) {
-        constexpr int kChunks = MB * SEGS * 256; // 16-byte chunks
-#pragma unroll
-        for (int c0 = 0; c0 < kChunks; c0 += THREADS) {
-            const int c = c0 + tid;
-            if (kChunks % THREADS == 0 || c < kChunks) {
-                const int m = c / (SEGS * 256), rem = c % (SEGS * 256);
-                const int sg = rem >> 8, g = rem & 255; // g = lane*4 + q within the segment
-                const int k = sg * kSegK + g * 8;
-                const int mr = (m0 + m < p.M) ? m0 + m : p.M - 1;
-                u32x4 v = u32x4{0, 0, 0, 0};
-                if (k < K)
-                    v = *reinterpret_cast<const u32x4*>(A + static_cast<long>(mr) * K + k);
-                *reinterpret_cast<u32x4*>(xs + ((m * SEGS + sg) * 256 + (g & 3) * 64 + (g >> 2)) * 16) = v;
-            }
-        }
-    }
-
     // 2) build the byte -> (code[hi], code[lo]) table while the weights fly.
     if constexpr (ABL == 0 || ABL == 3) {
         if constexpr (!CODEPTR) { // SGPR values picked by a v_cndmask chain, no memory
@@ -321,6 +332,8 @@ __global__ __launch_bounds__((FLAGS & kWaves16) ? 1024 : (FLAGS & kWaves8) ? 512
     }
     if constexpr (ABL == 1 || ABL == 2 || ABL == 4)
         asm volatile("" ::"v"(code_hi), "v"(code_lo));
+    if constexpr (XLDS) // the activation DMAs are older than the stage-0 loads (SEGS*RPW weights + as many scales)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SEGS * RPW * 2) : "memory");
     __syncthreads();
     zsh = opaque_zero();
 
@@ -651,17 +664,35 @@ template <typename T, int MB, int RPW, int SEGS, int EXTRA> void launch_dot(cons
     // supplied one): measured faster than passing the 16 values by value and selecting them with a
     // v_cndmask chain (profiles/: 4.9-5.3 us vs 5.4-6.2 us per launch at M = 1, N = K = 4096).
     constexpr int E = (EXTRA & (kWaves8 | kWaves16)) | kCodePtr;
-    if (single) {
-        if (p.absmax8)
-            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, E | kSingle | kNested>), grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, E | kSingle>), grid, block, 0, stream, p);
-    } else {
-        if (p.absmax8)
-            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, E | kNested>), grid, block, 0, stream, p);
-        else
-            hipLaunchKernelGGL((gemv4_dot_kernel<T, MB, RPW, SEGS, E>), grid, block, 0, stream, p);
+    // activations through LDS (one DMA copy per workgroup) whenever the image fits; debug flag 128 switches
+    // it off for A/B measurements
+    const int nseg = single ? SEGS : (p.K + kSegK - 1) / kSegK;
+    const size_t xbytes = static_cast<size_t>(MB) * nseg * 4096;
+    const bool xlds = xbytes <= 96 * 1024 && !(g_dot_flags & 128);
+#define BNB_DOT_GO(F)                                                                              \
+    do {                                                                                           \
+        auto kern = gemv4_dot_kernel<T, MB, RPW, SEGS, (F)>;                                       \
+        const size_t dyn = ((F) & kXLds) ? xbytes : 0;                                             \
+        static bool attr_done = false;                                                             \
+        if (dyn + 34 * 1024 > 64 * 1024 && !attr_done) {                                           \
+            BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                 \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
+            attr_done = true;                                                                      \
+        }                                                                                          \
+        hipLaunchKernelGGL(kern, grid, block, dyn, stream, p);                                     \
+    } while (0)
+    const int sel = (single ? 1 : 0) | (p.absmax8 ? 2 : 0) | (xlds ? 4 : 0);
+    switch (sel) {
+    case 0: BNB_DOT_GO(E); break;
+    case 1: BNB_DOT_GO(E | kSingle); break;
+    case 2: BNB_DOT_GO(E | kNested); break;
+    case 3: BNB_DOT_GO(E | kSingle | kNested); break;
+    case 4: BNB_DOT_GO(E | kXLds); break;
+    case 5: BNB_DOT_GO(E | kSingle | kXLds); break;
+    case 6: BNB_DOT_GO(E | kNested | kXLds); break;
+    default: BNB_DOT_GO(E | kSingle | kNested | kXLds); break;
     }
+#undef BNB_DOT_GO
 }
 
 template <typename T> void launch_generic(const GemvArgs& p, hipStream_t stream) {
@@ -752,15 +783,19 @@ template <typename T> void dispatch_dot(const GemvArgs& p, hipStream_t stream) {
 
     // Calibrated on MI355X (profiles/): 512-thread workgroups (one table build per 8 wavefronts),
     // 2 weight rows per wavefront once that still yields >= 256 workgroups, else 1.
+    // Calibrated on MI355X (profiles/r1_dot_ab.txt): with the activations in LDS one row per wavefront wins at
+    // M = 1 for every shape tried (4096^2: 4.73 vs 5.35 us; twice the wavefronts to hide latency and nothing
+    // left to amortise); two activation rows keep two weight rows per wavefront on the large matrices only
+    // (4096^2 M = 2: 5.47 vs 5.93 us; 8192^2: 19.1 vs 17.0; 4096 x 11008: 13.6 vs 11.4).
     int rpw = g_dot_rpw;
     if (rpw == 0)
-        rpw = (p.N >= 256 * 8 * 2) ? 2 : 1;
+        rpw = (p.M >= 2 && static_cast<long>(p.N) * p.K > (24L << 20)) ? 2 : 1;
     int segs = g_dot_segs;
     if (segs == 0)
         segs = (p.K > kSegK) ? 2 : 1;
     const int mb = (p.M >= 3) ? 4 : p.M;
     int extra = g_dot_flags & (kWaves8 | kWaves16);
-    if (g_dot_rpw == 0 && g_dot_flags == 0)
+    if (g_dot_rpw == 0 && (g_dot_flags & ~128) == 0)
         extra = (mb <= 2) ? kWaves8 : 0;
 
 #define BNB_DOT_CASE(MBV, RPWV, SEGSV, EX)                                                         \
@@ -770,7 +805,8 @@ template <typename T> void dispatch_dot(const GemvArgs& p, hipStream_t stream) {
     }
 #define BNB_DOT_ALLX(MBV, RPWV, SEGSV)                                                             \
     BNB_DOT_CASE(MBV, RPWV, SEGSV, 0) BNB_DOT_CASE(MBV, RPWV, SEGSV, kWaves8) BNB_DOT_CASE(MBV, RPWV, SEGSV, kWaves16)
-    BNB_DOT_ALLX(1, 2, 2) BNB_DOT_ALLX(1, 1, 2) BNB_DOT_ALLX(1, 4, 2) BNB_DOT_ALLX(2, 2, 2) BNB_DOT_ALLX(4, 1, 2)
+    BNB_DOT_ALLX(1, 2, 2) BNB_DOT_ALLX(1, 1, 2) BNB_DOT_ALLX(1, 4, 2) BNB_DOT_ALLX(2, 2, 2) BNB_DOT_ALLX(2, 1, 2)
+    BNB_DOT_ALLX(4, 1, 2)
     BNB_DOT_CASE(1, 1, 1, 0) BNB_DOT_CASE(1, 2, 1, 0) BNB_DOT_CASE(1, 4, 1, 0) BNB_DOT_CASE(1, 8, 1, 0)
     BNB_DOT_CASE(2, 1, 1, 0) BNB_DOT_CASE(2, 1, 2, 0) BNB_DOT_CASE(2, 2, 1, 0) BNB_DOT_CASE(2, 4, 1, 0)
     BNB_DOT_CASE(4, 1, 1, 0) BNB_DOT_CASE(4, 2, 1, 0)

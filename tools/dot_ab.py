@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""A/B of the dot kernel's activation path: LDS image filled by one DMA copy per workgroup (default) vs
+per-wavefront global loads (debug flag 128), production geometry, graph-replayed over 64 HBM-resident layers.
+    python tools/dot_ab.py [--n 4096 --k 4096]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bitsandbytes_amd as bnb  # noqa: E402
+import bitsandbytes_amd.functional as F  # noqa: E402
+from bitsandbytes_amd.backends import hip  # noqa: E402
+
+
+def bytes_alg(M, N, K, bs):
+    return N * K // 2 + 4 * N * K // bs + 2 * M * K + 2 * M * N
+
+
+def measure(layers, x, kernel, reps=10):
+    L = len(layers)
+    M, N = x.shape[0], layers[0][1].shape[0]
+    outs = torch.empty(L, M, N, device="cuda", dtype=x.dtype)
+
+    def step(i):
+        q, st = layers[i]
+        if st.nested:
+            hip._gemm_4bit_fused(x, q, st.shape, st.state2.absmax, st.blocksize, st.quant_type, None, st.absmax,
+                                 st.state2.code, st.offset, kernel=kernel, out=outs[i])
+        else:
+            hip._gemm_4bit_fused(x, q, st.shape, st.absmax, st.blocksize, st.quant_type, None, None, None, None,
+                                 kernel=kernel, out=outs[i])
+
+    for i in range(L):
+        step(i)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(L):
+            step(i)
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (reps * L) * 1e3, 0.0
+
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=4096)
+ap.add_argument("--k", type=int, default=4096)
+ap.add_argument("--dq", action="store_true")
+ap.add_argument("--quick", action="store_true")
+ap.add_argument("--m34", action="store_true")
+a = ap.parse_args()
+N, K = a.n, a.k
+L = max(8, int(640e6 // (N * K // 2)))
+g = torch.Generator(device="cuda").manual_seed(0)
+layers = []
+for _ in range(L):
+    W = (torch.randn(N, K, device="cuda", generator=g) / K**0.5).bfloat16()
+    layers.append(F.quantize_4bit(W, blocksize=64, quant_type="nf4", compress_statistics=a.dq))
+    del W
+print(f"# N={N} K={K} dq={a.dq} layers={L}")
+for M in (() if a.m34 else (1, 2)):
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    for rep in range(2):
+        for flags, name in ((0, "x via LDS-DMA"), (128, "x per wavefront")):
+            bnb.lib.bnb_mi355x_set_debug(0, flags)
+            tg, te = measure(layers, x, 1)
+            print(f"M={M} {name:16s} {tg:7.2f} us/launch  {bytes_alg(M, N, K, 64) / tg / 1e3:8.1f} GB/s")
+# rows per wavefront x workgroup size x activation path
+for M in ((3, 4) if a.m34 else (1, 2)):
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    for rpw in (1, 2, 4):
+        for wg, wname in ((0, "256thr"), (4, "512thr"), (64, "1024thr")):
+            if a.quick and wg != 4:
+                continue
+            for xl, xname in ((0, "xLDS"), (128, "xwave")):
+                bnb.lib.bnb_mi355x_set_tuning(rpw, 2, 0, 0)
+                bnb.lib.bnb_mi355x_set_debug(0, wg | xl)
+                tg, te = measure(layers, x, 1)
+                print(f"M={M} rpw{rpw} {wname:7s} {xname}: {tg:7.2f} us/launch  {bytes_alg(M, N, K, 64) / tg / 1e3:8.1f} GB/s")
+bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+bnb.lib.bnb_mi355x_set_debug(0, 0)
