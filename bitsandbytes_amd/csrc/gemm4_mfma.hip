@@ -1504,10 +1504,8 @@ Plan make_plan(int M, int N, int K) {
         cfg = 6;
     if (cfg == 10 && pl.mt == 4)
         cfg = 9; // 8 x 2 tiles with a 64-row A tile would need 161 KiB of LDS
-    if (cfg == 2 && !(pl.mt == 1 && nt <= 2))
-        cfg = 0; // 1024-thread workgroups only fit the register budget of the smallest tiles
-    if ((cfg == 1 || cfg == 4) && pl.mt * nt > 4)
-        cfg = (cfg == 1) ? 3 : 0;
+    if (cfg >= 1 && cfg <= 4)
+        cfg = 0; // retired v2 geometries
     pl.cfg = cfg;
     const int kWaves = kCfgWaves[cfg];
     if (cfg >= 7)
@@ -1663,18 +1661,8 @@ template <typename T, int MT, int NT> void launch_mfma(GemmArgs& p, int cfg, hip
         if (cfg == 5 || cfg == 6)
             return launch_mfma_dma<T, MT, 8>(p, stream);
     }
-    if constexpr (MT == 1 && NT <= 2) {
-        if (cfg == 2)
-            return launch_mfma_cfg<T, MT, NT, 16, 4>(p, stream);
-    }
-    if constexpr (MT * NT <= 4) {
-        if (cfg == 1)
-            return launch_mfma_cfg<T, MT, NT, 8, 8>(p, stream);
-        if (cfg == 4)
-            return launch_mfma_cfg<T, MT, NT, 4, 8>(p, stream);
-    }
-    if (cfg == 3)
-        return launch_mfma_cfg<T, MT, NT, 8, 4>(p, stream);
+    // (the 8- and 16-wavefront / depth-8 geometries of v2 were dropped after the sweeps: never faster, and
+    // several of them spilled registers)
     return launch_mfma_cfg<T, MT, NT, 4, 4>(p, stream);
 }
 

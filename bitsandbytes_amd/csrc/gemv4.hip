@@ -29,7 +29,7 @@
 namespace bnb {
 
 int g_dot_ablate = 0; // profiling only: see the ablation bits of DotFlags
-int g_dot_flags = 0;  // kWaves8 | kNT | kXLds selection (0 = default)
+int g_dot_flags = 0;  // sweeps: 4 = force 512-thread workgroups, 128 = activations per wavefront instead of LDS (0 = default)
 unsigned long long* g_dbg_buf = nullptr; // profiling only: device buffer for s_memtime stamps
 
 // Tuning knobs (overridable for sweeps through bnb_mi355x_set_tuning; see c_api.hip).
@@ -92,25 +92,19 @@ enum DotFlags : int {
     kSingle = 1,  // the whole K fits one iteration: no prefetch registers are allocated
     kNested = 2,  // double-quantised absmax reconstructed in-kernel
     kWaves8 = 4,  // 512-thread workgroups (8 wavefronts share one table build) instead of 256
-    kNT = 8,      // non-temporal weight / absmax loads (streamed once, keep them out of the way of x)
-    kXLds = 16,   // activations staged once per workgroup in LDS instead of per-wave global loads (kSingle only)
+    kXLds = 16,   // activations staged once per workgroup in LDS (one LDS-DMA copy) instead of per-wave global loads
     kCodePtr = 32, // code table read from a table pointer (device-resident built-in table or the caller's)
-    kWaves16 = 64, // 1024-thread workgroups: one table build per CU shared by 16 wavefronts
     // bits 8..: ablation for profiling builds (results are wrong): 1 = stream + reduce raw words, no decode;
     // 2 = no table build; 3 = no weight loads; 4 = weights only (no x / absmax traffic); 5 = empty kernel
 };
 
-template <typename T> __device__ __forceinline__ T ld_stream(const T* p, bool nt) {
-    return nt ? __builtin_nontemporal_load(p) : *p;
-}
-
 // T in {bf16, f16}; MB = activation rows per pass; RPW = weight rows per wavefront;
 // SEGS = 2048-k sub-segments per loop iteration.
 template <typename T, int MB, int RPW, int SEGS, int FLAGS>
-__global__ __launch_bounds__((FLAGS & kWaves16) ? 1024 : (FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kernel(const GemvArgs p) {
-    constexpr bool SINGLE = FLAGS & kSingle, NESTED = FLAGS & kNested, NTL = FLAGS & kNT, CODEPTR = FLAGS & kCodePtr;
+__global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kernel(const GemvArgs p) {
+    constexpr bool SINGLE = FLAGS & kSingle, NESTED = FLAGS & kNested, CODEPTR = FLAGS & kCodePtr;
     constexpr bool XLDS = FLAGS & kXLds;
-    constexpr int WAVES = (FLAGS & kWaves16) ? 16 : (FLAGS & kWaves8) ? 8 : 4;
+    constexpr int WAVES = (FLAGS & kWaves8) ? 8 : 4;
     constexpr int THREADS = WAVES * 64;
     constexpr int TPE = THREADS / 256; // threads cooperating on one table entry
     constexpr int ABL = FLAGS >> 8;
@@ -199,15 +193,15 @@ __global__ __launch_bounds__((FLAGS & kWaves16) ? 1024 : (FLAGS & kWaves8) ? 512
                 if constexpr (ABL == 3)
                     st.w[sg][r] = u32x4{static_cast<uint32_t>(lane), 0x12345678u, static_cast<uint32_t>(row), 0x9abcdef0u};
                 else
-                    st.w[sg][r] = ld_stream(reinterpret_cast<const u32x4*>(B + (e >> 1)), NTL);
+                    st.w[sg][r] = *reinterpret_cast<const u32x4*>(B + (e >> 1));
                 const long blk = e >> p.bs_shift;
                 if constexpr (ABL == 4) {
                     st.s[sg][r] = 1.0f;
                 } else if constexpr (NESTED) {
                     // scale reconstructed in compute_stage (needs the LDS code table)
-                    st.s[sg][r] = __builtin_bit_cast(float, static_cast<uint32_t>(ld_stream(p.absmax8 + blk, NTL)));
+                    st.s[sg][r] = __builtin_bit_cast(float, static_cast<uint32_t>(p.absmax8[blk]));
                 } else {
-                    st.s[sg][r] = ld_stream(absmax + blk, NTL);
+                    st.s[sg][r] = absmax[blk];
                 }
             }
             if constexpr (!XLDS && ABL != 4) {
@@ -368,235 +362,6 @@ __global__ __launch_bounds__((FLAGS & kWaves16) ? 1024 : (FLAGS & kWaves8) ? 512
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// gemv4_dotx_kernel — the production dot kernel. Same decode scheme as gemv4_dot_kernel above
-// (kept as the fallback for activations too large for LDS), restructured after on-device ablation
-// (profiles/): at M = 1, N = K = 4096 the weight stream alone costs ~2.2 us on top of a 1.8 us
-// launch-to-launch floor, and what was slowing the full kernel down was everything *around* it:
-//   * the 16 code values now arrive by value in the kernel arguments (SGPRs) and the table entry of
-//     a lane is picked with a v_cndmask chain - the table build needs no memory round trip and
-//     starts at cycle 0 (it used to wait ~1 us for a 64-byte gather);
-//   * activations are staged ONCE per workgroup into LDS (fully coalesced, issued BEFORE the weight
-//     loads so that their vmcnt wait does not drain the weight stream) instead of 8 KiB of
-//     per-wavefront global loads - that was 2x the weight bytes in L1/TA traffic; the LDS image is
-//     laid out so the per-lane 16-byte fragment reads are conflict-free (chunk lane*4+q at slot
-//     q*64+lane of each 2048-k segment);
-//   * up to 8 activation rows share one pass over the weights (the decode is shared, only the
-//     v_dot2c count grows), which covers M <= 8 without the matrix pipe.
-// XCH = 16-byte activation chunks staged per lane (compile time so they can sit in registers while
-// the weight loads are issued).
-// ---------------------------------------------------------------------------------------------
-enum DotxFlags : int { kxNested = 1, kxCodePtr = 2, kxDebug = 4 };
-
-#define BNB_STAMP(i)                                                                               \
-    if constexpr (DBG) {                                                                           \
-        if (lane == 0)                                                                             \
-            p.dbg[(static_cast<long>(blockIdx.x) * WAVES + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
-    }
-
-template <typename T, int MB, int RPW, int XCH, int FLAGS>
-__global__ __launch_bounds__(256) void gemv4_dotx_kernel(const GemvArgs p) {
-    constexpr bool NESTED = FLAGS & kxNested, CODEPTR = FLAGS & kxCodePtr, DBG = FLAGS & kxDebug;
-    constexpr int THREADS = 256, WAVES = 4, SEGS = 2;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* lut = reinterpret_cast<uint32_t*>(smem); // 32 KiB pair table
-    unsigned char* xs = smem + 256 * 32 * 4;           // MB * nseg * 4 KiB activation image
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int N = p.N, K = p.K;
-    const int nseg = (K + kSegK - 1) / kSegK;
-    float* code2 = reinterpret_cast<float*>(xs + MB * nseg * 4096);
-    const int row0 = (blockIdx.x * WAVES + wave) * RPW;
-    const int m0 = blockIdx.y * MB;
-
-    const T* __restrict__ A = static_cast<const T*>(p.A);
-    const uint8_t* __restrict__ B = p.B;
-    const float* __restrict__ absmax = p.absmax;
-
-    BNB_STAMP(0)
-    // ---- 1) activations -> registers (first vector loads of the kernel)
-    float code_hi = 0.f, code_lo = 0.f;
-    if constexpr (CODEPTR) {
-        const gfloat_ptr tbl = (gfloat_ptr)p.code16;
-        code_hi = tbl[tid >> 4];
-        code_lo = tbl[tid & 15];
-    }
-    const int total_chunks = MB * nseg * 256;
-    u32x4 xr[XCH];
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) {
-        const int c = tid + i * THREADS;
-        const int m = c / (nseg * 256), rem = c - m * (nseg * 256);
-        const int k = rem * 8; // chunk rem of the row covers k .. k+8
-        const int mr = (m0 + m < p.M) ? m0 + m : p.M - 1;
-        xr[i] = u32x4{0, 0, 0, 0};
-        if (c < total_chunks && k < K)
-            xr[i] = *reinterpret_cast<const u32x4*>(A + static_cast<long>(mr) * K + k);
-    }
-
-    // ---- 2) weights + scales of the first iteration
-    struct Stage {
-        u32x4 w[SEGS][RPW];
-        float s[SEGS][RPW];
-    };
-    auto load_stage = [&](Stage& st, int it) {
-#pragma unroll
-        for (int sg = 0; sg < SEGS; ++sg) {
-            const int k0 = (it * SEGS + sg) * kSegK + lane * 32;
-            const int kk = (k0 < K) ? k0 : 0;
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const int row = (row0 + r < N) ? row0 + r : N - 1;
-                const long e = static_cast<long>(row) * K + kk;
-                st.w[sg][r] = *reinterpret_cast<const u32x4*>(B + (e >> 1));
-                const long blk = e >> p.bs_shift;
-                if constexpr (NESTED)
-                    st.s[sg][r] = __builtin_bit_cast(float, static_cast<uint32_t>(p.absmax8[blk]));
-                else
-                    st.s[sg][r] = absmax[blk];
-            }
-        }
-    };
-    Stage cur;
-    load_stage(cur, 0);
-
-    // ---- 3) table build (no memory traffic unless the caller handed a code pointer)
-    {
-        if constexpr (!CODEPTR) {
-            const int hi = tid >> 4, lo = tid & 15;
-            code_hi = p.code[0];
-            code_lo = p.code[0];
-#pragma unroll
-            for (int j = 1; j < 16; ++j) {
-                code_hi = (hi == j) ? p.code[j] : code_hi;
-                code_lo = (lo == j) ? p.code[j] : code_lo;
-            }
-        }
-        const uint32_t pr = Pair2<T>::pack(code_hi, code_lo);
-        const u32x4 v = {pr, pr, pr, pr};
-        u32x4* dst = reinterpret_cast<u32x4*>(&lut[tid * 32]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            dst[j] = v;
-    }
-    float offset = 0.0f;
-    if constexpr (NESTED) {
-        code2[tid] = p.absmax_code[tid];
-        offset = p.absmax_offset[0];
-    }
-
-    // ---- 4) activation image: chunk g = lane'*4 + q of segment sg -> slot q*64 + lane'
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) {
-        const int c = tid + i * THREADS;
-        if (c < total_chunks) {
-            const int m = c / (nseg * 256), rem = c - m * (nseg * 256);
-            const int sg = rem >> 8, g = rem & 255;
-            *reinterpret_cast<u32x4*>(xs + ((m * nseg + sg) * 256 + (g & 3) * 64 + (g >> 2)) * 16) = xr[i];
-        }
-    }
-    BNB_STAMP(1)
-    __syncthreads();
-    const int zsh = opaque_zero();
-    BNB_STAMP(2)
-    if constexpr (DBG) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        BNB_STAMP(3)
-    }
-
-    float acc[MB][RPW];
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-            acc[m][r] = 0.0f;
-    const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
-
-    auto compute_stage = [&](const Stage& st, int it) {
-#pragma unroll
-        for (int sg = 0; sg < SEGS; ++sg) {
-            const int seg = it * SEGS + sg;
-            if (seg >= nseg)
-                break;
-            float part[RPW][MB][2];
-#pragma unroll
-            for (int r = 0; r < RPW; ++r)
-#pragma unroll
-                for (int m = 0; m < MB; ++m)
-                    part[r][m][0] = part[r][m][1] = 0.0f;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                u32x4 xf[MB];
-#pragma unroll
-                for (int m = 0; m < MB; ++m)
-                    xf[m] = *reinterpret_cast<const u32x4*>(xs + ((m * nseg + seg) * 256 + d * 64 + lane) * 16);
-#pragma unroll
-                for (int r = 0; r < RPW; ++r) {
-                    const uint32_t w = st.w[sg][r][d];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t byte = (w >> (8 * j + zsh)) & 0xFFu;
-                        const uint32_t pr = lut[(byte << 5) + lane_slot];
-#pragma unroll
-                        for (int m = 0; m < MB; ++m)
-                            part[r][m][j & 1] = Pair2<T>::dot2(pr, xf[m][j], part[r][m][j & 1]);
-                    }
-                }
-            }
-            const int k0 = seg * kSegK + lane * 32;
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                float scale;
-                if constexpr (NESTED) {
-                    const int kk = (k0 < K) ? k0 : 0;
-                    const int row = (row0 + r < N) ? row0 + r : N - 1;
-                    const long blk = (static_cast<long>(row) * K + kk) >> p.bs_shift;
-                    const uint32_t q8 = __builtin_bit_cast(uint32_t, st.s[sg][r]);
-                    scale = __fadd_rn(__fmul_rn(code2[q8], absmax[blk >> 8]), offset);
-                } else {
-                    scale = st.s[sg][r];
-                }
-                scale = (k0 < K) ? scale : 0.0f; // lanes past the end of the row contribute nothing
-#pragma unroll
-                for (int m = 0; m < MB; ++m)
-                    acc[m][r] = fmaf(scale, part[r][m][0] + part[r][m][1], acc[m][r]);
-            }
-        }
-    };
-
-    const int iters = (nseg + SEGS - 1) / SEGS;
-    for (int it = 0; it < iters; ++it) {
-        Stage nxt;
-        const bool more = it + 1 < iters;
-        if (more)
-            load_stage(nxt, it + 1);
-        compute_stage(cur, it);
-        if (more)
-            cur = nxt;
-    }
-
-    if constexpr (DBG) {
-        asm volatile("" ::"v"(acc[0][0]), "v"(acc[MB - 1][RPW - 1]));
-        BNB_STAMP(4)
-    }
-    T* __restrict__ out = static_cast<T*>(p.out);
-    const T* __restrict__ bias = static_cast<const T*>(p.bias);
-#pragma unroll
-    for (int m = 0; m < MB; ++m) {
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const float v = wave_sum(acc[m][r]);
-            const int row = row0 + r;
-            if (lane == 0 && row < N && m0 + m < p.M) {
-                const float b = bias ? static_cast<float>(bias[row]) : 0.0f;
-                out[static_cast<long>(m0 + m) * N + row] = static_cast<T>(v + b);
-            }
-        }
-    }
-    BNB_STAMP(5)
-}
-#undef BNB_STAMP
 
 // ---------------------------------------------------------------------------------------------
 // Generic fallback: any T (incl. fp32 activations), any K (odd, not a multiple of 32), any pointer
@@ -653,9 +418,19 @@ template <typename T, bool NESTED> __global__ __launch_bounds__(256) void gemv4_
     }
 }
 
-// runtime knob bits -> the FLAGS template argument (only a curated set of combinations is instantiated)
+constexpr size_t kXLdsMaxBytes = 96 * 1024; // activation image cap (the table takes another 32 KiB)
+
+// bytes of the LDS activation image for MB rows (whole 2048-k segments)
+inline size_t x_image_bytes(int mb, int K, int segs) {
+    const bool single = K <= segs * kSegK;
+    const int nseg = single ? segs : (K + kSegK - 1) / kSegK;
+    return static_cast<size_t>(mb) * nseg * 4096;
+}
+
+// One geometry (MB activation rows per pass, RPW weight rows per wavefront, SEGS segments per iteration,
+// 256- or 512-thread workgroups) -> the right FLAGS instance for this problem.
 template <typename T, int MB, int RPW, int SEGS, int EXTRA> void launch_dot(const GemvArgs& p, hipStream_t stream) {
-    constexpr int waves = (EXTRA & kWaves16) ? 16 : (EXTRA & kWaves8) ? 8 : 4;
+    constexpr int waves = (EXTRA & kWaves8) ? 8 : 4;
     const int rows_per_block = waves * RPW;
     dim3 grid((p.N + rows_per_block - 1) / rows_per_block, (p.M + MB - 1) / MB);
     dim3 block(waves * 64);
@@ -663,12 +438,12 @@ template <typename T, int MB, int RPW, int SEGS, int EXTRA> void launch_dot(cons
     // The table always comes through the pointer path (built-in device table unless the caller
     // supplied one): measured faster than passing the 16 values by value and selecting them with a
     // v_cndmask chain (profiles/: 4.9-5.3 us vs 5.4-6.2 us per launch at M = 1, N = K = 4096).
-    constexpr int E = (EXTRA & (kWaves8 | kWaves16)) | kCodePtr;
-    // activations through LDS (one DMA copy per workgroup) whenever the image fits; debug flag 128 switches
-    // it off for A/B measurements
-    const int nseg = single ? SEGS : (p.K + kSegK - 1) / kSegK;
-    const size_t xbytes = static_cast<size_t>(MB) * nseg * 4096;
-    const bool xlds = xbytes <= 96 * 1024 && !(g_dot_flags & 128);
+    constexpr int E = (EXTRA & kWaves8) | kCodePtr;
+    // activations through LDS (one DMA copy per workgroup) whenever the image fits (the dispatcher picks MB
+    // so that it does); debug flag 128 switches it off for A/B measurements. Per-wavefront global loads of
+    // the activations are only instantiated for MB = 1: with more rows the prefetch stage spills registers.
+    const size_t xbytes = x_image_bytes(MB, p.K, SEGS);
+    const bool xlds = xbytes <= kXLdsMaxBytes && (MB > 1 || !(g_dot_flags & 128));
 #define BNB_DOT_GO(F)                                                                              \
     do {                                                                                           \
         auto kern = gemv4_dot_kernel<T, MB, RPW, SEGS, (F)>;                                       \
@@ -676,21 +451,32 @@ template <typename T, int MB, int RPW, int SEGS, int EXTRA> void launch_dot(cons
         static bool attr_done = false;                                                             \
         if (dyn + 34 * 1024 > 64 * 1024 && !attr_done) {                                           \
             BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                 \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,          \
+                                              static_cast<int>(kXLdsMaxBytes)));                   \
             attr_done = true;                                                                      \
         }                                                                                          \
         hipLaunchKernelGGL(kern, grid, block, dyn, stream, p);                                     \
     } while (0)
-    const int sel = (single ? 1 : 0) | (p.absmax8 ? 2 : 0) | (xlds ? 4 : 0);
-    switch (sel) {
-    case 0: BNB_DOT_GO(E); break;
-    case 1: BNB_DOT_GO(E | kSingle); break;
-    case 2: BNB_DOT_GO(E | kNested); break;
-    case 3: BNB_DOT_GO(E | kSingle | kNested); break;
-    case 4: BNB_DOT_GO(E | kXLds); break;
-    case 5: BNB_DOT_GO(E | kSingle | kXLds); break;
-    case 6: BNB_DOT_GO(E | kNested | kXLds); break;
-    default: BNB_DOT_GO(E | kSingle | kNested | kXLds); break;
+    const int sel = (single ? 1 : 0) | (p.absmax8 ? 2 : 0);
+    if (xlds) {
+        switch (sel) {
+        case 0: BNB_DOT_GO(E | kXLds); break;
+        case 1: BNB_DOT_GO(E | kSingle | kXLds); break;
+        case 2: BNB_DOT_GO(E | kNested | kXLds); break;
+        default: BNB_DOT_GO(E | kSingle | kNested | kXLds); break;
+        }
+        return;
+    }
+    if constexpr (MB == 1) {
+        switch (sel) {
+        case 0: BNB_DOT_GO(E); break;
+        case 1: BNB_DOT_GO(E | kSingle); break;
+        case 2: BNB_DOT_GO(E | kNested); break;
+        default: BNB_DOT_GO(E | kSingle | kNested); break;
+        }
+    } else {
+        fprintf(stderr, "bitsandbytes_amd: gemv_4bit: internal error, activation image of %zu bytes does not fit\n", xbytes);
+        exit(1);
     }
 #undef BNB_DOT_GO
 }
@@ -703,72 +489,7 @@ template <typename T> void launch_generic(const GemvArgs& p, hipStream_t stream)
         hipLaunchKernelGGL((gemv4_generic_kernel<T, false>), grid, dim3(256), 0, stream, p);
 }
 
-template <typename T, int MB, int XCH> bool launch_dotx(const GemvArgs& p, hipStream_t stream) {
-    constexpr int RPW = 2;
-    const int nseg = (p.K + kSegK - 1) / kSegK;
-    const size_t smem = 256 * 32 * 4 + static_cast<size_t>(MB) * nseg * 4096 + 1024;
-    dim3 grid((p.N + 4 * RPW - 1) / (4 * RPW), (p.M + MB - 1) / MB);
-    const int flags = (p.absmax8 ? kxNested : 0) | (p.code16 ? kxCodePtr : 0);
-    if constexpr ((MB == 1 && XCH == 2) || (MB == 8 && XCH == 16)) {
-        if (g_dbg_buf && flags == 0) {
-            GemvArgs q = p;
-            q.dbg = g_dbg_buf;
-            auto kern = gemv4_dotx_kernel<T, MB, RPW, XCH, kxDebug>;
-            static bool attr_dbg = false;
-            if (!attr_dbg) {
-                BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_dbg = true;
-            }
-            hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, q);
-            return true;
-        }
-    }
-#define BNB_DOTX_LAUNCH(F)                                                                         \
-    if (flags == (F)) {                                                                            \
-        auto kern = gemv4_dotx_kernel<T, MB, RPW, XCH, (F)>;                                       \
-        static bool attr_done = false;                                                             \
-        if (!attr_done) {                                                                          \
-            BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                 \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_done = true;                                                                      \
-        }                                                                                          \
-        hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);                                \
-        return true;                                                                               \
-    }
-    BNB_DOTX_LAUNCH(0) BNB_DOTX_LAUNCH(kxNested) BNB_DOTX_LAUNCH(kxCodePtr)
-#undef BNB_DOTX_LAUNCH
-    return false; // nested + caller code pointer never occurs (the gemv op un-nests on the host)
-}
-
-// x-in-LDS dot kernel: MB rows per pass (1, 2, 4, 8), XCH = MB * nseg chunks per lane rounded up to a
-// power of two <= 16. Returns false when the activations do not fit (caller falls back).
-template <typename T> bool dispatch_dotx(const GemvArgs& p, hipStream_t stream) {
-    const int nseg = (p.K + kSegK - 1) / kSegK;
-    const int mb = p.M >= 5 ? 8 : p.M >= 3 ? 4 : p.M;
-    int need = mb * nseg;
-    int mbsel = mb;
-    while (need > 16 && mbsel > 1) { // too much activation per pass: fewer rows per pass, more passes
-        mbsel >>= 1;
-        need = mbsel * nseg;
-    }
-    if (need > 16)
-        return false;
-    const int xch = need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16;
-#define BNB_DOTX_CASE(MBV, XV)                                                                     \
-    if (mbsel == MBV && xch == XV)                                                                 \
-        return launch_dotx<T, MBV, XV>(p, stream);
-    BNB_DOTX_CASE(1, 2) BNB_DOTX_CASE(1, 4) BNB_DOTX_CASE(1, 8) BNB_DOTX_CASE(1, 16)
-    BNB_DOTX_CASE(2, 2) BNB_DOTX_CASE(2, 4) BNB_DOTX_CASE(2, 8) BNB_DOTX_CASE(2, 16)
-    BNB_DOTX_CASE(4, 4) BNB_DOTX_CASE(4, 8) BNB_DOTX_CASE(4, 16)
-    BNB_DOTX_CASE(8, 8) BNB_DOTX_CASE(8, 16)
-#undef BNB_DOTX_CASE
-    return false;
-}
-
 template <typename T> void dispatch_dot(const GemvArgs& p, hipStream_t stream) {
-    if (g_dot_ablate == 0 && (g_dot_flags & 32) && dispatch_dotx<T>(p, stream))
-        return;
     // profiling-only ablations of the M = 1, K <= 4096 configuration
     if (g_dot_ablate != 0 && p.M == 1 && !p.absmax8 && p.K <= 2 * kSegK) {
         dim3 grid((p.N + 7) / 8, 1);
@@ -781,39 +502,38 @@ template <typename T> void dispatch_dot(const GemvArgs& p, hipStream_t stream) {
 #undef BNB_ABL
     }
 
-    // Calibrated on MI355X (profiles/): 512-thread workgroups (one table build per 8 wavefronts),
-    // 2 weight rows per wavefront once that still yields >= 256 workgroups, else 1.
-    // Calibrated on MI355X (profiles/r1_dot_ab.txt): with the activations in LDS one row per wavefront wins at
-    // M = 1 for every shape tried (4096^2: 4.73 vs 5.35 us; twice the wavefronts to hide latency and nothing
-    // left to amortise); two activation rows keep two weight rows per wavefront on the large matrices only
-    // (4096^2 M = 2: 5.47 vs 5.93 us; 8192^2: 19.1 vs 17.0; 4096 x 11008: 13.6 vs 11.4).
-    int rpw = g_dot_rpw;
-    if (rpw == 0)
-        rpw = (p.M >= 2 && static_cast<long>(p.N) * p.K > (24L << 20)) ? 2 : 1;
+    // Geometry, calibrated on MI355X (profiles/r1_dot_ab.txt):
+    //  * 512-thread workgroups (one table build and one activation copy per 8 wavefronts);
+    //  * with the activations in LDS one weight row per wavefront wins at M = 1 for every shape tried
+    //    (4096^2: 4.73 vs 5.35 us - twice the wavefronts to hide latency and nothing left to amortise); two
+    //    activation rows keep two weight rows per wavefront on the large matrices only (4096^2 M = 2:
+    //    5.47 vs 5.93 us; 8192^2: 19.1 vs 17.0; 4096 x 11008: 13.6 vs 11.4);
+    //  * rows of A per pass: 4, 2 or 1 - the largest that M needs and whose LDS image fits.
     int segs = g_dot_segs;
-    if (segs == 0)
+    if (segs != 1 && segs != 2)
         segs = (p.K > kSegK) ? 2 : 1;
-    const int mb = (p.M >= 3) ? 4 : p.M;
-    int extra = g_dot_flags & (kWaves8 | kWaves16);
-    if (g_dot_rpw == 0 && (g_dot_flags & ~128) == 0)
-        extra = (mb <= 2) ? kWaves8 : 0;
+    int mb = (p.M >= 3) ? 4 : p.M;
+    while (mb > 1 && x_image_bytes(mb, p.K, segs) > kXLdsMaxBytes)
+        mb >>= 1;
+    int rpw = g_dot_rpw;
+    if (rpw != 1 && rpw != 2)
+        rpw = (mb == 2 && static_cast<long>(p.N) * p.K > (24L << 20)) ? 2 : 1;
+    if (mb == 4)
+        rpw = 1;
+    const int extra = (g_dot_flags & 64) ? 0 : kWaves8; // debug flag 64: 256-thread workgroups
 
-#define BNB_DOT_CASE(MBV, RPWV, SEGSV, EX)                                                         \
-    if (mb == MBV && rpw == RPWV && segs == SEGSV && extra == (EX)) {                              \
-        launch_dot<T, MBV, RPWV, SEGSV, (EX)>(p, stream);                                          \
+#define BNB_DOT_CASE(MBV, RPWV, SEGSV)                                                             \
+    if (mb == MBV && rpw == RPWV && segs == SEGSV) {                                               \
+        if (extra)                                                                                 \
+            launch_dot<T, MBV, RPWV, SEGSV, kWaves8>(p, stream);                                   \
+        else                                                                                       \
+            launch_dot<T, MBV, RPWV, SEGSV, 0>(p, stream);                                         \
         return;                                                                                    \
     }
-#define BNB_DOT_ALLX(MBV, RPWV, SEGSV)                                                             \
-    BNB_DOT_CASE(MBV, RPWV, SEGSV, 0) BNB_DOT_CASE(MBV, RPWV, SEGSV, kWaves8) BNB_DOT_CASE(MBV, RPWV, SEGSV, kWaves16)
-    BNB_DOT_ALLX(1, 2, 2) BNB_DOT_ALLX(1, 1, 2) BNB_DOT_ALLX(1, 4, 2) BNB_DOT_ALLX(2, 2, 2) BNB_DOT_ALLX(2, 1, 2)
-    BNB_DOT_ALLX(4, 1, 2)
-    BNB_DOT_CASE(1, 1, 1, 0) BNB_DOT_CASE(1, 2, 1, 0) BNB_DOT_CASE(1, 4, 1, 0) BNB_DOT_CASE(1, 8, 1, 0)
-    BNB_DOT_CASE(2, 1, 1, 0) BNB_DOT_CASE(2, 1, 2, 0) BNB_DOT_CASE(2, 2, 1, 0) BNB_DOT_CASE(2, 4, 1, 0)
-    BNB_DOT_CASE(4, 1, 1, 0) BNB_DOT_CASE(4, 2, 1, 0)
-#undef BNB_DOT_ALLX
+    BNB_DOT_CASE(1, 1, 2) BNB_DOT_CASE(1, 2, 2) BNB_DOT_CASE(2, 1, 2) BNB_DOT_CASE(2, 2, 2) BNB_DOT_CASE(4, 1, 2)
+    BNB_DOT_CASE(1, 1, 1) BNB_DOT_CASE(1, 2, 1) BNB_DOT_CASE(2, 1, 1) BNB_DOT_CASE(2, 2, 1) BNB_DOT_CASE(4, 1, 1)
 #undef BNB_DOT_CASE
-    // unsupported combination requested by a sweep: fall back to a safe one
-    launch_dot<T, 1, 1, 1, 0>(p, stream);
+    launch_dot<T, 1, 1, 2, kWaves8>(p, stream); // not reached
 }
 
 } // namespace

@@ -124,12 +124,12 @@ void bnb_mi355x_set_tuning(int dot_rows_per_wave, int dot_segments, int mfma_kno
 
 /* Profiling only. dot_ablation: 0 = normal; 1..5 run ablated variants of the dot kernel (stream only /
  * no table build / no weight loads / weights only / empty) whose RESULTS ARE WRONG. dot_flags selects
- * structural variants of the dot kernel (4 = 512-thread workgroups, 8 = non-temporal weight loads,
- * 16 = activations staged in LDS); results stay correct. Never set outside tools/sweep.py. */
+ * structural variants of the dot kernel whose results stay correct (64 = 256-thread workgroups,
+ * 128 = activations loaded per wavefront instead of staged in LDS, M = 1 only). Never set outside tools/. */
 void bnb_mi355x_set_debug(int dot_ablation, int dot_flags);
 
-/* Profiling only: when non-NULL, the M = 1 and M = 8 instances of the dot kernel write 8 s_memtime
- * stamps per wavefront (u64) into this device buffer (N/2 wavefronts). NULL switches it off. */
+/* Profiling only: when non-NULL, the producer/consumer MFMA kernel writes 16 s_memtime stamps per wavefront
+ * (u64) into this device buffer (tools/timeline_pc.py); the v2 MFMA kernel writes 8. NULL switches it off. */
 void bnb_mi355x_set_stamp_buffer(void* device_u64_buffer);
 
 /* Version / build identification: returns "bitsandbytes_amd <ver> gfx950". */

@@ -72,3 +72,51 @@ def test_no_cpu_kernels_registered_by_product():
     )
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT).stdout
     assert "RAISED" in out and "COMPUTED" not in out
+
+
+def _device_kernel_metadata():
+    """(name, private_segment_fixed_size, vgpr_count) of every kernel in the library's gfx950 code objects,
+    read from the HSA metadata notes (no GPU needed)."""
+    import re
+    import subprocess
+    import tempfile
+    from pathlib import Path
+
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    tools = [llvm / "llvm-objcopy", llvm / "clang-offload-bundler", llvm / "llvm-readelf"]
+    if not all(t.exists() for t in tools):
+        pytest.skip("ROCm LLVM binutils not available")
+    from bitsandbytes_amd.cextension import LIB_PATH
+
+    out = []
+    with tempfile.TemporaryDirectory() as td:
+        fat = Path(td) / "fat.bin"
+        subprocess.check_call([str(tools[0]), "-O", "binary", "--only-section=.hip_fatbin", str(LIB_PATH), str(fat)])
+        blob = fat.read_bytes()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+        assert starts, "no offload bundles found in .hip_fatbin"
+        for i, s in enumerate(starts):
+            piece = Path(td) / f"bundle{i}.bin"
+            piece.write_bytes(blob[s : starts[i + 1] if i + 1 < len(starts) else len(blob)])
+            co = Path(td) / f"dev{i}.co"
+            subprocess.check_call([str(tools[1]), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                                   f"--input={piece}", f"--output={co}"], stderr=subprocess.DEVNULL)
+            notes = subprocess.run([str(tools[2]), "--notes", str(co)], capture_output=True, text=True).stdout
+            for block in notes.split("- .agpr_count")[1:]:
+                name = re.search(r"\.name:\s+(\S+)", block)
+                scratch = re.search(r"\.private_segment_fixed_size:\s+(\d+)", block)
+                vgpr = re.search(r"\.vgpr_count:\s+(\d+)", block)
+                if name and scratch:
+                    out.append((name.group(1), int(scratch.group(1)), int(vgpr.group(1)) if vgpr else -1))
+    return out
+
+
+def test_no_kernel_spills_to_scratch():
+    """A register spill in these kernels is a performance bug with a correctness smell: a scratch reload is a
+    vector-memory op, its wait is vmcnt(0), and that drains the DMA rings / weight streams the kernels keep
+    in flight with counted waits. Every kernel of the library must have a zero private segment."""
+    meta = _device_kernel_metadata()
+    assert len(meta) > 100, f"expected the full kernel set, found {len(meta)}"
+    spilled = [(n, s) for n, s, _ in meta if s != 0]
+    assert not spilled, f"kernels using scratch: {spilled[:5]}"

@@ -89,9 +89,6 @@ def main():
         del W
     print(f"# N={N} K={K} bs={bs} layers={L} ({L * bytes_alg(1, N, K, bs) / 1e6:.0f} MB rotated)")
     print(f"{'kernel':8s} {'M':>3s} {'knobs':>12s} {'graph_us':>9s} {'evpair_us':>9s} {'GB/s(graph)':>11s} {'TFLOP/s':>8s}")
-    FL = {0: "base", 4: "w8", 64: "w16"}
-    if a.mfma_only:
-        FL = {}
     x1 = torch.randn(1, K, device="cuda", generator=g).bfloat16()
     # correctness reference for the structural variants (they must not change results beyond rounding)
     bnb.lib.bnb_mi355x_set_debug(0, 0)
@@ -101,28 +98,15 @@ def main():
         return hip._gemm_4bit_fused(xx, q0, st0.shape, st0.absmax, st0.blocksize, st0.quant_type, None, None, None, None, kernel=1).float()
 
     y_ref = run1(x1)
-    for M in (() if a.mfma_only else (1, 2, 3, 4, 5, 8)):
-        x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
-        bnb.lib.bnb_mi355x_set_debug(0, 32)
-        tg, te = measure(layers, x, 1)
-        bnb.lib.bnb_mi355x_set_debug(0, 0)
-        print(f"{'dotx':8s} {M:3d} {'default':>16s} {tg:9.2f} {te:9.2f} {bytes_alg(M, N, K, bs) / tg / 1e3:11.1f} {2 * M * N * K / tg / 1e6:8.2f}")
-    for rpw in (1, 2, 4):
-        for fl, name in FL.items():
+    FLD = {0: "512thr xLDS", 64: "256thr xLDS", 128: "512thr xwave"}
+    for rpw in (() if a.mfma_only else (1, 2)):
+        for fl, name in FLD.items():
             bnb.lib.bnb_mi355x_set_tuning(rpw, 2, 0, 0)
             bnb.lib.bnb_mi355x_set_debug(0, fl)
             err = float((run1(x1) - y_ref).norm() / y_ref.norm())
             tg, te = measure(layers, x1, 1)
             print(f"{'dot':8s} {1:3d} {f'rpw{rpw} {name}':>16s} {tg:9.2f} {te:9.2f} {bytes_alg(1, N, K, bs) / tg / 1e3:11.1f} {2 * N * K / tg / 1e6:8.2f}  relerr_vs_base={err:.1e}")
-    global CODE16
-    CODE16 = F.get_4bit_type("nf4", device="cuda")
-    for rpw in (1, 2, 4):
-        for fl, name in FL.items():
-            bnb.lib.bnb_mi355x_set_tuning(rpw, 2, 0, 0)
-            bnb.lib.bnb_mi355x_set_debug(0, fl)
-            tg, te = measure(layers, x1, 1)
-            print(f"{'dot-ptr':8s} {1:3d} {f'rpw{rpw} {name}':>16s} {tg:9.2f} {te:9.2f} {bytes_alg(1, N, K, bs) / tg / 1e3:11.1f} {2 * N * K / tg / 1e6:8.2f}")
-    CODE16 = None
+    bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
     bnb.lib.bnb_mi355x_set_debug(0, 0)
     for abl, name in (() if a.mfma_only else ((5, "empty"), (4, "weights-only"), (1, "stream-only"), (3, "no-weight-loads"), (0, "full rpw2 seg2"))):
         bnb.lib.bnb_mi355x_set_debug(abl, 0)
@@ -130,21 +114,13 @@ def main():
         tg, te = measure(layers, x1, 1)
         print(f"{'dot-abl':8s} {1:3d} {name:>16s} {tg:9.2f} {te:9.2f} {bytes_alg(1, N, K, bs) / tg / 1e3:11.1f}")
     bnb.lib.bnb_mi355x_set_debug(0, 0)
-    for M in (() if a.quick else (2, 4)):
-        x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
-        for rpw in ((2,) if M == 2 else (1,)):
-            for fl, name in FL.items():
-                bnb.lib.bnb_mi355x_set_tuning(rpw, 2, 0, 0)
-                bnb.lib.bnb_mi355x_set_debug(0, fl)
-                tg, te = measure(layers, x, 1)
-                print(f"{'dot':8s} {M:3d} {f'rpw{rpw} {name}':>16s} {tg:9.2f} {te:9.2f} {bytes_alg(M, N, K, bs) / tg / 1e3:11.1f} {2 * M * N * K / tg / 1e6:8.2f}")
     bnb.lib.bnb_mi355x_set_debug(0, 0)
     bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
     if a.dot_only:
         return
     for abl, name in ((11, "stream+A"), (12, "stream only"), (0, "full")):
         x = torch.randn(8, K, device="cuda", generator=g).bfloat16()
-        for cfgks in (501, 601, 201):
+        for cfgks in (501, 601):
             bnb.lib.bnb_mi355x_set_debug(abl, 0)
             bnb.lib.bnb_mi355x_set_tuning(0, 0, 1, cfgks)
             tg, te = measure(layers, x, 2)

@@ -27,7 +27,8 @@ ap.add_argument("--cfgks", type=int, default=0)
 args = ap.parse_args()
 bnb.lib.bnb_mi355x_set_tuning(0, 0, args.nt, args.cfgks)
 if args.kernel == 1:
-    bnb.lib.bnb_mi355x_set_debug(0, 32)
+    sys.exit("the stamped dot-kernel variant was retired (see profiles/r1_timeline_dotx_smemtime.txt for its record); "
+             "use --kernel 2 (v2 MFMA) or tools/timeline_pc.py")
 for M in (1, 8):
     x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
     nw = N // 2 if args.kernel == 1 else 4096 * 4
