@@ -329,6 +329,25 @@ def test_gemm_4bit_shapes_both_kernels(M, N, K, dtype):
         assert e < REL_TOL, f"kernel={kernel} rel err {e}"
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 256, 8192), (2, 256, 11008), (2, 130, 8192), (4, 128, 8192), (3, 64, 14336),
+                                   (1, 64, 32768), (1, 16, 53248), (2, 24, 26624), (7, 40, 6144), (1, 300, 2048),
+                                   (2, 300, 2048), (4, 300, 1024)])
+@pytest.mark.parametrize("dq", [False, True], ids=["absmax32", "nested"])
+def test_dot_kernel_long_and_short_rows(M, N, K, dq):
+    """The dot kernel's activation image in LDS: several loop iterations over K, images that only fit with
+    fewer activation rows per pass (K = 14336 at M = 3), rows too long for any image (K = 53248 falls back to
+    per-wavefront loads) and the single-segment geometry (K <= 2048)."""
+    F = _F()
+    W = (torch.randn(N, K) / K**0.5).bfloat16()
+    x = torch.randn(M, K).bfloat16()
+    bias = torch.randn(N).bfloat16()
+    q, st = F.quantize_4bit(W.to(DEV), blocksize=64, quant_type="nf4", compress_statistics=dq)
+    y_ref = _oracle_y(x, q, st, bias)
+    y = _run_kernel(1, x.to(DEV), q, st, bias.to(DEV))
+    assert rel_err(y.cpu(), y_ref) < REL_TOL
+    assert torch.equal(y, _run_kernel(1, x.to(DEV), q, st, bias.to(DEV)))  # bit-reproducible
+
+
 @pytest.mark.parametrize("quant_type,blocksize,dq", [("fp4", 128, True), ("nf4", 64, True), ("fp4", 64, False),
                                                       ("nf4", 32, False), ("nf4", 256, True), ("nf4", 4096, False)])
 @pytest.mark.parametrize("M", [1, 4, 16, 48])
