@@ -1467,11 +1467,12 @@ struct Plan {
              // v3 LDS-DMA kernel (NT = 1): 5: 16 waves, 6: 8 waves;  v4 tiled LDS-DMA kernel (128 columns): 7;
              // v4b ring kernel (128 columns, 128-k chunks, 4-deep ring): 8
              // v4 with 8 wavefronts: 9: 8 x 1 n-tile (128 columns), 10: 8 x 2 n-tiles (256 columns)
-             // v5 producer/consumer kernel: 11: 8 consumers x 1 n-tile (128 columns), 12: 4 x 2 (128), 13: 8 x 2 (256)
+             // v5 producer/consumer kernel: 11: 8 consumers x 1 n-tile (128 columns), 12: 4 x 2 (128), 13: 8 x 2 (256),
+             // 14: 4 x 1 (64 columns)
 };
 
-constexpr int kCfgWaves[14] = {4, 8, 16, 8, 4, 16, 8, 1, 1, 1, 1, 1, 1, 1};
-constexpr int kCfgCols[14] = {0, 0, 0, 0, 0, 16, 16, 128, 128, 128, 256, 128, 128, 256};
+constexpr int kCfgWaves[15] = {4, 8, 16, 8, 4, 16, 8, 1, 1, 1, 1, 1, 1, 1, 1};
+constexpr int kCfgCols[15] = {0, 0, 0, 0, 0, 16, 16, 128, 128, 128, 256, 128, 128, 256, 64};
 
 // Tile shape and K-slice count for a problem: a pure function of (M, N, K) and the tuning knobs,
 // shared by the launch and by the workspace-size query.
@@ -1499,6 +1500,9 @@ Plan make_plan(int M, int N, int K) {
         const bool big = static_cast<long>(N) * K >= (32L << 20) && N >= 1024;
         if (pl.mt >= 2 || big) {
             cfg = 11; // producer/consumer kernel: 8 consumer wavefronts x 16 columns share one A tile
+            if (pl.mt >= 3 && !big)
+                cfg = 14; // small matrix, tall tile: 64-column workgroups need half the K slices, i.e. half the
+                          // slab traffic (4096^2 M = 64: 14.6 vs 15.4 us); on large matrices 128 columns win
             pl.nt = nt = 1;
         } else {
             cfg = (pl.mt == 1) ? 5 : 6; // 16 wavefronts x 1 chunk; 8 x 2 measured +-1 % on fp32 absmax, 5 % behind on nested bs 128
@@ -1506,7 +1510,7 @@ Plan make_plan(int M, int N, int K) {
             gx = (N + 15) / 16;
         }
     }
-    if (cfg < 0 || cfg > 13)
+    if (cfg < 0 || cfg > 14)
         cfg = 0;
     if (cfg == 13 && pl.mt > 2)
         cfg = 11; // 8 x 2 consumers with a > 32-row A tile do not fit the 160 KiB of LDS
@@ -1648,6 +1652,8 @@ template <typename T, int MT, int NT> void launch_mfma(GemmArgs& p, int cfg, hip
         return launch_mfma_pc<T, MT, 8, 1>(p, stream);
     if (cfg == 12)
         return launch_mfma_pc<T, MT, 4, 2>(p, stream);
+    if (cfg == 14)
+        return launch_mfma_pc<T, MT, 4, 1>(p, stream);
     if (cfg == 13) {
         if constexpr (pc_depth(MT, 8, 2, true) >= 2)
             return launch_mfma_pc<T, MT, 8, 2>(p, stream);

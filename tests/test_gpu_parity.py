@@ -546,7 +546,7 @@ def test_backward_through_matmul_4bit_gpu():
     assert rel_err(x.grad.float().cpu(), g_ref.cpu()) < 2e-2
 
 
-@pytest.mark.parametrize("cfg", [0, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("cfg", [0, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
 @pytest.mark.parametrize("M,N,K,ks", [(5, 256, 1024, 1), (16, 200, 2048, 2), (33, 384, 1024, 1), (64, 512, 4096, 4),
                                       (64, 1000, 2816, 1), (100, 128, 512, 2)])
 def test_mfma_kernel_variants(cfg, M, N, K, ks):

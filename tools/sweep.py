@@ -129,7 +129,7 @@ def main():
     Ms = [1, 8, 16, 64] if a.quick else [1, 4, 8, 16, 32, 64]
     if a.ms:
         Ms = [int(v) for v in a.ms.split(",")]
-    names = {7: "tile", 8: "ring", 9: "t8x1", 10: "t8x2", 11: "pc8x1", 12: "pc4x2", 13: "pc8x2"}
+    names = {7: "tile", 8: "ring", 9: "t8x1", 10: "t8x2", 11: "pc8x1", 12: "pc4x2", 13: "pc8x2", 14: "pc4x1"}
     CFG = {int(c): names.get(int(c), f"cfg{c}") for c in a.cfgs.split(",")}
     KSS = tuple(int(v) for v in a.kss.split(","))
     for M in Ms:
