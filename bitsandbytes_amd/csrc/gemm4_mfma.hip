@@ -1,31 +1,32 @@
-// gemm4_mfma.hip — fused 4-bit dequantize + MFMA GEMM for small batches (5 <= M, typically <= 128) on gfx950.
+// gemm4_mfma.hip — fused 4-bit dequantize + MFMA GEMM for small batches (3 <= M, typically <= 128) on gfx950.
 //   out[M, N] = A[M, K] * dequant(B)[N, K]^T (+ bias)
 //
 // The reference has tensor-core kernels for this only on NVIDIA (csrc/gemm_4bit_sm80.cu:127-457,
 // csrc/gemm_4bit_sm75.cu:97-305: mma.sync + ldmatrix + smem-staged dequantized B tiles); on ROCm it
 // writes the whole dequantized weight to HBM and calls hipBLASLt
-// (bitsandbytes/backends/cuda/ops.py:904-916). This is the missing MFMA kernel, designed for CDNA4
-// rather than translated:
+// (bitsandbytes/backends/cuda/ops.py:904-916). These are the missing MFMA kernels, designed for CDNA4
+// rather than translated. Common to all of them:
 //
 //  * v_mfma_f32_16x16x32_{bf16,f16}: A operand = activations (row m = lane%16), B operand = weights
 //    (column n = lane%16), both hold k = 8*(lane/16) + i. Because the weight column of a lane equals
-//    the accumulator column of that lane, the per-(column, block) absmax is a per-lane scalar.
-//  * Weights never touch LDS. Lane (n, g) loads the 8 packed bytes holding k = k0 + 16 g .. + 16 of
-//    its own row straight into registers (the four lane groups cover one 64-element quantization
-//    block), turns them into two B fragments with the same bank-private byte -> bf16x2 table as the
-//    gemv kernel (8 conflict-free ds_read_b32), and issues two MFMAs per M-tile. The fp32 partial
-//    tile of that 64-k block is then scaled by the lane's fp32 absmax and added to the running
+//    the accumulator column of that lane, the per-(column, block) absmax is a per-lane scalar: the fp32
+//    partial tile of a 64-k block (two MFMAs) is scaled by the lane's fp32 absmax and added to the running
 //    accumulator (4 v_fma per tile), so the scale is applied exactly, in fp32, after the MFMA — the
-//    same idea as the reference's CDNA SIMT path (csrc/gemm_4bit_simt.cu:436-444), but on the
-//    matrix pipe.
-//  * Activations come straight from L2 as MFMA fragments (no LDS staging, no barriers in the loop);
-//    a 4-block register ring per wavefront keeps one full 128-B line of every row in flight.
-//  * Work decomposition = (column group of 16*NT columns) x (K range split over the workgroup's 4
-//    wavefronts, combined through LDS) x (optional cross-workgroup K slice). Cross-workgroup slices
-//    exist only to put >= 256 workgroups on the chip when N is small. Each such slice writes its fp32 partial tile to its own
-//    slab of a workspace with plain stores; a small finalize kernel adds the slabs in slice order,
-//    adds the bias and rounds once. No atomics: results are bit-reproducible run to run (the
-//    reference's test_matmul_4bit_weight_orientation demands exact equality between calls).
+//    same idea as the reference's CDNA SIMT path (csrc/gemm_4bit_simt.cu:436-444), but on the matrix pipe.
+//  * Packed bytes become B fragments through the same bank-private byte -> bf16x2 LDS table as the gemv
+//    kernel (conflict-free ds_read_b32).
+//  * Cross-workgroup K slices exist only to put ~256 workgroups on the chip. Each slice writes its fp32
+//    partial tile to its own slab of a workspace with plain stores; a small finalize kernel adds the slabs
+//    in slice order, adds the bias and rounds once. No atomics: results are bit-reproducible run to run
+//    (the reference's test_matmul_4bit_weight_orientation demands exact equality between calls).
+//
+// The kernels, in the order they were written (each one's header says what the previous one taught):
+//   gemm4_mfma_kernel       (v2)  16*NT columns, weights straight to registers, register ring    [variants only]
+//   gemm4_mfma_dma_kernel   (v3)  16 columns, weights by LDS-DMA in full lines, K split over wavefronts  [M <= 16, small matrices]
+//   gemm4_mfma_tile_kernel  (v4)  128-column tile, A shared through LDS, two-stage double buffer   [variants only]
+//   gemm4_mfma_ring_kernel  (v4b) v4 with a 4-deep ring of 128-k chunks                             [variants only]
+//   gemm4_mfma_pc_kernel    (v5)  producer / consumer wavefronts, private weight rings              [M > 16 or large matrices]
+// make_plan() below holds the selection rule.
 #include "bnb_common.h"
 
 #include <mutex>

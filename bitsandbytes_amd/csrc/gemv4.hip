@@ -1,12 +1,12 @@
-// gemv4.hip — fused 4-bit dequantize + dot-product kernel for decode-sized batches (M <= 4 rows of A
+// gemv4.hip — fused 4-bit dequantize + dot-product kernel for decode-sized batches (1, 2 or 4 rows of A
 // per pass) on gfx950.   out[m, n] = sum_k A[m, k] * code[B[n, k]] * scale[n, k / bs]  (+ bias[n])
 //
 // Replaces, on MI355X, the reference's kgemm_4bit_inference_naive (csrc/kernels.cu:1452-1567) and the
 // small-M range of gemm_4bit_simt (csrc/gemm_4bit_simt.cu:109-480). It is not a translation of
 // either: those map one logical 32-lane warp to an output column and decode nibbles with shifts and
-// an LDS/const table per nibble; this kernel is built around three CDNA4 facts:
+// an LDS/const table per nibble; this kernel is built around four CDNA4 facts:
 //
-//  * HBM-bound, so the only job is to keep ~8 MB of loads in flight. A wavefront owns RPW whole
+//  * HBM-bound, so the first job is to keep the weight bytes in flight. A wavefront owns RPW whole
 //    weight rows; lane l reads bytes [16 l, 16 l + 16) of each 1 KiB row segment with one
 //    global_load_dwordx4, i.e. every load instruction covers 1 KiB contiguous (eight full 128-B
 //    lines). All loads of an iteration (and of the next one) are issued before any arithmetic.
@@ -17,8 +17,10 @@
 //  * A random 4-byte LDS gather would be ~4-way bank-conflicted. The table is therefore stored
 //    32x replicated, entry e of copy j at dword e*32 + j, and lane l only ever reads copy l%32:
 //    each lane owns its bank, so the gather is conflict-free for any data. 32 KiB of the CU's
-//    160 KiB LDS buys a 2-cycles-per-64-bytes decode. The table is built from 16 SGPR-resident
-//    code values (no vector memory traffic) while the first weight loads are in flight.
+//    160 KiB LDS buys a 2-cycles-per-64-bytes decode. The table is built while the first weight
+//    loads are in flight.
+//  * The activations are the same for every row: one LDS-DMA copy per workgroup (issued first, source-side
+//    bank swizzle) instead of every wavefront pulling them through L1 again - see step 0 of the kernel.
 //
 // The per-block scale multiplies the fp32 partial sum of each 32-nibble run (one run never
 // straddles a quantization block because blocksize >= 32 and K % 32 == 0), so absmax is applied in
