@@ -216,10 +216,12 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_kernel(const GemmArgs 
     {
         const uint32_t pr = Mma<T>::pack(code_hi, code_lo);
         const u32x4 v = {pr, pr, pr, pr};
+        // chunk order rotated by the entry's index in the wavefront: conflict-free ds_write_b128 (see gemv4.hip)
         u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * 32]) + (tid % TPE) * (8 / TPE);
+        const int rot = (tid & 63) / TPE;
 #pragma unroll
         for (int j = 0; j < 8 / TPE; ++j)
-            dst[j] = v;
+            dst[(j + rot) % (8 / TPE)] = v;
     }
     float offset = 0.0f;
     if constexpr (NESTED) {
@@ -478,10 +480,12 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmA
     {
         const uint32_t pr = Mma<T>::pack(code_hi, code_lo);
         const u32x4 v = {pr, pr, pr, pr};
+        // chunk order rotated by the entry's index in the wavefront: conflict-free ds_write_b128 (see gemv4.hip)
         u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * 32]) + (tid % TPE) * (8 / TPE);
+        const int rot = (tid & 63) / TPE;
 #pragma unroll
         for (int j = 0; j < 8 / TPE; ++j)
-            dst[j] = v;
+            dst[(j + rot) % (8 / TPE)] = v;
     }
     float offset = 0.0f;
     if constexpr (NESTED) {
@@ -703,10 +707,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_tile_kernel(const GemmA
     {
         const uint32_t pr = Mma<T>::pack(code_hi, code_lo);
         const u32x4 v = {pr, pr, pr, pr};
+        // chunk order rotated by the entry's index in the wavefront: conflict-free ds_write_b128 (see gemv4.hip)
         u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * 32]) + (tid % TPE) * (8 / TPE);
+        const int rot = (tid & 63) / TPE;
 #pragma unroll
         for (int j = 0; j < 8 / TPE; ++j)
-            dst[j] = v;
+            dst[(j + rot) % (8 / TPE)] = v;
     }
     float offset = 0.0f;
     if constexpr (NESTED) {
@@ -937,7 +943,7 @@ __global__ __launch_bounds__(256) void gemm4_mfma_ring_kernel(const GemmArgs p) 
         u32x4* dst = reinterpret_cast<u32x4*>(&lut[tid * 32]);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            dst[j] = v;
+            dst[(j + tid) & 7] = v; // rotated chunk order: conflict-free ds_write_b128 (see gemv4.hip)
     }
     float offset = 0.0f;
     if constexpr (NESTED) {
@@ -1136,7 +1142,7 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
             u32x4* dst = reinterpret_cast<u32x4*>(&lut[e * 32]);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                dst[j] = v;
+                dst[(j + e) & 7] = v; // rotated chunk order: conflict-free ds_write_b128 (see gemv4.hip)
             if constexpr (NESTED)
                 code2[e] = code2_v;
         }

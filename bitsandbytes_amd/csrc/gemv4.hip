@@ -96,6 +96,8 @@ enum DotFlags : int {
     kWaves8 = 4,  // 512-thread workgroups (8 wavefronts share one table build) instead of 256
     kXLds = 16,   // activations staged once per workgroup in LDS (one LDS-DMA copy) instead of per-wave global loads
     kCodePtr = 32, // code table read from a table pointer (device-resident built-in table or the caller's)
+    kLut64 = 64,  // 64 table copies, 256 B per entry: the LDS address of a look-up is ONE v_perm_b32
+                  // (byte 0 = the lane's offset, byte 1 = the packed weight byte) instead of shift + mask + or
     // bits 8..: ablation for profiling builds (results are wrong): 1 = stream + reduce raw words, no decode;
     // 2 = no table build; 3 = no weight loads; 4 = weights only (no x / absmax traffic); 5 = empty kernel
 };
@@ -104,14 +106,16 @@ enum DotFlags : int {
 // SEGS = 2048-k sub-segments per loop iteration.
 template <typename T, int MB, int RPW, int SEGS, int FLAGS>
 __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kernel(const GemvArgs p) {
-    constexpr bool SINGLE = FLAGS & kSingle, NESTED = FLAGS & kNested, CODEPTR = FLAGS & kCodePtr;
+    constexpr bool SINGLE = FLAGS & kSingle, NESTED = FLAGS & kNested, CODEPTR = FLAGS & kCodePtr, LUT64 = FLAGS & kLut64;
+    constexpr int COPIES = LUT64 ? 64 : 32; // table copies = dwords per entry
     constexpr bool XLDS = FLAGS & kXLds;
     constexpr int WAVES = (FLAGS & kWaves8) ? 8 : 4;
     constexpr int THREADS = WAVES * 64;
     constexpr int TPE = THREADS / 256; // threads cooperating on one table entry
     constexpr int ABL = FLAGS >> 8;
+    static_assert(kLut64 < 256, "flag bits below the ablation field");
 
-    __shared__ __attribute__((aligned(16))) uint32_t lut[256 * 32];
+    __shared__ __attribute__((aligned(16))) uint32_t lut[256 * COPIES];
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[]; // XLDS: MB * ceil(K/2048) * 4 KiB activation image
     // segments of 2048 k in the activation image: a compile-time constant when the whole K fits one iteration
     const int nseg = SINGLE ? SEGS : (p.K + kSegK - 1) / kSegK;
@@ -229,6 +233,10 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
     const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
     float offset = 0.0f;
     int zsh = 0; // opaque zero, set after the barrier (see opaque_zero())
+    // kLut64: selector of v_perm_b32(S0 = weight dword, S1 = lane offset): result bytes {S1.b0, S0.b[j], 0, 0}
+    uint32_t perm_sel = 0x0C0C0400u;
+    const uint32_t lane_off64 = static_cast<uint32_t>(lane) * 4u;
+    const auto lut_lds = (const __attribute__((address_space(3))) uint32_t*)lut;
 
     // x fragment (4 x 16 B = this lane's 32 activations of segment sg, row m)
     auto x_frag = [&](const Stage& st, int it, int sg, int m, int q) -> u32x4 {
@@ -269,8 +277,16 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
                     const uint32_t w = st.w[sg][r][d];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const uint32_t byte = (w >> (8 * j + zsh)) & 0xFFu;
-                        const uint32_t pr = lut[(byte << 5) + lane_slot];
+                        uint32_t pr;
+                        if constexpr (LUT64) {
+                            // address = byte * 256 + lane * 4, assembled by one byte permute
+                            const uint32_t addr = __builtin_amdgcn_perm(w, lane_off64, perm_sel + (j << 8));
+                            pr = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(
+                                reinterpret_cast<const __attribute__((address_space(3))) unsigned char*>(lut_lds) + addr);
+                        } else {
+                            const uint32_t byte = (w >> (8 * j + zsh)) & 0xFFu;
+                            pr = lut[(byte << 5) + lane_slot];
+                        }
 #pragma unroll
                         for (int m = 0; m < MB; ++m)
                             part[m][j & 1] = Pair2<T>::dot2(pr, xf[m][d][j], part[m][j & 1]);
@@ -315,11 +331,17 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
         }
         const uint32_t pr = Pair2<T>::pack(code_hi, code_lo);
         const u32x4 v = {pr, pr, pr, pr};
-        // entry `entry` = 8 x 16 B; TPE lanes share it
-        u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * 32]) + (tid % TPE) * (8 / TPE);
+        // entry `entry` = COPIES dwords; TPE lanes share it
+        // All chunks of an entry hold the same value, so the ORDER in which a lane writes its chunks is free:
+        // rotating it by the entry's index in the wavefront spreads the 8 lanes that a ds_write_b128 services
+        // together over all 32 bank quads (written in natural order they are 4- to 8-way conflicted: their
+        // addresses are 64 or 128 bytes apart).
+        constexpr int NCH = COPIES / 4 / TPE;
+        u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * COPIES]) + (tid % TPE) * NCH;
+        const int rot = (tid & 63) / TPE;
 #pragma unroll
-        for (int j = 0; j < 8 / TPE; ++j)
-            dst[j] = v;
+        for (int j = 0; j < NCH; ++j)
+            dst[(j + rot) % NCH] = v;
         if constexpr (NESTED) {
             if (tid < 256)
                 code2[tid] = p.absmax_code[tid];
@@ -332,6 +354,7 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SEGS * RPW * 2) : "memory");
     __syncthreads();
     zsh = opaque_zero();
+    perm_sel += static_cast<uint32_t>(zsh); // same fence for the permute form of the decode
 
     // 3) main loop: prefetch iteration it+1, consume iteration it
     if constexpr (SINGLE) {
@@ -445,41 +468,60 @@ template <typename T, int MB, int RPW, int SEGS, int EXTRA> void launch_dot(cons
     // so that it does); debug flag 128 switches it off for A/B measurements. Per-wavefront global loads of
     // the activations are only instantiated for MB = 1: with more rows the prefetch stage spills registers.
     const size_t xbytes = x_image_bytes(MB, p.K, SEGS);
+    const size_t lds_pad = static_cast<size_t>((g_dot_flags >> 8) & 0xFF) * 1024; // profiling: occupancy experiments
     const bool xlds = xbytes <= kXLdsMaxBytes && (MB > 1 || !(g_dot_flags & 128));
+    // 64-copy table (look-up address = one v_perm_b32) as long as two workgroups still share a CU, i.e. table +
+    // nested code table + activation image <= 80 KiB (measured: 84 KiB per workgroup drops to one per CU and
+    // costs 1.4 us at 4096^2); debug flag 32 forces the 32-copy table.
+    // Every workgroup builds its own table, so the larger one only pays while a CU sees few workgroups
+    // (profiles/r1_dot_ab.txt: 4096^2 M = 1 4.48 vs 4.58 us, nested 4.82 vs 5.09, 8192^2 11.6 vs 12.1; but
+    // 11008 x 4096 M = 1 = 1376 workgroups 9.3 vs 8.1). At M = 2 it only won in the two-rows-per-wavefront
+    // geometry of the large matrices (11008 x 4096: 10.9 vs 11.6; 4096^2: 5.19 vs 5.11).
+    const bool few_wgs = static_cast<long>(grid.x) * grid.y <= 1024;
+    const bool lut64 = !(g_dot_flags & 32) && few_wgs && (MB == 1 || (MB == 2 && RPW == 2)) &&
+                       64 * 1024 + (p.absmax8 ? 1024 : 0) + (xlds ? xbytes : 0) <= 80 * 1024;
 #define BNB_DOT_GO(F)                                                                              \
     do {                                                                                           \
         auto kern = gemv4_dot_kernel<T, MB, RPW, SEGS, (F)>;                                       \
-        const size_t dyn = ((F) & kXLds) ? xbytes : 0;                                             \
-        static bool attr_done = false;                                                             \
-        if (dyn + 34 * 1024 > 64 * 1024 && !attr_done) {                                           \
+        const size_t dyn = (((F) & kXLds) ? xbytes : 0) + lds_pad;                                 \
+        const size_t stat = (((F) & kLut64) ? 64 : 32) * 1024 + 2048;                              \
+        static size_t attr_bytes = 0;                                                              \
+        if (dyn + stat > 64 * 1024 && dyn > attr_bytes) {                                          \
             BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                 \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,          \
-                                              static_cast<int>(kXLdsMaxBytes)));                   \
-            attr_done = true;                                                                      \
+                                              static_cast<int>(dyn)));                             \
+            attr_bytes = dyn;                                                                      \
         }                                                                                          \
         hipLaunchKernelGGL(kern, grid, block, dyn, stream, p);                                     \
     } while (0)
-    const int sel = (single ? 1 : 0) | (p.absmax8 ? 2 : 0);
+#define BNB_DOT_SEL(X)                                                                             \
+    switch ((single ? 1 : 0) | (p.absmax8 ? 2 : 0)) {                                              \
+    case 0: BNB_DOT_GO(E | (X)); break;                                                            \
+    case 1: BNB_DOT_GO(E | kSingle | (X)); break;                                                  \
+    case 2: BNB_DOT_GO(E | kNested | (X)); break;                                                  \
+    default: BNB_DOT_GO(E | kSingle | kNested | (X)); break;                                       \
+    }
     if (xlds) {
-        switch (sel) {
-        case 0: BNB_DOT_GO(E | kXLds); break;
-        case 1: BNB_DOT_GO(E | kSingle | kXLds); break;
-        case 2: BNB_DOT_GO(E | kNested | kXLds); break;
-        default: BNB_DOT_GO(E | kSingle | kNested | kXLds); break;
+        if constexpr (MB <= 2) {
+            if (lut64) {
+                BNB_DOT_SEL(kXLds | kLut64)
+                return;
+            }
         }
+        BNB_DOT_SEL(kXLds)
         return;
     }
     if constexpr (MB == 1) {
-        switch (sel) {
-        case 0: BNB_DOT_GO(E); break;
-        case 1: BNB_DOT_GO(E | kSingle); break;
-        case 2: BNB_DOT_GO(E | kNested); break;
-        default: BNB_DOT_GO(E | kSingle | kNested); break;
+        if (lut64) {
+            BNB_DOT_SEL(kLut64)
+        } else {
+            BNB_DOT_SEL(0)
         }
     } else {
         fprintf(stderr, "bitsandbytes_amd: gemv_4bit: internal error, activation image of %zu bytes does not fit\n", xbytes);
         exit(1);
     }
+#undef BNB_DOT_SEL
 #undef BNB_DOT_GO
 }
 
@@ -492,12 +534,20 @@ template <typename T> void launch_generic(const GemvArgs& p, hipStream_t stream)
 }
 
 template <typename T> void dispatch_dot(const GemvArgs& p, hipStream_t stream) {
-    // profiling-only ablations of the M = 1, K <= 4096 configuration
+    // profiling-only ablations of the M = 1, K <= 4096 configuration, in the production geometry
+    // (one row per wavefront, 512 threads, activations in LDS)
     if (g_dot_ablate != 0 && p.M == 1 && !p.absmax8 && p.K <= 2 * kSegK) {
         dim3 grid((p.N + 7) / 8, 1);
 #define BNB_ABL(A)                                                                                 \
     if (g_dot_ablate == A) {                                                                       \
-        hipLaunchKernelGGL((gemv4_dot_kernel<T, 1, 2, 2, kSingle | (A << 8)>), grid, dim3(256), 0, stream, p); \
+        auto kern = gemv4_dot_kernel<T, 1, 1, 2, kSingle | kXLds | kWaves8 | kCodePtr | kLut64 | (A << 8)>;        \
+        static bool attr_done = false;                                                             \
+        if (!attr_done) {                                                                          \
+            BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                 \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 8192));  \
+            attr_done = true;                                                                      \
+        }                                                                                          \
+        hipLaunchKernelGGL(kern, grid, dim3(512), 2 * 4096, stream, p);                            \
         return;                                                                                    \
     }
         BNB_ABL(1) BNB_ABL(2) BNB_ABL(3) BNB_ABL(4) BNB_ABL(5)

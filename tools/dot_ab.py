@@ -56,6 +56,8 @@ ap.add_argument("--k", type=int, default=4096)
 ap.add_argument("--dq", action="store_true")
 ap.add_argument("--quick", action="store_true")
 ap.add_argument("--m34", action="store_true")
+ap.add_argument("--ldspad", action="store_true", help="M = 1 time vs extra (unused) dynamic LDS per workgroup")
+ap.add_argument("--ablate", action="store_true", help="ablations of the M = 1 kernel (results wrong by design), HBM-resident and cache-hot")
 a = ap.parse_args()
 N, K = a.n, a.k
 L = max(8, int(640e6 // (N * K // 2)))
@@ -66,10 +68,31 @@ for _ in range(L):
     layers.append(F.quantize_4bit(W, blocksize=64, quant_type="nf4", compress_statistics=a.dq))
     del W
 print(f"# N={N} K={K} dq={a.dq} layers={L}")
+if a.ldspad:
+    x = torch.randn(1, K, device="cuda", generator=g).bfloat16()
+    print("extra LDS KiB per workgroup (on top of 32 KiB table + 8 KiB activations) -> us per launch")
+    for pad in (0, 8, 16, 24, 32, 36, 40, 44, 48, 64, 80):
+        bnb.lib.bnb_mi355x_set_debug(0, pad << 8)
+        t, _ = measure(layers, x, 1)
+        print(f"  +{pad:3d} KiB  (total {40 + pad:3d} KiB)  {t:6.2f} us")
+    bnb.lib.bnb_mi355x_set_debug(0, 0)
+    sys.exit(0)
+if a.ablate:
+    x = torch.randn(1, K, device="cuda", generator=g).bfloat16()
+    names = {5: "empty (x DMA + table loads only)", 4: "weights only (no x, no absmax, no decode)",
+             1: "stream only (all loads, no decode)", 2: "no table build", 3: "no weight loads", 0: "full kernel"}
+    print(f"{'variant':44s} {'HBM-resident us':>16s} {'cache-hot us':>13s}")
+    for abl in (5, 4, 1, 2, 3, 0):
+        bnb.lib.bnb_mi355x_set_debug(abl, 0)
+        t_cold, _ = measure(layers, x, 1)
+        t_hot, _ = measure(layers[:2] * 16, x, 1)
+        print(f"{names[abl]:44s} {t_cold:16.2f} {t_hot:13.2f}")
+    bnb.lib.bnb_mi355x_set_debug(0, 0)
+    sys.exit(0)
 for M in (() if a.m34 else (1, 2)):
     x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
     for rep in range(2):
-        for flags, name in ((0, "x via LDS-DMA"), (128, "x per wavefront")):
+        for flags, name in ((0, "x via LDS-DMA"), (32, "x LDS, 32-copy LUT"), (128, "x per wavefront")):
             bnb.lib.bnb_mi355x_set_debug(0, flags)
             tg, te = measure(layers, x, 1)
             print(f"M={M} {name:16s} {tg:7.2f} us/launch  {bytes_alg(M, N, K, 64) / tg / 1e3:8.1f} GB/s")
