@@ -218,10 +218,11 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_kernel(const GemmArgs 
         const u32x4 v = {pr, pr, pr, pr};
         // chunk order rotated by the entry's index in the wavefront: conflict-free ds_write_b128 (see gemv4.hip)
         u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * 32]) + (tid % TPE) * (8 / TPE);
-        const int rot = (tid & 63) / TPE;
+        constexpr int NCH = 8 / TPE;
+        const int rot = (NCH >= 8) ? (tid & 63) : (tid & 63) * NCH / 8; // distinct bank quads within 8 lanes
 #pragma unroll
-        for (int j = 0; j < 8 / TPE; ++j)
-            dst[(j + rot) % (8 / TPE)] = v;
+        for (int j = 0; j < NCH; ++j)
+            dst[(j + rot) % NCH] = v;
     }
     float offset = 0.0f;
     if constexpr (NESTED) {
@@ -360,7 +361,9 @@ typedef __attribute__((address_space(3))) void* dma_dst_t;
 
 template <typename T, int MT, bool NESTED, int kWaves>
 __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmArgs p) {
-    constexpr int kLutBytes = 256 * 32 * 4;
+    // 64 table copies, 256 B per entry: the look-up address byte * 256 + lane * 4 is one v_perm_b32 (see
+    // gemv4.hip); this kernel runs one workgroup per CU, so the 64 KiB are free
+    constexpr int kLutBytes = 256 * 64 * 4;
     constexpr int kThreads = kWaves * 64;
     constexpr int TPE = kThreads / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -481,11 +484,12 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmA
         const uint32_t pr = Mma<T>::pack(code_hi, code_lo);
         const u32x4 v = {pr, pr, pr, pr};
         // chunk order rotated by the entry's index in the wavefront: conflict-free ds_write_b128 (see gemv4.hip)
-        u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * 32]) + (tid % TPE) * (8 / TPE);
-        const int rot = (tid & 63) / TPE;
+        u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * 64]) + (tid % TPE) * (16 / TPE);
+        constexpr int NCH = 16 / TPE;
+        const int rot = (NCH >= 8) ? (tid & 63) : (tid & 63) * NCH / 8; // distinct bank quads within 8 lanes
 #pragma unroll
-        for (int j = 0; j < 8 / TPE; ++j)
-            dst[(j + rot) % (8 / TPE)] = v;
+        for (int j = 0; j < NCH; ++j)
+            dst[(j + rot) % NCH] = v;
     }
     float offset = 0.0f;
     if constexpr (NESTED) {
@@ -494,8 +498,9 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmA
         offset = p.absmax_offset[0];
     }
     __syncthreads();
-    const int zsh = opaque_zero();
-    const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
+    const uint32_t perm_sel = 0x0C0C0400u + static_cast<uint32_t>(opaque_zero()); // {lane offset, weight byte q, 0, 0}
+    const uint32_t lane_off = static_cast<uint32_t>(lane) * 4u +
+                              static_cast<uint32_t>(reinterpret_cast<uintptr_t>((dma_dst_t)lut));
 
     for (int c = c_begin; c < c_end; ++c) {
         if (c > c_begin)
@@ -511,7 +516,8 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmA
                 const uint32_t w = w2[j];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    bf[j][q] = lut[(((w >> (8 * q + zsh)) & 0xFFu) << 5) + lane_slot];
+                    bf[j][q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(
+                        __builtin_amdgcn_perm(w, lane_off, perm_sel + (q << 8)));
             }
             float scale;
             if constexpr (NESTED) {
@@ -709,10 +715,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_tile_kernel(const GemmA
         const u32x4 v = {pr, pr, pr, pr};
         // chunk order rotated by the entry's index in the wavefront: conflict-free ds_write_b128 (see gemv4.hip)
         u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * 32]) + (tid % TPE) * (8 / TPE);
-        const int rot = (tid & 63) / TPE;
+        constexpr int NCH = 8 / TPE;
+        const int rot = (NCH >= 8) ? (tid & 63) : (tid & 63) * NCH / 8; // distinct bank quads within 8 lanes
 #pragma unroll
-        for (int j = 0; j < 8 / TPE; ++j)
-            dst[(j + rot) % (8 / TPE)] = v;
+        for (int j = 0; j < NCH; ++j)
+            dst[(j + rot) % NCH] = v;
     }
     float offset = 0.0f;
     if constexpr (NESTED) {
@@ -1570,7 +1577,7 @@ template <typename T, int MT, int NT, int WAVES, int DEPTH> void launch_mfma_cfg
 template <typename T, int MT, int WAVES> void launch_mfma_dma(GemmArgs& p, hipStream_t stream) {
     const int gx = (p.N + 15) / 16;
     const int gz = (p.M + MT * 16 - 1) / (MT * 16);
-    const size_t smem = 256 * 32 * 4 + static_cast<size_t>(WAVES) * 2048 + static_cast<size_t>(WAVES - 1) * MT * 1024 + 1024;
+    const size_t smem = 256 * 64 * 4 + static_cast<size_t>(WAVES) * 2048 + static_cast<size_t>(WAVES - 1) * MT * 1024 + 1024;
     dim3 grid(gx, p.kslices, gz);
     auto kern = p.absmax8 ? gemm4_mfma_dma_kernel<T, MT, true, WAVES> : gemm4_mfma_dma_kernel<T, MT, false, WAVES>;
     static bool attr_set[2] = {false, false};

@@ -338,7 +338,7 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
         // addresses are 64 or 128 bytes apart).
         constexpr int NCH = COPIES / 4 / TPE;
         u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * COPIES]) + (tid % TPE) * NCH;
-        const int rot = (tid & 63) / TPE;
+        const int rot = (NCH >= 8) ? (tid & 63) : (tid & 63) * NCH / 8; // distinct bank quads within 8 lanes
 #pragma unroll
         for (int j = 0; j < NCH; ++j)
             dst[(j + rot) % NCH] = v;
