@@ -359,34 +359,53 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_kernel(const GemmArgs 
 typedef __attribute__((address_space(1))) const void* dma_src_t;
 typedef __attribute__((address_space(3))) void* dma_dst_t;
 
-template <typename T, int MT, bool NESTED, int kWaves>
-__global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmArgs p) {
+// AROWS > 0 (MT = 1, M <= AROWS): the wavefront's slice of A ([AROWS rows][256 k]) also travels by LDS-DMA -
+// AROWS/2 fully coalesced instructions of 2 rows x 512 B - instead of 8 fragment-shaped register loads whose
+// 64-byte pieces cost the L1 two requests per 128-B line: the s_memtime stamps showed a wavefront spending
+// 6.5 k cycles just ISSUING its loads at M = 8 (profiles/r1_timeline_mfma_v3_smemtime.txt). Source-side XOR
+// swizzle and fragment addresses as in the producer/consumer kernel. The image costs AROWS * 512 B per
+// wavefront, so the 8-row variant goes back to the 32-copy table.
+template <typename T, int MT, bool NESTED, int kWaves, int AROWS>
+__global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(
+    // hot arguments as separate scalars: eligible for kernarg preload into SGPRs (see gemv4.hip)
+    const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, void* hot_out, const float* hot_code16, int hot_M,
+    int hot_N, int hot_K, int hot_bs_shift, int hot_kslices, int hot_quant_type, const GemmArgs p) {
     // 64 table copies, 256 B per entry: the look-up address byte * 256 + lane * 4 is one v_perm_b32 (see
     // gemv4.hip); this kernel runs one workgroup per CU, so the 64 KiB are free
-    constexpr int kLutBytes = 256 * 64 * 4;
+    static_assert(AROWS == 0 || (MT == 1 && (AROWS == 4 || AROWS == 8)), "A image: 4 or 8 rows, one M tile");
+    constexpr int COPIES = (AROWS == 8) ? 32 : 64;
+    constexpr int kLutBytes = 256 * COPIES * 4;
+    constexpr int kABytes = AROWS * 512;                    // per wavefront
     constexpr int kThreads = kWaves * 64;
     constexpr int TPE = kThreads / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
     unsigned char* wring = smem + kLutBytes;                                          // [kWaves][2048]
-    float* red = reinterpret_cast<float*>(smem + kLutBytes + kWaves * 2048);           // [kWaves-1][MT][64][4]
+    unsigned char* aimg = smem + kLutBytes + kWaves * 2048;                            // [kWaves][AROWS * 512]
+    float* red = reinterpret_cast<float*>(aimg + kWaves * kABytes);                    // [kWaves-1][MT][64][4]
     float* code2 = red + (kWaves - 1) * MT * 256;                                      // nested: [256]
 
     const int tid = threadIdx.x;
-    const gfloat_ptr tbl = (gfloat_ptr)(p.code16 ? p.code16 : (p.quant_type == kNF4 ? kNF4Code : kFP4Code));
+    // profiling only (bnb_mi355x_set_stamp_buffer): 8 s_memtime stamps per wavefront
+#define BNB_V3_STAMP(i)                                                                            \
+    if (p.dbg && (tid & 63) == 0)                                                                  \
+        p.dbg[((static_cast<long>(blockIdx.x) * gridDim.y + blockIdx.y) * kWaves + (tid >> 6)) * 16 + (i)] = \
+            __builtin_amdgcn_s_memtime();
+    BNB_V3_STAMP(0)
+    const gfloat_ptr tbl = (gfloat_ptr)(hot_code16 ? hot_code16 : (hot_quant_type == kNF4 ? kNF4Code : kFP4Code));
     const int entry = tid / TPE;
     const float code_hi = tbl[entry >> 4];
     const float code_lo = tbl[entry & 15];
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane & 15, lg = lane >> 4;
-    const int N = p.N, K = p.K, M = p.M;
+    const int N = hot_N, K = hot_K, M = hot_M;
     const int m_base = blockIdx.z * (MT * 16);
     const int col0 = blockIdx.x * 16;
 
     // chunk (256 k) range of this wavefront
     const int chunks_total = K >> 8;
-    const int per_wg = (chunks_total + p.kslices - 1) / p.kslices;
+    const int per_wg = (chunks_total + hot_kslices - 1) / hot_kslices;
     const int wg_begin = blockIdx.y * per_wg;
     const int wg_end = (wg_begin + per_wg < chunks_total) ? wg_begin + per_wg : chunks_total;
     const int wg_chunks = (wg_end > wg_begin) ? wg_end - wg_begin : 0;
@@ -401,7 +420,7 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmA
     for (int h = 0; h < 2; ++h) {
         int row = col0 + h * 8 + r8;
         row = (row < N) ? row : N - 1;
-        dsrc[h] = p.B + static_cast<long>(row) * (K >> 1) + ((s8 ^ r8) << 4);
+        dsrc[h] = hot_B + static_cast<long>(row) * (K >> 1) + ((s8 ^ r8) << 4);
     }
     unsigned char* wbuf = wring + wave * 2048;
     // fragment read offsets inside the wavefront's 2 KiB image (block b adds its own chunk index)
@@ -411,7 +430,7 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmA
     int rown = col0 + ln;
     rown = (rown < N) ? rown : N - 1;
     const long rowk = static_cast<long>(rown) * K;
-    const T* __restrict__ A = static_cast<const T*>(p.A);
+    const T* __restrict__ A = static_cast<const T*>(hot_A);
     const T* arow[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -430,14 +449,14 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmA
             __builtin_amdgcn_global_load_lds((dma_src_t)(dsrc[h] + static_cast<long>(c) * 128), (dma_dst_t)(wbuf + h * 1024),
                                              16, 0, 0);
         const long e = rowk + (static_cast<long>(c) << 8);
-        if (p.bs_shift == 6) {
+        if (hot_bs_shift == 6) {
             if constexpr (NESTED) {
                 const uint32_t q4 = *reinterpret_cast<const uint32_t*>(p.absmax8 + (e >> 6));
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
                     st.s[b] = __builtin_bit_cast(float, (q4 >> (8 * b)) & 0xFFu);
             } else {
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.absmax + (e >> 6));
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(hot_absmax + (e >> 6));
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
                     st.s[b] = s4[b];
@@ -445,14 +464,26 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmA
         } else {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const long q = (e + b * 64) >> p.bs_shift;
+                const long q = (e + b * 64) >> hot_bs_shift;
                 if constexpr (NESTED)
                     st.s[b] = __builtin_bit_cast(float, static_cast<uint32_t>(p.absmax8[q]));
                 else
-                    st.s[b] = p.absmax[q];
+                    st.s[b] = hot_absmax[q];
             }
         }
         const int kb = c << 8;
+        if constexpr (AROWS > 0) {
+            const int r2 = lane >> 5, s32 = lane & 31;
+#pragma unroll
+            for (int i = 0; i < AROWS / 2; ++i) {
+                const int row = 2 * i + r2;
+                int m = m_base + row;
+                m = (m < M) ? m : M - 1;
+                const T* src = A + static_cast<long>(m) * K + kb + ((s32 ^ (row & 15)) << 3);
+                __builtin_amdgcn_global_load_lds((dma_src_t)src, (dma_dst_t)(aimg + wave * kABytes + i * 1024), 16, 0, 0);
+            }
+            return;
+        }
         // A rows >= M are never stored and MFMA rows are independent, so those lanes skip the load
         // altogether (exec-masked): the fragment loads then cost M/16 of a full tile in L1/TA time.
 #pragma unroll
@@ -480,12 +511,13 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmA
             st.a[b][mt][0] = st.a[b][mt][1] = u32x4{0, 0, 0, 0}; // rows >= M stay zero (finite) in the skipped lanes
     if (c_begin < c_end)
         issue_chunk(st, c_begin);
+    BNB_V3_STAMP(1)
     {
         const uint32_t pr = Mma<T>::pack(code_hi, code_lo);
         const u32x4 v = {pr, pr, pr, pr};
         // chunk order rotated by the entry's index in the wavefront: conflict-free ds_write_b128 (see gemv4.hip)
-        u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * 64]) + (tid % TPE) * (16 / TPE);
-        constexpr int NCH = 16 / TPE;
+        constexpr int NCH = COPIES / 4 / TPE;
+        u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * COPIES]) + (tid % TPE) * NCH;
         const int rot = (NCH >= 8) ? (tid & 63) : (tid & 63) * NCH / 8; // distinct bank quads within 8 lanes
 #pragma unroll
         for (int j = 0; j < NCH; ++j)
@@ -497,15 +529,23 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmA
             code2[tid] = p.absmax_code[tid];
         offset = p.absmax_offset[0];
     }
+    BNB_V3_STAMP(2)
     __syncthreads();
+    BNB_V3_STAMP(3)
     const uint32_t perm_sel = 0x0C0C0400u + static_cast<uint32_t>(opaque_zero()); // {lane offset, weight byte q, 0, 0}
-    const uint32_t lane_off = static_cast<uint32_t>(lane) * 4u +
-                              static_cast<uint32_t>(reinterpret_cast<uintptr_t>((dma_dst_t)lut));
+    const uint32_t lut_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((dma_dst_t)lut));
+    const uint32_t lane_off = static_cast<uint32_t>(lane) * 4u + lut_base;          // 64-copy table
+    const uint32_t lane_off32 = static_cast<uint32_t>(lane & 31) * 4u + lut_base;   // 32-copy table
+    // A image fragment address: row (clamped to the image) * 512 + ((b*8 + lg*2 + j) ^ row) * 16
+    const int arow_l = (AROWS > 0 && ln >= AROWS) ? AROWS - 1 : ln;
+    const uint32_t a_lane = static_cast<uint32_t>(arow_l * 512 + (((lg * 2) ^ arow_l) << 4));
 
     for (int c = c_begin; c < c_end; ++c) {
         if (c > c_begin)
             issue_chunk(st, c);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA'd image and this chunk's register loads
+        if (c == c_begin)
+            BNB_V3_STAMP(4)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int cidx = (2 * b + (lg >> 1)) ^ rd_sw;
@@ -515,22 +555,38 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmA
             for (int j = 0; j < 2; ++j) {
                 const uint32_t w = w2[j];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    bf[j][q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(
-                        __builtin_amdgcn_perm(w, lane_off, perm_sel + (q << 8)));
+                for (int q = 0; q < 4; ++q) {
+                    if constexpr (COPIES == 64) {
+                        bf[j][q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(
+                            __builtin_amdgcn_perm(w, lane_off, perm_sel + (q << 8)));
+                    } else {
+                        const uint32_t byte = __builtin_amdgcn_ubfe(w, static_cast<uint32_t>(8 * q) + (perm_sel & 1u), 8u);
+                        bf[j][q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(
+                            (byte << 7) + lane_off32);
+                    }
+                }
             }
             float scale;
             if constexpr (NESTED) {
-                const long q = (rowk + (static_cast<long>(c) << 8) + b * 64) >> p.bs_shift;
+                const long q = (rowk + (static_cast<long>(c) << 8) + b * 64) >> hot_bs_shift;
                 const uint32_t q8 = __builtin_bit_cast(uint32_t, st.s[b]);
-                scale = __fadd_rn(__fmul_rn(code2[q8], p.absmax[q >> 8]), offset);
+                scale = __fadd_rn(__fmul_rn(code2[q8], hot_absmax[q >> 8]), offset);
             } else {
                 scale = st.s[b];
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                f32x4 part = Mma<T>::run(st.a[b][mt][0], bf[0], f32x4{0.f, 0.f, 0.f, 0.f});
-                part = Mma<T>::run(st.a[b][mt][1], bf[1], part);
+                u32x4 a0, a1;
+                if constexpr (AROWS > 0) {
+                    const unsigned char* ab = aimg + wave * kABytes;
+                    a0 = *reinterpret_cast<const u32x4*>(ab + (a_lane ^ static_cast<uint32_t>((b * 8 + 0) << 4)));
+                    a1 = *reinterpret_cast<const u32x4*>(ab + (a_lane ^ static_cast<uint32_t>((b * 8 + 1) << 4)));
+                } else {
+                    a0 = st.a[b][mt][0];
+                    a1 = st.a[b][mt][1];
+                }
+                f32x4 part = Mma<T>::run(a0, bf[0], f32x4{0.f, 0.f, 0.f, 0.f});
+                part = Mma<T>::run(a1, bf[1], part);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     acc[mt][r] = fmaf(scale, part[r], acc[mt][r]);
@@ -538,12 +594,14 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmA
         }
     }
 
+    BNB_V3_STAMP(5)
     if (wave > 0) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
             *reinterpret_cast<f32x4*>(red + (((wave - 1) * MT + mt) * 64 + lane) * 4) = acc[mt];
     }
     __syncthreads();
+    BNB_V3_STAMP(6)
     if (wave != 0)
         return;
 #pragma unroll
@@ -555,12 +613,12 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmA
             for (int r = 0; r < 4; ++r)
                 acc[mt][r] += o[r];
         }
-    T* __restrict__ out = static_cast<T*>(p.out);
+    T* __restrict__ out = static_cast<T*>(hot_out);
     const T* __restrict__ bias = static_cast<const T*>(p.bias);
     const int col = col0 + ln;
     if (col >= N)
         return;
-    const float bv = (bias && p.kslices == 1) ? static_cast<float>(bias[col]) : 0.0f;
+    const float bv = (bias && hot_kslices == 1) ? static_cast<float>(bias[col]) : 0.0f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -569,12 +627,14 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(const GemmA
             if (m >= M)
                 continue;
             const long o = static_cast<long>(m) * N + col;
-            if (p.kslices == 1)
+            if (hot_kslices == 1)
                 out[o] = static_cast<T>(acc[mt][r] + bv);
             else
                 p.ws[static_cast<long>(blockIdx.y) * M * N + o] = acc[mt][r];
         }
     }
+    BNB_V3_STAMP(7)
+#undef BNB_V3_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1077,7 +1137,10 @@ template <int kCount> __device__ __forceinline__ void wait_vmcnt() {
 constexpr int kPcProducers = 4;
 
 template <typename T, int MT, bool NESTED, int CW, int NTW, int D>
-__global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel(const GemmArgs p) {
+__global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel(
+    // hot arguments as separate scalars: eligible for kernarg preload into SGPRs (see gemv4.hip)
+    const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, void* hot_out, const float* hot_code16, int hot_M,
+    int hot_N, int hot_K, int hot_bs_shift, int hot_kslices, int hot_quant_type, const GemmArgs p) {
     constexpr int kLutBytes = 256 * 32 * 4;
     constexpr int XB = MT * 16 * 512;                          // bytes of one A stage
     constexpr int SB = NTW * 256 * (NESTED ? 2 : 1);           // scale bytes of one slot
@@ -1097,11 +1160,11 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = p.N, K = p.K, M = p.M;
+    const int N = hot_N, K = hot_K, M = hot_M;
     const int m_base = blockIdx.z * (MT * 16);
 
     const int chunks_total = K >> 8;
-    const int per_wg = (chunks_total + p.kslices - 1) / p.kslices;
+    const int per_wg = (chunks_total + hot_kslices - 1) / hot_kslices;
     const int c_begin = blockIdx.y * per_wg;
     const int c_end = (c_begin + per_wg < chunks_total) ? c_begin + per_wg : chunks_total;
     const int n = (c_end > c_begin) ? c_end - c_begin : 0;
@@ -1115,7 +1178,7 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
     if (wave >= CW) {
         // ---------------- producers: the A tile, instruction i of a stage belongs to producer i % NP
         const int pw = wave - CW;
-        const T* __restrict__ A = static_cast<const T*>(p.A);
+        const T* __restrict__ A = static_cast<const T*>(hot_A);
         const int r2 = lane >> 5, s32 = lane & 31;
         auto issue_a = [&](int c, int stage) {
 #pragma unroll
@@ -1133,7 +1196,7 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
         // issued so that their counted wait leaves the DMAs in flight.
         static_assert(NP * 64 == 256, "one table entry per producer thread");
         const int e = tid - CW * 64;
-        const gfloat_ptr tbl = (gfloat_ptr)(p.code16 ? p.code16 : (p.quant_type == kNF4 ? kNF4Code : kFP4Code));
+        const gfloat_ptr tbl = (gfloat_ptr)(hot_code16 ? hot_code16 : (hot_quant_type == kNF4 ? kNF4Code : kFP4Code));
         const float code_hi = tbl[e >> 4];
         const float code_lo = tbl[e & 15];
         float code2_v = 0.0f;
@@ -1177,7 +1240,7 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
         for (int h = 0; h < 2; ++h) {
             int row = colw + t * 16 + h * 8 + r8;
             row = (row < N) ? row : N - 1;
-            wsrc[t][h] = p.B + static_cast<long>(row) * (K >> 1) + ((s8 ^ r8) << 4);
+            wsrc[t][h] = hot_B + static_cast<long>(row) * (K >> 1) + ((s8 ^ r8) << 4);
         }
     // scale DMA: lane L fetches the scale of (row L >> 2, 64-k block L & 3) -> LDS offset 4 L, i.e. the four
     // scales of a row are 16 contiguous bytes
@@ -1200,13 +1263,13 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
                                                  (dma_dst_t)(dst + (t * 2 + h) * 1024), 16, 0, 0);
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-            const long q = (srow[t] + (static_cast<long>(c) << 8)) >> p.bs_shift;
+            const long q = (srow[t] + (static_cast<long>(c) << 8)) >> hot_bs_shift;
             if constexpr (NESTED) {
                 __builtin_amdgcn_global_load_lds((dma_src_t)(p.absmax8 + q), (dma_dst_t)(dst + NTW * 2048 + t * 256), 1, 0, 0);
-                __builtin_amdgcn_global_load_lds((dma_src_t)(p.absmax + (q >> 8)),
+                __builtin_amdgcn_global_load_lds((dma_src_t)(hot_absmax + (q >> 8)),
                                                  (dma_dst_t)(dst + NTW * 2048 + NTW * 256 + t * 256), 4, 0, 0);
             } else {
-                __builtin_amdgcn_global_load_lds((dma_src_t)(p.absmax + q), (dma_dst_t)(dst + NTW * 2048 + t * 256), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((dma_src_t)(hot_absmax + q), (dma_dst_t)(dst + NTW * 2048 + t * 256), 4, 0, 0);
             }
         }
     };
@@ -1358,14 +1421,14 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
     }
 
     BNB_PC_STAMP(14)
-    T* __restrict__ out = static_cast<T*>(p.out);
+    T* __restrict__ out = static_cast<T*>(hot_out);
     const T* __restrict__ bias = static_cast<const T*>(p.bias);
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
         const int col = colw + t * 16 + ln;
         if (col >= N)
             continue;
-        const float bv = (bias && p.kslices == 1) ? static_cast<float>(bias[col]) : 0.0f;
+        const float bv = (bias && hot_kslices == 1) ? static_cast<float>(bias[col]) : 0.0f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -1374,7 +1437,7 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
                 if (m >= M)
                     continue;
                 const long o = static_cast<long>(m) * N + col;
-                if (p.kslices == 1)
+                if (hot_kslices == 1)
                     out[o] = static_cast<T>(acc[mt][t][r] + bv);
                 else
                     p.ws[static_cast<long>(blockIdx.y) * M * N + o] = acc[mt][t][r];
@@ -1574,19 +1637,32 @@ template <typename T, int MT, int NT, int WAVES, int DEPTH> void launch_mfma_cfg
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p);
 }
 
-template <typename T, int MT, int WAVES> void launch_mfma_dma(GemmArgs& p, hipStream_t stream) {
+template <typename T, int MT, int WAVES, int AROWS> void launch_mfma_dma_one(GemmArgs& p, hipStream_t stream) {
     const int gx = (p.N + 15) / 16;
     const int gz = (p.M + MT * 16 - 1) / (MT * 16);
-    const size_t smem = 256 * 64 * 4 + static_cast<size_t>(WAVES) * 2048 + static_cast<size_t>(WAVES - 1) * MT * 1024 + 1024;
+    constexpr size_t kLut = 256 * ((AROWS == 8) ? 32 : 64) * 4;
+    const size_t smem = kLut + static_cast<size_t>(WAVES) * 2048 + static_cast<size_t>(WAVES) * AROWS * 512 +
+                        static_cast<size_t>(WAVES - 1) * MT * 1024 + 1024;
     dim3 grid(gx, p.kslices, gz);
-    auto kern = p.absmax8 ? gemm4_mfma_dma_kernel<T, MT, true, WAVES> : gemm4_mfma_dma_kernel<T, MT, false, WAVES>;
+    auto kern = p.absmax8 ? gemm4_mfma_dma_kernel<T, MT, true, WAVES, AROWS> : gemm4_mfma_dma_kernel<T, MT, false, WAVES, AROWS>;
     static bool attr_set[2] = {false, false};
     if (smem > 64 * 1024 && !attr_set[p.absmax8 ? 1 : 0]) {
         BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
         attr_set[p.absmax8 ? 1 : 0] = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p.A, p.B, p.absmax, p.out, p.code16, p.M, p.N, p.K, p.bs_shift, p.kslices, p.quant_type, p);
+}
+
+template <typename T, int MT, int WAVES> void launch_mfma_dma(GemmArgs& p, hipStream_t stream) {
+    if constexpr (MT == 1) {
+        // the whole batch fits a 4- or 8-row A image (p.M rows at grid.z = 1)
+        if (p.M <= 4 && !(g_mfma_knob0 & 8))
+            return launch_mfma_dma_one<T, MT, WAVES, 4>(p, stream);
+        if (p.M <= 8 && !(g_mfma_knob0 & 8))
+            return launch_mfma_dma_one<T, MT, WAVES, 8>(p, stream);
+    }
+    launch_mfma_dma_one<T, MT, WAVES, 0>(p, stream);
 }
 
 template <typename T, int MT, int WAVES, int NTW> void launch_mfma_tile(GemmArgs& p, hipStream_t stream) {
@@ -1642,7 +1718,7 @@ template <typename T, int MT, bool NESTED, int CW, int NTW, int D> void launch_m
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3((CW + kPcProducers) * 64), smem, stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3((CW + kPcProducers) * 64), smem, stream, p.A, p.B, p.absmax, p.out, p.code16, p.M, p.N, p.K, p.bs_shift, p.kslices, p.quant_type, p);
 }
 
 // deepest ring (<= 4 chunks) that fits

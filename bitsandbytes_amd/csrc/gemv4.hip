@@ -105,7 +105,12 @@ enum DotFlags : int {
 // T in {bf16, f16}; MB = activation rows per pass; RPW = weight rows per wavefront;
 // SEGS = 2048-k sub-segments per loop iteration.
 template <typename T, int MB, int RPW, int SEGS, int FLAGS>
-__global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kernel(const GemvArgs p) {
+__global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kernel(
+    // The hot arguments are separate scalars so that the command processor can PRELOAD them into SGPRs
+    // (-mllvm -amdgpu-kernarg-preload-count=16, gfx950 kernarg preload): a wavefront otherwise starts with a
+    // dependent s_load from a kernarg buffer that is cold in every cache. The rest stays in the struct.
+    const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, void* hot_out, const float* hot_code16, int hot_N,
+    int hot_K, int hot_M, int hot_bs_shift, int hot_quant_type, const GemvArgs p) {
     constexpr bool SINGLE = FLAGS & kSingle, NESTED = FLAGS & kNested, CODEPTR = FLAGS & kCodePtr, LUT64 = FLAGS & kLut64;
     constexpr int COPIES = LUT64 ? 64 : 32; // table copies = dwords per entry
     constexpr bool XLDS = FLAGS & kXLds;
@@ -118,7 +123,7 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
     __shared__ __attribute__((aligned(16))) uint32_t lut[256 * COPIES];
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[]; // XLDS: MB * ceil(K/2048) * 4 KiB activation image
     // segments of 2048 k in the activation image: a compile-time constant when the whole K fits one iteration
-    const int nseg = SINGLE ? SEGS : (p.K + kSegK - 1) / kSegK;
+    const int nseg = SINGLE ? SEGS : (hot_K + kSegK - 1) / kSegK;
     __shared__ float code2[NESTED ? 256 : 1];
 
     const int tid = threadIdx.x;
@@ -138,8 +143,8 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
             const int m = (MB == 1) ? 0 : piece / (nseg * 4);
             const int sr = (piece - m * nseg * 4) * 64 + ln0; // slot within the row
             const int k = (sr ^ ((sr >> 4) & 3)) * 8;
-            const int mr = (blockIdx.y * MB + m < p.M) ? blockIdx.y * MB + m : p.M - 1;
-            const T* src = static_cast<const T*>(p.A) + static_cast<long>(mr) * p.K + ((k < p.K) ? k : 0);
+            const int mr = (blockIdx.y * MB + m < hot_M) ? blockIdx.y * MB + m : hot_M - 1;
+            const T* src = static_cast<const T*>(hot_A) + static_cast<long>(mr) * hot_K + ((k < hot_K) ? k : 0);
             // Spelled in asm on purpose: with the builtin the compiler sees LDS-DMA and ordinary loads
             // pending on the same counter, treats vmcnt as out-of-order and turns every later wait for a
             // loaded register into vmcnt(0) - draining the weight stream before the table build. Being
@@ -158,24 +163,24 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
     float code_hi = 0.f, code_lo = 0.f;
     const int entry = tid / TPE; // table entry this lane (co-)writes
     if constexpr (CODEPTR) {
-        const gfloat_ptr tbl = (gfloat_ptr)(p.code16 ? p.code16 : (p.quant_type == kNF4 ? kNF4Code : kFP4Code));
+        const gfloat_ptr tbl = (gfloat_ptr)(hot_code16 ? hot_code16 : (hot_quant_type == kNF4 ? kNF4Code : kFP4Code));
         code_hi = tbl[entry >> 4];
         code_lo = tbl[entry & 15];
     }
 
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int N = p.N, K = p.K;
+    const int N = hot_N, K = hot_K;
     const int row0 = (blockIdx.x * WAVES + wave) * RPW;
     const int m0 = blockIdx.y * MB;
 
-    const T* __restrict__ A = static_cast<const T*>(p.A);
-    const uint8_t* __restrict__ B = p.B;
-    const float* __restrict__ absmax = p.absmax;
+    const T* __restrict__ A = static_cast<const T*>(hot_A);
+    const uint8_t* __restrict__ B = hot_B;
+    const float* __restrict__ absmax = hot_absmax;
 
     if constexpr (ABL == 5) {
         if (lane == 0 && row0 < N)
-            static_cast<T*>(p.out)[row0] = static_cast<T>(code_hi);
+            static_cast<T*>(hot_out)[row0] = static_cast<T>(code_hi);
         return;
     }
 
@@ -200,7 +205,7 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
                     st.w[sg][r] = u32x4{static_cast<uint32_t>(lane), 0x12345678u, static_cast<uint32_t>(row), 0x9abcdef0u};
                 else
                     st.w[sg][r] = *reinterpret_cast<const u32x4*>(B + (e >> 1));
-                const long blk = e >> p.bs_shift;
+                const long blk = e >> hot_bs_shift;
                 if constexpr (ABL == 4) {
                     st.s[sg][r] = 1.0f;
                 } else if constexpr (NESTED) {
@@ -213,7 +218,7 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
             if constexpr (!XLDS && ABL != 4) {
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
-                    const int mr = (m0 + m < p.M) ? m0 + m : p.M - 1;
+                    const int mr = (m0 + m < hot_M) ? m0 + m : hot_M - 1;
                     const T* ap = A + static_cast<long>(mr) * K + kk;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
@@ -297,7 +302,7 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
                 if constexpr (NESTED) {
                     const int kk = (k0 < K) ? k0 : 0;
                     const int row = (row0 + r < N) ? row0 + r : N - 1;
-                    const long blk = (static_cast<long>(row) * K + kk) >> p.bs_shift;
+                    const long blk = (static_cast<long>(row) * K + kk) >> hot_bs_shift;
                     const uint32_t q8 = __builtin_bit_cast(uint32_t, st.s[sg][r]);
                     scale = __fadd_rn(__fmul_rn(code2[q8], absmax[blk >> 8]), offset);
                 } else {
@@ -371,7 +376,7 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
     }
 
     // 4) wavefront reduction + epilogue (bias add in fp32, one rounding to T)
-    T* __restrict__ out = static_cast<T*>(p.out);
+    T* __restrict__ out = static_cast<T*>(hot_out);
     const T* __restrict__ bias = static_cast<const T*>(p.bias);
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
@@ -379,7 +384,7 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
         for (int r = 0; r < RPW; ++r) {
             const float v = wave_sum(acc[m][r]);
             const int row = row0 + r;
-            if (lane == 0 && row < N && m0 + m < p.M) {
+            if (lane == 0 && row < N && m0 + m < hot_M) {
                 const float b = bias ? static_cast<float>(bias[row]) : 0.0f;
                 out[static_cast<long>(m0 + m) * N + row] = static_cast<T>(v + b);
             }
@@ -492,7 +497,7 @@ template <typename T, int MB, int RPW, int SEGS, int EXTRA> void launch_dot(cons
                                               static_cast<int>(dyn)));                             \
             attr_bytes = dyn;                                                                      \
         }                                                                                          \
-        hipLaunchKernelGGL(kern, grid, block, dyn, stream, p);                                     \
+        hipLaunchKernelGGL(kern, grid, block, dyn, stream, p.A, p.B, p.absmax, p.out, p.code16, p.N, p.K, p.M, p.bs_shift, p.quant_type, p);                                    \
     } while (0)
 #define BNB_DOT_SEL(X)                                                                             \
     switch ((single ? 1 : 0) | (p.absmax8 ? 2 : 0)) {                                              \
@@ -538,16 +543,16 @@ template <typename T> void dispatch_dot(const GemvArgs& p, hipStream_t stream) {
     // (one row per wavefront, 512 threads, activations in LDS)
     if (g_dot_ablate != 0 && p.M == 1 && !p.absmax8 && p.K <= 2 * kSegK) {
         dim3 grid((p.N + 7) / 8, 1);
-#define BNB_ABL(A)                                                                                 \
-    if (g_dot_ablate == A) {                                                                       \
-        auto kern = gemv4_dot_kernel<T, 1, 1, 2, kSingle | kXLds | kWaves8 | kCodePtr | kLut64 | (A << 8)>;        \
+#define BNB_ABL(ABLV)                                                                                 \
+    if (g_dot_ablate == ABLV) {                                                                       \
+        auto kern = gemv4_dot_kernel<T, 1, 1, 2, kSingle | kXLds | kWaves8 | kCodePtr | kLut64 | (ABLV << 8)>;        \
         static bool attr_done = false;                                                             \
         if (!attr_done) {                                                                          \
             BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                 \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8192));  \
             attr_done = true;                                                                      \
         }                                                                                          \
-        hipLaunchKernelGGL(kern, grid, dim3(512), 2 * 4096, stream, p);                            \
+        hipLaunchKernelGGL(kern, grid, dim3(512), 2 * 4096, stream, p.A, p.B, p.absmax, p.out, p.code16, p.N, p.K, p.M, p.bs_shift, p.quant_type, p);                            \
         return;                                                                                    \
     }
         BNB_ABL(1) BNB_ABL(2) BNB_ABL(3) BNB_ABL(4) BNB_ABL(5)
