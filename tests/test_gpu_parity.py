@@ -229,6 +229,52 @@ def test_blockwise_8bit_dense_vs_oracle():
     assert torch.equal(q.cpu(), q_o) and torch.equal(am.cpu(), am_o)
 
 
+@pytest.mark.parametrize("blocksize", [64, 128, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16], ids=["fp32", "fp16", "bf16"])
+def test_blockwise_8bit_general_vs_oracle(blocksize, dtype):
+    """8-bit blockwise as an op in its own right: every blocksize and input dtype, ragged sizes,
+    all-zero blocks, unaligned views; codes and absmax bit-exact, dequantize bit-exact."""
+    F = _F()
+    code = F.create_dynamic_map()
+    for n in (blocksize * 37 + 5, 3, 256 * 1024 + 777):
+        A = (torch.randn(n) * 0.1).to(dtype)
+        A[::7] = 0
+        if n > 3 * blocksize:
+            A[blocksize : 2 * blocksize] = 0  # an all-zero block -> codes 0, absmax 0
+        q_o, am_o = O.quantize_blockwise(A, code, blocksize)
+        q, am = torch.ops.bitsandbytes.quantize_blockwise.default(A.to(DEV), code.to(DEV), blocksize)
+        assert torch.equal(q.cpu(), q_o), f"n={n}"
+        assert torch.equal(am.cpu(), am_o), f"n={n}"
+        for out_dtype in (torch.float32, dtype):
+            d = torch.ops.bitsandbytes.dequantize_blockwise.default(q, am, code.to(DEV), blocksize, out_dtype)
+            assert same_values_ftz(d.cpu(), O.dequantize_blockwise(q_o, am_o, code, blocksize, out_dtype))
+    # unaligned view (offset by one element): scalar path
+    base = (torch.randn(blocksize * 9 + 1) * 0.3).to(dtype).to(DEV)
+    view = base[1:]
+    q_o, am_o = O.quantize_blockwise(view.cpu().contiguous(), code, blocksize)
+    q, am = torch.ops.bitsandbytes.quantize_blockwise.default(view, code.to(DEV), blocksize)
+    assert torch.equal(q.cpu(), q_o) and torch.equal(am.cpu(), am_o)
+
+
+def test_blockwise_8bit_every_bin():
+    """All 65536 discretisation bins (and their neighbourhood) with absmax pinned to 1: the threshold /
+    cell-table encoder must reproduce the reference's 64K-entry table exactly."""
+    F = _F()
+    code = F.create_dynamic_map()
+    u = torch.arange(65536, dtype=torch.float64)
+    centres = (-1.0 + 2.0 * u / 65535.0)
+    vals = torch.cat([centres, centres + 1.0 / 65535.0 * 0.499, centres - 1.0 / 65535.0 * 0.499,
+                      centres + 1.0 / 65535.0 * 0.501]).clamp(-1, 1).float()
+    pad = (-vals.numel()) % 255
+    vals = torch.cat([vals, torch.zeros(pad)])
+    A = torch.cat([torch.ones(vals.numel() // 255, 1), vals.view(-1, 255)], dim=1).reshape(-1).contiguous()
+    q_o, am_o = O.quantize_blockwise(A, code, 256)
+    q, am = torch.ops.bitsandbytes.quantize_blockwise.default(A.to(DEV), code.to(DEV), 256)
+    bad = (q.cpu() != q_o).nonzero()
+    assert bad.numel() == 0, f"{bad.numel()} codes differ, first at {bad[0].item()}: x={A[bad[0]].item()!r}"
+    assert torch.equal(am.cpu(), am_o)
+
+
 @pytest.mark.parametrize("quant_type,blocksize", [("nf4", 64), ("fp4", 128)])
 def test_double_quant_state_vs_oracle(quant_type, blocksize):
     F = _F()

@@ -84,6 +84,28 @@ def main():
             print(f"{name:10s} {DT[dt][1]:5s} {qt:3s} {bs:5d} {t:8.2f} {per / t / 1e3:8.1f} {per / t / 1e3 / 8000:8.3f}")
         del src, packed, absmax, outs
         torch.cuda.empty_cache()
+    # 8-bit blockwise pair (the double-quant helper): n elements of fp32 <-> uint8 + absmax per 256
+    import bitsandbytes_amd.functional as F
+    code = F.create_dynamic_map().cuda()
+    n8 = n
+    per8 = n8 * 4 + n8 + 4 * (n8 // 256)
+    R = max(4, int(600e6 // per8) + 1)
+    src = [torch.randn(n8, device="cuda") for _ in range(R)]
+    q8 = [torch.empty(n8, device="cuda", dtype=torch.uint8) for _ in range(R)]
+    am8 = [torch.empty(n8 // 256, device="cuda") for _ in range(R)]
+    out8 = [torch.empty(n8, device="cuda") for _ in range(R)]
+
+    def launch_q8(s):
+        for i in range(R):
+            lib.bnb_mi355x_quantize_8bit(ptr(code), ptr(src[i]), 0, ptr(am8[i]), ptr(q8[i]), 256, n8, ct.c_void_p(s.cuda_stream))
+
+    def launch_d8(s):
+        for i in range(R):
+            lib.cdequantize_blockwise_fp32(ptr(code), ptr(q8[i]), ptr(am8[i]), ptr(out8[i]), 256, n8, ct.c_void_p(s.cuda_stream))
+
+    for name, fn in (("quantize8", launch_q8), ("dequant8", launch_d8)):
+        t = time_graph(fn) / R
+        print(f"{name:10s} {'fp32':5s} {'dyn':3s} {256:5d} {t:8.2f} {per8 / t / 1e3:8.1f} {per8 / t / 1e3 / 8000:8.3f}")
 
 
 if __name__ == "__main__":
