@@ -14,9 +14,10 @@
 // The 64 K-entry table is never materialised and no element pays the division: val(u) is monotone in u,
 // so every midpoint i has a threshold bin T_i = min{u : val(u) > mid_i} (found once per workgroup by a
 // 16-step search that evaluates val() with exactly the expression above) and q = #{i : T_i <= u} - an
-// integer count. A 1024-cell table over u (64 bins per cell) gives the count below the cell and the
-// number of thresholds inside it, so an element costs two LDS reads and, almost always, one compare
-// (the dynamic map is dense only around zero). Same function of u, bit for bit.
+// integer count. A 1024-cell table over u (64 bins per cell) gives the count below the cell and, when the cell
+// holds exactly one threshold, its offset inside the cell: an element then costs ONE LDS read and one compare;
+// the few cells with several thresholds (the dynamic map is dense only around zero) count them in a short
+// loop. Same function of u, bit for bit.
 //
 // dequantize: out[i] = T(code[A[i]] * absmax[i / blocksize])   (reference csrc/cpu_ops.cpp:436-486).
 //
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void quantize8_kernel(const float* __restrict_
                                                         int vec_ok) {
     __shared__ float mid[256];
     __shared__ uint32_t thr[256];   // T_i, ascending; thr[255] = 65536
-    __shared__ uint16_t cell[1024]; // (#thresholds below the cell) | (#thresholds inside the cell) << 8
+    __shared__ uint32_t cell[1024]; // see the table build below
     const int tid = threadIdx.x;
     mid[tid] = (tid < 255) ? 0.5f * (code[tid] + code[tid + 1]) : __builtin_inff();
     __syncthreads();
@@ -91,16 +92,24 @@ __global__ __launch_bounds__(256) void quantize8_kernel(const float* __restrict_
         thr[tid] = hi;
     }
     __syncthreads();
-    for (int c = tid; c < 1024; c += 256) {
-        // thresholds <= 64c - 1 and <= 64c + 63, by binary search over the ascending thr[0..254]
+    __shared__ uint8_t below_s[1025];
+    for (int c = tid; c < 1025; c += 256) {
+        // thresholds below bin 64c, by binary search over the ascending thr[0..254]
         const unsigned first = static_cast<unsigned>(c) * 64u;
-        int below = 0, upto = 0;
+        int below = 0;
 #pragma unroll
-        for (int step = 128; step >= 1; step >>= 1) {
+        for (int step = 128; step >= 1; step >>= 1)
             below += (below + step - 1 < 255 && thr[below + step - 1] < first) ? step : 0;
-            upto += (upto + step - 1 < 255 && thr[upto + step - 1] < first + 64u) ? step : 0;
-        }
-        cell[c] = static_cast<uint16_t>(below | ((upto - below) << 8));
+        below_s[c] = static_cast<uint8_t>(below);
+    }
+    __syncthreads();
+    for (int c = tid; c < 1024; c += 256) {
+        // bits 0-7: thresholds below the cell; bits 8-15: thresholds inside the cell; bits 16-21: offset of the
+        // first one inside the cell (what the common single-threshold case compares against)
+        const int below = below_s[c];
+        const int inside = static_cast<int>(below_s[c + 1]) - below;
+        const unsigned off = (inside > 0) ? (thr[below] - static_cast<unsigned>(c) * 64u) : 0u;
+        cell[c] = static_cast<uint32_t>(below) | (static_cast<uint32_t>(inside) << 8) | (off << 16);
     }
     __syncthreads();
 
@@ -134,9 +143,16 @@ __global__ __launch_bounds__(256) void quantize8_kernel(const float* __restrict_
                 const unsigned u = bin_of(x[sp][j], inv);
                 const unsigned ce = cell[u >> 6];
                 unsigned q = ce & 0xFFu;
-                const unsigned cnt = ce >> 8;
-                for (unsigned t = 0; t < cnt; ++t)
-                    q += (thr[(ce & 0xFFu) + t] <= u) ? 1u : 0u;
+                const unsigned cnt = (ce >> 8) & 0xFFu;
+                if (cnt > 1u) { // several thresholds in this cell (the code is dense only around zero): binary search
+                    unsigned lo = 0;
+#pragma unroll
+                    for (unsigned step = 128; step >= 1; step >>= 1)
+                        lo += (lo + step - 1 < cnt && thr[q + lo + step - 1] <= u) ? step : 0u;
+                    q += lo;
+                } else {
+                    q += (cnt == 1u && (u & 63u) >= (ce >> 16)) ? 1u : 0u;
+                }
                 q = (m == 0.0f) ? 0u : q;
                 q4 |= q << (8 * j);
             }
@@ -199,7 +215,7 @@ void launch_quantize8(const float* code, const T* A, float* absmax, uint8_t* out
     const long units = (n + unit_elems - 1) / unit_elems;
     long grid = (units + 3) / 4;
     if (grid > 2048)
-        grid = 2048;
+        grid = 2048; // 8 workgroups per CU: fewer (1024) measured slower, the loads need the wavefronts
 #define BNB_Q8_CASE(BS)                                                                            \
     case BS:                                                                                       \
         hipLaunchKernelGGL((quantize8_kernel<T, BS>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, code, A, \
