@@ -482,6 +482,15 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(
                 const T* src = A + static_cast<long>(m) * K + kb + ((s32 ^ (row & 15)) << 3);
                 __builtin_amdgcn_global_load_lds((dma_src_t)src, (dma_dst_t)(aimg + wave * kABytes + i * 1024), 16, 0, 0);
             }
+            // 9 <= M <= 16 with the 8-row image: rows 8.. still come as fragment-shaped register loads, but only
+            // for the lanes that own them - half the L1 requests of the all-register path
+            if (AROWS == 8 && ln >= 8 && m_base + ln < M) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    st.a[b][0][0] = *reinterpret_cast<const u32x4*>(arow[0] + kb + b * 64);
+                    st.a[b][0][1] = *reinterpret_cast<const u32x4*>(arow[0] + kb + b * 64 + 8);
+                }
+            }
             return;
         }
         // A rows >= M are never stored and MFMA rows are independent, so those lanes skip the load
@@ -581,6 +590,10 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(
                     const unsigned char* ab = aimg + wave * kABytes;
                     a0 = *reinterpret_cast<const u32x4*>(ab + (a_lane ^ static_cast<uint32_t>((b * 8 + 0) << 4)));
                     a1 = *reinterpret_cast<const u32x4*>(ab + (a_lane ^ static_cast<uint32_t>((b * 8 + 1) << 4)));
+                    if (AROWS == 8 && ln >= 8) { // rows beyond the image (only meaningful when M > 8; else never stored)
+                        a0 = st.a[b][mt][0];
+                        a1 = st.a[b][mt][1];
+                    }
                 } else {
                     a0 = st.a[b][mt][0];
                     a1 = st.a[b][mt][1];
@@ -1659,8 +1672,8 @@ template <typename T, int MT, int WAVES> void launch_mfma_dma(GemmArgs& p, hipSt
         // the whole batch fits a 4- or 8-row A image (p.M rows at grid.z = 1)
         if (p.M <= 4 && !(g_mfma_knob0 & 8))
             return launch_mfma_dma_one<T, MT, WAVES, 4>(p, stream);
-        if (p.M <= 8 && !(g_mfma_knob0 & 8))
-            return launch_mfma_dma_one<T, MT, WAVES, 8>(p, stream);
+        if (p.M <= ((g_mfma_knob0 & 16) ? 8 : 16) && !(g_mfma_knob0 & 8))
+            return launch_mfma_dma_one<T, MT, WAVES, 8>(p, stream); // rows 8..15 by register loads (hybrid)
     }
     launch_mfma_dma_one<T, MT, WAVES, 0>(p, stream);
 }
