@@ -1391,6 +1391,10 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
             };
             fetch_lut(0, 0);
             fetch_a(0);
+            // Two-deep software pipeline: block b's MFMAs are issued, and only the partial tiles of block b-1
+            // - finished long ago - are scaled and accumulated, so the wavefront never sits waiting for the
+            // matrix pipe to drain before it can issue the next block's reads.
+            f32x4 part[2][MT][NTW];
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int st = b & 1;
@@ -1399,30 +1403,40 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
                     fetch_lut(b + 1, st ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
                 // (2) all MFMAs of block b
-                f32x4 part[MT][NTW];
 #pragma unroll
                 for (int t = 0; t < NTW; ++t)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        part[mt][t] = Mma<T>::run(af[mt][0], bf[st][t][0], f32x4{0.f, 0.f, 0.f, 0.f});
-                        part[mt][t] = Mma<T>::run(af[mt][1], bf[st][t][1], part[mt][t]);
+                        part[st][mt][t] = Mma<T>::run(af[mt][0], bf[st][t][0], f32x4{0.f, 0.f, 0.f, 0.f});
+                        part[st][mt][t] = Mma<T>::run(af[mt][1], bf[st][t][1], part[st][mt][t]);
                     }
                 __builtin_amdgcn_sched_barrier(0);
-                // (3) the A fragments of block b+1 are read while the matrix pipe drains block b
+                // (3) the A fragments of block b+1 are read while the matrix pipe works on block b
                 if (b + 1 < 4)
                     fetch_a(b + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                // (4) fp32 scale of the 64-k partial tiles
+                // (4) fp32 scale of the 64-k partial tiles of block b-1
+                if (b > 0) {
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) {
-                    const float scale = sc4[t][b];
+                    for (int t = 0; t < NTW; ++t) {
+                        const float scale = sc4[t][b - 1];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
+                        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            acc[mt][t][r] = fmaf(scale, part[mt][t][r], acc[mt][t][r]);
+                            for (int r = 0; r < 4; ++r)
+                                acc[mt][t][r] = fmaf(scale, part[st ^ 1][mt][t][r], acc[mt][t][r]);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const float scale = sc4[t][3];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[mt][t][r] = fmaf(scale, part[1][mt][t][r], acc[mt][t][r]);
             }
             if (k < 4)
                 BNB_PC_STAMP(4 + 3 * k)

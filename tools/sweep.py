@@ -118,14 +118,6 @@ def main():
     bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
     if a.dot_only:
         return
-    for abl, name in ((11, "stream+A"), (12, "stream only"), (0, "full")):
-        x = torch.randn(8, K, device="cuda", generator=g).bfloat16()
-        for cfgks in (501, 601):
-            bnb.lib.bnb_mi355x_set_debug(abl, 0)
-            bnb.lib.bnb_mi355x_set_tuning(0, 0, 1, cfgks)
-            tg, te = measure(layers, x, 2)
-            print(f"{'mfma-abl':8s} {8:3d} {f'{name} cfg{cfgks}':>20s} {tg:9.2f} {te:9.2f} {bytes_alg(8, N, K, bs) / tg / 1e3:11.1f}")
-    bnb.lib.bnb_mi355x_set_debug(0, 0)
     Ms = [1, 8, 16, 64] if a.quick else [1, 4, 8, 16, 32, 64]
     if a.ms:
         Ms = [int(v) for v in a.ms.split(",")]
