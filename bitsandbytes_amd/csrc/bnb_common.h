@@ -33,6 +33,28 @@ enum QuantType : int { kGeneral8bit = 0, kFP4 = 1, kNF4 = 2 };
 #define BNB_CHECK_LAUNCH() BNB_HIP_CHECK(hipPeekAtLastError())
 
 // ---------------------------------------------------------------------------------------------
+// Dynamic LDS above 64 KiB needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel. The attribute
+// belongs to (kernel, device), so it is tracked per device: a process that drives several GPUs must set it
+// on each of them. Raised monotonically, never lowered. Host-side, thread-safe.
+// ---------------------------------------------------------------------------------------------
+struct LdsLimit {
+    static constexpr int kMaxDevices = 64;
+    size_t bytes[kMaxDevices] = {};
+};
+inline void ensure_dynamic_lds(LdsLimit& state, const void* kernel, size_t dynamic_bytes, size_t static_bytes = 0) {
+    if (dynamic_bytes + static_bytes <= 64 * 1024)
+        return;
+    int dev = 0;
+    BNB_HIP_CHECK(hipGetDevice(&dev));
+    dev = (dev >= 0 && dev < LdsLimit::kMaxDevices) ? dev : 0;
+    // a racing duplicate call is harmless (same value); the plain array keeps the fast path lock-free
+    if (dynamic_bytes > state.bytes[dev]) {
+        BNB_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dynamic_bytes)));
+        state.bytes[dev] = dynamic_bytes;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Element types. fp16/bf16 travel as their native clang types so that conversions lower to the
 // gfx950 hardware converts (v_cvt_f16_f32 / v_cvt_pk_bf16_f32, both round-to-nearest-even).
 // ---------------------------------------------------------------------------------------------

@@ -1655,12 +1655,8 @@ template <typename T, int MT, int NT, int WAVES, int DEPTH> void launch_mfma_cfg
     const size_t smem = 256 * 32 * 4 + static_cast<size_t>(WAVES - 1) * MT * NT * 256 * 4 + 1024;
     dim3 grid(gx, p.kslices, gz);
     auto kern = p.absmax8 ? gemm4_mfma_kernel<T, MT, NT, true, WAVES, DEPTH> : gemm4_mfma_kernel<T, MT, NT, false, WAVES, DEPTH>;
-    static bool attr_set[2] = {false, false};
-    if (smem > 64 * 1024 && !attr_set[p.absmax8 ? 1 : 0]) {
-        BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
-        attr_set[p.absmax8 ? 1 : 0] = true;
-    }
+    static LdsLimit lds_limit[2];
+    ensure_dynamic_lds(lds_limit[p.absmax8 ? 1 : 0], reinterpret_cast<const void*>(kern), smem);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p);
 }
 
@@ -1672,12 +1668,8 @@ template <typename T, int MT, int WAVES, int AROWS> void launch_mfma_dma_one(Gem
                         static_cast<size_t>(WAVES - 1) * MT * 1024 + 1024;
     dim3 grid(gx, p.kslices, gz);
     auto kern = p.absmax8 ? gemm4_mfma_dma_kernel<T, MT, true, WAVES, AROWS> : gemm4_mfma_dma_kernel<T, MT, false, WAVES, AROWS>;
-    static bool attr_set[2] = {false, false};
-    if (smem > 64 * 1024 && !attr_set[p.absmax8 ? 1 : 0]) {
-        BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
-        attr_set[p.absmax8 ? 1 : 0] = true;
-    }
+    static LdsLimit lds_limit[2];
+    ensure_dynamic_lds(lds_limit[p.absmax8 ? 1 : 0], reinterpret_cast<const void*>(kern), smem);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p.A, p.B, p.absmax, p.out, p.code16, p.M, p.N, p.K, p.bs_shift, p.kslices, p.quant_type, p);
 }
 
@@ -1699,12 +1691,8 @@ template <typename T, int MT, int WAVES, int NTW> void launch_mfma_tile(GemmArgs
     const size_t smem = 256 * 32 * 4 + 2 * static_cast<size_t>(MT) * 16 * 512 + static_cast<size_t>(WAVES) * 2 * NTW * 2048 + 1024;
     dim3 grid(gx, p.kslices, gz);
     auto kern = p.absmax8 ? gemm4_mfma_tile_kernel<T, MT, true, WAVES, NTW> : gemm4_mfma_tile_kernel<T, MT, false, WAVES, NTW>;
-    static bool attr_set[2] = {false, false};
-    if (smem > 64 * 1024 && !attr_set[p.absmax8 ? 1 : 0]) {
-        BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
-        attr_set[p.absmax8 ? 1 : 0] = true;
-    }
+    static LdsLimit lds_limit[2];
+    ensure_dynamic_lds(lds_limit[p.absmax8 ? 1 : 0], reinterpret_cast<const void*>(kern), smem);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p);
 }
 
@@ -1715,12 +1703,8 @@ template <typename T, int MT> void launch_mfma_ring(GemmArgs& p, hipStream_t str
     const size_t smem = 256 * 32 * 4 + static_cast<size_t>(D) * MT * 16 * 256 + 4 * D * 2048 + 1024;
     dim3 grid(gx, p.kslices, gz);
     auto kern = p.absmax8 ? gemm4_mfma_ring_kernel<T, MT, true, D> : gemm4_mfma_ring_kernel<T, MT, false, D>;
-    static bool attr_set[2] = {false, false};
-    if (smem > 64 * 1024 && !attr_set[p.absmax8 ? 1 : 0]) {
-        BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
-        attr_set[p.absmax8 ? 1 : 0] = true;
-    }
+    static LdsLimit lds_limit[2];
+    ensure_dynamic_lds(lds_limit[p.absmax8 ? 1 : 0], reinterpret_cast<const void*>(kern), smem);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
 }
 
@@ -1739,12 +1723,8 @@ template <typename T, int MT, bool NESTED, int CW, int NTW, int D> void launch_m
     const int gz = (p.M + MT * 16 - 1) / (MT * 16);
     dim3 grid(gx, p.kslices, gz);
     auto kern = gemm4_mfma_pc_kernel<T, MT, NESTED, CW, NTW, D>;
-    static bool attr_set = false;
-    if (smem > 64 * 1024 && !attr_set) {
-        BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
-        attr_set = true;
-    }
+    static LdsLimit lds_limit;
+    ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), smem);
     hipLaunchKernelGGL(kern, grid, dim3((CW + kPcProducers) * 64), smem, stream, p.A, p.B, p.absmax, p.out, p.code16, p.M, p.N, p.K, p.bs_shift, p.kslices, p.quant_type, p);
 }
 

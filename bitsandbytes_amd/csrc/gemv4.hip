@@ -490,13 +490,8 @@ template <typename T, int MB, int RPW, int SEGS, int EXTRA> void launch_dot(cons
         auto kern = gemv4_dot_kernel<T, MB, RPW, SEGS, (F)>;                                       \
         const size_t dyn = (((F) & kXLds) ? xbytes : 0) + lds_pad;                                 \
         const size_t stat = (((F) & kLut64) ? 64 : 32) * 1024 + 2048;                              \
-        static size_t attr_bytes = 0;                                                              \
-        if (dyn + stat > 64 * 1024 && dyn > attr_bytes) {                                          \
-            BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                 \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,          \
-                                              static_cast<int>(dyn)));                             \
-            attr_bytes = dyn;                                                                      \
-        }                                                                                          \
+        static LdsLimit lds_limit;                                                                 \
+        ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), dyn, stat);             \
         hipLaunchKernelGGL(kern, grid, block, dyn, stream, p.A, p.B, p.absmax, p.out, p.code16, p.N, p.K, p.M, p.bs_shift, p.quant_type, p);                                    \
     } while (0)
 #define BNB_DOT_SEL(X)                                                                             \
@@ -546,12 +541,8 @@ template <typename T> void dispatch_dot(const GemvArgs& p, hipStream_t stream) {
 #define BNB_ABL(ABLV)                                                                                 \
     if (g_dot_ablate == ABLV) {                                                                       \
         auto kern = gemv4_dot_kernel<T, 1, 1, 2, kSingle | kXLds | kWaves8 | kCodePtr | kLut64 | (ABLV << 8)>;        \
-        static bool attr_done = false;                                                             \
-        if (!attr_done) {                                                                          \
-            BNB_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                 \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 8192));  \
-            attr_done = true;                                                                      \
-        }                                                                                          \
+        static LdsLimit lds_limit;                                                                 \
+        ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), 8192, 66 * 1024);       \
         hipLaunchKernelGGL(kern, grid, dim3(512), 2 * 4096, stream, p.A, p.B, p.absmax, p.out, p.code16, p.N, p.K, p.M, p.bs_shift, p.quant_type, p);                            \
         return;                                                                                    \
     }
