@@ -83,7 +83,6 @@ struct GemvArgs {
     int M, N, K;
     int bs_shift;
     int quant_type;
-    float code[16];             // the 16 code values by value (kernarg -> SGPRs) when code16 == NULL
     unsigned long long* dbg;    // profiling builds only: per-wavefront s_memtime stamps (8 per wave), else NULL
 };
 
@@ -95,7 +94,6 @@ enum DotFlags : int {
     kNested = 2,  // double-quantised absmax reconstructed in-kernel
     kWaves8 = 4,  // 512-thread workgroups (8 wavefronts share one table build) instead of 256
     kXLds = 16,   // activations staged once per workgroup in LDS (one LDS-DMA copy) instead of per-wave global loads
-    kCodePtr = 32, // code table read from a table pointer (device-resident built-in table or the caller's)
     kLut64 = 64,  // 64 table copies, 256 B per entry: the LDS address of a look-up is ONE v_perm_b32
                   // (byte 0 = the lane's offset, byte 1 = the packed weight byte) instead of shift + mask + or
     // bits 8..: ablation for profiling builds (results are wrong): 1 = stream + reduce raw words, no decode;
@@ -111,7 +109,7 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
     // dependent s_load from a kernarg buffer that is cold in every cache. The rest stays in the struct.
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, void* hot_out, const float* hot_code16, int hot_N,
     int hot_K, int hot_M, int hot_bs_shift, int hot_quant_type, const GemvArgs p) {
-    constexpr bool SINGLE = FLAGS & kSingle, NESTED = FLAGS & kNested, CODEPTR = FLAGS & kCodePtr, LUT64 = FLAGS & kLut64;
+    constexpr bool SINGLE = FLAGS & kSingle, NESTED = FLAGS & kNested, LUT64 = FLAGS & kLut64;
     constexpr int COPIES = LUT64 ? 64 : 32; // table copies = dwords per entry
     constexpr bool XLDS = FLAGS & kXLds;
     constexpr int WAVES = (FLAGS & kWaves8) ? 8 : 4;
@@ -159,14 +157,12 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
     }
     // The two code values this lane needs for its table entry are the next vector loads of the
     // kernel: vmcnt retires in order, so waiting for them later never waits for the weight stream.
-    // (caller-supplied table pointer only; the built-in tables travel by value in the kernel arguments)
-    float code_hi = 0.f, code_lo = 0.f;
+    // (the caller's table if one was passed - the legacy gemv op does - else the device-resident built-in one;
+    // passing the 16 values by value and selecting with v_cndmask measured 0.6-0.9 us slower)
     const int entry = tid / TPE; // table entry this lane (co-)writes
-    if constexpr (CODEPTR) {
-        const gfloat_ptr tbl = (gfloat_ptr)(hot_code16 ? hot_code16 : (hot_quant_type == kNF4 ? kNF4Code : kFP4Code));
-        code_hi = tbl[entry >> 4];
-        code_lo = tbl[entry & 15];
-    }
+    const gfloat_ptr tbl = (gfloat_ptr)(hot_code16 ? hot_code16 : (hot_quant_type == kNF4 ? kNF4Code : kFP4Code));
+    float code_hi = tbl[entry >> 4];
+    float code_lo = tbl[entry & 15];
 
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -324,16 +320,6 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
 
     // 2) build the byte -> (code[hi], code[lo]) table while the weights fly.
     if constexpr (ABL == 0 || ABL == 3) {
-        if constexpr (!CODEPTR) { // SGPR values picked by a v_cndmask chain, no memory
-            const int hi = entry >> 4, lo = entry & 15;
-            code_hi = p.code[0];
-            code_lo = p.code[0];
-#pragma unroll
-            for (int j = 1; j < 16; ++j) {
-                code_hi = (hi == j) ? p.code[j] : code_hi;
-                code_lo = (lo == j) ? p.code[j] : code_lo;
-            }
-        }
         const uint32_t pr = Pair2<T>::pack(code_hi, code_lo);
         const u32x4 v = {pr, pr, pr, pr};
         // entry `entry` = COPIES dwords; TPE lanes share it
@@ -468,7 +454,7 @@ template <typename T, int MB, int RPW, int SEGS, int EXTRA> void launch_dot(cons
     // The table always comes through the pointer path (built-in device table unless the caller
     // supplied one): measured faster than passing the 16 values by value and selecting them with a
     // v_cndmask chain (profiles/: 4.9-5.3 us vs 5.4-6.2 us per launch at M = 1, N = K = 4096).
-    constexpr int E = (EXTRA & kWaves8) | kCodePtr;
+    constexpr int E = (EXTRA & kWaves8);
     // activations through LDS (one DMA copy per workgroup) whenever the image fits (the dispatcher picks MB
     // so that it does); debug flag 128 switches it off for A/B measurements. Per-wavefront global loads of
     // the activations are only instantiated for MB = 1: with more rows the prefetch stage spills registers.
@@ -540,7 +526,7 @@ template <typename T> void dispatch_dot(const GemvArgs& p, hipStream_t stream) {
         dim3 grid((p.N + 7) / 8, 1);
 #define BNB_ABL(ABLV)                                                                                 \
     if (g_dot_ablate == ABLV) {                                                                       \
-        auto kern = gemv4_dot_kernel<T, 1, 1, 2, kSingle | kXLds | kWaves8 | kCodePtr | kLut64 | (ABLV << 8)>;        \
+        auto kern = gemv4_dot_kernel<T, 1, 1, 2, kSingle | kXLds | kWaves8 | kLut64 | (ABLV << 8)>;        \
         static LdsLimit lds_limit;                                                                 \
         ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), 8192, 66 * 1024);       \
         hipLaunchKernelGGL(kern, grid, dim3(512), 2 * 4096, stream, p.A, p.B, p.absmax, p.out, p.code16, p.N, p.K, p.M, p.bs_shift, p.quant_type, p);                            \
@@ -609,12 +595,6 @@ void gemv_4bit_dot(int dtype, const void* A, const uint8_t* B, const float* absm
     p.bs_shift = ilog2(blocksize);
     p.quant_type = quant_type;
     p.dbg = nullptr;
-    {
-        static const float nf4[16] = {BNB_NF4_VALUES};
-        static const float fp4[16] = {BNB_FP4_VALUES};
-        for (int i = 0; i < 16; ++i)
-            p.code[i] = (quant_type == kNF4) ? nf4[i] : fp4[i];
-    }
 
     const bool fast_ok = (dtype != 0) && (K % 32 == 0) && (blocksize >= 32) && is_pow2(blocksize) &&
                          aligned_to(A, 16) && aligned_to(B, 16);
