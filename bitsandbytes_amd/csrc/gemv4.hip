@@ -469,7 +469,7 @@ template <typename T, int MB, int RPW, int SEGS, int EXTRA> void launch_dot(cons
     // 11008 x 4096 M = 1 = 1376 workgroups 9.3 vs 8.1). At M = 2 it only won in the two-rows-per-wavefront
     // geometry of the large matrices (11008 x 4096: 10.9 vs 11.6; 4096^2: 5.19 vs 5.11).
     const bool few_wgs = static_cast<long>(grid.x) * grid.y <= 1024;
-    const bool lut64 = !(g_dot_flags & 32) && few_wgs && (MB == 1 || (MB == 2 && RPW == 2)) &&
+    const bool lut64 = !(g_dot_flags & 32) && few_wgs && MB <= 2 &&
                        64 * 1024 + (p.absmax8 ? 1024 : 0) + (xlds ? xbytes : 0) <= 80 * 1024;
 #define BNB_DOT_GO(F)                                                                              \
     do {                                                                                           \
