@@ -163,6 +163,9 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
     const gfloat_ptr tbl = (gfloat_ptr)(hot_code16 ? hot_code16 : (hot_quant_type == kNF4 ? kNF4Code : kFP4Code));
     float code_hi = tbl[entry >> 4];
     float code_lo = tbl[entry & 15];
+    float code2_v = 0.0f; // nested: this thread's entry of the 256-entry absmax code, loaded BEFORE the weight stream
+    if constexpr (NESTED)
+        code2_v = p.absmax_code[tid & 255];
 
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -183,6 +186,7 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
     struct Stage {
         u32x4 w[SEGS][RPW];
         float s[SEGS][RPW];
+        float s2[NESTED ? SEGS : 1][NESTED ? RPW : 1]; // nested: second-level absmax of the block's 256-group
         u32x4 x[XLDS ? 1 : SEGS][XLDS ? 1 : MB][4];
     };
 
@@ -207,6 +211,7 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
                 } else if constexpr (NESTED) {
                     // scale reconstructed in compute_stage (needs the LDS code table)
                     st.s[sg][r] = __builtin_bit_cast(float, static_cast<uint32_t>(p.absmax8[blk]));
+                    st.s2[sg][r] = absmax[blk >> 8]; // issued with the stage: a load inside the decode would expose its latency
                 } else {
                     st.s[sg][r] = absmax[blk];
                 }
@@ -296,11 +301,8 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
                 const int k0 = (it * SEGS + sg) * kSegK + lane * 32;
                 float scale;
                 if constexpr (NESTED) {
-                    const int kk = (k0 < K) ? k0 : 0;
-                    const int row = (row0 + r < N) ? row0 + r : N - 1;
-                    const long blk = (static_cast<long>(row) * K + kk) >> hot_bs_shift;
                     const uint32_t q8 = __builtin_bit_cast(uint32_t, st.s[sg][r]);
-                    scale = __fadd_rn(__fmul_rn(code2[q8], absmax[blk >> 8]), offset);
+                    scale = __fadd_rn(__fmul_rn(code2[q8], st.s2[sg][r]), offset);
                 } else {
                     scale = st.s[sg][r];
                 }
@@ -335,14 +337,14 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
             dst[(j + rot) % NCH] = v;
         if constexpr (NESTED) {
             if (tid < 256)
-                code2[tid] = p.absmax_code[tid];
+                code2[tid] = code2_v;
             offset = p.absmax_offset[0];
         }
     }
     if constexpr (ABL == 1 || ABL == 2 || ABL == 4)
         asm volatile("" ::"v"(code_hi), "v"(code_lo));
-    if constexpr (XLDS) // the activation DMAs are older than the stage-0 loads (SEGS*RPW weights + as many scales)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SEGS * RPW * 2) : "memory");
+    if constexpr (XLDS) // the activation DMAs are older than the stage-0 loads (SEGS*RPW weights + as many scales, two when nested)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SEGS * RPW * (NESTED ? 3 : 2)) : "memory");
     __syncthreads();
     zsh = opaque_zero();
     perm_sel += static_cast<uint32_t>(zsh); // same fence for the permute form of the decode
