@@ -123,3 +123,119 @@ def test_ref_fused_cpu_gemv_baseline_path(ref):
         y = O.ref_fused_gemv(x, wp, amt, N, K, 64, "nf4")
         y32 = O.gemm_4bit(x, q, (N, K), am, 64, "nf4")[1]
         assert (y.float() - y32).norm() / y32.norm() < 1e-2
+
+
+# ------------------------------------------------------------------------------------------ host layer vs live reference
+# In this interpreter the reference owns the ``bitsandbytes::`` ops and their CPU kernels, so running
+# bitsandbytes_amd's modules on CPU tensors exercises OUR host logic (dtype policy, bias handling, quant-state
+# plumbing, state-dict layout) on top of the REFERENCE's arithmetic: results must match the reference's own
+# modules bit for bit.
+def _pair_linear(ref_bnb, compress_statistics, quant_type, storage, bias=True):
+    import bitsandbytes_amd.nn as mnn
+
+    torch.manual_seed(11)
+    fp = torch.nn.Linear(192, 64, bias=bias)
+    theirs = ref_bnb.nn.Linear4bit(192, 64, bias=bias, compress_statistics=compress_statistics, quant_type=quant_type,
+                                   quant_storage=storage)
+    mine = mnn.Linear4bit(192, 64, bias=bias, compress_statistics=compress_statistics, quant_type=quant_type,
+                          quant_storage=storage)
+    theirs.load_state_dict(fp.state_dict())
+    mine.load_state_dict(fp.state_dict())
+    return theirs.to("cpu"), mine.to("cpu")
+
+
+@pytest.mark.parametrize("quant_type", ["nf4", "fp4"])
+@pytest.mark.parametrize("compress_statistics", [False, True])
+@pytest.mark.parametrize("storage", [torch.uint8, torch.bfloat16], ids=["u8", "bf16storage"])
+def test_linear4bit_module_matches_reference_module(ref, quant_type, compress_statistics, storage):
+    bnb, _ = ref
+    theirs, mine = _pair_linear(bnb, compress_statistics, quant_type, storage)
+    assert torch.equal(theirs.weight.data.view(torch.uint8), mine.weight.data.view(torch.uint8))
+    assert mine.weight.dtype == theirs.weight.dtype and mine.weight.shape == theirs.weight.shape
+    for x in (torch.randn(1, 192), torch.randn(3, 5, 192), torch.randn(7, 192).bfloat16(), torch.randn(2, 192).half()):
+        y_t, y_m = theirs(x), mine(x)
+        assert y_t.dtype == y_m.dtype and y_t.shape == y_m.shape
+        assert torch.equal(y_t, y_m)
+    # state dicts: same keys, same bytes; each implementation loads the other's
+    sd_t, sd_m = theirs.state_dict(), mine.state_dict()
+    assert set(sd_t) == set(sd_m)
+    for k in sd_t:  # byte comparison: packed weights viewed as bf16 storage contain NaN bit patterns
+        assert sd_t[k].dtype == sd_m[k].dtype and sd_t[k].shape == sd_m[k].shape, k
+        assert torch.equal(sd_t[k].contiguous().view(torch.uint8), sd_m[k].contiguous().view(torch.uint8)), k
+    import bitsandbytes_amd.nn as mnn
+
+    stats = {k[len("weight."):]: v for k, v in sd_t.items() if k.startswith("weight.")}
+    w_mine = mnn.Params4bit.from_prequantized(sd_t["weight"], dict(stats), device="cpu")
+    w_theirs = bnb.nn.Params4bit.from_prequantized(sd_m["weight"], dict(stats), device="cpu")
+    assert torch.equal(w_mine.data.view(torch.uint8), w_theirs.data.view(torch.uint8))
+    for f in ("absmax", "code", "blocksize", "quant_type", "dtype", "shape", "nested"):
+        a, b = getattr(w_mine.quant_state, f), getattr(w_theirs.quant_state, f)
+        assert torch.equal(a, b) if isinstance(a, torch.Tensor) else a == b, f
+
+
+def test_matmul_4bit_backward_matches_reference(ref):
+    bnb, F = ref
+    import bitsandbytes_amd as mine
+
+    W = (torch.randn(48, 128) / 11).bfloat16()
+    q, st = F.quantize_4bit(W, quant_type="nf4")
+    grads = []
+    for impl in (bnb, mine):
+        x = torch.randn(6, 128, dtype=torch.bfloat16, requires_grad=True)
+        torch.manual_seed(0)
+        x.data.copy_(torch.randn(6, 128).bfloat16())
+        y = impl.matmul_4bit(x, q.t(), st)  # [K, N] orientation, as Linear4bit passes it
+        y.float().pow(2).sum().backward()
+        grads.append((y.detach().clone(), x.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
+@pytest.mark.parametrize("cls", ["EmbeddingNF4", "EmbeddingFP4"])
+@pytest.mark.parametrize("dim", [64, 72])
+def test_embedding4bit_matches_reference_module(ref, cls, dim):
+    bnb, _ = ref
+    import bitsandbytes_amd.nn as mnn
+
+    # the fused row-gather op is ours; on CPU it is played by the oracle (test infrastructure)
+    try:
+        @torch.library.register_kernel("bitsandbytes_amd::dequantize_4bit_rows", "cpu")
+        def _(A, absmax, indices, row_len, blocksize, quant_type, dtype):
+            n_rows = A.numel() * A.element_size() * 2 // row_len
+            packed = A.contiguous().view(torch.uint8).view(n_rows, row_len // 2)
+            idx = indices.reshape(-1).long()
+            return O.dequantize_4bit(packed[idx].reshape(-1, 1), absmax.view(n_rows, -1)[idx].reshape(-1), blocksize,
+                                     quant_type, (*indices.shape, row_len), dtype)
+    except RuntimeError:
+        pass  # already registered by an earlier parametrisation
+    torch.manual_seed(5)
+    fp = torch.nn.Embedding(40, dim)
+    theirs, mine = getattr(bnb.nn, cls)(40, dim), getattr(mnn, cls)(40, dim)
+    theirs.load_state_dict(fp.state_dict())
+    mine.load_state_dict(fp.state_dict())
+    theirs, mine = theirs.to("cpu"), mine.to("cpu")
+    assert torch.equal(theirs.weight.data, mine.weight.data)
+    idx = torch.tensor([[0, 39, 3], [3, 3, 17]])
+    assert same_values(mine(idx), theirs(idx))
+
+
+@pytest.mark.parametrize("compress_statistics", [False, True])
+def test_parametrize_matches_reference(ref, compress_statistics):
+    bnb, _ = ref
+    import bitsandbytes.nn.parametrize as rp
+
+    import bitsandbytes_amd.nn.parametrize as mp
+
+    class Experts(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(9)
+            self.w = torch.nn.Parameter(torch.randn(3, 32, 64) * 0.1)
+
+    a, b = Experts(), Experts()
+    rp.replace_parameter_4bit(a, "w", compress_statistics=compress_statistics, quant_type="nf4")
+    mp.replace_parameter_4bit(b, "w", compress_statistics=compress_statistics, quant_type="nf4")
+    assert torch.equal(a.w, b.w)
+    sd_a, sd_b = a.state_dict(), b.state_dict()
+    assert set(sd_a) == set(sd_b)
+    for k in sd_a:
+        assert torch.equal(sd_a[k], sd_b[k]), k
