@@ -239,3 +239,42 @@ def test_parametrize_matches_reference(ref, compress_statistics):
     assert set(sd_a) == set(sd_b)
     for k in sd_a:
         assert torch.equal(sd_a[k], sd_b[k]), k
+
+
+@pytest.mark.parametrize("quant_type", ["nf4", "fp4"])
+@pytest.mark.parametrize("compress_statistics", [False, True])
+@pytest.mark.parametrize("storage", [torch.uint8, torch.float16, torch.float32], ids=["u8", "f16storage", "f32storage"])
+def test_functional_wrappers_match_reference(ref, quant_type, compress_statistics, storage):
+    """functional.quantize_4bit / dequantize_4bit / gemv_4bit / (de)quantize_blockwise: same outputs, same
+    QuantState contents, same shapes and dtypes as the reference wrappers."""
+    _, F = ref
+    import bitsandbytes_amd.functional as MF
+
+    A = (torch.randn(96, 160) * 0.3).half()
+    q_r, st_r = F.quantize_4bit(A, blocksize=64, compress_statistics=compress_statistics, quant_type=quant_type,
+                                quant_storage=storage)
+    q_m, st_m = MF.quantize_4bit(A, blocksize=64, compress_statistics=compress_statistics, quant_type=quant_type,
+                                 quant_storage=storage)
+    assert q_r.dtype == q_m.dtype and q_r.shape == q_m.shape
+    assert torch.equal(q_r.contiguous().view(torch.uint8), q_m.contiguous().view(torch.uint8))
+    for f in ("absmax", "code", "blocksize", "quant_type", "dtype", "shape", "nested", "offset"):
+        a, b = getattr(st_r, f), getattr(st_m, f)
+        assert torch.equal(a, b) if isinstance(a, torch.Tensor) else a == b, f
+    if compress_statistics:
+        for f in ("absmax", "code", "blocksize", "dtype"):
+            a, b = getattr(st_r.state2, f), getattr(st_m.state2, f)
+            assert torch.equal(a, b) if isinstance(a, torch.Tensor) else a == b, f"state2.{f}"
+    d_r, d_m = F.dequantize_4bit(q_r, st_r), MF.dequantize_4bit(q_m, st_m)
+    assert d_r.dtype == d_m.dtype and d_r.shape == d_m.shape and same_values(d_r, d_m)
+    # absmax= / blocksize= calling convention (no QuantState)
+    if not compress_statistics:
+        for mod, q, st in ((F, q_r, st_r), (MF, q_m, st_m)):
+            with pytest.raises(ValueError):  # both require `out` when no QuantState is given
+                mod.dequantize_4bit(q, absmax=st.absmax, blocksize=64, quant_type=quant_type)
+        # (the out= form has no CPU kernel in the reference either; the GPU suite covers it on the HIP path)
+    # 8-bit pair through the wrappers
+    v = torch.randn(1000) * 0.01
+    c_r, s_r = F.quantize_blockwise(v, blocksize=256)
+    c_m, s_m = MF.quantize_blockwise(v, blocksize=256)
+    assert torch.equal(c_r, c_m) and torch.equal(s_r.absmax, s_m.absmax) and torch.equal(s_r.code, s_m.code)
+    assert same_values(F.dequantize_blockwise(c_r, s_r), MF.dequantize_blockwise(c_m, s_m))
