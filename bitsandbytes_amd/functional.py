@@ -418,3 +418,9 @@ def gemv_4bit(A: Tensor, B: Tensor, out: Optional[Tensor] = None, transposed_A=F
         torch.ops.bitsandbytes.gemv_4bit.out(*args, out=out)
         return out
     return torch.ops.bitsandbytes.gemv_4bit.default(*args)
+
+
+def has_avx512bf16() -> bool:
+    """Reference ``functional.has_avx512bf16`` asks its CPU library whether the AVX512-BF16 gemv path exists
+    (functional.py:1670-1674). This package ships no CPU kernels, so the answer is always False."""
+    return False

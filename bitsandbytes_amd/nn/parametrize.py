@@ -62,18 +62,26 @@ def replace_parameter_4bit(module: nn.Module, param_name: str, compress_statisti
 def _attach(module: nn.Module, param_name: str, state: F.QuantState) -> None:
     # unsafe=True: the parametrization changes shape and dtype (packed bytes -> fp tensor)
     P.register_parametrization(module, param_name, Bnb4bitParametrization(state), unsafe=True)
+    _register_parametrization_hooks(module, param_name)
+
+
+def _register_parametrization_hooks(module: nn.Module, param_name: str) -> None:
+    """State-dict hook (clean key layout) + the forward hook pair that caches the dequantized tensor for the
+    duration of one forward of the owning module (same private name as the reference's helper: its tests
+    register the pair directly)."""
     if hasattr(module, "register_state_dict_post_hook"):
         module.register_state_dict_post_hook(_StateDictHook(param_name))
-    # cache the dequantized tensor for the duration of one forward of the owning module
-    module.register_forward_pre_hook(_cache_on)
-    module.register_forward_hook(_cache_off, always_call=True)  # also runs when forward raises / is aborted
+    module.register_forward_pre_hook(_enable_parametrization_cache)
+    # always_call: also runs when forward raises or is aborted (non-reentrant activation checkpointing stops
+    # its recompute mid-forward), otherwise the enable count leaks and the cache is never cleared again
+    module.register_forward_hook(_disable_parametrization_cache, always_call=True)
 
 
-def _cache_on(module: nn.Module, inputs: tuple[Any, ...]) -> None:
+def _enable_parametrization_cache(module: nn.Module, inputs: tuple[Any, ...]) -> None:
     P._cache_enabled += 1
 
 
-def _cache_off(module: nn.Module, inputs: tuple[Any, ...], output: Any) -> None:
+def _disable_parametrization_cache(module: nn.Module, inputs: tuple[Any, ...], output: Any) -> None:
     # never below zero: with always_call the hook may fire without a matching pre-hook, and a negative
     # counter would read as "enabled" forever and pin every dequantized tensor in memory
     P._cache_enabled = max(0, P._cache_enabled - 1)
