@@ -20,6 +20,7 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "tests")), r
 SELECTIONS = [
     ("tests/test_linear4bit.py", "not compile and not fsdp", 170),
     ("tests/test_parametrize.py", "", 80),
+    ("tests/test_autograd.py", "matmul_4bit", 40),
     ("tests/test_ops.py", "4bit", 250),
     ("tests/test_modules.py", "(embedding or 4bit or NF4 or FP4) and not 8bit and not Int8 and not int8", 20),
     # default: everything 4-bit except the long gemv / large-tensor sweeps (they dominate the runtime on CPU)
