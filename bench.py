@@ -20,8 +20,10 @@ re-assembled by RCCL all-gathers, bucketed GRAPH_CHUNK steps per collective and 
 stream so they overlap the next chunk's weight streaming.
 
 Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed per launch inside the
-same process) and, at N = 1 on rank 0, "cpu_baseline" (the reference's own AVX512-BF16 fused CPU
-gemv from oracle/_ref when the host supports it, else the scalar port from oracle/).
+same process; "traffic" from two rocprofv3 PMC passes run as child processes), at N = 1 on rank 0
+"cpu_baseline" (the reference's own AVX512-BF16 fused CPU gemv from oracle/_ref when the host supports it,
+else the scalar port from oracle/) and "headline_sweep_N4096_K4096" (M = 1..64, the other half of
+BASELINE.json's metric; --no-sweep skips it).
 """
 import argparse
 import json
@@ -158,7 +160,8 @@ def main():
     ap.add_argument("--quant-type", default="nf4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue steps eagerly instead of replaying a hipGraph")
-    ap.add_argument("--sweep", action="store_true", help="also time M = 1..64 at N = K = 4096 (headline sweep)")
+    ap.add_argument("--sweep", action="store_true", help="(default at N = 1) also time M = 1..64 at N = K = 4096: the headline sweep of BASELINE.json's metric")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the M = 1..64 sweep")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # workload run under rocprofv3 --pmc
     args = ap.parse_args()
@@ -330,7 +333,7 @@ def main():
     kernel_us_events = sum(kept) / len(kept) * 1e3
 
     sweep = None
-    if args.sweep and rank == 0:
+    if (args.sweep or (world == 1 and not args.no_sweep)) and rank == 0:
         sweep = []
         for m_rows in (1, 2, 4, 8, 16, 32, 64):
             t_us = per_launch_us(m_rows, reps=5)
