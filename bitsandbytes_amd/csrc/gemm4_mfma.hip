@@ -368,8 +368,11 @@ typedef __attribute__((address_space(3))) void* dma_dst_t;
 template <typename T, int MT, bool NESTED, int kWaves, int AROWS>
 __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(
     // hot arguments as separate scalars: eligible for kernarg preload into SGPRs (see gemv4.hip)
-    const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, void* hot_out, const float* hot_code16, int hot_M,
-    int hot_N, int hot_K, int hot_bs_shift, int hot_kslices, int hot_quant_type, const GemmArgs p) {
+    // (exactly the 14 preloadable dwords: 16 user SGPRs minus the kernarg segment pointer; the output pointer is
+    // needed last and stays in the struct)
+    const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const float* hot_code16, int hot_M, int hot_N,
+    int hot_K, int hot_bs_shift, int hot_kslices, int hot_quant_type, const GemmArgs p) {
+    void* const hot_out = p.out;
     // 64 table copies, 256 B per entry: the look-up address byte * 256 + lane * 4 is one v_perm_b32 (see
     // gemv4.hip); this kernel runs one workgroup per CU, so the 64 KiB are free
     static_assert(AROWS == 0 || (MT == 1 && (AROWS == 4 || AROWS == 8)), "A image: 4 or 8 rows, one M tile");
@@ -1152,8 +1155,11 @@ constexpr int kPcProducers = 4;
 template <typename T, int MT, bool NESTED, int CW, int NTW, int D>
 __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel(
     // hot arguments as separate scalars: eligible for kernarg preload into SGPRs (see gemv4.hip)
-    const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, void* hot_out, const float* hot_code16, int hot_M,
-    int hot_N, int hot_K, int hot_bs_shift, int hot_kslices, int hot_quant_type, const GemmArgs p) {
+    // (exactly the 14 preloadable dwords: 16 user SGPRs minus the kernarg segment pointer; the output pointer is
+    // needed last and stays in the struct)
+    const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const float* hot_code16, int hot_M, int hot_N,
+    int hot_K, int hot_bs_shift, int hot_kslices, int hot_quant_type, const GemmArgs p) {
+    void* const hot_out = p.out;
     constexpr int kLutBytes = 256 * 32 * 4;
     constexpr int XB = MT * 16 * 512;                          // bytes of one A stage
     constexpr int SB = NTW * 256 * (NESTED ? 2 : 1);           // scale bytes of one slot
@@ -1670,7 +1676,7 @@ template <typename T, int MT, int WAVES, int AROWS> void launch_mfma_dma_one(Gem
     auto kern = p.absmax8 ? gemm4_mfma_dma_kernel<T, MT, true, WAVES, AROWS> : gemm4_mfma_dma_kernel<T, MT, false, WAVES, AROWS>;
     static LdsLimit lds_limit[2];
     ensure_dynamic_lds(lds_limit[p.absmax8 ? 1 : 0], reinterpret_cast<const void*>(kern), smem);
-    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p.A, p.B, p.absmax, p.out, p.code16, p.M, p.N, p.K, p.bs_shift, p.kslices, p.quant_type, p);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p.A, p.B, p.absmax, p.code16, p.M, p.N, p.K, p.bs_shift, p.kslices, p.quant_type, p);
 }
 
 template <typename T, int MT, int WAVES> void launch_mfma_dma(GemmArgs& p, hipStream_t stream) {
@@ -1725,7 +1731,7 @@ template <typename T, int MT, bool NESTED, int CW, int NTW, int D> void launch_m
     auto kern = gemm4_mfma_pc_kernel<T, MT, NESTED, CW, NTW, D>;
     static LdsLimit lds_limit;
     ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), smem);
-    hipLaunchKernelGGL(kern, grid, dim3((CW + kPcProducers) * 64), smem, stream, p.A, p.B, p.absmax, p.out, p.code16, p.M, p.N, p.K, p.bs_shift, p.kslices, p.quant_type, p);
+    hipLaunchKernelGGL(kern, grid, dim3((CW + kPcProducers) * 64), smem, stream, p.A, p.B, p.absmax, p.code16, p.M, p.N, p.K, p.bs_shift, p.kslices, p.quant_type, p);
 }
 
 // deepest ring (<= 4 chunks) that fits

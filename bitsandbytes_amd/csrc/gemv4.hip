@@ -107,8 +107,14 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
     // The hot arguments are separate scalars so that the command processor can PRELOAD them into SGPRs
     // (-mllvm -amdgpu-kernarg-preload-count=16, gfx950 kernarg preload): a wavefront otherwise starts with a
     // dependent s_load from a kernarg buffer that is cold in every cache. The rest stays in the struct.
-    const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, void* hot_out, const float* hot_code16, int hot_N,
-    int hot_K, int hot_M, int hot_bs_shift, int hot_quant_type, const GemvArgs p) {
+    // (13 of the 14 preloadable dwords - 16 user SGPRs minus the kernarg segment pointer: everything the loads of
+    // the first stage and the table build depend on, including the nested uint8 absmax pointer - fetched from the
+    // struct it would put a cold s_load in front of the weight stream; the output pointer and the nested
+    // offset are needed late and stay in the struct)
+    const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, const float* hot_code16,
+    int hot_N, int hot_K, int hot_packed /* M | bs_shift << 24 | quant_type << 29 */, const GemvArgs p) {
+    const int hot_M = hot_packed & 0xFFFFFF, hot_bs_shift = (hot_packed >> 24) & 31, hot_quant_type = (hot_packed >> 29) & 3;
+    void* const hot_out = p.out;
     constexpr bool SINGLE = FLAGS & kSingle, NESTED = FLAGS & kNested, LUT64 = FLAGS & kLut64;
     constexpr int COPIES = LUT64 ? 64 : 32; // table copies = dwords per entry
     constexpr bool XLDS = FLAGS & kXLds;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
                     st.s[sg][r] = 1.0f;
                 } else if constexpr (NESTED) {
                     // scale reconstructed in compute_stage (needs the LDS code table)
-                    st.s[sg][r] = __builtin_bit_cast(float, static_cast<uint32_t>(p.absmax8[blk]));
+                    st.s[sg][r] = __builtin_bit_cast(float, static_cast<uint32_t>(hot_absmax8[blk]));
                     st.s2[sg][r] = absmax[blk >> 8]; // issued with the stage: a load inside the decode would expose its latency
                 } else {
                     st.s[sg][r] = absmax[blk];
@@ -480,7 +486,8 @@ template <typename T, int MB, int RPW, int SEGS, int EXTRA> void launch_dot(cons
         const size_t stat = (((F) & kLut64) ? 64 : 32) * 1024 + 2048;                              \
         static LdsLimit lds_limit;                                                                 \
         ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), dyn, stat);             \
-        hipLaunchKernelGGL(kern, grid, block, dyn, stream, p.A, p.B, p.absmax, p.out, p.code16, p.N, p.K, p.M, p.bs_shift, p.quant_type, p);                                    \
+        hipLaunchKernelGGL(kern, grid, block, dyn, stream, p.A, p.B, p.absmax, p.absmax8, p.code16, p.N, p.K, \
+                           (p.M & 0xFFFFFF) | (p.bs_shift << 24) | (p.quant_type << 29), p);                                    \
     } while (0)
 #define BNB_DOT_SEL(X)                                                                             \
     switch ((single ? 1 : 0) | (p.absmax8 ? 2 : 0)) {                                              \
@@ -531,7 +538,8 @@ template <typename T> void dispatch_dot(const GemvArgs& p, hipStream_t stream) {
         auto kern = gemv4_dot_kernel<T, 1, 1, 2, kSingle | kXLds | kWaves8 | kLut64 | (ABLV << 8)>;        \
         static LdsLimit lds_limit;                                                                 \
         ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), 8192, 66 * 1024);       \
-        hipLaunchKernelGGL(kern, grid, dim3(512), 2 * 4096, stream, p.A, p.B, p.absmax, p.out, p.code16, p.N, p.K, p.M, p.bs_shift, p.quant_type, p);                            \
+        hipLaunchKernelGGL(kern, grid, dim3(512), 2 * 4096, stream, p.A, p.B, p.absmax, p.absmax8, p.code16, p.N, p.K, \
+                           (p.M & 0xFFFFFF) | (p.bs_shift << 24) | (p.quant_type << 29), p);                            \
         return;                                                                                    \
     }
         BNB_ABL(1) BNB_ABL(2) BNB_ABL(3) BNB_ABL(4) BNB_ABL(5)
