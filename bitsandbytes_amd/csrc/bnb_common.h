@@ -5,6 +5,8 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -35,11 +37,13 @@ enum QuantType : int { kGeneral8bit = 0, kFP4 = 1, kNF4 = 2 };
 // ---------------------------------------------------------------------------------------------
 // Dynamic LDS above 64 KiB needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel. The attribute
 // belongs to (kernel, device), so it is tracked per device: a process that drives several GPUs must set it
-// on each of them. Raised monotonically, never lowered. Host-side, thread-safe.
+// on each of them. Raised monotonically, never lowered. Host-side; callable from several threads: the fast
+// path is one relaxed atomic load, the (rare) raise is serialised so the attribute and the record agree.
 // ---------------------------------------------------------------------------------------------
 struct LdsLimit {
     static constexpr int kMaxDevices = 64;
-    size_t bytes[kMaxDevices] = {};
+    std::atomic<size_t> bytes[kMaxDevices] = {};
+    std::mutex raise;
 };
 inline void ensure_dynamic_lds(LdsLimit& state, const void* kernel, size_t dynamic_bytes, size_t static_bytes = 0) {
     if (dynamic_bytes + static_bytes <= 64 * 1024)
@@ -47,10 +51,12 @@ inline void ensure_dynamic_lds(LdsLimit& state, const void* kernel, size_t dynam
     int dev = 0;
     BNB_HIP_CHECK(hipGetDevice(&dev));
     dev = (dev >= 0 && dev < LdsLimit::kMaxDevices) ? dev : 0;
-    // a racing duplicate call is harmless (same value); the plain array keeps the fast path lock-free
-    if (dynamic_bytes > state.bytes[dev]) {
+    if (dynamic_bytes <= state.bytes[dev].load(std::memory_order_acquire))
+        return;
+    std::lock_guard<std::mutex> lock(state.raise);
+    if (dynamic_bytes > state.bytes[dev].load(std::memory_order_relaxed)) {
         BNB_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dynamic_bytes)));
-        state.bytes[dev] = dynamic_bytes;
+        state.bytes[dev].store(dynamic_bytes, std::memory_order_release);
     }
 }
 
