@@ -61,6 +61,14 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+def _check_c_int_count(n: int, what: str) -> None:
+    """The reference ABI carries element counts as C ``int`` (csrc/pythonInterface.cpp:346-444;
+    tests/test_functional.py:698-716 pins 2**31 - 1 as the largest supported size). ctypes would wrap a
+    larger value silently, so refuse it here."""
+    if n >= 2**31:
+        raise ValueError(f"{what}: {n} elements exceed the C-ABI limit of 2**31 - 1")
+
+
 # ------------------------------------------------------------------------------------------ quantize_4bit
 @register_kernel("bitsandbytes::quantize_4bit", "cuda")
 def _(A: torch.Tensor, blocksize: int, quant_type: str, quant_storage: torch.dtype):
@@ -91,6 +99,7 @@ def _dequantize_4bit_impl(A, absmax, blocksize, quant_type, dtype, out):
         raise ValueError(f"quant_type must be 'nf4' or 'fp4', got {quant_type!r}")
     if absmax.dtype != torch.float32:
         raise ValueError(f"absmax must be float32, got {absmax.dtype}")
+    _check_c_int_count(out.numel(), "dequantize_4bit")
     A = A.contiguous()
     absmax = absmax.contiguous()
     fn = getattr(lib, f"cdequantize_blockwise_{_DT_NAME[dtype]}_{quant_type}")
@@ -100,6 +109,7 @@ def _dequantize_4bit_impl(A, absmax, blocksize, quant_type, dtype, out):
 
 @register_kernel("bitsandbytes::dequantize_4bit", "cuda")
 def _(A, absmax, blocksize: int, quant_type: str, shape: Sequence[int], dtype: torch.dtype) -> torch.Tensor:
+    _check_c_int_count(prod(shape), "dequantize_4bit")
     out = torch.empty(tuple(shape), dtype=dtype, device=A.device)
     _dequantize_4bit_impl(A, absmax, blocksize, quant_type, dtype, out)
     return out
@@ -169,6 +179,7 @@ def _dequantize_blockwise_impl(A, absmax, code, blocksize, dtype, out):
         raise ValueError(f"A must be uint8, got {A.dtype}")
     if blocksize <= 0 or (blocksize & (blocksize - 1)):
         raise ValueError(f"blocksize must be a positive power of two, got {blocksize}")
+    _check_c_int_count(A.numel(), "dequantize_blockwise")
     A = A.contiguous()
     fn = getattr(lib, f"cdequantize_blockwise_{_DT_NAME[dtype]}")
     with _device_of(A):

@@ -20,13 +20,14 @@
 //    in slice order, adds the bias and rounds once. No atomics: results are bit-reproducible run to run
 //    (the reference's test_matmul_4bit_weight_orientation demands exact equality between calls).
 //
-// The kernels, in the order they were written (each one's header says what the previous one taught):
-//   gemm4_mfma_kernel       (v2)  16*NT columns, weights straight to registers, register ring    [variants only]
-//   gemm4_mfma_dma_kernel   (v3)  16 columns, weights by LDS-DMA in full lines, K split over wavefronts  [M <= 16, small matrices]
-//   gemm4_mfma_tile_kernel  (v4)  128-column tile, A shared through LDS, two-stage double buffer   [variants only]
-//   gemm4_mfma_ring_kernel  (v4b) v4 with a 4-deep ring of 128-k chunks                             [variants only]
-//   gemm4_mfma_pc_kernel    (v5)  producer / consumer wavefronts, private weight rings              [M > 16 or large matrices]
-// make_plan() below holds the selection rule.
+// Two kernels ship (make_plan() below holds the selection rule):
+//   gemm4_mfma_dma_kernel  16 columns per workgroup, weights by LDS-DMA in full lines, K split over the
+//                          workgroup's wavefronts                                     [M <= 16, small matrices]
+//   gemm4_mfma_pc_kernel   producer / consumer wavefronts, A tile shared through LDS by 64-256 columns,
+//                          private weight rings per consumer                          [M > 16 or large matrices]
+// Three earlier generations (weights straight to registers in fragment-shaped 32-byte pieces; a 128-column
+// two-stage tile with workgroup barriers; the same with a 4-deep ring) were measured and retired - what each
+// taught is in DESIGN.md section 3.3 and their sweep record in profiles/r1_sweep_mfma_variants.txt.
 #include "bnb_common.h"
 
 #include <mutex>
@@ -36,7 +37,7 @@ namespace bnb {
 
 extern unsigned long long* g_dbg_buf; // gemv4.hip (profiling only)
 extern int g_dot_ablate;               // gemv4.hip (profiling only): 11 / 12 select the MFMA ablations
-int g_mfma_knob0 = 0; // NT override (0 = heuristic)
+int g_mfma_knob0 = 0; // sweeps: bits 8 / 16 select the A-image variants of the LDS-DMA kernel (launch_mfma_dma)
 int g_mfma_knob1 = 0; // K-slice count override (0 = heuristic)
 
 namespace {
@@ -95,261 +96,15 @@ struct GemmArgs {
     int steps_total; // K / 256
 };
 
-constexpr int kKC = 256;   // K granularity of the kernel: one pipeline group = 4 quantization blocks of 64
-// Workgroup geometry is a template parameter pair: WAVES wavefronts split the workgroup's K range,
-// each keeps DEPTH 64-k blocks in flight (4 blocks x 32 B = one full 128-B line of every weight row).
-// Bytes in flight per CU = WAVES * DEPTH * 512 B * NT: (16, 4) and (8, 8) reach the ~32 KiB that the
-// dot kernel needs to cover HBM latency; (4, 4) is kept for register-heavy tiles.
-
-// gemm4_mfma_kernel (v2, "wave-independent streaming"). What on-device profiling of v1 taught
-// (profiles/): at these sizes a launch is bound by per-wavefront serial instruction latency and
-// fixed costs, not by throughput. So: no workgroup barriers in the main loop, no LDS staging of the
-// activations, small code, and every workgroup small enough that N/16 of them fill the chip
-// without a second (finalize) launch whenever M <= 16.
-//   * A workgroup owns NT*16 output columns; its 4 wavefronts split the K range and combine through
-//     LDS at the end. Cross-workgroup K slices (grid.y) are only used when N/(16 NT) < ~256.
-//   * Per 64-k block a lane loads 8 packed bytes of its column (global_load_dwordx2), its fp32
-//     absmax, and - straight from L2, fragment-shaped, full 128-B lines per row over a 4-block group -
-//     the two 16-byte A fragments per M-tile. Rows >= M simply re-read row M-1: MFMA rows are
-//     independent and those rows are never stored, so no masking instructions are needed.
-//   * Four blocks are kept in flight per wavefront in a register ring (static indices: the loop is
-//     unrolled by the ring depth); waits are the compiler's counted vmcnt in issue order.
-template <typename T, int MT, int NT, bool NESTED, int kWaves, int kDepth>
-__global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_kernel(const GemmArgs p) {
-    constexpr int kLutBytes = 256 * 32 * 4;
-    constexpr int kThreads = kWaves * 64;
-    constexpr int TPE = kThreads / 256; // lanes cooperating on one table entry
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
-    float* red = reinterpret_cast<float*>(smem + kLutBytes); // [kWaves-1][MT][NT][64][4]
-    float* code2 = red + (kWaves - 1) * MT * NT * 256;       // nested: [256]
-
-    const int tid = threadIdx.x;
-#define MFMA_STAMP(i)                                                                              \
-    if (p.dbg && (tid & 63) == 0)                                                                  \
-        p.dbg[((static_cast<long>(blockIdx.x) * gridDim.y + blockIdx.y) * kWaves + (tid >> 6)) * 8 + (i)] =          \
-            __builtin_amdgcn_s_memtime();
-    MFMA_STAMP(0)
-    // first vector loads of the kernel (vmcnt retires in order): this lane's two code values
-    const gfloat_ptr tbl = (gfloat_ptr)(p.code16 ? p.code16 : (p.quant_type == kNF4 ? kNF4Code : kFP4Code));
-    const int entry = tid / TPE;
-    const float code_hi = tbl[entry >> 4];
-    const float code_lo = tbl[entry & 15];
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int ln = lane & 15; // column within an n-tile (B operand / accumulator), row within an m-tile (A operand)
-    const int lg = lane >> 4; // k group
-    const int N = p.N, K = p.K, M = p.M;
-    const int m_base = blockIdx.z * (MT * 16);
-    const int col0 = blockIdx.x * (NT * 16);
-
-    // K range of this wavefront, in blocks of 64: slice of the workgroup (grid.y), then split over the waves
-    const int blocks_total = K >> 6;
-    // (K is a multiple of 256, so every range below is a whole number of 4-block groups; ranges that
-    //  are not a multiple of kDepth end with a partly filled ring, handled by the per-block guards)
-    const int per_wg = ((blocks_total / 4 + p.kslices - 1) / p.kslices) * 4;
-    const int wg_begin = blockIdx.y * per_wg;
-    const int wg_end = (wg_begin + per_wg < blocks_total) ? wg_begin + per_wg : blocks_total;
-    const int wg_blocks = (wg_end > wg_begin) ? wg_end - wg_begin : 0;
-    const int per_wave = ((wg_blocks / 4 + kWaves - 1) / kWaves) * 4;
-    const int b_begin = wg_begin + wave * per_wave;
-    const int b_end = (b_begin + per_wave < wg_end) ? b_begin + per_wave : wg_end;
-    const int nb = (b_end > b_begin) ? b_end - b_begin : 0; // multiple of 4
-
-    const uint8_t* __restrict__ B = p.B;
-    const T* __restrict__ A = static_cast<const T*>(p.A);
-
-    long rowoff[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        int row = col0 + t * 16 + ln;
-        row = (row < N) ? row : N - 1;
-        rowoff[t] = static_cast<long>(row) * K;
-    }
-    const T* arow[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int m = m_base + mt * 16 + ln;
-        m = (m < M) ? m : M - 1;
-        arow[mt] = A + static_cast<long>(m) * K + lg * 16;
-    }
-
-    struct Stage {
-        u32x2 w[NT];
-        float s[NT];
-        u32x4 a[MT][2];
-    };
-    auto load_block = [&](Stage& st, int blk) {
-        const int kb = blk << 6;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const long e = rowoff[t] + kb;
-            st.w[t] = *reinterpret_cast<const u32x2*>(B + ((e + lg * 16) >> 1));
-            const long q = e >> p.bs_shift;
-            if constexpr (NESTED)
-                st.s[t] = __builtin_bit_cast(float, static_cast<uint32_t>(p.absmax8[q]));
-            else
-                st.s[t] = p.absmax[q];
-        }
-        if (p.ablate == 2)
-            return;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            st.a[mt][0] = *reinterpret_cast<const u32x4*>(arow[mt] + kb);
-            st.a[mt][1] = *reinterpret_cast<const u32x4*>(arow[mt] + kb + 8);
-        }
-    };
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- prologue: first ring of blocks in flight, then the table build under their latency
-    Stage ring[kDepth];
-#pragma unroll
-    for (int d = 0; d < kDepth; ++d)
-        if (d < nb)
-            load_block(ring[d], b_begin + d);
-    {
-        const uint32_t pr = Mma<T>::pack(code_hi, code_lo);
-        const u32x4 v = {pr, pr, pr, pr};
-        // chunk order rotated by the entry's index in the wavefront: conflict-free ds_write_b128 (see gemv4.hip)
-        u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * 32]) + (tid % TPE) * (8 / TPE);
-        constexpr int NCH = 8 / TPE;
-        const int rot = (NCH >= 8) ? (tid & 63) : (tid & 63) * NCH / 8; // distinct bank quads within 8 lanes
-#pragma unroll
-        for (int j = 0; j < NCH; ++j)
-            dst[(j + rot) % NCH] = v;
-    }
-    float offset = 0.0f;
-    if constexpr (NESTED) {
-        if (tid < 256)
-            code2[tid] = p.absmax_code[tid];
-        offset = p.absmax_offset[0];
-    }
-    MFMA_STAMP(1)
-    __syncthreads();
-    const int zsh = opaque_zero();
-    MFMA_STAMP(2)
-    const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
-
-    auto consume = [&](const Stage& st, int blk) {
-        if (p.ablate != 0) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                uint32_t v = st.w[t][0] ^ st.w[t][1];
-                if (p.ablate == 1)
-                    v ^= st.a[0][0][0] ^ st.a[0][1][3];
-                acc[0][t][0] += __builtin_bit_cast(float, (v & 0x007fffffu) | 0x3f800000u) * st.s[t];
-            }
-            return;
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            u32x4 bf[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const uint32_t w = st.w[t][j];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    bf[j][q] = lut[(((w >> (8 * q + zsh)) & 0xFFu) << 5) + lane_slot];
-            }
-            float scale;
-            if constexpr (NESTED) {
-                const long q = (rowoff[t] + (static_cast<long>(blk) << 6)) >> p.bs_shift;
-                const uint32_t q8 = __builtin_bit_cast(uint32_t, st.s[t]);
-                scale = __fadd_rn(__fmul_rn(code2[q8], p.absmax[q >> 8]), offset);
-            } else {
-                scale = st.s[t];
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                f32x4 part = Mma<T>::run(st.a[mt][0], bf[0], f32x4{0.f, 0.f, 0.f, 0.f});
-                part = Mma<T>::run(st.a[mt][1], bf[1], part);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[mt][t][r] = fmaf(scale, part[r], acc[mt][t][r]);
-            }
-        }
-    };
-
-    // ---- main loop over groups of kDepth blocks (ring indices are compile-time)
-    for (int g = 0; g < nb; g += kDepth) {
-#pragma unroll
-        for (int d = 0; d < kDepth; ++d) {
-            if (g + d < nb) {
-                consume(ring[d], b_begin + g + d);
-                if (g + kDepth + d < nb)
-                    load_block(ring[d], b_begin + g + kDepth + d);
-            }
-        }
-    }
-
-    if (p.dbg) {
-        asm volatile("" ::"v"(acc[0][0]));
-        MFMA_STAMP(3)
-    }
-    // ---- combine the wavefronts' K partials through LDS, then bias + store (or slab store)
-    if (wave > 0) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                *reinterpret_cast<f32x4*>(red + ((((wave - 1) * MT + mt) * NT + t) * 64 + lane) * 4) = acc[mt][t];
-    }
-    MFMA_STAMP(4)
-    __syncthreads();
-    MFMA_STAMP(5)
-    if (wave != 0)
-        return;
-#pragma unroll
-    for (int w = 0; w < kWaves - 1; ++w)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const f32x4 o = *reinterpret_cast<const f32x4*>(red + (((w * MT + mt) * NT + t) * 64 + lane) * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[mt][t][r] += o[r];
-            }
-
-    T* __restrict__ out = static_cast<T*>(p.out);
-    const T* __restrict__ bias = static_cast<const T*>(p.bias);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int col = col0 + t * 16 + ln;
-        if (col >= N)
-            continue;
-        const float b = (bias && p.kslices == 1) ? static_cast<float>(bias[col]) : 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m_base + mt * 16 + lg * 4 + r;
-                if (m >= M)
-                    continue;
-                const long o = static_cast<long>(m) * N + col;
-                if (p.kslices == 1)
-                    out[o] = static_cast<T>(acc[mt][t][r] + b);
-                else
-                    p.ws[static_cast<long>(blockIdx.y) * M * N + o] = acc[mt][t][r];
-            }
-        }
-    }
-    MFMA_STAMP(6)
-#undef MFMA_STAMP
-}
+constexpr int kKC = 256;   // K granularity of the kernels: one pipeline group = 4 quantization blocks of 64
 
 // ---------------------------------------------------------------------------------------------
-// gemm4_mfma_dma_kernel (v3): same decomposition as v2 for NT = 1, but the weights travel
-// HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) in FULL 128-byte lines: on-device ablation of v2
-// (profiles/) showed that fetching a row's line in four 32-byte pieces (what the MFMA B-fragment
-// layout asks for) streams the same bytes ~2x slower than the dot kernel's 1-KiB-per-instruction
-// pattern. Here one DMA instruction moves 8 rows x 128 B; two of them bring the wavefront's whole
+// gemm4_mfma_dma_kernel ("v3" in profiles/): a workgroup owns 16 output columns, its wavefronts split the
+// K range and combine through LDS at the end; cross-workgroup K slices (grid.y) are only used when N/16
+// workgroups would not fill the chip. The weights travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4)
+// in FULL 128-byte lines: on-device ablation of the retired register-ring kernel (profiles/) showed that
+// fetching a row's line in four 32-byte pieces (what the MFMA B-fragment layout asks for) streams the same
+// bytes ~2x slower than the dot kernel's 1-KiB-per-instruction pattern. Here one DMA instruction moves 8 rows x 128 B; two of them bring the wavefront's whole
 // 256-k chunk of its 16 columns. The image is lane-linear in LDS (hardware constraint), so the
 // bank swizzle is applied on the SOURCE side: lane (r, s) fetches 16-byte chunk s ^ r of row r, which
 // permutes within one 128-B line (coalescing untouched) and makes the per-block 8-byte fragment
@@ -654,480 +409,9 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// gemm4_mfma_tile_kernel (v4): the tiled kernel for the larger batches (M up to 64 per pass).
-// Workgroup tile = (MT*16 rows of A) x (128 weight columns): 4 wavefronts x 2 n-tiles. Per 256-k
-// chunk everything arrives by LDS-DMA in full lines and is double-buffered:
-//   * the A tile [MT*16][256] is fetched ONCE per workgroup (source-side XOR swizzle by row & 15 ->
-//     conflict-free ds_read_b128 fragment reads) and shared by the 4 wavefronts - this is what
-//     v2/v3 lack: there every 16 columns re-read all of A from L2;
-//   * every wavefront DMAs the 32 weight rows it owns (4 instructions of 8 rows x 128 B).
-// A raw s_barrier pair per chunk publishes / retires a buffer; waits are counted (vmcnt(N) leaves
-// the next chunk's DMAs in flight across the barrier). Scales: one 16-byte load per lane per n-tile.
-// The K range can be sliced across workgroups (grid.y) to fill the chip; slices meet in the
-// deterministic slab finalize.
-// ---------------------------------------------------------------------------------------------
-template <typename T, int MT, bool NESTED, int WAVES, int NTW>
-__global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_tile_kernel(const GemmArgs p) {
-    // WAVES wavefronts x NTW n-tiles each = WAVES*NTW*16 columns per workgroup
-    constexpr int kLutBytes = 256 * 32 * 4;
-    constexpr int XB = MT * 16 * 512;            // bytes of one A stage
-    constexpr int WB = NTW * 2048;               // bytes of one weight stage of one wavefront
-    constexpr int XI = MT * 8;                   // DMA instructions per A stage (2 rows each)
-    constexpr int XIW = XI / WAVES;              // ... per wavefront
-    static_assert(XI % WAVES == 0, "A-tile DMA instructions must divide evenly over the wavefronts");
-    constexpr int kLoadsPerChunk = NTW * 2 + XIW + NTW; // vm ops one wavefront issues per chunk
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
-    unsigned char* xring = smem + kLutBytes;                 // [2][XB]
-    unsigned char* wring = xring + 2 * XB;                   // [WAVES][2][WB]
-    float* code2 = reinterpret_cast<float*>(wring + WAVES * 2 * WB);
-
-    const int tid = threadIdx.x;
-    const gfloat_ptr tbl = (gfloat_ptr)(p.code16 ? p.code16 : (p.quant_type == kNF4 ? kNF4Code : kFP4Code));
-    constexpr int TPE = WAVES / 4; // lanes cooperating on one table entry
-    const int entry = tid / TPE;
-    const float code_hi = tbl[entry >> 4];
-    const float code_lo = tbl[entry & 15];
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ln = lane & 15, lg = lane >> 4;
-    const int N = p.N, K = p.K, M = p.M;
-    const int m_base = blockIdx.z * (MT * 16);
-    const int colw = blockIdx.x * (WAVES * NTW * 16) + wave * (NTW * 16); // first column of this wavefront
-
-    const int chunks_total = K >> 8;
-    const int per_wg = (chunks_total + p.kslices - 1) / p.kslices;
-    const int c_begin = blockIdx.y * per_wg;
-    const int c_end = (c_begin + per_wg < chunks_total) ? c_begin + per_wg : chunks_total;
-
-    // ---- DMA sources
-    const int r8 = lane >> 3, s8 = lane & 7;
-    const uint8_t* wsrc[NTW][2];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            int row = colw + t * 16 + h * 8 + r8;
-            row = (row < N) ? row : N - 1;
-            wsrc[t][h] = p.B + static_cast<long>(row) * (K >> 1) + ((s8 ^ r8) << 4);
-        }
-    const T* __restrict__ A = static_cast<const T*>(p.A);
-    const T* xsrc[XIW];
-    const int r2 = lane >> 5, s32 = lane & 31;
-#pragma unroll
-    for (int i = 0; i < XIW; ++i) {
-        const int row = 2 * (wave + WAVES * i) + r2; // row of the A tile this lane fetches in instruction i
-        int m = m_base + row;
-        m = (m < M) ? m : M - 1;
-        xsrc[i] = A + static_cast<long>(m) * K + ((s32 ^ (row & 15)) << 3);
-    }
-    unsigned char* wbase = wring + wave * (2 * WB);
-
-    long rowk[NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-        int row = colw + t * 16 + ln;
-        row = (row < N) ? row : N - 1;
-        rowk[t] = static_cast<long>(row) * K;
-    }
-    const int rd_row = (ln >> 3) * 1024 + (ln & 7) * 128;
-    const int rd_sw = ln & 7;
-
-    struct Scales {
-        float s[NTW][4];
-    };
-    auto issue_chunk = [&](Scales& sc, int c, int buf) {
-#pragma unroll
-        for (int i = 0; i < XIW; ++i)
-            __builtin_amdgcn_global_load_lds((dma_src_t)(xsrc[i] + (static_cast<long>(c) << 8)),
-                                             (dma_dst_t)(xring + buf * XB + (wave + WAVES * i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                __builtin_amdgcn_global_load_lds((dma_src_t)(wsrc[t][h] + static_cast<long>(c) * 128),
-                                                 (dma_dst_t)(wbase + buf * WB + (t * 2 + h) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const long e = rowk[t] + (static_cast<long>(c) << 8);
-            if (p.bs_shift == 6 && !NESTED) {
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.absmax + (e >> 6));
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    sc.s[t][b] = s4[b];
-            } else if (p.bs_shift == 6) {
-                const uint32_t q4 = *reinterpret_cast<const uint32_t*>(p.absmax8 + (e >> 6));
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    sc.s[t][b] = __builtin_bit_cast(float, (q4 >> (8 * b)) & 0xFFu);
-            } else {
-                // blocksize >= 128: one scale per 2, 4 or more 64-k blocks; a single (uniform-shape) load
-                // per block index keeps the vm-op count per chunk equal to kLoadsPerChunk only for
-                // blocksize 64, so larger blocksizes use the conservative wait below
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const long q = (e + b * 64) >> p.bs_shift;
-                    if constexpr (NESTED)
-                        sc.s[t][b] = __builtin_bit_cast(float, static_cast<uint32_t>(p.absmax8[q]));
-                    else
-                        sc.s[t][b] = p.absmax[q];
-                }
-            }
-        }
-    };
-
-    f32x4 acc[MT][NTW];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-            acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    Scales sc_cur, sc_nxt;
-    if (c_begin < c_end)
-        issue_chunk(sc_cur, c_begin, 0);
-    {
-        const uint32_t pr = Mma<T>::pack(code_hi, code_lo);
-        const u32x4 v = {pr, pr, pr, pr};
-        // chunk order rotated by the entry's index in the wavefront: conflict-free ds_write_b128 (see gemv4.hip)
-        u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * 32]) + (tid % TPE) * (8 / TPE);
-        constexpr int NCH = 8 / TPE;
-        const int rot = (NCH >= 8) ? (tid & 63) : (tid & 63) * NCH / 8; // distinct bank quads within 8 lanes
-#pragma unroll
-        for (int j = 0; j < NCH; ++j)
-            dst[(j + rot) % NCH] = v;
-    }
-    float offset = 0.0f;
-    if constexpr (NESTED) {
-        if (tid < 256)
-            code2[tid] = p.absmax_code[tid];
-        offset = p.absmax_offset[0];
-    }
-    const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
-    const bool fixed_count = (p.bs_shift == 6);
-
-    for (int c = c_begin; c < c_end; ++c) {
-        const int buf = (c - c_begin) & 1;
-        const bool more = c + 1 < c_end;
-        if (more)
-            issue_chunk(sc_nxt, c + 1, buf ^ 1);
-        // chunk c (DMAs and scale loads of this wavefront) has landed; chunk c+1 may stay in flight
-        if (more && fixed_count)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoadsPerChunk) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier(); // every wavefront's part of the A tile (and the table, first time) is in LDS
-        const int zsh = opaque_zero();
-
-        const unsigned char* xb = xring + buf * XB;
-        const unsigned char* wb = wbase + buf * WB;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            u32x4 af[MT][2];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int idx = (b * 8 + lg * 2 + j) ^ ln;
-                    af[mt][j] = *reinterpret_cast<const u32x4*>(xb + (mt * 16 + ln) * 512 + (idx << 4));
-                }
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                const int cidx = (2 * b + (lg >> 1)) ^ rd_sw;
-                const u32x2 w2 = *reinterpret_cast<const u32x2*>(wb + t * 2048 + rd_row + (cidx << 4) + (lg & 1) * 8);
-                u32x4 bf[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const uint32_t w = w2[j];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        bf[j][q] = lut[(((w >> (8 * q + zsh)) & 0xFFu) << 5) + lane_slot];
-                }
-                float scale;
-                if constexpr (NESTED) {
-                    const long q = (rowk[t] + (static_cast<long>(c) << 8) + b * 64) >> p.bs_shift;
-                    const uint32_t q8 = __builtin_bit_cast(uint32_t, sc_cur.s[t][b]);
-                    scale = __fadd_rn(__fmul_rn(code2[q8], p.absmax[q >> 8]), offset);
-                } else {
-                    scale = sc_cur.s[t][b];
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    f32x4 part = Mma<T>::run(af[mt][0], bf[0], f32x4{0.f, 0.f, 0.f, 0.f});
-                    part = Mma<T>::run(af[mt][1], bf[1], part);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        acc[mt][t][r] = fmaf(scale, part[r], acc[mt][t][r]);
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier(); // everybody is done reading stage `buf`: it may be refilled next iteration
-        sc_cur = sc_nxt;
-    }
-
-    T* __restrict__ out = static_cast<T*>(p.out);
-    const T* __restrict__ bias = static_cast<const T*>(p.bias);
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-        const int col = colw + t * 16 + ln;
-        if (col >= N)
-            continue;
-        const float bv = (bias && p.kslices == 1) ? static_cast<float>(bias[col]) : 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m_base + mt * 16 + lg * 4 + r;
-                if (m >= M)
-                    continue;
-                const long o = static_cast<long>(m) * N + col;
-                if (p.kslices == 1)
-                    out[o] = static_cast<T>(acc[mt][t][r] + bv);
-                else
-                    p.ws[static_cast<long>(blockIdx.y) * M * N + o] = acc[mt][t][r];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// gemm4_mfma_ring_kernel (v4b): v4 with a D-deep LDS ring of 128-k chunks and ONE barrier per chunk.
-// v4's two-stage double buffer exposes a full DMA latency per chunk (measured ~3 us per 256-k chunk at
-// M = 64); here D-1 chunks are in flight while one is consumed. Per 128-k chunk and wavefront:
-// MT A-tile DMAs (4 rows x 256 B each), 2 weight DMAs (16 rows x 64 B each, one per n-tile) and one
-// scale load per n-tile (two for nested absmax) - a fixed count, so the consumer waits with a counted
-// vmcnt that leaves the younger chunks in flight across the barrier. Source-side swizzles:
-// A chunk s ^ (row & 15) (256-B rows), weight chunk s ^ ((row >> 2) & 3) (64-B rows); both make the
-// fragment reads conflict-free.
-// ---------------------------------------------------------------------------------------------
-template <typename T, int MT, bool NESTED, int D>
-__global__ __launch_bounds__(256) void gemm4_mfma_ring_kernel(const GemmArgs p) {
-    constexpr int NTW = 2;
-    constexpr int kLutBytes = 256 * 32 * 4;
-    constexpr int XB = MT * 16 * 256;  // bytes of one A stage (128 k)
-    constexpr int WB = NTW * 1024;     // bytes of one weight stage of one wavefront
-    constexpr int kL = MT + NTW + NTW * (NESTED ? 2 : 1); // vm ops per wavefront per chunk
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
-    unsigned char* xring = smem + kLutBytes;    // [D][XB]
-    unsigned char* wring = xring + D * XB;      // [4 waves][D][WB]
-    float* code2 = reinterpret_cast<float*>(wring + 4 * D * WB);
-
-    const int tid = threadIdx.x;
-    const gfloat_ptr tbl = (gfloat_ptr)(p.code16 ? p.code16 : (p.quant_type == kNF4 ? kNF4Code : kFP4Code));
-    const float code_hi = tbl[tid >> 4];
-    const float code_lo = tbl[tid & 15];
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ln = lane & 15, lg = lane >> 4;
-    const int N = p.N, K = p.K, M = p.M;
-    const int m_base = blockIdx.z * (MT * 16);
-    const int colw = blockIdx.x * 128 + wave * (NTW * 16);
-
-    // chunk = 128 k; K slices are handed out in units of 256 k (two chunks)
-    const int groups = K >> 8;
-    const int per_wg = (groups + p.kslices - 1) / p.kslices;
-    const int c_begin = blockIdx.y * per_wg * 2;
-    const int c_last = (blockIdx.y + 1) * per_wg * 2;
-    const int c_end = (c_last < 2 * groups) ? c_last : 2 * groups;
-
-    // ---- DMA sources
-    const T* __restrict__ A = static_cast<const T*>(p.A);
-    const T* xsrc[MT];
-    {
-        const int r4 = lane >> 4, s16 = lane & 15;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int row = 4 * (wave + 4 * i) + r4;
-            int m = m_base + row;
-            m = (m < M) ? m : M - 1;
-            xsrc[i] = A + static_cast<long>(m) * K + ((s16 ^ (row & 15)) << 3);
-        }
-    }
-    const uint8_t* wsrc[NTW];
-    {
-        const int r16 = lane >> 2, s4 = lane & 3;
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            int row = colw + t * 16 + r16;
-            row = (row < N) ? row : N - 1;
-            wsrc[t] = p.B + static_cast<long>(row) * (K >> 1) + ((s4 ^ ((r16 >> 2) & 3)) << 4);
-        }
-    }
-    unsigned char* wbase = wring + wave * (D * WB);
-    long rowk[NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-        int row = colw + t * 16 + ln;
-        row = (row < N) ? row : N - 1;
-        rowk[t] = static_cast<long>(row) * K;
-    }
-    const int w_rd = ln * 64 + (lg & 1) * 8;
-    const int w_sw = (ln >> 2) & 3;
-    const bool bs64 = (p.bs_shift == 6);
-
-    struct Scales {
-        float s[NTW][2];
-        float s2[NTW]; // nested: second-level absmax of this chunk
-    };
-    auto issue_chunk = [&](Scales& sc, int c, int buf) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-            __builtin_amdgcn_global_load_lds((dma_src_t)(xsrc[i] + (static_cast<long>(c) << 7)),
-                                             (dma_dst_t)(xring + buf * XB + (wave + 4 * i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-            __builtin_amdgcn_global_load_lds((dma_src_t)(wsrc[t] + static_cast<long>(c) * 64),
-                                             (dma_dst_t)(wbase + buf * WB + t * 1024), 16, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const long e = rowk[t] + (static_cast<long>(c) << 7);
-            const long q = e >> p.bs_shift;
-            if constexpr (NESTED) {
-                if (bs64) {
-                    const uint32_t q2 = *reinterpret_cast<const uint16_t*>(p.absmax8 + q);
-                    sc.s[t][0] = __builtin_bit_cast(float, q2 & 0xFFu);
-                    sc.s[t][1] = __builtin_bit_cast(float, q2 >> 8);
-                } else {
-                    const uint32_t q1 = p.absmax8[q];
-                    sc.s[t][0] = sc.s[t][1] = __builtin_bit_cast(float, q1);
-                }
-                sc.s2[t] = p.absmax[q >> 8];
-            } else {
-                if (bs64) {
-                    using f32x2 = __attribute__((ext_vector_type(2))) float;
-                    const f32x2 v = *reinterpret_cast<const f32x2*>(p.absmax + q);
-                    sc.s[t][0] = v[0];
-                    sc.s[t][1] = v[1];
-                } else {
-                    sc.s[t][0] = sc.s[t][1] = p.absmax[q];
-                }
-            }
-        }
-    };
-
-    f32x4 acc[MT][NTW];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-            acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    Scales sc[D];
-#pragma unroll
-    for (int d = 0; d < D - 1; ++d)
-        if (c_begin + d < c_end)
-            issue_chunk(sc[d], c_begin + d, d);
-    {
-        const uint32_t pr = Mma<T>::pack(code_hi, code_lo);
-        const u32x4 v = {pr, pr, pr, pr};
-        u32x4* dst = reinterpret_cast<u32x4*>(&lut[tid * 32]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            dst[(j + tid) & 7] = v; // rotated chunk order: conflict-free ds_write_b128 (see gemv4.hip)
-    }
-    float offset = 0.0f;
-    if constexpr (NESTED) {
-        code2[tid] = p.absmax_code[tid];
-        offset = p.absmax_offset[0];
-    }
-    const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
-
-    for (int c0 = c_begin; c0 < c_end; c0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int c = c0 + d;
-            if (c >= c_end)
-                break;
-            // chunk c of this wavefront has landed; up to D-2 younger chunks stay in flight
-            const int younger = (c_end - 1 - c < D - 2) ? c_end - 1 - c : D - 2;
-            if (younger >= 2)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kL) : "memory");
-            else if (younger == 1)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kL) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier(); // chunk c complete for everybody; everybody done with chunk c-1
-            if (c + D - 1 < c_end)
-                issue_chunk(sc[(d + D - 1) % D], c + D - 1, (d + D - 1) % D);
-            const int zsh = opaque_zero();
-
-            const unsigned char* xb = xring + d * XB;
-            const unsigned char* wb = wbase + d * WB;
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                u32x4 af[MT][2];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int idx = (b * 8 + lg * 2 + j) ^ ln;
-                        af[mt][j] = *reinterpret_cast<const u32x4*>(xb + (mt * 16 + ln) * 256 + (idx << 4));
-                    }
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) {
-                    const int cidx = (2 * b + (lg >> 1)) ^ w_sw;
-                    const u32x2 w2 = *reinterpret_cast<const u32x2*>(wb + t * 1024 + w_rd + (cidx << 4));
-                    u32x4 bf[2];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const uint32_t w = w2[j];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            bf[j][q] = lut[(((w >> (8 * q + zsh)) & 0xFFu) << 5) + lane_slot];
-                    }
-                    float scale;
-                    if constexpr (NESTED) {
-                        const uint32_t q8 = __builtin_bit_cast(uint32_t, sc[d].s[t][b]);
-                        scale = __fadd_rn(__fmul_rn(code2[q8], sc[d].s2[t]), offset);
-                    } else {
-                        scale = sc[d].s[t][b];
-                    }
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        f32x4 part = Mma<T>::run(af[mt][0], bf[0], f32x4{0.f, 0.f, 0.f, 0.f});
-                        part = Mma<T>::run(af[mt][1], bf[1], part);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            acc[mt][t][r] = fmaf(scale, part[r], acc[mt][t][r]);
-                    }
-                }
-            }
-        }
-    }
-
-    T* __restrict__ out = static_cast<T*>(p.out);
-    const T* __restrict__ bias = static_cast<const T*>(p.bias);
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-        const int col = colw + t * 16 + ln;
-        if (col >= N)
-            continue;
-        const float bv = (bias && p.kslices == 1) ? static_cast<float>(bias[col]) : 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m_base + mt * 16 + lg * 4 + r;
-                if (m >= M)
-                    continue;
-                const long o = static_cast<long>(m) * N + col;
-                if (p.kslices == 1)
-                    out[o] = static_cast<T>(acc[mt][t][r] + bv);
-                else
-                    p.ws[static_cast<long>(blockIdx.y) * M * N + o] = acc[mt][t][r];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// gemm4_mfma_pc_kernel (v5, "producer / consumers"). What v4 gets wrong (measured ~3 us per 256-k chunk
-// at M = 64 against ~1.3 us of LDS traffic): its two-stage double buffer keeps ONE chunk (16 KiB per CU)
-// of weights in flight, so every chunk eats most of an HBM round trip, and because vmcnt retires in
+// gemm4_mfma_pc_kernel ("v5" in profiles/, "producer / consumers"). What the retired two-stage tiled kernel
+// ("v4") got wrong (measured ~3 us per 256-k chunk at M = 64 against ~1.3 us of LDS traffic): its double
+// buffer kept ONE chunk (16 KiB per CU) of weights in flight, so every chunk eats most of an HBM round trip, and because vmcnt retires in
 // order, the short-distance A prefetch of a wavefront forces all of its older weight DMAs to complete.
 // Here the two streams are decoupled by giving them to different wavefronts (vmcnt is per wavefront):
 //   * CW consumer wavefronts each own NTW*16 weight columns and a PRIVATE D-deep LDS ring of 256-k
@@ -1136,11 +420,11 @@ __global__ __launch_bounds__(256) void gemm4_mfma_ring_kernel(const GemmArgs p) 
 //     right after the wavefront has consumed it: no barrier is involved in the weight stream at all and
 //     D-1 chunks per wavefront stay in flight across everything else.
 //   * one producer wavefront streams the shared A tile [MT*16][256] into a two-stage buffer (source-side
-//     XOR swizzle, conflict-free ds_read_b128 fragment reads as in v4) and is the only one that waits
+//     XOR swizzle, conflict-free ds_read_b128 fragment reads) and is the only one that waits
 //     for it. ONE s_barrier per chunk: arriving at barrier k the producer guarantees A(k) has landed and
 //     the consumers guarantee they are done with A(k-1), whose stage the producer refills right after.
 //   * an A fragment is read once per (m-tile, k-step) and used for the wavefront's NTW n-tiles.
-// K slices across workgroups / slab finalize exactly as v4.
+// K slices across workgroups write fp32 slabs; gemm4_finalize_kernel adds them.
 // ---------------------------------------------------------------------------------------------
 template <int kCount> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kCount) : "memory");
@@ -1572,79 +856,60 @@ float* get_internal_workspace(size_t bytes, hipStream_t stream) {
 }
 
 struct Plan {
-    int mt, nt, ks;
-    int cfg; // v2 register-ring kernel: 0: 4 waves x 4 blocks, 1: 8 x 8, 2: 16 x 4, 3: 8 x 4, 4: 4 x 8
-             // v3 LDS-DMA kernel (NT = 1): 5: 16 waves, 6: 8 waves;  v4 tiled LDS-DMA kernel (128 columns): 7;
-             // v4b ring kernel (128 columns, 128-k chunks, 4-deep ring): 8
-             // v4 with 8 wavefronts: 9: 8 x 1 n-tile (128 columns), 10: 8 x 2 n-tiles (256 columns)
-             // v5 producer/consumer kernel: 11: 8 consumers x 1 n-tile (128 columns), 12: 4 x 2 (128), 13: 8 x 2 (256),
+    int mt, ks;
+    int cfg; // LDS-DMA kernel (16 columns): 5: 16 wavefronts, 6: 8 wavefronts
+             // producer/consumer kernel: 11: 8 consumers x 1 n-tile (128 columns), 12: 4 x 2 (128), 13: 8 x 2 (256),
              // 14: 4 x 1 (64 columns)
+             // (0-4 and 7-10 were the register-ring and two-stage tiled generations: retired, their sweep record is
+             // profiles/r1_sweep_mfma_variants.txt)
 };
 
-constexpr int kCfgWaves[15] = {4, 8, 16, 8, 4, 16, 8, 1, 1, 1, 1, 1, 1, 1, 1};
-constexpr int kCfgCols[15] = {0, 0, 0, 0, 0, 16, 16, 128, 128, 128, 256, 128, 128, 256, 64};
+constexpr bool cfg_is_dma(int cfg) { return cfg == 5 || cfg == 6; }
+constexpr bool cfg_is_pc(int cfg) { return cfg >= 11 && cfg <= 14; }
+constexpr int cfg_cols(int cfg) { return cfg == 13 ? 256 : cfg == 14 ? 64 : cfg_is_pc(cfg) ? 128 : 16; }
+constexpr int cfg_waves(int cfg) { return cfg == 5 ? 16 : 8; } // wavefronts that split a workgroup's K range (LDS-DMA kernel)
 
-// Tile shape and K-slice count for a problem: a pure function of (M, N, K) and the tuning knobs,
+// Kernel, tile shape and K-slice count for a problem: a pure function of (M, N, K) and the tuning knobs,
 // shared by the launch and by the workspace-size query.
 Plan make_plan(int M, int N, int K) {
     Plan pl;
     pl.mt = (M > 48) ? 4 : (M > 32) ? 3 : (M > 16) ? 2 : 1;
-    int nt = g_mfma_knob0;
-    if (nt == 0)
-        nt = (pl.mt >= 3) ? 2 : 1;
-    if (nt != 1 && nt != 2 && nt != 4)
-        nt = 1;
-    if (pl.mt >= 3 && nt == 4)
-        nt = 2;
-    pl.nt = nt;
     const int groups = K / kKC; // units of 4 blocks
-    int gx = (N + 16 * nt - 1) / (16 * nt);
     const int gz = (M + pl.mt * 16 - 1) / (pl.mt * 16);
     int ks = g_mfma_knob1 % 100;
     int cfg = g_mfma_knob1 / 100;
-    if (g_mfma_knob1 == 0) {
-        // Calibrated on MI355X (profiles/r1_sweep_mfma_variants.txt): the tiled kernel (A shared through
-        // LDS by 128 columns) wins once the A tile is big (M > 32) or the weight matrix is large; the
+    if (!cfg_is_dma(cfg) && !cfg_is_pc(cfg)) {
+        // Calibrated on MI355X (profiles/r1_sweep_mfma_variants.txt): the producer/consumer kernel (A shared
+        // through LDS by 64-128 columns) wins once the A tile is big (M > 16) or the weight matrix is large; the
         // 16-column LDS-DMA kernel wins for small batches on small matrices, where a second (finalize)
         // launch would cost more than it saves.
         const bool big = static_cast<long>(N) * K >= (32L << 20) && N >= 1024;
         if (pl.mt >= 2 || big) {
-            cfg = 11; // producer/consumer kernel: 8 consumer wavefronts x 16 columns share one A tile
+            cfg = 11; // 8 consumer wavefronts x 16 columns share one A tile
             if (pl.mt >= 3 && !big)
                 cfg = 14; // small matrix, tall tile: 64-column workgroups need half the K slices, i.e. half the
                           // slab traffic (4096^2 M = 64: 14.6 vs 15.4 us); on large matrices 128 columns win
-            pl.nt = nt = 1;
         } else {
-            cfg = (pl.mt == 1) ? 5 : 6; // 16 wavefronts x 1 chunk; 8 x 2 measured +-1 % on fp32 absmax, 5 % behind on nested bs 128
-            pl.nt = nt = 1;
-            gx = (N + 15) / 16;
+            cfg = 5; // 16 wavefronts x 1 chunk; 8 x 2 measured +-1 % on fp32 absmax, 5 % behind on nested bs 128
         }
     }
-    if (cfg < 0 || cfg > 14)
-        cfg = 0;
     if (cfg == 13 && pl.mt > 2)
         cfg = 11; // 8 x 2 consumers with a > 32-row A tile do not fit the 160 KiB of LDS
-    if ((cfg == 5 || cfg == 6) && (nt != 1 || pl.mt > 2))
-        cfg = 0;
+    if (cfg_is_dma(cfg) && pl.mt > 2)
+        cfg = 11; // the LDS-DMA kernel holds at most a 32-row A tile
     if (cfg == 5 && pl.mt != 1)
         cfg = 6;
-    if (cfg == 10 && pl.mt == 4)
-        cfg = 9; // 8 x 2 tiles with a 64-row A tile would need 161 KiB of LDS
-    if (cfg >= 1 && cfg <= 4)
-        cfg = 0; // retired v2 geometries
     pl.cfg = cfg;
-    const int kWaves = kCfgWaves[cfg];
-    if (cfg >= 7)
-        gx = (N + kCfgCols[cfg] - 1) / kCfgCols[cfg];
+    const int gx = (N + cfg_cols(cfg) - 1) / cfg_cols(cfg);
     if (ks == 0) {
-        if (cfg >= 7)
+        if (cfg_is_pc(cfg))
             ks = 256 / (gx * gz); // these kernels run one workgroup per CU: fill the 256 CUs but never spill into
                                   // a second round (11008 x 4096: 3 slices = 258 workgroups measured 18.8 us, 2 slices 15.2)
         else
             ks = (gx * gz >= 192) ? 1 : (256 + gx * gz - 1) / (gx * gz); // fill the 256 CUs once
     }
-    int max_ks = groups / kWaves > 0 ? groups / kWaves : 1; // keep >= 1 group per wavefront
-    if (cfg >= 7)
+    int max_ks = groups / cfg_waves(cfg) > 0 ? groups / cfg_waves(cfg) : 1; // keep >= 1 group per wavefront
+    if (cfg_is_pc(cfg))
         max_ks = groups / 2 > 0 ? groups / 2 : 1;           // >= 2 chunks per workgroup so the ring has something to overlap
     if (ks > max_ks)
         ks = max_ks;
@@ -1653,17 +918,6 @@ Plan make_plan(int M, int N, int K) {
     const int per = (groups + ks - 1) / ks;
     pl.ks = (groups + per - 1) / per; // every slice non-empty
     return pl;
-}
-
-template <typename T, int MT, int NT, int WAVES, int DEPTH> void launch_mfma_cfg(GemmArgs& p, hipStream_t stream) {
-    const int gx = (p.N + 16 * NT - 1) / (16 * NT);
-    const int gz = (p.M + MT * 16 - 1) / (MT * 16);
-    const size_t smem = 256 * 32 * 4 + static_cast<size_t>(WAVES - 1) * MT * NT * 256 * 4 + 1024;
-    dim3 grid(gx, p.kslices, gz);
-    auto kern = p.absmax8 ? gemm4_mfma_kernel<T, MT, NT, true, WAVES, DEPTH> : gemm4_mfma_kernel<T, MT, NT, false, WAVES, DEPTH>;
-    static LdsLimit lds_limit[2];
-    ensure_dynamic_lds(lds_limit[p.absmax8 ? 1 : 0], reinterpret_cast<const void*>(kern), smem);
-    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p);
 }
 
 template <typename T, int MT, int WAVES, int AROWS> void launch_mfma_dma_one(GemmArgs& p, hipStream_t stream) {
@@ -1688,30 +942,6 @@ template <typename T, int MT, int WAVES> void launch_mfma_dma(GemmArgs& p, hipSt
             return launch_mfma_dma_one<T, MT, WAVES, 8>(p, stream); // rows 8..15 by register loads (hybrid)
     }
     launch_mfma_dma_one<T, MT, WAVES, 0>(p, stream);
-}
-
-template <typename T, int MT, int WAVES, int NTW> void launch_mfma_tile(GemmArgs& p, hipStream_t stream) {
-    constexpr int BN = WAVES * NTW * 16;
-    const int gx = (p.N + BN - 1) / BN;
-    const int gz = (p.M + MT * 16 - 1) / (MT * 16);
-    const size_t smem = 256 * 32 * 4 + 2 * static_cast<size_t>(MT) * 16 * 512 + static_cast<size_t>(WAVES) * 2 * NTW * 2048 + 1024;
-    dim3 grid(gx, p.kslices, gz);
-    auto kern = p.absmax8 ? gemm4_mfma_tile_kernel<T, MT, true, WAVES, NTW> : gemm4_mfma_tile_kernel<T, MT, false, WAVES, NTW>;
-    static LdsLimit lds_limit[2];
-    ensure_dynamic_lds(lds_limit[p.absmax8 ? 1 : 0], reinterpret_cast<const void*>(kern), smem);
-    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p);
-}
-
-template <typename T, int MT> void launch_mfma_ring(GemmArgs& p, hipStream_t stream) {
-    constexpr int D = 4;
-    const int gx = (p.N + 127) / 128;
-    const int gz = (p.M + MT * 16 - 1) / (MT * 16);
-    const size_t smem = 256 * 32 * 4 + static_cast<size_t>(D) * MT * 16 * 256 + 4 * D * 2048 + 1024;
-    dim3 grid(gx, p.kslices, gz);
-    auto kern = p.absmax8 ? gemm4_mfma_ring_kernel<T, MT, true, D> : gemm4_mfma_ring_kernel<T, MT, false, D>;
-    static LdsLimit lds_limit[2];
-    ensure_dynamic_lds(lds_limit[p.absmax8 ? 1 : 0], reinterpret_cast<const void*>(kern), smem);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
 }
 
 constexpr size_t pc_smem_bytes(int MT, int CW, int NTW, int D, bool nested) {
@@ -1749,43 +979,26 @@ template <typename T, int MT, int CW, int NTW> void launch_mfma_pc(GemmArgs& p, 
         launch_mfma_pc_one<T, MT, false, CW, NTW, pc_depth(MT, CW, NTW, false)>(p, stream);
 }
 
-template <typename T, int MT, int NT> void launch_mfma(GemmArgs& p, int cfg, hipStream_t stream) {
-    // v5 producer/consumer geometries. LDS: 32 KiB table + 2 x MT*8 KiB A stages + CW*D ring slots.
-    if (cfg == 11)
-        return launch_mfma_pc<T, MT, 8, 1>(p, stream);
+template <typename T, int MT> void launch_mfma(GemmArgs& p, int cfg, hipStream_t stream) {
+    // LDS-DMA kernel: make_plan() only selects it for MT <= 2
+    if constexpr (MT == 1) {
+        if (cfg == 5)
+            return launch_mfma_dma<T, MT, 16>(p, stream);
+    }
+    if constexpr (MT <= 2) {
+        if (cfg_is_dma(cfg))
+            return launch_mfma_dma<T, MT, 8>(p, stream);
+    }
+    // producer/consumer geometries. LDS: 32 KiB table + 2 x MT*8 KiB A stages + CW*D ring slots.
     if (cfg == 12)
         return launch_mfma_pc<T, MT, 4, 2>(p, stream);
     if (cfg == 14)
         return launch_mfma_pc<T, MT, 4, 1>(p, stream);
-    if (cfg == 13) {
-        if constexpr (pc_depth(MT, 8, 2, true) >= 2)
+    if constexpr (pc_depth(MT, 8, 2, true) >= 2) {
+        if (cfg == 13)
             return launch_mfma_pc<T, MT, 8, 2>(p, stream);
-        else
-            return launch_mfma_pc<T, MT, 8, 1>(p, stream);
     }
-    if (cfg == 8)
-        return launch_mfma_ring<T, MT>(p, stream);
-    if (cfg == 7)
-        return launch_mfma_tile<T, MT, 4, 2>(p, stream);
-    if (cfg == 9)
-        return launch_mfma_tile<T, MT, 8, 1>(p, stream);
-    if constexpr (MT <= 3) { // 8 x 2 tiles with a 64-row A tile would need 161 KiB of LDS
-        if (cfg == 10)
-            return launch_mfma_tile<T, MT, 8, 2>(p, stream);
-    }
-    if (cfg == 10)
-        return launch_mfma_tile<T, MT, 8, 1>(p, stream);
-    if constexpr (NT == 1 && MT <= 2) {
-        if constexpr (MT == 1) {
-            if (cfg == 5)
-                return launch_mfma_dma<T, MT, 16>(p, stream);
-        }
-        if (cfg == 5 || cfg == 6)
-            return launch_mfma_dma<T, MT, 8>(p, stream);
-    }
-    // (the 8- and 16-wavefront / depth-8 geometries of v2 were dropped after the sweeps: never faster, and
-    // several of them spilled registers)
-    return launch_mfma_cfg<T, MT, NT, 4, 4>(p, stream);
+    return launch_mfma_pc<T, MT, 8, 1>(p, stream); // cfg 11
 }
 
 template <typename T> void dispatch_mfma(GemmArgs& p, float* ws, size_t ws_bytes, hipStream_t stream) {
@@ -1807,17 +1020,20 @@ template <typename T> void dispatch_mfma(GemmArgs& p, float* ws, size_t ws_bytes
     }
     p.ws = ws;
     p.kslices = pl.ks;
-    const int mt = pl.mt, nt = pl.nt;
-
-#define BNB_MFMA_CASE(MTV, NTV)                                                                    \
-    if (mt == MTV && nt == NTV) {                                                                  \
-        launch_mfma<T, MTV, NTV>(p, pl.cfg, stream);                                               \
-    } else
-    BNB_MFMA_CASE(1, 1) BNB_MFMA_CASE(1, 2) BNB_MFMA_CASE(1, 4) BNB_MFMA_CASE(2, 1) BNB_MFMA_CASE(2, 2)
-    BNB_MFMA_CASE(2, 4) BNB_MFMA_CASE(3, 1) BNB_MFMA_CASE(3, 2) BNB_MFMA_CASE(4, 1) BNB_MFMA_CASE(4, 2) {
-        launch_mfma<T, 1, 1>(p, pl.cfg, stream);
+    switch (pl.mt) {
+    case 1:
+        launch_mfma<T, 1>(p, pl.cfg, stream);
+        break;
+    case 2:
+        launch_mfma<T, 2>(p, pl.cfg, stream);
+        break;
+    case 3:
+        launch_mfma<T, 3>(p, pl.cfg, stream);
+        break;
+    default:
+        launch_mfma<T, 4>(p, pl.cfg, stream);
+        break;
     }
-#undef BNB_MFMA_CASE
     BNB_CHECK_LAUNCH();
 
     if (pl.ks > 1) {

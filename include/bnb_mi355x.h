@@ -119,7 +119,8 @@ void bnb_mi355x_gemm_4bit(int kernel, int dtype, const void* A, const uint8_t* B
 size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N, int K, int blocksize);
 
 /* Tuning overrides for sweeps (0 = built-in heuristic): rows per wavefront and 2048-k segments per
- * iteration of the dot kernel; reserved knobs for the MFMA kernel. Not thread-safe; bench/test use only. */
+ * iteration of the dot kernel; MFMA kernels: knob0 = A-image variant bits of the LDS-DMA kernel, knob1 =
+ * 100 * cfg + K-slice count (cfg 5/6 LDS-DMA, 11-14 producer/consumer geometries). Not thread-safe; bench/test use only. */
 void bnb_mi355x_set_tuning(int dot_rows_per_wave, int dot_segments, int mfma_knob0, int mfma_knob1);
 
 /* Profiling only. dot_ablation: 0 = normal; 1..5 run ablated variants of the dot kernel (stream only /
@@ -129,7 +130,7 @@ void bnb_mi355x_set_tuning(int dot_rows_per_wave, int dot_segments, int mfma_kno
 void bnb_mi355x_set_debug(int dot_ablation, int dot_flags);
 
 /* Profiling only: when non-NULL, the producer/consumer MFMA kernel writes 16 s_memtime stamps per wavefront
- * (u64) into this device buffer (tools/timeline_pc.py); the v2 MFMA kernel writes 8. NULL switches it off. */
+ * (u64) into this device buffer (tools/timeline_pc.py); the LDS-DMA MFMA kernel writes 8 (tools/timeline_v3.py). NULL switches it off. */
 void bnb_mi355x_set_stamp_buffer(void* device_u64_buffer);
 
 /* Version / build identification: returns "bitsandbytes_amd <ver> gfx950". */

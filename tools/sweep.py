@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--dot-only", action="store_true")
     ap.add_argument("--mfma-only", action="store_true")
-    ap.add_argument("--cfgs", default="9,11,12,13", help="MFMA tile-kernel geometries to sweep (cfg codes)")
+    ap.add_argument("--cfgs", default="5,6,11,12,13,14", help="MFMA kernel geometries to sweep (cfg codes, see make_plan)")
     ap.add_argument("--ms", default="", help="comma list of M values for the MFMA sweep")
     ap.add_argument("--kss", default="2,4,8,16", help="K-slice counts to sweep")
     a = ap.parse_args()
@@ -121,7 +121,7 @@ def main():
     Ms = [1, 8, 16, 64] if a.quick else [1, 4, 8, 16, 32, 64]
     if a.ms:
         Ms = [int(v) for v in a.ms.split(",")]
-    names = {7: "tile", 8: "ring", 9: "t8x1", 10: "t8x2", 11: "pc8x1", 12: "pc4x2", 13: "pc8x2", 14: "pc4x1"}
+    names = {5: "dma16w", 6: "dma8w", 11: "pc8x1", 12: "pc4x2", 13: "pc8x2", 14: "pc4x1"}
     CFG = {int(c): names.get(int(c), f"cfg{c}") for c in a.cfgs.split(",")}
     KSS = tuple(int(v) for v in a.kss.split(","))
     for M in Ms:
@@ -132,24 +132,16 @@ def main():
         print(f"{'mfma':8s} {M:3d} {'auto':>14s} {tg:9.2f} {te:9.2f} {bytes_alg(M, N, K, bs) / tg / 1e3:11.1f} {2 * M * N * K / tg / 1e6:8.2f}")
         if a.quick:
             continue
-        for nt in (1, 2):
-            if mt >= 3 and nt == 4:
+        for cfg, cname in CFG.items():
+            dma = cfg in (5, 6)
+            if dma and (mt > 2 or (cfg == 5 and mt != 1)):
                 continue
-            for cfg, cname in CFG.items():
-                if cfg == 2 and not (mt == 1 and nt <= 2):
+            for ks in ((1, 2) if dma else KSS):
+                if dma and ks == 2 and N // 16 >= 192:
                     continue
-                if cfg in (1, 4) and mt * nt > 4:
-                    continue
-                if cfg in (5, 6) and (nt != 1 or mt > 2 or (cfg == 5 and mt != 1)):
-                    continue
-                for ks in (KSS if cfg >= 7 else (1, 2)):
-                    if cfg >= 7 and nt != 1:
-                        continue
-                    if cfg < 7 and ks == 2 and (N // (16 * nt)) >= 192:
-                        continue
-                    bnb.lib.bnb_mi355x_set_tuning(0, 0, nt, cfg * 100 + ks)
-                    tg, te = measure(layers, x, 2)
-                    print(f"{'mfma':8s} {M:3d} {f'nt{nt} {cname} ks{ks}':>14s} {tg:9.2f} {te:9.2f} {bytes_alg(M, N, K, bs) / tg / 1e3:11.1f} {2 * M * N * K / tg / 1e6:8.2f}")
+                bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, cfg * 100 + ks)
+                tg, te = measure(layers, x, 2)
+                print(f"{'mfma':8s} {M:3d} {f'{cname} ks{ks}':>14s} {tg:9.2f} {te:9.2f} {bytes_alg(M, N, K, bs) / tg / 1e3:11.1f} {2 * M * N * K / tg / 1e6:8.2f}")
     bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
     # standalone quantize / dequantize streams (C1 shapes)
     W = (torch.randn(4096, 4096, device="cuda") ).half()
