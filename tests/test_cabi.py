@@ -120,3 +120,53 @@ def test_no_kernel_spills_to_scratch():
     assert len(meta) > 100, f"expected the full kernel set, found {len(meta)}"
     spilled = [(n, s) for n, s, _ in meta if s != 0]
     assert not spilled, f"kernels using scratch: {spilled[:5]}"
+
+
+def test_launch_plan_workspace_query_is_pure_host_logic():
+    """bnb_mi355x_gemm_4bit_workspace_bytes runs make_plan() on the host (no GPU call): for every BASELINE
+    shape the split-K workspace is a whole number of fp32 [M, N] slabs, bounded by one slab per 512 k of K
+    (>= 2 chunks of 256 k per slice), zero where no MFMA split-K launch can happen, and the query is a pure
+    function (same answer twice)."""
+    from bitsandbytes_amd import cextension as ce
+
+    assert ce.lib
+    q = ce.lib.bnb_mi355x_gemm_4bit_workspace_bytes
+    BF16 = 2
+    shapes = [(4096, 4096), (8192, 8192), (11008, 4096), (4096, 11008), (1376, 4096), (512, 11008), (128, 512),
+              (1000, 2816)]
+    for N, K in shapes:
+        for M in (1, 2, 3, 4, 8, 16, 17, 32, 33, 48, 49, 64, 100, 128):
+            for kernel in (0, 2):
+                w = q(kernel, BF16, M, N, K, 64)
+                assert w == q(kernel, BF16, M, N, K, 64)
+                slab = M * N * 4
+                assert w % slab == 0, (M, N, K, w)
+                ks = w // slab
+                assert ks == 0 or 2 <= ks <= max(2, K // 512), (M, N, K, ks)
+                if kernel == 0 and M <= 2:
+                    assert w == 0, "M <= 2 runs the dot kernel: no workspace"
+        assert q(1, BF16, 64, N, K, 64) == 0, "explicit dot kernel never needs a workspace"
+        assert q(0, 0, 64, N, K, 64) == 0, "fp32 activations never take the MFMA path"
+        assert q(0, BF16, 64, N, K, 32) == 0, "blocksize 32 is outside the MFMA kernels' preconditions"
+    # headline shape: single-launch plans (no finalize pass) up to M = 16, split-K above
+    assert q(0, BF16, 16, 4096, 4096, 64) == 0
+    assert q(0, BF16, 64, 4096, 4096, 64) > 0
+    assert q(0, BF16, 64, 4096, 4100, 64) == 0, "K % 256 != 0 falls back to the dot kernel"
+
+
+def test_bench_contract_flags_and_algorithmic_bytes():
+    """bench.py keeps the driver's contract (--gpus/--steps/--warmup, defaults that finish in minutes) and
+    prices a step with SURVEY section 8(d)'s algorithmic-byte formula."""
+    import subprocess
+    import sys
+
+    import bench
+
+    assert bench.algorithmic_bytes(1, 4096, 4096, 64) == 9_453_568
+    assert bench.algorithmic_bytes(64, 8192, 8192, 64) == 33_554_432 + 4_194_304 + 2 * 1_048_576
+    assert bench.HBM_PEAK_GBS == 8000.0 and bench.LAYERS * bench.algorithmic_bytes(1, 4096, 4096, 64) > 256 * 2**20
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in out.stdout
