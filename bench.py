@@ -86,7 +86,7 @@ def cpu_baseline(M, N, K, blocksize, quant_type):
         dt = time.perf_counter() - t0
         if (iters >= 20 and dt > 10.0) or dt > 30.0:  # a bounded ~10 s sample
             break
-    return {
+    out = {
         "value": round(nbytes * iters / dt / 1e9, 3),
         "unit": "GB/s",
         "cores": cores,
@@ -94,6 +94,33 @@ def cpu_baseline(M, N, K, blocksize, quant_type):
         "ms_per_step": round(dt / iters * 1e3, 4),
         "sample": f"{iters} forward passes of the same M={M} N=K={N} workload in {dt:.1f} s; {what}",
     }
+    # the other two CPU legs SURVEY section 8(d) lists beside the fused gemv, each a bounded ~2 s sample
+    def timed(fn, budget=2.0):
+        fn()
+        n, t0 = 0, time.perf_counter()
+        while n < 3 or time.perf_counter() - t0 < budget:
+            fn()
+            n += 1
+        return (time.perf_counter() - t0) / n * 1e3, n
+
+    try:
+        if O.ref_lib_usable():
+            deq = lambda: torch.nn.functional.linear(  # noqa: E731
+                x, O.ref_dequantize_4bit(q, am, blocksize, quant_type, (N, K), torch.bfloat16))
+            deq_kind = "reference dequantizeBlockwise4bitCpu (csrc/cpu_ops.cpp:304-434) + torch F.linear"
+        else:
+            deq = lambda: torch.nn.functional.linear(  # noqa: E731
+                x, O.dequantize_4bit(q, am, blocksize, quant_type, (N, K), torch.bfloat16))
+            deq_kind = "oracle dequantize_4bit + torch F.linear"
+        ms, n = timed(deq)
+        out["unfused_dequantize_linear"] = {"ms_per_step": round(ms, 3), "iters": n, "what": deq_kind,
+                                            "torch_threads": torch.get_num_threads()}
+        ms, n = timed(lambda: O.quantize_4bit(W, blocksize, quant_type))
+        out["quantize_4bit"] = {"ms_per_call": round(ms, 3), "iters": n, "cores": 1,
+                                "what": f"oracle scalar port of backends/default/ops.py:225-259 on a {N}x{K} bf16 weight"}
+    except Exception as exc:  # informational
+        out["other_legs_error"] = f"{type(exc).__name__}: {exc}"[:200]
+    return out
 
 
 def pmc_traffic(extra_args, kernel_substr="gemv4_dot_kernel", timeout_s=90):
