@@ -31,7 +31,8 @@
 namespace bnb {
 
 int g_dot_ablate = 0; // profiling only: see the ablation bits of DotFlags
-int g_dot_flags = 0;  // sweeps: 4 = force 512-thread workgroups, 128 = activations per wavefront instead of LDS (0 = default)
+int g_dot_flags = 0;  // sweeps (0 = default): 32 = force the 32-copy table, 64 = 256-thread workgroups, 128 = activations
+                      // per wavefront instead of LDS (M = 1 only), bits 8..15 = KiB of LDS padding (occupancy experiments)
 unsigned long long* g_dbg_buf = nullptr; // profiling only: device buffer for s_memtime stamps
 
 // Tuning knobs (overridable for sweeps through bnb_mi355x_set_tuning; see c_api.hip).
