@@ -86,6 +86,69 @@ def create_dynamic_map(signed: bool = True, max_exponent_bits: int = 7, total_bi
     return torch.tensor(values, dtype=torch.float32)
 
 
+def _pad_code_with_zeros(sorted_values: list) -> list:
+    """A code with fewer than 256 levels is stored in 256 entries: the spare entries are zeros placed in the
+    middle of the ascending list (between its lower and upper halves), as the reference's constructors do."""
+    gap = 256 - len(sorted_values)
+    half = len(sorted_values) // 2
+    return sorted_values[:half] + [0.0] * gap + sorted_values[half:]
+
+
+def create_linear_map(signed: bool = True, total_bits: int = 8, add_zero: bool = True) -> Tensor:
+    """Uniform code on [-1, 1] (or [0, 1]): ``2**total_bits`` levels, one fewer for a signed code that has to
+    contain an exact zero. Same tensor as reference functional.py:150-166."""
+    levels = 2**total_bits
+    if signed and (add_zero or total_bits < 8):
+        levels -= 1  # an odd number of levels puts one of them exactly on zero
+    values = torch.linspace(-1.0 if signed else 0.0, 1.0, levels)
+    if levels == 256:
+        return values
+    return torch.tensor(_pad_code_with_zeros(values.tolist()), dtype=torch.float32)
+
+
+def create_fp8_map(signed: bool = True, exponent_bits: int = 5, precision_bits: int = 2, total_bits: int = 8) -> Tensor:
+    """Code of a miniature floating-point format: every (exponent field E, mantissa field m) pair, with
+    bias ``2**(exponent_bits - 1)``, subnormals at E = 0, both signs when ``signed``; normalised to max 1 and
+    zero-padded to 256 entries. Same tensor as reference functional.py:227-293 (including its exponent
+    convention, under which larger E means a smaller magnitude - irrelevant after sorting and normalising)."""
+    if exponent_bits + precision_bits != total_bits - (1 if signed else 0):
+        raise AssertionError("exponent_bits + precision_bits (+ sign) must equal total_bits")
+    bias = 2 ** (exponent_bits - 1)
+    values: list[float] = []
+    for e_field in range(2**exponent_bits):
+        for m_field in range(2**precision_bits):
+            fraction = m_field / 2**precision_bits
+            if e_field == 0:
+                magnitude = fraction * 2.0**-bias
+            else:
+                magnitude = (1.0 + fraction) * 2.0 ** -(e_field - bias - 1)
+            values.append(magnitude)
+            if signed:
+                values.append(-magnitude)
+    values.extend([0.0] * (256 - len(values)))
+    values.sort()
+    code = torch.tensor(values, dtype=torch.float32)
+    return code / code.max()
+
+
+def create_normal_map(offset: float = 0.9677083, use_extra_value: bool = True) -> Tensor:
+    """NormalFloat code (the construction NF4's 16 constants come from, QLoRA appendix): quantiles of N(0, 1)
+    at evenly spaced probabilities between ``offset`` and 1/2 on the positive side (8 of them, or 7 without the
+    extra value) and 7 mirrored ones on the negative side, plus zero, normalised to [-1, 1] and stored sorted in
+    256 entries. Same tensor as reference functional.py:169-224; needs scipy."""
+    try:
+        from scipy.stats import norm
+    except ImportError as exc:  # same failure mode as the reference
+        raise ImportError("Scipy is required for `create_normal_map`.") from exc
+
+    n_pos = 8 if use_extra_value else 7
+    positive = norm.ppf(torch.linspace(offset, 0.5, n_pos + 1)[:-1]).tolist()
+    negative = (-norm.ppf(torch.linspace(offset, 0.5, 8)[:-1])).tolist()
+    values = torch.tensor(positive + [0.0] * (256 - len(positive) - len(negative)) + negative, dtype=torch.float32)
+    values = values.sort().values
+    return values / values.max()
+
+
 _NF4_VALUES = [
     -1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453,
     -0.28444138169288635, -0.18477343022823334, -0.09105003625154495, 0.0,

@@ -69,6 +69,46 @@ def test_blockwise_8bit_live_and_c_abi(ref, dtype):
     assert torch.equal(d, O.ref_dequantize_blockwise(q, am, code, 256, torch.float32))
 
 
+# Code tensors stay alive for the whole process. The reference's CPU kernel caches its 64K-entry table per code
+# POINTER, guarded only by a 4-value fingerprint (entries 0, 1, 127, 255: csrc/cpu_ops.cpp:522-558); two different
+# maps can share it - linear 4-bit and fp8 e5m2 both read (-1, -6/7, 0, 1) - so a freed code whose address is
+# recycled for the other map makes the REFERENCE quantize with a stale table. Distinct live addresses avoid that
+# (the oracle and the HIP kernel keep no cache).
+_LIVE_CODES = []
+
+
+@pytest.mark.parametrize("which", ["dynamic_unsigned", "linear8", "linear4", "fp8_e4m3", "fp8_e5m2", "fp4_as_map", "normal"])
+def test_blockwise_8bit_other_code_maps_live(ref, which):
+    """The oracle's 8-bit rule on code maps with repeated entries (few-bit maps are zero-padded to 256) and on
+    non-dynamic 8-bit maps, against the reference op and the reference library's C ABI."""
+    _, F = ref
+    code = {
+        "dynamic_unsigned": lambda: F.create_dynamic_map(signed=False),
+        "linear8": lambda: F.create_linear_map(True, 8),
+        "linear4": lambda: F.create_linear_map(True, 4),
+        "fp8_e4m3": lambda: F.create_fp8_map(True, 4, 3, 8),
+        "fp8_e5m2": lambda: F.create_fp8_map(True, 5, 2, 8),
+        "fp4_as_map": lambda: F.create_fp8_map(True, 2, 1, 4),
+        "normal": lambda: F.create_normal_map(),
+    }[which]().float()
+    _LIVE_CODES.append(code)
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(256 * 41 + 9, generator=g)
+    if which == "dynamic_unsigned":
+        A = A.abs()
+    A[512:768] = 0
+    A[::13] = 0
+    for bs in (256, 64, 4096):
+        q_ref, am_ref = torch.ops.bitsandbytes.quantize_blockwise.default(A, code, bs)
+        q, am = O.quantize_blockwise(A, code, bs)
+        assert torch.equal(q, q_ref) and torch.equal(am, am_ref), f"bs={bs}"
+        q_c, am_c = O.ref_quantize_blockwise(A, code, bs)
+        assert torch.equal(q, q_c) and torch.equal(am, am_c), f"bs={bs} (C ABI)"
+        d = O.dequantize_blockwise(q, am, code, bs, torch.float32)
+        assert torch.equal(d, O.ref_dequantize_blockwise(q, am, code, bs, torch.float32))
+        assert torch.equal(d, torch.ops.bitsandbytes.dequantize_blockwise.default(q_ref, am_ref, code, bs, torch.float32))
+
+
 def test_ref_c_abi_dequantize_4bit(ref):
     A = torch.randn(64, 256).bfloat16()
     q, am = O.quantize_4bit(A, 64, "nf4")
@@ -85,6 +125,40 @@ def test_dynamic_map_and_code_tables_match_reference(ref):
     for qt in ("nf4", "fp4"):
         assert torch.equal(MF.get_4bit_type(qt, device="cpu").view(torch.int32),
                            F.get_4bit_type(qt, device="cpu").view(torch.int32))
+
+
+def test_every_code_map_constructor_matches_reference(ref):
+    """create_dynamic_map / create_linear_map / create_fp8_map / create_normal_map: bit-identical tensors for the
+    parameterisations the reference's own tests use (tests/test_functional.py:225-300) and then some."""
+    _, F = ref
+    import bitsandbytes_amd.functional as MF
+
+    def same(a, b, what):
+        assert a.dtype == b.dtype == torch.float32 and a.shape == b.shape == (256,), what
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), what
+
+    def same_call(name, *args, **kw):
+        """Equal tensors, or - for parameter combinations the reference rejects - the same rejection."""
+        try:
+            expect = getattr(F, name)(*args, **kw)
+        except AssertionError:
+            with pytest.raises(AssertionError):
+                getattr(MF, name)(*args, **kw)
+            return
+        same(getattr(MF, name)(*args, **kw), expect, f"{name}{args}{kw}")
+
+    for signed in (True, False):
+        for bits in range(2, 9):
+            same_call("create_linear_map", signed, total_bits=bits)
+            for mx in range(1, bits + 1):
+                same_call("create_dynamic_map", signed, mx, bits)
+            for e in range(1, bits - (1 if signed else 0) + 1):
+                same_call("create_fp8_map", signed, e, bits - e - (1 if signed else 0), bits)
+        same_call("create_linear_map", signed, add_zero=False)
+    same_call("create_fp8_map", True, 4, 4, 8)  # exponent + precision bits that do not add up: both reject
+    for extra in (True, False):
+        same_call("create_normal_map", use_extra_value=extra)
+    same_call("create_normal_map", offset=0.95)
 
 
 def test_quant_state_dict_format_matches_reference(ref):

@@ -290,6 +290,42 @@ def test_blockwise_8bit_general_vs_oracle(blocksize, dtype):
     assert torch.equal(q.cpu(), q_o) and torch.equal(am.cpu(), am_o)
 
 
+@pytest.mark.parametrize("which", ["dynamic_unsigned", "linear8", "linear4", "linear2", "fp8_e4m3", "fp8_e5m2",
+                                   "fp4_as_map", "normal", "dynamic3"])
+def test_blockwise_8bit_other_code_maps(which):
+    """Code maps other than the signed dynamic one: the reference's linear / fp8 / normal / few-bit constructors
+    (few-bit maps are zero-padded to 256 entries, so up to 253 decision thresholds fall into ONE cell of the
+    encoder's table - the dense-cell search path). Every discretisation bin +- just under half a bin with absmax
+    pinned to 1, plus random blocks; codes, absmax and the dequantized values bit-exact against the oracle."""
+    F = _F()
+    code = {
+        "dynamic_unsigned": lambda: F.create_dynamic_map(signed=False),
+        "linear8": lambda: F.create_linear_map(True, 8),
+        "linear4": lambda: F.create_linear_map(True, 4),
+        "linear2": lambda: F.create_linear_map(True, 2),
+        "fp8_e4m3": lambda: F.create_fp8_map(True, 4, 3, 8),
+        "fp8_e5m2": lambda: F.create_fp8_map(True, 5, 2, 8),
+        "fp4_as_map": lambda: F.create_fp8_map(True, 2, 1, 4),
+        "normal": lambda: F.create_normal_map(),
+        "dynamic3": lambda: F.create_dynamic_map(True, 3, 3),
+    }[which]()
+    u = torch.arange(65536, dtype=torch.float64)
+    centres = -1.0 + 2.0 * u / 65535.0
+    vals = torch.cat([centres, centres + 0.499 / 65535.0, centres - 0.499 / 65535.0]).clamp(-1, 1).float()
+    vals = torch.cat([vals, torch.zeros((-vals.numel()) % 255)])
+    A = torch.cat([torch.ones(vals.numel() // 255, 1), vals.view(-1, 255)], dim=1).reshape(-1).contiguous()
+    R = torch.randn(256 * 61 + 17) * 0.2
+    R[256:512] = 0
+    for data, bs in ((A, 256), (R, 256), (R, 64), (R, 2048)):
+        q_o, am_o = O.quantize_blockwise(data, code, bs)
+        q, am = torch.ops.bitsandbytes.quantize_blockwise.default(data.to(DEV), code.to(DEV), bs)
+        bad = (q.cpu() != q_o).nonzero()
+        assert bad.numel() == 0, f"bs={bs}: {bad.numel()} codes differ, first x={data[bad[0]].item()!r}"
+        assert torch.equal(am.cpu(), am_o)
+        d = torch.ops.bitsandbytes.dequantize_blockwise.default(q, am, code.to(DEV), bs, torch.float32)
+        assert same_values_ftz(d.cpu(), O.dequantize_blockwise(q_o, am_o, code, bs, torch.float32))
+
+
 def test_blockwise_8bit_every_bin():
     """All 65536 discretisation bins (and their neighbourhood) with absmax pinned to 1: the threshold /
     cell-table encoder must reproduce the reference's 64K-entry table exactly."""

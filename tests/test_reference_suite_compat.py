@@ -25,6 +25,8 @@ SELECTIONS = [
     ("tests/test_modules.py", "(embedding or 4bit or NF4 or FP4) and not 8bit and not Int8 and not int8", 20),
     # default: everything 4-bit except the long gemv / large-tensor sweeps (they dominate the runtime on CPU)
     ("tests/test_functional.py", "4bit" if FULL else "4bit and not benchmark and not test_gemv_4bit and not quant_large", 60),
+    # the general 8-bit blockwise op: dynamic / linear / fp8 code maps, QuantState round trip
+    ("tests/test_functional.py", "Test8BitBlockwiseQuantizeFunctional and not bench", 8),
 ]
 if FULL:
     SELECTIONS.append(("tests/test_linear4bit.py", "compile", 100))
