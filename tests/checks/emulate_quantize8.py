@@ -3,10 +3,14 @@ search), re-stated in numpy and compared with the oracle on every discretisation
 constructor - including few-bit maps whose zero padding puts up to 253 thresholds into one cell. A development aid
 (run without a GPU); the on-device parity test is tests/test_gpu_parity.py::test_blockwise_8bit_other_code_maps."""
 import sys
-import numpy as np, torch
-sys.path.insert(0, '/root/repo')
-from oracle import oracle as O
-import bitsandbytes_amd.functional as F
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+import bitsandbytes_amd.functional as F  # noqa: E402
+from oracle import oracle as O  # noqa: E402
 
 f32 = np.float32
 def bin_value(u):

@@ -4,7 +4,7 @@ is quantized on the GPU and by the CPU oracle, codes compared bit for bit.
 Blocks of 4096 start with the element 1.0, so absmax = 1 and the scaled value is the pattern itself.
 Takes a few minutes (the oracle runs ~15 ns/element on one host core). Run once per encoder change:
 
-    python tools/exhaustive_quantize.py [--quant-type nf4|fp4|both] [--stride 1]
+    python tests/checks/exhaustive_quantize.py [--quant-type nf4|fp4|both] [--stride 1]
 """
 import argparse
 import sys
@@ -14,7 +14,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import bitsandbytes_amd.functional as F  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 

@@ -29,7 +29,7 @@ if [[ "$WHAT" == *" stream "* ]]; then
   echo "=== stream bench"; timeout 600 python tools/stream_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/stream_bench.txt
 fi
 if [[ "$WHAT" == *" exhaustive "* ]]; then
-  echo "=== exhaustive encoder check"; timeout 1500 python tools/exhaustive_quantize.py 2>&1 | grep -v amdgpu.ids | tee $OUT/exhaustive_quantize.txt
+  echo "=== exhaustive encoder check"; timeout 1500 python tests/checks/exhaustive_quantize.py 2>&1 | grep -v amdgpu.ids | tee $OUT/exhaustive_quantize.txt
 fi
 if [[ "$WHAT" == *" configs "* ]]; then
   echo "=== configs bench"; timeout 900 python tools/configs_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/configs_bench.txt
