@@ -74,6 +74,30 @@ def test_no_cpu_kernels_registered_by_product():
     assert "RAISED" in out and "COMPUTED" not in out
 
 
+def test_only_the_checkers_touch_the_oracle():
+    """oracle/ is test infrastructure: nothing in the product package, in tools/ or in bench.py outside its
+    cpu_baseline leg may import it; importing the product does not pull it in either."""
+    import subprocess
+    import sys
+
+    offenders = []
+    for top in ("bitsandbytes_amd", "tools", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".sh")):
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b|oracle/|libbnb4_oracle", text, flags=re.M):
+                        offenders.append(os.path.relpath(os.path.join(dirpath, f), ROOT))
+    assert not offenders, f"oracle referenced outside tests/, smoke() and bench.py's cpu_baseline: {offenders}"
+    bench_src = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle import|import oracle", bench_src)]
+    assert len(uses) == 1 and bench_src.rfind("def ", 0, uses[0]) == bench_src.find("def cpu_baseline"), \
+        "bench.py may import the oracle only inside cpu_baseline()"
+    out = subprocess.run([sys.executable, "-c", "import sys, bitsandbytes_amd; print(any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules))"],
+                         capture_output=True, text=True, cwd=ROOT).stdout
+    assert out.strip() == "False"
+
+
 def _device_kernel_metadata():
     """(name, private_segment_fixed_size, vgpr_count) of every kernel in the library's gfx950 code objects,
     read from the HSA metadata notes (no GPU needed)."""
