@@ -37,6 +37,17 @@ def golden():
     return _GOLDEN
 
 
+_GOLDEN_M8 = None
+
+
+def golden_8bit_maps():
+    """tests/golden/golden_8bit_maps.npz (make_golden_8bit_maps.py): the 8-bit op on the other code maps."""
+    global _GOLDEN_M8
+    if _GOLDEN_M8 is None:
+        _GOLDEN_M8 = np.load(os.path.join(ROOT, "tests", "golden", "golden_8bit_maps.npz"))
+    return _GOLDEN_M8
+
+
 def from_bits(arr: np.ndarray, dtype_code: int) -> torch.Tensor:
     """Inverse of make_golden.bits()."""
     t = torch.from_numpy(np.ascontiguousarray(arr))

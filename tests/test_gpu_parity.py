@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import DT, QT, from_bits, golden, gpu_ready, rel_err, same_values_ftz
+from conftest import DT, QT, from_bits, golden, golden_8bit_maps, gpu_ready, rel_err, same_values_ftz
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 REL_TOL = 1e-2  # north_star tolerance for the bf16/fp16 dequant+matmul
 DEV = "cuda"
 G = golden()
+M8 = golden_8bit_maps()
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -324,6 +325,21 @@ def test_blockwise_8bit_other_code_maps(which):
         assert torch.equal(am.cpu(), am_o)
         d = torch.ops.bitsandbytes.dequantize_blockwise.default(q, am, code.to(DEV), bs, torch.float32)
         assert same_values_ftz(d.cpu(), O.dequantize_blockwise(q_o, am_o, code, bs, torch.float32))
+
+
+@pytest.mark.parametrize("i", range(int(M8["m8/count"][0])))
+def test_blockwise_8bit_other_code_maps_golden(i):
+    """The same code maps against vectors produced by the reference itself (tests/golden/golden_8bit_maps.npz)."""
+    bs, n = (int(v) for v in M8[f"m8/{i}/meta"])
+    code = from_bits(M8[f"m8/{i}/code"], 0).to(DEV)
+    A = from_bits(M8[f"m8/{i}/A"], 0).to(DEV)
+    name = str(M8[f"m8/{i}/name"])
+    q, am = torch.ops.bitsandbytes.quantize_blockwise.default(A, code, bs)
+    bad = np.nonzero(q.cpu().numpy() != M8[f"m8/{i}/q"])[0]
+    assert bad.size == 0, f"{name} bs={bs}: {bad.size} codes differ, first x={A[int(bad[0])].item()!r}"
+    assert np.array_equal(am.cpu().view(torch.int32).numpy(), M8[f"m8/{i}/absmax"]), name
+    d = torch.ops.bitsandbytes.dequantize_blockwise.default(q, am, code, bs, torch.float32)
+    assert same_values_ftz(d.cpu(), from_bits(M8[f"m8/{i}/deq_fp32"], 0)), name
 
 
 def test_blockwise_8bit_every_bin():

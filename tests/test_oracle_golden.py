@@ -5,10 +5,11 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import DT, QT, from_bits, golden, rel_err, same_values, same_values_ftz
+from conftest import DT, QT, from_bits, golden, golden_8bit_maps, rel_err, same_values, same_values_ftz
 from oracle import oracle as O
 
 G = golden()
+M8 = golden_8bit_maps()
 
 
 def test_code_tables_bit_exact():
@@ -81,3 +82,19 @@ def test_gemm_4bit_vs_reference(i):
     # reference CPU result (T-rounded weights, T output): one output ulp of T plus accumulation order
     tol = {0: 2e-6, 1: 1.5e-3, 2: 1e-2}[dt_c]
     assert rel_err(y, y_ref) < tol
+
+
+@pytest.mark.parametrize("i", range(int(M8["m8/count"][0])))
+def test_blockwise_8bit_other_code_maps_vs_reference(i):
+    """Linear / fp8 / normal / few-bit / unsigned-dynamic code maps (zero-padded maps have repeated entries),
+    incl. values on and one ulp either side of every decision boundary."""
+    bs, n = (int(v) for v in M8[f"m8/{i}/meta"])
+    code = from_bits(M8[f"m8/{i}/code"], 0)
+    A = from_bits(M8[f"m8/{i}/A"], 0)
+    q, am = O.quantize_blockwise(A, code, bs)
+    name = str(M8[f"m8/{i}/name"])
+    bad = np.nonzero(q.numpy() != M8[f"m8/{i}/q"])[0]
+    assert bad.size == 0, f"{name} bs={bs}: {bad.size} codes differ, first x={A[int(bad[0])].item()!r}"
+    assert np.array_equal(am.view(torch.int32).numpy(), M8[f"m8/{i}/absmax"]), name
+    d = O.dequantize_blockwise(q, am, code, bs, torch.float32)
+    assert same_values(d, from_bits(M8[f"m8/{i}/deq_fp32"], 0)), name
