@@ -140,6 +140,11 @@ def pmc_traffic(extra_args, kernel_substr="gemv4_dot_kernel", timeout_s=90):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, {"error": "rocprofv3 not on PATH"}
+    # never nest profilers: when this process is itself being traced (rocprofv3 -- python bench.py) the counter
+    # passes are skipped instead of starting a second profiler inside the first
+    if any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ) or \
+            "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, {"skipped": "bench.py is already running under a profiler; run it bare for the PMC passes"}
     detail = {}
     vals = {}
     here = os.path.abspath(__file__)
