@@ -46,6 +46,20 @@ def register():
         qt = "fp4" if float(code[1]) > 0 else "nf4"
         return O.gemm_4bit(A, B, shapeB, absmax, blocksize, qt)[0]
 
+    # the out= variants (reference _ops.py:178-212, 323-350, 377-406): same arithmetic, written into `out`
+    @rk("bitsandbytes::dequantize_4bit.out", "cpu")
+    def _(A, absmax, blocksize, quant_type, shape, dtype, out):
+        out.copy_(O.dequantize_4bit(A, absmax, blocksize, quant_type, shape, dtype))
+
+    @rk("bitsandbytes::dequantize_blockwise.out", "cpu")
+    def _(A, absmax, code, blocksize, dtype, out):
+        out.copy_(O.dequantize_blockwise(A, absmax, code, blocksize, dtype))
+
+    @rk("bitsandbytes::gemv_4bit.out", "cpu")
+    def _(A, B, shapeB, absmax, code, blocksize, out):
+        qt = "fp4" if float(code[1]) > 0 else "nf4"
+        out.copy_(O.gemm_4bit(A, B, shapeB, absmax, blocksize, qt)[0])
+
     @rk("bitsandbytes_amd::dequantize_4bit_rows", "cpu")
     def _(A, absmax, indices, row_len, blocksize, quant_type, dtype):
         num_rows = A.numel() * A.element_size() * 2 // row_len

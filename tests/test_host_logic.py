@@ -77,6 +77,40 @@ def test_quant_state_roundtrip(quant_type, double_quant):
     assert err < (0.0735 if quant_type == "nf4" else 0.098) * 1.15 * (1.1 if double_quant else 1.0)
 
 
+def test_out_and_legacy_keyword_arguments():
+    """out= buffers are written in place and returned; the pre-QuantState keyword form (absmax=, code=, blocksize=)
+    gives the same values; nested 8-bit states survive as_dict / from_dict (reference functional.py:613-769,
+    :992-1077, :1300-1334; tests/test_functional.py:113-172)."""
+    A = torch.randn(4096)
+    out = torch.empty(4096, dtype=torch.uint8)
+    C, S = F.quantize_blockwise(A, out=out)
+    assert C.data_ptr() == out.data_ptr()
+    buf = torch.empty(4096)
+    D = F.dequantize_blockwise(C, S, out=buf)
+    assert D.data_ptr() == buf.data_ptr()
+    assert torch.equal(D, F.dequantize_blockwise(C, absmax=S.absmax, code=S.code, blocksize=4096))
+    for dtype in (torch.float32, torch.float16, torch.bfloat16):
+        X = torch.randn(256, 256).to(dtype)
+        Cn, Sn = F.quantize_blockwise(X, blocksize=256, nested=True)
+        assert Sn.nested and Sn.state2 is not None and Sn.offset is not None
+        Sr = F.QuantState.from_dict(Sn.as_dict(), device=torch.device("cpu"))
+        Y = F.dequantize_blockwise(Cn, Sr)
+        assert Y.dtype == dtype and (X.float() - Y.float()).abs().mean() < 0.011
+    W = torch.randn(64, 128).bfloat16()
+    q, st = F.quantize_4bit(W, quant_type="nf4")
+    o = torch.empty(64, 128, dtype=torch.bfloat16)
+    d = F.dequantize_4bit(q, st, out=o)
+    assert d.data_ptr() == o.data_ptr() and torch.equal(d, F.dequantize_4bit(q, st))
+    o2 = torch.empty(64, 128, dtype=torch.bfloat16)
+    assert torch.equal(d, F.dequantize_4bit(q, absmax=st.absmax, out=o2, blocksize=64, quant_type="nf4"))
+    with pytest.raises(ValueError, match="both absmax and out"):
+        F.dequantize_4bit(q, absmax=st.absmax, blocksize=64, quant_type="nf4")
+    x = torch.randn(1, 128).bfloat16()
+    y = torch.empty(1, 64, dtype=torch.bfloat16)
+    r = F.gemv_4bit(x, q.t(), out=y, state=st)
+    assert r.data_ptr() == y.data_ptr() and torch.equal(r, F.gemv_4bit(x, q.t(), state=st))
+
+
 def test_quant_storage_views_are_byte_identical():
     W = torch.randn(32, 64).half()
     q8, _ = F.quantize_4bit(W, quant_type="nf4", quant_storage=torch.uint8)
