@@ -352,3 +352,30 @@ def test_functional_wrappers_match_reference(ref, quant_type, compress_statistic
     c_m, s_m = MF.quantize_blockwise(v, blocksize=256)
     assert torch.equal(c_r, c_m) and torch.equal(s_r.absmax, s_m.absmax) and torch.equal(s_r.code, s_m.code)
     assert same_values(F.dequantize_blockwise(c_r, s_r), MF.dequantize_blockwise(c_m, s_m))
+
+
+def test_replace_linear_matches_reference(ref):
+    """utils.replace_linear swaps exactly the modules the reference's does (same walk order, skip list, bias flag)."""
+    bnb_ref, _ = ref
+    from bitsandbytes_amd.utils import replace_linear as mine
+
+    def tree():
+        torch.manual_seed(0)
+        inner = torch.nn.Sequential(torch.nn.Linear(16, 32, bias=False), torch.nn.ReLU(), torch.nn.Linear(32, 16))
+        m = torch.nn.Sequential()
+        m.add_module("inner", inner)
+        m.add_module("proj", torch.nn.Linear(16, 16))
+        m.add_module("lm_head", torch.nn.Linear(16, 4))
+        return m
+
+    class Marker(torch.nn.Linear):
+        pass
+
+    calls = {"mine": [], "ref": []}
+    a = mine(tree(), lambda i, o, b: (calls["mine"].append((i, o, b)), Marker(i, o, b))[1], copy_weights=True)
+    b = bnb_ref.utils.replace_linear(tree(), lambda i, o, b: (calls["ref"].append((i, o, b)), Marker(i, o, b))[1],
+                                     copy_weights=True)
+    assert calls["mine"] == calls["ref"]
+    assert [(n, type(m).__name__) for n, m in a.named_modules()] == [(n, type(m).__name__) for n, m in b.named_modules()]
+    for (_, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(pa, pb)

@@ -329,3 +329,30 @@ def test_linear4bit_traces_under_torch_compile():
     compiled = torch.compile(net, backend="aot_eager", fullgraph=True)
     with torch.no_grad():
         assert torch.equal(compiled(x), want)
+
+
+def test_replace_linear_walks_the_module_tree():
+    """utils.replace_linear: nested children, skip list, bias flag, copy_weights (reference utils.py:121-163)."""
+    from bitsandbytes_amd.utils import pack_dict_to_tensor, replace_linear, unpack_tensor_to_dict
+
+    class Block(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1 = torch.nn.Linear(64, 128, bias=False)
+            self.act = torch.nn.GELU()
+            self.fc2 = torch.nn.Linear(128, 64)
+
+    model = torch.nn.Sequential()
+    model.add_module("body", torch.nn.ModuleList([Block(), Block()]))
+    model.add_module("lm_head", torch.nn.Linear(64, 10))
+    out = replace_linear(model, lambda i, o, b: Linear4bit(i, o, b, quant_type="nf4", compute_dtype=torch.float32))
+    assert out is model and type(model.lm_head) is torch.nn.Linear
+    for blk in model.body:
+        assert isinstance(blk.fc1, Linear4bit) and blk.fc1.bias is None and (blk.fc1.in_features, blk.fc1.out_features) == (64, 128)
+        assert isinstance(blk.fc2, Linear4bit) and blk.fc2.bias is not None and isinstance(blk.act, torch.nn.GELU)
+    plain = torch.nn.Sequential(torch.nn.Linear(8, 8))
+    w = plain[0].weight
+    replace_linear(plain, lambda i, o, b: torch.nn.Linear(i, o, b), skip_modules=(), copy_weights=True)
+    assert plain[0].weight is w
+    d = {"quant_type": "nf4", "blocksize": 64, "shape": [4, 8], "nested": {"a": 1.5}}
+    assert unpack_tensor_to_dict(pack_dict_to_tensor(d)) == d
