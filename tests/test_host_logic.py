@@ -356,3 +356,28 @@ def test_replace_linear_walks_the_module_tree():
     assert plain[0].weight is w
     d = {"quant_type": "nf4", "blocksize": 64, "shape": [4, 8], "nested": {"a": 1.5}}
     assert unpack_tensor_to_dict(pack_dict_to_tensor(d)) == d
+
+
+@pytest.mark.parametrize("double_quant", [False, True])
+def test_state_dict_travels_through_safetensors(tmp_path, double_quant):
+    """The packed state-dict form holds tensors only (the QuantState's non-tensor fields ride in a uint8 JSON blob,
+    reference functional.py:545-578), so a quantised layer round-trips through a .safetensors file and
+    Params4bit.from_prequantized rebuilds it - the way HF NF4 checkpoints are stored."""
+    st = pytest.importorskip("safetensors.torch")
+    torch.manual_seed(0)
+    layer = Linear4bit(128, 64, bias=True, quant_type="nf4", compress_statistics=double_quant, compute_dtype=torch.bfloat16)
+    layer = layer.to("cpu")  # quantises on the move (test-only oracle backend), like .to("cuda") does
+    assert layer.weight.quant_state is not None and layer.weight.dtype == torch.uint8
+    sd = {k: v.contiguous() for k, v in layer.state_dict().items()}
+    assert all(isinstance(v, torch.Tensor) for v in sd.values())
+    path = str(tmp_path / "layer.safetensors")
+    st.save_file(sd, path)
+    loaded = st.load_file(path)
+    assert set(loaded) == set(sd) and all(torch.equal(loaded[k], sd[k]) for k in sd)
+    qs = {k[len("weight."):]: v for k, v in loaded.items() if k.startswith("weight.")}
+    w = Params4bit.from_prequantized(loaded["weight"], qs, device="cpu")
+    assert torch.equal(w.data, layer.weight.data)
+    x = torch.randn(3, 128).bfloat16()
+    y_ref = layer(x)
+    y = bnb.matmul_4bit(x, w, bias=loaded["bias"].to(x.dtype), quant_state=w.quant_state)
+    assert torch.equal(y, y_ref)
