@@ -379,3 +379,54 @@ def test_replace_linear_matches_reference(ref):
     assert [(n, type(m).__name__) for n, m in a.named_modules()] == [(n, type(m).__name__) for n, m in b.named_modules()]
     for (_, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         assert torch.equal(pa, pb)
+
+
+def test_mode_a_reference_python_binds_our_library():
+    """INTEGRATION.md mode A, as far as it goes without a GPU: the reference's own loader classes wrap OUR shared
+    library, classify it as a GPU build (get_context / cget_managed_ptr), its unmodified
+    bitsandbytes/backends/cuda/ops.py imports against it (every _setup_ctypes call, :16-66), the 4-bit / 8-bit
+    symbols resolve to real functions with the argtypes the reference assigns, symbols outside this path become the
+    reference's raise-on-call stubs, and the reference's CUDA-key kernels get registered. Runs in a subprocess: the
+    reference's "cuda" kernels must not be registered in the interpreter that also imports bitsandbytes_amd."""
+    import subprocess
+    import sys
+    import textwrap
+
+    from conftest import ROOT
+
+    script = textwrap.dedent(f"""
+        import ctypes as ct, importlib, sys
+        sys.path.insert(0, {ROOT!r})
+        import torch
+        from oracle.ref_import import import_reference
+        bnb = import_reference()
+        ce = bnb.cextension
+        dll = ct.cdll.LoadLibrary({ROOT!r} + "/bitsandbytes_amd/libbitsandbytes_mi355x.so")
+        assert hasattr(dll, "get_context") and hasattr(dll, "cget_managed_ptr")   # cextension.py:371-372
+        wrapped = ce.CudaBNBNativeLibrary(dll)
+        assert wrapped.compiled_with_cuda
+        ce.lib = wrapped
+        bnb.lib = wrapped
+        ops = importlib.import_module("bitsandbytes.backends.cuda.ops")
+        assert ops.lib is wrapped
+        for d in ("fp32", "fp16", "bf16"):
+            for name, nargs in ((f"cgemm_4bit_{{d}}", 14), (f"cgemm_4bit_inference_naive_{{d}}", 13),
+                                (f"cquantize_blockwise_{{d}}", 6), (f"cdequantize_blockwise_{{d}}", 7),
+                                (f"cquantize_blockwise_{{d}}_nf4", 6), (f"cdequantize_blockwise_{{d}}_fp4", 7)):
+                fn = getattr(wrapped, name)
+                assert isinstance(fn, ct._CFuncPtr), name
+                assert len(fn.argtypes) == nargs, (name, len(fn.argtypes))
+        stub = wrapped.cigemmlt_32
+        assert not isinstance(stub, ct._CFuncPtr)
+        try:
+            stub()
+            raise SystemExit("stub did not raise")
+        except RuntimeError:
+            pass
+        for op in ("gemm_4bit", "gemv_4bit", "quantize_4bit", "dequantize_4bit", "quantize_blockwise", "dequantize_blockwise"):
+            assert torch._C._dispatch_has_kernel_for_dispatch_key(f"bitsandbytes::{{op}}", "CUDA"), op
+        assert wrapped.get_context() not in (None, 0)
+        print("MODE_A_OK")
+    """)
+    proc = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert "MODE_A_OK" in proc.stdout, proc.stdout[-1500:] + proc.stderr[-2500:]
