@@ -75,3 +75,45 @@ def test_shard_validation():
     assert not sts.nested and sts.absmax.dtype == torch.float32 and sts.shape == (32, 128)
     full = F.dequantize_4bit(q, st)
     assert torch.equal(F.dequantize_4bit(qs, sts), full[32:])
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("N,K,bs", [(11008 // 16, 4096 // 8, 64), (256, 1376, 32), (64, 2048, 128), (8, 4096, 64)])
+@pytest.mark.parametrize("dq", [False, True], ids=["fp32-absmax", "nested"])
+@pytest.mark.parametrize("quant_storage", [torch.uint8, torch.bfloat16], ids=["u8", "bf16-storage"])
+def test_every_shard_reproduces_its_rows(world, N, K, bs, dq, quant_storage):
+    """shard_quant_state for 2 / 4 / 8 ranks (BASELINE config 4 shards the FFN matrices over 1-8 GPUs; shapes here
+    are those scaled down): every rank's packed shard + state dequantizes to exactly its rows of the unsharded
+    weight, the per-rank matmul is exactly its column block, and the rank-major concatenation that the all-gather
+    produces is the full output - for plain and nested absmax (both the sliced and the un-nested fallback branch)
+    and for non-uint8 quant_storage views."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle_cpu_backend
+
+    _oracle_cpu_backend.register()
+    import bitsandbytes_amd as bnb
+    import bitsandbytes_amd.functional as F
+    from bitsandbytes_amd.parallel import shard_quant_state
+
+    if N % world:
+        pytest.skip("rows not divisible by the world size")
+    torch.manual_seed(N + K + world)
+    W = (torch.randn(N, K) / K**0.5).bfloat16()
+    q, st = F.quantize_4bit(W, blocksize=bs, quant_type="nf4", compress_statistics=dq, quant_storage=quant_storage)
+    full = F.dequantize_4bit(q, st)
+    x = torch.randn(3, K).bfloat16()
+    y_full = bnb.matmul_4bit(x, q, st)
+    ns = N // world
+    parts = []
+    for r in range(world):
+        qs, sts = shard_quant_state(q, st, r, world)
+        assert qs.dtype == torch.uint8 and qs.numel() == ns * K // 2 and tuple(sts.shape) == (ns, K)
+        blocks = ns * K // bs
+        assert sts.nested == (dq and blocks % 256 == 0)
+        assert torch.equal(F.dequantize_4bit(qs, sts), full[r * ns:(r + 1) * ns]), f"rank {r}"
+        y_r = bnb.matmul_4bit(x, qs, sts)
+        assert torch.equal(y_r, y_full[:, r * ns:(r + 1) * ns]), f"rank {r}"
+        parts.append(y_r)
+    # what ShardedLinear4bit.gather does with the rank-major all-gather buffer
+    buf = torch.stack(parts)  # [G, M, ns]
+    assert torch.equal(buf.permute(1, 0, 2).reshape(3, N), y_full)
