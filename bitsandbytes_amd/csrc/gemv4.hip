@@ -31,7 +31,7 @@
 namespace bnb {
 
 int g_dot_ablate = 0; // profiling only: see the ablation bits of DotFlags
-int g_dot_flags = 0;  // sweeps (0 = default): 32 = force the 32-copy table, 64 = 256-thread workgroups, 128 = activations
+int g_dot_flags = 0;  // sweeps (0 = default): 16 = EXPERIMENTAL diagonal-MFMA decode, 32 = force the 32-copy table, 64 = 256-thread workgroups, 128 = activations
                       // per wavefront instead of LDS (M = 1 only), bits 8..15 = KiB of LDS padding (occupancy experiments)
 unsigned long long* g_dbg_buf = nullptr; // profiling only: device buffer for s_memtime stamps
 
@@ -43,8 +43,15 @@ namespace {
 
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
 template <typename T> struct Pair2;
 template <> struct Pair2<bf16> {
+    // one 16x16x32 MFMA: a, b = this lane's 8 bf16 of the A / B operand (4 packed dwords each)
+    static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
+        using V = __attribute__((ext_vector_type(8))) bf16;
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(V, a), __builtin_bit_cast(V, b), c, 0, 0, 0);
+    }
     static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
         using V = __attribute__((ext_vector_type(2))) bf16;
         V v;
@@ -58,6 +65,10 @@ template <> struct Pair2<bf16> {
     }
 };
 template <> struct Pair2<f16> {
+    static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
+        using V = __attribute__((ext_vector_type(8))) f16;
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(V, a), __builtin_bit_cast(V, b), c, 0, 0, 0);
+    }
     static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
         using V = __attribute__((ext_vector_type(2))) f16;
         V v;
@@ -94,6 +105,8 @@ enum DotFlags : int {
     kSingle = 1,  // the whole K fits one iteration: no prefetch registers are allocated
     kNested = 2,  // double-quantised absmax reconstructed in-kernel
     kWaves8 = 4,  // 512-thread workgroups (8 wavefronts share one table build) instead of 256
+    kDiag = 8,    // EXPERIMENTAL (debug flag 16; written after round 1's GPU budget was spent - not yet run on
+                  // hardware): products on the matrix pipe instead of v_dot2c, see "diagonal MFMA" in the kernel
     kXLds = 16,   // activations staged once per workgroup in LDS (one LDS-DMA copy) instead of per-wave global loads
     kLut64 = 64,  // 64 table copies, 256 B per entry: the LDS address of a look-up is ONE v_perm_b32
                   // (byte 0 = the lane's offset, byte 1 = the packed weight byte) instead of shift + mask + or
@@ -119,6 +132,8 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
     constexpr bool SINGLE = FLAGS & kSingle, NESTED = FLAGS & kNested, LUT64 = FLAGS & kLut64;
     constexpr int COPIES = LUT64 ? 64 : 32; // table copies = dwords per entry
     constexpr bool XLDS = FLAGS & kXLds;
+    constexpr bool DIAG = FLAGS & kDiag;
+    static_assert(!DIAG || XLDS, "the diagonal-MFMA decode reads its activation fragments from the LDS image");
     constexpr int WAVES = (FLAGS & kWaves8) ? 8 : 4;
     constexpr int THREADS = WAVES * 64;
     constexpr int TPE = THREADS / 256; // threads cooperating on one table entry
@@ -237,11 +252,15 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
     };
 
     float acc[MB][RPW];
+    f32x4 acc4[DIAG ? MB : 1][DIAG ? RPW : 1]; // DIAG: running 16x16 tile per output, only its diagonal is meaningful
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int r = 0; r < RPW; ++r)
+        for (int r = 0; r < RPW; ++r) {
             acc[m][r] = 0.0f;
+            if constexpr (DIAG)
+                acc4[m][r] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
 
     const uint32_t lane_slot = static_cast<uint32_t>(lane & 31);
     float offset = 0.0f;
@@ -262,7 +281,88 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
         }
     };
 
+    // byte j of weight dword w -> (code[hi nibble], code[lo nibble]) as a packed pair, from this lane's table copy
+    auto lut_pair = [&](uint32_t w, int j) -> uint32_t {
+        if constexpr (LUT64) {
+            // address = byte * 256 + lane * 4, assembled by one byte permute
+            const uint32_t addr = __builtin_amdgcn_perm(w, lane_off64, perm_sel + (j << 8));
+            return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(
+                reinterpret_cast<const __attribute__((address_space(3))) unsigned char*>(lut_lds) + addr);
+        } else {
+            const uint32_t byte = (w >> (8 * j + zsh)) & 0xFFu;
+            return lut[(byte << 5) + lane_slot];
+        }
+    };
+    auto block_scale = [&](const Stage& st, int it, int sg, int r) -> float {
+        const int k0 = (it * SEGS + sg) * kSegK + lane * 32;
+        float scale;
+        if constexpr (NESTED) {
+            const uint32_t q8 = __builtin_bit_cast(uint32_t, st.s[sg][r]);
+            scale = __fadd_rn(__fmul_rn(code2[q8], st.s2[sg][r]), offset);
+        } else {
+            scale = st.s[sg][r];
+        }
+        return (k0 < K) ? scale : 0.0f; // lanes past the end of the row contribute nothing
+    };
+
+    // "Diagonal MFMA" decode (kDiag). With this lane's 8 decoded weights as the A operand and the 8 matching
+    // activations as the B operand, v_mfma_f32_16x16x32 computes D[i][j] = sum over the four lanes (i, g) x (j, g)
+    // of 8-element dots; on the diagonal that is the sum of the dots of lanes {i, i+16, i+32, i+48} - a 64-lane
+    // batched dot on the matrix pipe, every lane keeping its coalesced 16-byte ownership of the row. The four
+    // lanes of a diagonal element must share one absmax block, so the raw dwords are first transposed 4x4 between
+    // "dword d of the lane" and "16-lane row g" (two v_permlane32_swap + two v_permlane16_swap): afterwards
+    // lane (i, g) holds, in register d', dword g of original lane L = i + 16 d', the diagonal element i of MFMA
+    // d' is the complete 32-nibble run of lane L, and it is scaled by L's fp32 scale (one ds_bpermute per d')
+    // before it joins the running tile. Index algebra checked in numpy (tests/checks/emulate_diag_mfma.py).
+    auto compute_stage_diag = [&](const Stage& st, int it) {
+        const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+        for (int sg = 0; sg < SEGS; ++sg) {
+            u32x4 xf[MB][4]; // [m][d']: the 8 activations of x chunk 4 L + g, L = li + 16 d'
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int dp = 0; dp < 4; ++dp) {
+                    const int L = li + 16 * dp;
+                    xf[m][dp] = *reinterpret_cast<const u32x4*>(
+                        xs + ((m * nseg + it * SEGS + sg) * 256 + L * 4 + (lg ^ ((L >> 2) & 3))) * 16);
+                }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                uint32_t w0 = st.w[sg][r][0], w1 = st.w[sg][r][1], w2 = st.w[sg][r][2], w3 = st.w[sg][r][3];
+                {
+                    auto a = __builtin_amdgcn_permlane32_swap(w0, w2, false, false);
+                    auto b = __builtin_amdgcn_permlane32_swap(w1, w3, false, false);
+                    auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                    auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                    w0 = c[0], w1 = c[1], w2 = d[0], w3 = d[1];
+                }
+                const uint32_t wt[4] = {w0, w1, w2, w3};
+                const int scale_bits = __builtin_bit_cast(int, block_scale(st, it, sg, r));
+#pragma unroll
+                for (int dp = 0; dp < 4; ++dp) {
+                    u32x4 a_frag;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        a_frag[j] = lut_pair(wt[dp], j);
+                    const float s_dp = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((li + 16 * dp) * 4, scale_bits));
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        const f32x4 t = Pair2<T>::mfma(a_frag, xf[m][dp], f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc4[m][r][e] = fmaf(s_dp, t[e], acc4[m][r][e]);
+                    }
+                }
+            }
+        }
+    };
+
     auto compute_stage = [&](const Stage& st, int it) {
+        if constexpr (DIAG) {
+            compute_stage_diag(st, it);
+            return;
+        }
 #pragma unroll
         for (int sg = 0; sg < SEGS; ++sg) {
             u32x4 xf[MB][4];
@@ -290,30 +390,13 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
                     const uint32_t w = st.w[sg][r][d];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        uint32_t pr;
-                        if constexpr (LUT64) {
-                            // address = byte * 256 + lane * 4, assembled by one byte permute
-                            const uint32_t addr = __builtin_amdgcn_perm(w, lane_off64, perm_sel + (j << 8));
-                            pr = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(
-                                reinterpret_cast<const __attribute__((address_space(3))) unsigned char*>(lut_lds) + addr);
-                        } else {
-                            const uint32_t byte = (w >> (8 * j + zsh)) & 0xFFu;
-                            pr = lut[(byte << 5) + lane_slot];
-                        }
+                        const uint32_t pr = lut_pair(w, j);
 #pragma unroll
                         for (int m = 0; m < MB; ++m)
                             part[m][j & 1] = Pair2<T>::dot2(pr, xf[m][d][j], part[m][j & 1]);
                     }
                 }
-                const int k0 = (it * SEGS + sg) * kSegK + lane * 32;
-                float scale;
-                if constexpr (NESTED) {
-                    const uint32_t q8 = __builtin_bit_cast(uint32_t, st.s[sg][r]);
-                    scale = __fadd_rn(__fmul_rn(code2[q8], st.s2[sg][r]), offset);
-                } else {
-                    scale = st.s[sg][r];
-                }
-                scale = (k0 < K) ? scale : 0.0f; // lanes past the end of the row contribute nothing
+                const float scale = block_scale(st, it, sg, r);
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
                     acc[m][r] = fmaf(scale, part[m][0] + part[m][1], acc[m][r]);
@@ -377,6 +460,13 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
     for (int m = 0; m < MB; ++m) {
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
+            if constexpr (DIAG) {
+                // the tile's diagonal: element j lives in lane (j, g = j / 4), register j % 4
+                const int j = lane & 15;
+                const f32x4 t = acc4[m][r];
+                const float d = ((j & 3) == 0) ? t[0] : ((j & 3) == 1) ? t[1] : ((j & 3) == 2) ? t[2] : t[3];
+                acc[m][r] = ((lane >> 4) == (j >> 2)) ? d : 0.0f;
+            }
             const float v = wave_sum(acc[m][r]);
             const int row = row0 + r;
             if (lane == 0 && row < N && m0 + m < hot_M) {
@@ -496,6 +586,19 @@ template <typename T, int MB, int RPW, int SEGS, int EXTRA> void launch_dot(cons
     case 1: BNB_DOT_GO(E | kSingle | (X)); break;                                                  \
     case 2: BNB_DOT_GO(E | kNested | (X)); break;                                                  \
     default: BNB_DOT_GO(E | kSingle | kNested | (X)); break;                                       \
+    }
+    if constexpr (E != 0) {
+        // EXPERIMENTAL diagonal-MFMA decode (debug flag 16), production workgroup size only
+        if (xlds && (g_dot_flags & 16)) {
+            if constexpr (MB <= 2) {
+                if (lut64) {
+                    BNB_DOT_SEL(kXLds | kLut64 | kDiag)
+                    return;
+                }
+            }
+            BNB_DOT_SEL(kXLds | kDiag)
+            return;
+        }
     }
     if (xlds) {
         if constexpr (MB <= 2) {

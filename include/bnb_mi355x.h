@@ -125,7 +125,8 @@ void bnb_mi355x_set_tuning(int dot_rows_per_wave, int dot_segments, int mfma_kno
 
 /* Profiling only. dot_ablation: 0 = normal; 1..5 run ablated variants of the dot kernel (stream only /
  * no table build / no weight loads / weights only / empty) whose RESULTS ARE WRONG. dot_flags selects
- * structural variants of the dot kernel whose results stay correct (32 = 32-copy decode table, 64 = 256-thread
+ * structural variants of the dot kernel whose results stay correct (16 = EXPERIMENTAL diagonal-MFMA decode, not yet
+ * validated on hardware; 32 = 32-copy decode table, 64 = 256-thread
  * workgroups, 128 = activations loaded per wavefront instead of staged in LDS, M = 1 only; bits 8..15 = KiB of
  * LDS padding for occupancy experiments). Never set outside tools/. */
 void bnb_mi355x_set_debug(int dot_ablation, int dot_flags);

@@ -50,6 +50,15 @@ def measure(layers, x, kernel, reps=10):
     return e0.elapsed_time(e1) / (reps * L) * 1e3, 0.0
 
 
+def run_one(x, layer, kernel=1):
+    q, st = layer
+    if st.nested:
+        return hip._gemm_4bit_fused(x, q, st.shape, st.state2.absmax, st.blocksize, st.quant_type, None, st.absmax,
+                                    st.state2.code, st.offset, kernel=kernel)
+    return hip._gemm_4bit_fused(x, q, st.shape, st.absmax, st.blocksize, st.quant_type, None, None, None, None,
+                                kernel=kernel)
+
+
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=4096)
 ap.add_argument("--k", type=int, default=4096)
@@ -57,6 +66,7 @@ ap.add_argument("--dq", action="store_true")
 ap.add_argument("--quick", action="store_true")
 ap.add_argument("--m34", action="store_true")
 ap.add_argument("--ldspad", action="store_true", help="M = 1 time vs extra (unused) dynamic LDS per workgroup")
+ap.add_argument("--diag", action="store_true", help="EXPERIMENTAL diagonal-MFMA decode (debug flag 16) vs production, M = 1..8")
 ap.add_argument("--ablate", action="store_true", help="ablations of the M = 1 kernel (results wrong by design), HBM-resident and cache-hot")
 a = ap.parse_args()
 N, K = a.n, a.k
@@ -87,6 +97,23 @@ if a.ablate:
         t_cold, _ = measure(layers, x, 1)
         t_hot, _ = measure(layers[:2] * 16, x, 1)
         print(f"{names[abl]:44s} {t_cold:16.2f} {t_hot:13.2f}")
+    bnb.lib.bnb_mi355x_set_debug(0, 0)
+    sys.exit(0)
+if a.diag:
+    # EXPERIMENTAL diagonal-MFMA decode (debug flag 16) against the production v_dot2c decode, dot kernel forced
+    # (kernel = 1) for every M; relative error of each against fp32 dequantize + matmul on layer 0
+    q0, st0 = layers[0]
+    W0 = F.dequantize_4bit(q0, st0).float()
+    print(f"{'M':>3s} {'decode':>10s} {'us/launch':>10s} {'GB/s':>9s} {'rel err':>9s}")
+    for M in (1, 2, 3, 4, 8):
+        x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+        y_ref = x.float() @ W0.t()
+        for flags, name in ((0, "v_dot2c"), (16, "diag-mfma"), (16 | 32, "diag lut32")):
+            bnb.lib.bnb_mi355x_set_debug(0, flags)
+            tg, _ = measure(layers, x, 1)
+            y = run_one(x, layers[0])
+            err = float((y.float() - y_ref).norm() / y_ref.norm())
+            print(f"{M:3d} {name:>10s} {tg:10.2f} {bytes_alg(M, N, K, 64) / tg / 1e3:9.1f} {err:9.2e}")
     bnb.lib.bnb_mi355x_set_debug(0, 0)
     sys.exit(0)
 for M in (() if a.m34 else (1, 2)):
