@@ -318,37 +318,37 @@ __global__ __launch_bounds__((FLAGS & kWaves8) ? 512 : 256) void gemv4_dot_kerne
         const int li = lane & 15, lg = lane >> 4;
 #pragma unroll
         for (int sg = 0; sg < SEGS; ++sg) {
-            u32x4 xf[MB][4]; // [m][d']: the 8 activations of x chunk 4 L + g, L = li + 16 d'
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int dp = 0; dp < 4; ++dp) {
-                    const int L = li + 16 * dp;
-                    xf[m][dp] = *reinterpret_cast<const u32x4*>(
-                        xs + ((m * nseg + it * SEGS + sg) * 256 + L * 4 + (lg ^ ((L >> 2) & 3))) * 16);
-                }
+            uint32_t wt[RPW][4]; // transposed raw dwords: wt[r][d'] = dword lg of original lane li + 16 d'
+            int scale_bits[RPW];
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                uint32_t w0 = st.w[sg][r][0], w1 = st.w[sg][r][1], w2 = st.w[sg][r][2], w3 = st.w[sg][r][3];
-                {
-                    auto a = __builtin_amdgcn_permlane32_swap(w0, w2, false, false);
-                    auto b = __builtin_amdgcn_permlane32_swap(w1, w3, false, false);
-                    auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-                    auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-                    w0 = c[0], w1 = c[1], w2 = d[0], w3 = d[1];
-                }
-                const uint32_t wt[4] = {w0, w1, w2, w3};
-                const int scale_bits = __builtin_bit_cast(int, block_scale(st, it, sg, r));
+                const auto a = __builtin_amdgcn_permlane32_swap(st.w[sg][r][0], st.w[sg][r][2], false, false);
+                const auto b = __builtin_amdgcn_permlane32_swap(st.w[sg][r][1], st.w[sg][r][3], false, false);
+                const auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                const auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                wt[r][0] = c[0], wt[r][1] = c[1], wt[r][2] = d[0], wt[r][3] = d[1];
+                scale_bits[r] = __builtin_bit_cast(int, block_scale(st, it, sg, r));
+            }
 #pragma unroll
-                for (int dp = 0; dp < 4; ++dp) {
+            for (int dp = 0; dp < 4; ++dp) {
+                // the 8 activations of x chunk 4 L + lg, L = li + 16 d' (same swizzled slot rule as x_frag), read
+                // per d' so that only MB fragments are live at a time
+                const int L = li + 16 * dp;
+                u32x4 xf[MB];
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+                    xf[m] = *reinterpret_cast<const u32x4*>(
+                        xs + ((m * nseg + it * SEGS + sg) * 256 + L * 4 + (lg ^ ((L >> 2) & 3))) * 16);
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
                     u32x4 a_frag;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        a_frag[j] = lut_pair(wt[dp], j);
-                    const float s_dp = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((li + 16 * dp) * 4, scale_bits));
+                        a_frag[j] = lut_pair(wt[r][dp], j);
+                    const float s_dp = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(L * 4, scale_bits[r]));
 #pragma unroll
                     for (int m = 0; m < MB; ++m) {
-                        const f32x4 t = Pair2<T>::mfma(a_frag, xf[m][dp], f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+                        const f32x4 t = Pair2<T>::mfma(a_frag, xf[m], f32x4{0.0f, 0.0f, 0.0f, 0.0f});
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             acc4[m][r][e] = fmaf(s_dp, t[e], acc4[m][r][e]);
