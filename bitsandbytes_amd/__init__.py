@@ -9,7 +9,7 @@ design: without the HIP library every op raises.
 """
 from . import _ops  # noqa: F401  op schemas + fake kernels (importable without a GPU)
 from . import functional  # noqa: F401
-from .autograd import MatMul4Bit, matmul_4bit
+from .autograd import MatMul4Bit, matmul_4bit, matmul_4bit_grouped
 from .cextension import lib
 from .backends import hip as _hip_backend  # noqa: F401  registers the "cuda"-key (HIP) kernels
 from . import nn  # noqa: F401
@@ -18,4 +18,4 @@ from .parallel import ShardedLinear4bit, shard_linear4bit  # noqa: F401
 
 __version__ = "0.1.0"
 
-__all__ = ["functional", "nn", "utils", "matmul_4bit", "MatMul4Bit", "lib", "ShardedLinear4bit", "shard_linear4bit"]
+__all__ = ["functional", "nn", "utils", "matmul_4bit", "matmul_4bit_grouped", "MatMul4Bit", "lib", "ShardedLinear4bit", "shard_linear4bit"]

@@ -127,3 +127,43 @@ def matmul_4bit(
         out.copy_(result)
         return out
     return result
+
+
+def matmul_4bit_grouped(A: torch.Tensor, weights, quant_states, biases=None):
+    """``[matmul_4bit(A, B_i, state_i, bias=bias_i) for i]`` for 4-bit weights that share their input - the Q/K/V
+    projections of an attention block, the gate/up projections of an MLP. On MI355X a decode-sized batch (M <= 4) is
+    ONE launch of the streaming kernel over the concatenated output rows (``bnb_mi355x_gemm_4bit_grouped``): one
+    kernel boundary, one decode-table build and one activation copy per CU instead of one per matrix. Outputs are
+    bit-identical to the separate calls; anything the grouped launch does not cover (autograd, mixed statistics
+    formats, legacy [K, N] weights, CPU tensors) takes the separate calls.
+    New functionality on top of the reference (which issues one gemm_4bit per Linear4bit, nn/modules.py:609-637)."""
+    n = len(weights)
+    biases = [None] * n if biases is None else list(biases)
+    if len(quant_states) != n or len(biases) != n:
+        raise ValueError("weights, quant_states and biases must have the same length")
+
+    def separate():
+        return [matmul_4bit(A, w, s, bias=b) for w, s, b in zip(weights, quant_states, biases)]
+
+    if n == 0:
+        return []
+    s0 = quant_states[0]
+    K = A.shape[-1]
+    groupable = (
+        A.device.type == "cuda" and A.numel() > 0
+        and not (torch.is_grad_enabled() and (A.requires_grad or any(b is not None and b.requires_grad for b in biases)))
+        and not _is_compiling()
+        and all(len(s.shape) == 2 and s.shape[1] == K and s.blocksize == s0.blocksize and s.quant_type == s0.quant_type
+                and s.nested == s0.nested and (not s.nested or s.state2.blocksize == 256) for s in quant_states)
+    )
+    if not groupable:
+        return separate()
+    from ..backends import hip
+
+    mats = []
+    for w, s, b in zip(weights, quant_states, biases):
+        if s.nested:
+            mats.append((w.view(-1, 1), s.shape, s.state2.absmax, b, s.absmax, s.state2.code, s.offset))
+        else:
+            mats.append((w.view(-1, 1), s.shape, s.absmax, b, None, None, None))
+    return hip.gemm_4bit_grouped(A, mats, s0.blocksize, s0.quant_type)

@@ -295,6 +295,68 @@ def _gemm_4bit_fused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8
     return out
 
 
+def gemm_4bit_grouped(A: torch.Tensor, mats, blocksize: int, quant_type: str):
+    """``[A @ dequant(B_i).T (+ bias_i) for i]`` for several packed weights that share the activations, in ONE launch
+    of the streaming kernel when M <= 4 (``bnb_mi355x_gemm_4bit_grouped``; larger M and odd shapes are issued matrix
+    by matrix inside the library). ``mats``: sequence of ``(B, shapeB, absmax, bias, absmax_8bit, absmax_code,
+    absmax_offset)`` with the argument meaning of the ``gemm_4bit`` op; all matrices share K, blocksize, quant_type
+    and nested-ness. Results are bit-identical to separate ``gemm_4bit`` calls."""
+    import ctypes as ct
+
+    K = A.shape[-1]
+    M = A.numel() // K if K else 0
+    if A.dtype not in _DT_CODE:
+        raise RuntimeError(f"unsupported dtype {A.dtype}")
+    if quant_type not in _QT_CODE:
+        raise ValueError(f"quant_type must be 'nf4' or 'fp4', got {quant_type!r}")
+    count = len(mats)
+    if count == 0:
+        return []
+    nested = mats[0][4] is not None
+    if K % blocksize != 0 or M > 4 or count > 8:
+        # outside the grouped kernel's range: the single-matrix op (its own routing, its own split-K workspace)
+        return [torch.ops.bitsandbytes.gemm_4bit.default(A, B, shapeB, absmax, blocksize, quant_type, bias, a8, ac, ao)
+                for (B, shapeB, absmax, bias, a8, ac, ao) in mats]
+    A = A.contiguous()
+    keep, outs = [], []
+    cols = {k: [] for k in ("B", "absmax", "a8", "ac", "ao", "out", "bias")}
+    Ns = []
+    for (B, shapeB, absmax, bias, a8, ac, ao) in mats:
+        N = int(shapeB[0])
+        if int(shapeB[1]) != K:
+            raise RuntimeError(f"A inner dim ({K}) does not match weight ({shapeB[1]})")
+        if (a8 is not None) != nested:
+            raise RuntimeError("gemm_4bit_grouped: all matrices must be nested (double-quantised) or none")
+        if absmax.dtype != torch.float32:
+            raise RuntimeError(f"absmax must be float32, got {absmax.dtype}")
+        if bias is not None:
+            if bias.ndim != 1 or bias.dtype != A.dtype:
+                raise RuntimeError("bias must be 1D and of A's dtype")
+            bias = bias.contiguous()
+        B = B.contiguous()
+        absmax = absmax.contiguous()
+        out = torch.empty((*A.shape[:-1], N), dtype=A.dtype, device=A.device)
+        a8 = None if a8 is None else a8.contiguous()
+        ac = None if ac is None else ac.contiguous()
+        ao = None if ao is None else ao.to(dtype=torch.float32)
+        keep += [B, absmax, bias, a8, ac, ao]
+        for k, t in zip(("B", "absmax", "a8", "ac", "ao", "out", "bias"), (B, absmax, a8, ac, ao, out, bias)):
+            cols[k].append(_ptr(t))
+        Ns.append(N)
+        outs.append(out)
+
+    def arr(vals):
+        return (ct.c_void_p * count)(*vals)
+
+    with _device_of(A):
+        lib.bnb_mi355x_gemm_4bit_grouped(
+            _DT_CODE[A.dtype], A.data_ptr(), count, arr(cols["B"]), arr(cols["absmax"]),
+            arr(cols["a8"]) if nested else None, arr(cols["ac"]) if nested else None, arr(cols["ao"]) if nested else None,
+            arr(cols["out"]), arr(cols["bias"]), (ct.c_int32 * count)(*Ns), M, K, blocksize, _QT_CODE[quant_type], _stream(A),
+        )
+    return outs
+
+
 def _gemm_4bit_unfused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8bit, absmax_code, absmax_offset):
     if absmax_8bit is not None:
         absmax_dq = torch.empty_like(absmax_8bit, dtype=torch.float32)
@@ -327,4 +389,4 @@ def _(
     return _gemm_4bit_unfused(*args)
 
 
-__all__ = ["FUSED_MAX_M", "prod"]
+__all__ = ["FUSED_MAX_M", "gemm_4bit_grouped", "prod"]

@@ -27,6 +27,15 @@ void dequantize_8bit_bf16(const float*, const uint8_t*, const float*, void*, int
 void gemv_4bit_dot(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                    const float* absmax_code, const float* absmax_offset, const float* code16, void* out,
                    const void* bias, int M, int N, int K, int blocksize, int quant_type, hipStream_t stream);
+// gemv4_stream.hip
+void gemv_4bit_stream(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
+                      const float* absmax_code, const float* absmax_offset, const float* code16, void* out,
+                      const void* bias, int M, int N, int K, int blocksize, int quant_type, hipStream_t stream);
+bool gemv_4bit_grouped(int dtype, const void* A, int count, const uint8_t* const* B, const float* const* absmax,
+                       const uint8_t* const* absmax8, const float* const* absmax_code, const float* const* absmax_offset,
+                       void* const* out, const void* const* bias, const int* N, int M, int K, int blocksize, int quant_type,
+                       hipStream_t stream);
+void gemv_4bit_stream_tuning(int ns, int sw, int rows_per_wg, int nt, int waves);
 extern int g_dot_rpw, g_dot_segs, g_dot_ablate, g_dot_flags;
 extern unsigned long long* g_dbg_buf;
 // gemm4_mfma.hip
@@ -40,17 +49,17 @@ extern int g_mfma_knob0, g_mfma_knob1;
 
 namespace {
 
-// M at or below which the wave64 dot kernel is used; above it the MFMA kernel (when supported).
-// MI355X-specific replacement for the reference's per-arch heuristic
-// (bitsandbytes/backends/cuda/ops.py:814-843), calibrated on gfx950 — see DESIGN.md.
-constexpr int kDotMaxM = 2;
+// M at or below which the streaming dot kernel is used (its activations live in registers: 32 fp32 per row and
+// lane); above it the MFMA kernels (when supported). MI355X-specific replacement for the reference's per-arch
+// heuristic (bitsandbytes/backends/cuda/ops.py:814-843), calibrated on gfx950 — see DESIGN.md.
+constexpr int kStreamMaxM = 4;
 
 bool route_to_mfma(int kernel, int dtype, const void* A, const uint8_t* B, int M, int N, int K, int blocksize) {
-    if (kernel == 1)
+    if (kernel == 1 || kernel == 3)
         return false;
     if (kernel == 2)
         return gemm_4bit_mfma_supported(dtype, A, B, M, N, K, blocksize);
-    return (M > kDotMaxM) && gemm_4bit_mfma_supported(dtype, A, B, M, N, K, blocksize);
+    return (M > kStreamMaxM) && gemm_4bit_mfma_supported(dtype, A, B, M, N, K, blocksize);
 }
 
 void gemm_4bit_dispatch(int kernel, int dtype, const void* A, const uint8_t* B, const float* absmax,
@@ -66,9 +75,12 @@ void gemm_4bit_dispatch(int kernel, int dtype, const void* A, const uint8_t* B, 
     if (route_to_mfma(kernel, dtype, A, B, M, N, K, blocksize))
         gemm_4bit_mfma(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, code16, out, bias, M, N, K, blocksize,
                        quant_type, workspace, workspace_bytes, stream);
-    else
+    else if (kernel == 1) // round 1's dot kernel, kept for A/B measurements until the streaming kernel has replaced it
         gemv_4bit_dot(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, code16, out, bias, M, N, K, blocksize,
                       quant_type, stream);
+    else
+        gemv_4bit_stream(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, code16, out, bias, M, N, K, blocksize,
+                         quant_type, stream);
 }
 
 } // namespace
@@ -173,17 +185,17 @@ void cgemm_4bit_fp32(const float* A, const uint8_t* B, const float* absmax, cons
 void cgemm_4bit_inference_naive_fp16(int m, int n, int k, void* A, unsigned char* B, float* absmax, float* datatype,
                                      void* out, int, int, int, int blocksize, bnb_stream_t s) {
     (void)n;
-    gemv_4bit_dot(1, A, B, absmax, nullptr, nullptr, nullptr, datatype, out, nullptr, 1, m, k, blocksize, kNF4, S(s));
+    gemv_4bit_stream(1, A, B, absmax, nullptr, nullptr, nullptr, datatype, out, nullptr, 1, m, k, blocksize, kNF4, S(s));
 }
 void cgemm_4bit_inference_naive_bf16(int m, int n, int k, void* A, unsigned char* B, float* absmax, float* datatype,
                                      void* out, int, int, int, int blocksize, bnb_stream_t s) {
     (void)n;
-    gemv_4bit_dot(2, A, B, absmax, nullptr, nullptr, nullptr, datatype, out, nullptr, 1, m, k, blocksize, kNF4, S(s));
+    gemv_4bit_stream(2, A, B, absmax, nullptr, nullptr, nullptr, datatype, out, nullptr, 1, m, k, blocksize, kNF4, S(s));
 }
 void cgemm_4bit_inference_naive_fp32(int m, int n, int k, float* A, unsigned char* B, float* absmax, float* datatype,
                                      float* out, int, int, int, int blocksize, bnb_stream_t s) {
     (void)n;
-    gemv_4bit_dot(0, A, B, absmax, nullptr, nullptr, nullptr, datatype, out, nullptr, 1, m, k, blocksize, kNF4, S(s));
+    gemv_4bit_stream(0, A, B, absmax, nullptr, nullptr, nullptr, datatype, out, nullptr, 1, m, k, blocksize, kNF4, S(s));
 }
 
 // ------------------------------------------------------------------ loader symbols
@@ -233,6 +245,25 @@ void bnb_mi355x_gemm_4bit(int kernel, int dtype, const void* A, const uint8_t* B
     gemm_4bit_dispatch(kernel, dtype, A, B, absmax, absmax_8bit, absmax_code, absmax_offset, code16, out, bias, M, N, K,
                        blocksize, quant_type, workspace, workspace_bytes, S(s));
 }
+void bnb_mi355x_gemm_4bit_grouped(int dtype, const void* A, int count, const uint8_t* const* B, const float* const* absmax,
+                                  const uint8_t* const* absmax_8bit, const float* const* absmax_code,
+                                  const float* const* absmax_offset, void* const* out, const void* const* bias, const int* N,
+                                  int M, int K, int blocksize, int quant_type, bnb_stream_t s) {
+    if (count <= 0 || M <= 0)
+        return;
+    if (quant_type != kFP4 && quant_type != kNF4) {
+        fprintf(stderr, "bitsandbytes_amd: gemm_4bit_grouped: quant_type must be 1 (FP4) or 2 (NF4), got %d\n", quant_type);
+        exit(1);
+    }
+    if (gemv_4bit_grouped(dtype, A, count, B, absmax, absmax_8bit, absmax_code, absmax_offset, out, bias, N, M, K, blocksize,
+                          quant_type, S(s)))
+        return;
+    // not a streaming-kernel shape (M > 4, more than 8 matrices, odd K ...): one launch per matrix, same results
+    for (int i = 0; i < count; ++i)
+        gemm_4bit_dispatch(0, dtype, A, B[i], absmax[i], absmax_8bit ? absmax_8bit[i] : nullptr,
+                           absmax_code ? absmax_code[i] : nullptr, absmax_offset ? absmax_offset[i] : nullptr, nullptr, out[i],
+                           bias ? bias[i] : nullptr, M, N[i], K, blocksize, quant_type, nullptr, 0, S(s));
+}
 size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N, int K, int blocksize) {
     // alignment of A/B is unknown here; assume the aligned (fast) case, an unused workspace is harmless
     static const int dummy_aligned[4] __attribute__((aligned(16))) = {0, 0, 0, 0};
@@ -246,6 +277,9 @@ void bnb_mi355x_set_tuning(int dot_rows_per_wave, int dot_segments, int mfma_kno
     g_dot_segs = dot_segments;
     g_mfma_knob0 = mfma_knob0;
     g_mfma_knob1 = mfma_knob1;
+}
+void bnb_mi355x_set_stream_tuning(int ring_depth, int segments, int rows_per_workgroup, int nontemporal, int waves) {
+    gemv_4bit_stream_tuning(ring_depth, segments, rows_per_workgroup, nontemporal, waves);
 }
 void bnb_mi355x_set_debug(int dot_ablation, int dot_flags) {
     g_dot_ablate = dot_ablation;

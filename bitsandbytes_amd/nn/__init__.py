@@ -7,7 +7,8 @@ from .modules import (
     LinearFP4,
     LinearNF4,
     Params4bit,
+    linear4bit_group_forward,
 )
 
 __all__ = ["Linear4bit", "LinearFP4", "LinearNF4", "Params4bit", "Embedding4bit", "EmbeddingFP4", "EmbeddingNF4",
-           "parametrize"]
+           "parametrize", "linear4bit_group_forward"]

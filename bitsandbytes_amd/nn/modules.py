@@ -275,6 +275,37 @@ class Linear4bit(nn.Linear):
         return matmul_4bit(x, self.weight, bias=bias, quant_state=quant_state).to(inp_dtype)
 
 
+def linear4bit_group_forward(layers, x: torch.Tensor):
+    """``[layer(x) for layer in layers]`` for :class:`Linear4bit` layers that consume the same input (Q/K/V, gate/up).
+    Same dtype policy as :meth:`Linear4bit.forward`; when every layer computes in the same dtype the matmuls go through
+    :func:`bitsandbytes_amd.matmul_4bit_grouped` - one launch for a decode-sized batch on MI355X - and the outputs are
+    bit-identical to calling the layers one by one."""
+    from ..autograd import matmul_4bit_grouped
+
+    layers = list(layers)
+    for layer in layers:
+        fix_4bit_weight_quant_state_from_module(layer)
+        if not layer.compute_type_is_set:
+            layer.set_compute_type(x)
+            layer.compute_type_is_set = True
+    dtypes = {layer.compute_dtype for layer in layers}
+    if len(dtypes) != 1:
+        return [layer(x) for layer in layers]
+    compute_dtype = dtypes.pop()
+    inp_dtype = x.dtype
+    xc = x if compute_dtype is None else x.to(compute_dtype)
+    biases = []
+    for layer in layers:
+        bias = layer.bias
+        if bias is not None:
+            if bias.dtype != xc.dtype:
+                bias.data = bias.data.to(xc.dtype)
+            bias = bias.to(compute_dtype)
+        biases.append(bias)
+    ys = matmul_4bit_grouped(xc, [layer.weight for layer in layers], [layer.weight.quant_state for layer in layers], biases)
+    return [y.to(inp_dtype) for y in ys]
+
+
 class LinearFP4(Linear4bit):
     def __init__(self, input_features, output_features, bias=True, compute_dtype=None, compress_statistics=True,
                  quant_storage=torch.uint8, device=None):

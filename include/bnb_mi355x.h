@@ -111,17 +111,32 @@ void bnb_mi355x_quantize_8bit(const float* code, const void* A, int dtype, float
 void bnb_mi355x_dequantize_4bit_rows(int dtype, const unsigned char* A, const float* absmax, const void* indices, int index_bytes, void* out, long rows_out, long num_rows, int row_len, int blocksize, int quant_type, bnb_stream_t stream);
 
 /* gemm_4bit with an explicit kernel choice and a caller-owned split-K workspace:
- * kernel = 0 auto, 1 wave64 dot kernel, 2 MFMA kernel. dtype as above; code16 may be NULL.
+ * kernel = 0 auto, 1 round-1 wave64 dot kernel (A/B measurements), 2 MFMA kernel, 3 streaming dot kernel. dtype as above; code16 may be NULL.
  * workspace: device buffer of bnb_mi355x_gemm_4bit_workspace_bytes(...) bytes (may be NULL / smaller:
  * the MFMA kernel then uses fewer K slices, or a library-owned per-stream buffer when NULL and the
  * stream is not being captured). Its contents are scratch; no initialisation is required. */
 void bnb_mi355x_gemm_4bit(int kernel, int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, const float* code16, void* out, const void* bias, int M, int N, int K, int blocksize, int quant_type, void* workspace, size_t workspace_bytes, bnb_stream_t stream);
 size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N, int K, int blocksize);
 
+/* Grouped gemm_4bit: `count` weight matrices applied to the SAME activations A[M, K] in one launch -
+ *   out[i][M, N[i]] = A * dequant(B[i])^T (+ bias[i])        i = 0 .. count-1
+ * (the Q/K/V projections of an attention block, the gate/up projections of an MLP: reference callers issue one
+ * gemm_4bit per matrix, bitsandbytes/nn/modules.py:609-637). All matrices share K, blocksize, quant_type and
+ * nested-ness (absmax_8bit is NULL, or non-NULL for every matrix). The arrays are HOST arrays of device pointers
+ * / ints, read during the call. For M <= 4 and count <= 8 this is ONE launch of the streaming kernel over the
+ * concatenated rows (one kernel boundary, one decode-table build, one activation copy per CU); otherwise the
+ * matrices are launched one by one. Results are bit-identical to `count` separate cgemm_4bit_* calls. */
+void bnb_mi355x_gemm_4bit_grouped(int dtype, const void* A, int count, const uint8_t* const* B, const float* const* absmax, const uint8_t* const* absmax_8bit, const float* const* absmax_code, const float* const* absmax_offset, void* const* out, const void* const* bias, const int* N, int M, int K, int blocksize, int quant_type, bnb_stream_t stream);
+
 /* Tuning overrides for sweeps (0 = built-in heuristic): rows per wavefront and 2048-k segments per
  * iteration of the dot kernel; MFMA kernels: knob0 = A-image variant bits of the LDS-DMA kernel, knob1 =
  * 100 * cfg + K-slice count (cfg 5/6 LDS-DMA, 11-14 producer/consumer geometries). Not thread-safe; bench/test use only. */
 void bnb_mi355x_set_tuning(int dot_rows_per_wave, int dot_segments, int mfma_knob0, int mfma_knob1);
+
+/* Sweep-only overrides of the streaming kernel (0 / -1 = built-in choice): ring depth (2, 3, 6; bf16 M = 1 fp32-absmax
+ * NF4 only), 2048-k segments side by side, rows per workgroup, non-temporal weight loads (0 / 1, -1 = default on),
+ * wavefronts per workgroup (8; same restriction as ring depth). Every setting computes the same results. Atomics. */
+void bnb_mi355x_set_stream_tuning(int ring_depth, int segments, int rows_per_workgroup, int nontemporal, int waves);
 
 /* Profiling only. dot_ablation: 0 = normal; 1..5 run ablated variants of the dot kernel (stream only /
  * no table build / no weight loads / weights only / empty) whose RESULTS ARE WRONG. dot_flags selects

@@ -866,3 +866,172 @@ def test_linear4bit_under_torch_compile_aot_eager():
         got1 = compiled(x[:1])
     assert torch.equal(got, want)
     assert torch.equal(got1, net(x[:1]))
+
+
+# ------------------------------------------------------------------------------------------ streaming dot kernel (round 2)
+def _oracle_y_full(x, q, st, bias=None):
+    """fp32-dequantize (oracle) + CPU fp64 matmul over ALL rows: the same oracle as `_oracle_y`, fast enough for the
+    BASELINE-sized matrices (the scalar C gemm of the oracle is not)."""
+    N, K = int(st.shape[0]), int(st.shape[1])
+    if st.nested:
+        absmax = O.dequantize_blockwise(st.absmax.cpu(), st.state2.absmax.cpu(), st.state2.code.cpu(), 256, torch.float32)
+        absmax = absmax + st.offset.cpu().float()
+    else:
+        absmax = st.absmax.cpu()
+    W = O.dequantize_4bit(q.cpu(), absmax, st.blocksize, st.quant_type, (N, K), torch.float32)
+    y = x.cpu().double() @ W.double().t()
+    if bias is not None:
+        y = y + bias.cpu().double()
+    return y
+
+
+STREAM_SHAPES = [  # (M, N, K)
+    (1, 4096, 4096), (1, 256, 2048), (1, 31, 96), (2, 300, 2816), (3, 130, 1024), (4, 512, 4096), (1, 16, 53248),
+    (2, 64, 14336), (4, 40, 11008), (7, 96, 4096), (1, 1000, 32), (2, 5, 6144), (4, 8, 36864), (1, 300, 8192),
+]
+
+
+@pytest.mark.parametrize("M,N,K", STREAM_SHAPES)
+@pytest.mark.parametrize("variant", ["bf16-nf4-64", "fp16-nf4-64", "fp32-nf4-64", "bf16-fp4-128-nested", "fp16-nf4-32",
+                                     "bf16-nf4-4096", "fp32-fp4-64-nested", "bf16-nf4-64-nested"])
+def test_stream_kernel_vs_oracle(M, N, K, variant):
+    """csrc/gemv4_stream.hip through bnb_mi355x_gemm_4bit(kernel = 3): every activation dtype, both code tables,
+    nested absmax, blocksizes from one lane's run (32) to two segments (4096), ragged K tails (K % 2048 != 0), rows
+    longer than one workgroup's wavefronts (K = 36864 / 53248: several phases), M = 7 (passes of 4 over grid.y)."""
+    F = _F()
+    parts = variant.split("-")
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[parts[0]]
+    qt, bs, dq = parts[1], int(parts[2]), "nested" in parts
+    if K % bs:
+        pytest.skip("K must be a multiple of the blocksize for the fused op")
+    W = (torch.randn(N, K) / K**0.5).to(dt)
+    x = torch.randn(M, K).to(dt)
+    bias = torch.randn(N).to(dt)
+    q, st = F.quantize_4bit(W.to(DEV), blocksize=bs, quant_type=qt, compress_statistics=dq)
+    y_ref = _oracle_y_full(x, q, st, bias)
+    y = _run_kernel(3, x.to(DEV), q, st, bias.to(DEV))
+    assert y.shape == (M, N) and y.dtype == dt
+    tol = 2e-5 if dt == torch.float32 else REL_TOL
+    assert rel_err(y.cpu(), y_ref) < tol
+    # the fp32 accumulation itself (before the output rounding) is much tighter than the tolerance
+    if dt != torch.float32:
+        assert rel_err(y.cpu(), y_ref.to(dt)) < 3e-3
+    assert torch.equal(y, _run_kernel(3, x.to(DEV), q, st, bias.to(DEV)))  # bit-reproducible
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (2, 1376, 4096), (1, 512, 11008), (4, 300, 8192), (1, 64, 36864)])
+def test_stream_kernel_geometry_independent(M, N, K):
+    """Segment partials are combined in fixed order: ring depth, segments side by side, rows per workgroup, cache
+    policy and wavefront count must not change a single bit (the reference demands run-to-run equality,
+    tests/test_functional.py:1016-1034; here it also holds across launch geometries)."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    W = (torch.randn(N, K) / K**0.5).bfloat16()
+    x = torch.randn(M, K).bfloat16()
+    q, st = F.quantize_4bit(W.to(DEV), blocksize=64, quant_type="nf4")
+    y0 = _run_kernel(3, x.to(DEV), q, st)
+    assert rel_err(y0.cpu(), _oracle_y_full(x, q, st)) < REL_TOL
+    try:
+        for tune in [(2, 0, 0, -1, 0), (3, 0, 0, -1, 0), (6, 0, 0, -1, 0), (0, 1, 0, -1, 0), (0, 0, 3, -1, 0),
+                     (0, 0, 0, 0, 0), (0, 0, 0, -1, 8), (0, 2, 7, 0, 8)]:
+            bnb.lib.bnb_mi355x_set_stream_tuning(*tune)
+            assert torch.equal(_run_kernel(3, x.to(DEV), q, st), y0), f"tuning {tune}"
+    finally:
+        bnb.lib.bnb_mi355x_set_stream_tuning(0, 0, 0, -1, 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("dq", [False, True], ids=["absmax32", "nested"])
+@pytest.mark.parametrize("M", [1, 2, 4, 6])
+def test_matmul_4bit_grouped_equals_separate_calls(dtype, dq, M):
+    """bnb_mi355x_gemm_4bit_grouped: Q/K/V-like (4096 / 1024 / 1024 rows) and gate/up-like groups, with and without
+    bias, must be bit-identical to one matmul_4bit per matrix (M = 6 exercises the library's own fallback)."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    K = 2048
+    x = torch.randn(M, K, device=DEV).to(dtype)
+    for Ns, qt in (((1024, 256, 256), "nf4"), ((704, 704), "fp4"), ((96,), "nf4"), (tuple([64] * 9), "nf4")):
+        ws, sts, bs_ = [], [], []
+        for i, N in enumerate(Ns):
+            W = (torch.randn(N, K, device=DEV) / K**0.5).to(dtype)
+            q, st = F.quantize_4bit(W, blocksize=64, quant_type=qt, compress_statistics=dq)
+            ws.append(q)
+            sts.append(st)
+            bs_.append(torch.randn(N, device=DEV).to(dtype) if i % 2 == 0 else None)
+        ys = bnb.matmul_4bit_grouped(x, ws, sts, bs_)
+        for y, w, s, b in zip(ys, ws, sts, bs_):
+            y1 = bnb.matmul_4bit(x, w, s, bias=b)
+            assert y.shape == y1.shape and torch.equal(y, y1)
+
+
+def test_linear4bit_group_forward_gpu():
+    from bitsandbytes_amd.nn import Linear4bit, linear4bit_group_forward
+
+    torch.manual_seed(5)
+    layers = []
+    for n_out in (512, 128, 128):
+        ref = torch.nn.Linear(1024, n_out, bias=True)
+        layer = Linear4bit(1024, n_out, bias=True, quant_type="nf4", compute_dtype=torch.bfloat16)
+        layer.load_state_dict(ref.state_dict())
+        layers.append(layer.to(DEV))
+    for shape in ((1, 1024), (1, 3, 1024), (40, 1024)):
+        x = torch.randn(*shape, device=DEV)
+        ys = linear4bit_group_forward(layers, x)
+        for y, layer in zip(ys, layers):
+            assert torch.equal(y, layer(x))
+
+
+# ------------------------------------------------------------------------------------------ BASELINE configs at full size
+C4_SHAPES = [(11008, 4096), (4096, 11008), (1376, 4096), (512, 11008)]  # Llama FFN matrices and their 8-way row shards
+
+
+@pytest.mark.parametrize("N,K", C4_SHAPES)
+@pytest.mark.parametrize("M", [1, 64])
+@pytest.mark.parametrize("dq", [False, True], ids=["absmax32", "nested"])
+def test_config4_llama_ffn_shapes_full(N, K, M, dq):
+    """BASELINE.json configs[3]: Linear4bit NF4 on the Llama-3-8B FFN shapes and the per-GPU shards of the 8-way
+    row split (1376 = 10.75 x 128 columns is ragged against every MFMA tile), M = 1 (streaming kernel) and M = 64
+    (MFMA producer/consumer kernel), every output row against the fp32-dequantize + fp64-matmul oracle."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    W = (torch.randn(N, K, device=DEV) / K**0.5).bfloat16()
+    x = torch.randn(M, K, device=DEV).bfloat16()
+    bias = torch.randn(N, device=DEV).bfloat16()
+    q, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4", compress_statistics=dq)
+    del W
+    y = bnb.matmul_4bit(x, q, st, bias=bias)
+    assert y.shape == (M, N)
+    assert rel_err(y.cpu(), _oracle_y_full(x, q, st, bias)) < REL_TOL
+    assert torch.equal(bnb.matmul_4bit(x, q, st, bias=bias), y)
+
+
+@pytest.mark.parametrize("M", [1, 64])
+def test_config3_8192_all_rows(M):
+    """BASELINE.json configs[2] (gemm_4bit NF4 bf16 M = 64, N = K = 8192) checked on ALL 8192 output rows (and the
+    same matrix at M = 1)."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    N = K = 8192
+    W = (torch.randn(N, K, device=DEV) / K**0.5).bfloat16()
+    x = torch.randn(M, K, device=DEV).bfloat16()
+    q, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4")
+    del W
+    y = bnb.matmul_4bit(x, q, st)
+    assert rel_err(y.cpu(), _oracle_y_full(x, q, st)) < REL_TOL
+
+
+def test_config5_fp4_nested_bs128_full():
+    """BASELINE.json configs[4]: FP4, double quant, blocksize 128, bf16, M = 1, N = K = 4096, all rows."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    N = K = 4096
+    W = (torch.randn(N, K, device=DEV) / K**0.5).bfloat16()
+    x = torch.randn(1, K, device=DEV).bfloat16()
+    q, st = F.quantize_4bit(W, blocksize=128, quant_type="fp4", compress_statistics=True)
+    y = bnb.matmul_4bit(x, q, st)
+    assert rel_err(y.cpu(), _oracle_y_full(x, q, st)) < REL_TOL
