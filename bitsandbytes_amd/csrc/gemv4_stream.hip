@@ -35,6 +35,10 @@
 
 namespace bnb {
 
+#ifdef BNB_PROFILING
+extern unsigned long long* g_dbg_buf; // gemv4.hip (profiling builds)
+#endif
+
 namespace {
 
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
@@ -68,7 +72,21 @@ struct StreamMat {
     int row_start;    // first row of this matrix in the concatenated row space
 };
 
+// Profiling builds (-DBNB_PROFILING, libbitsandbytes_mi355x_prof.so, tools/ only): per-wavefront s_memtime stamps.
+#ifdef BNB_PROFILING
+#define BNB_ST_STAMP(i)                                                                            \
+    {                                                                                              \
+        if (p.dbg && lane == 0)                                                                    \
+            p.dbg[(static_cast<long>(blockIdx.x) * WAVES + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    }
+#else
+#define BNB_ST_STAMP(i) {}
+#endif
+
 struct StreamArgs {
+#ifdef BNB_PROFILING
+    unsigned long long* dbg;
+#endif
     const void* A;
     const float* code16;
     int M, K, bs_shift;
@@ -100,15 +118,18 @@ template <> __device__ __forceinline__ void unpack16<f16>(const u32x4& v, float*
     using h2 = __attribute__((ext_vector_type(2))) f16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const h2 h = __builtin_bit_cast(h2, v[i]);
+        const uint32_t e = v[i]; // (a copy: __builtin_bit_cast applied to the vector-element lvalue reads element 0)
+        const h2 h = __builtin_bit_cast(h2, e);
         dst[2 * i] = static_cast<float>(h[0]);
         dst[2 * i + 1] = static_cast<float>(h[1]);
     }
 }
 template <> __device__ __forceinline__ void unpack16<float>(const u32x4& v, float* dst) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        dst[i] = __builtin_bit_cast(float, v[i]);
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t e = v[i]; // (a copy: see unpack16<f16>)
+        dst[i] = __builtin_bit_cast(float, e);
+    }
 }
 
 // T in {bf16, f16, float}; MB = activation rows held in registers; WAVES = wavefronts per workgroup (16 at MB = 1,
@@ -143,6 +164,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     const int nrows = (rows_total - row_begin < R) ? rows_total - row_begin : R;
     const int m0 = blockIdx.y * MB;
     const int sw = wave % SW, g = wave / SW;
+    BNB_ST_STAMP(0)
 
     // LDS map: table | nested code(s) (1 KiB per matrix) | segment partials [R][S][MB] | activation image [MB][SW][2048] T
     constexpr int kCode2Bytes = (GROUPED ? kMaxGroup : 1) * 1024;
@@ -342,14 +364,24 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         if (ph > 0)
             __syncthreads(); // everyone is done with the previous activation image
         // (1) this phase's activation image (LDS-DMA, oldest in the queue), then the first NS ring stages
+        if (ph == 0)
+            BNB_ST_STAMP(9)
         issue_x(ph);
+        if (ph == 0)
+            BNB_ST_STAMP(10)
         seg = ph * SW + sw;
         n_items = items_of(seg);
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             issue(st[j], j);
             __builtin_amdgcn_sched_barrier(0); // keep the queue in stage order: (weights, scale) of stage 0, of stage 1, ...
+            if (ph == 0 && j == 0)
+                BNB_ST_STAMP(11)
+            if (ph == 0 && j == 1)
+                BNB_ST_STAMP(12)
         }
+        if (ph == 0)
+            BNB_ST_STAMP(1)
         if (ph == 0) {
             // (2) decode table, built while the loads fly: entry e (a packed byte) = 32 copies of
             // (code[e >> 4], code[e & 15]) in fp32, 256 B per entry, copy c at byte 8 c. Chunk c16 of the table
@@ -376,25 +408,35 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             }
         }
         // (3) the activation DMAs are older than the NS ring stages: wait until only those remain in flight
+        if (ph == 0)
+            BNB_ST_STAMP(2)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS * LPS) : "memory");
         __syncthreads();
+        if (ph == 0)
+            BNB_ST_STAMP(3)
         // an opaque zero ties the decode to program order after the barrier (without it LLVM hoists the first
         // look-up address - and its vmcnt wait - above the table build)
         perm_sel = 0x0C0C0400u + static_cast<uint32_t>(opaque_zero());
         load_slice();
+        if (ph == 0)
+            BNB_ST_STAMP(4)
         // (4) rounds of NS items; the refill of a stage is issued right after the stage was consumed, valid or not
         for (int base = 0; base < n_items; base += NS) {
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
                 if (base + j < n_items)
                     compute(st[j], base + j);
+                if (ph == 0 && base == 0 && j == 0)
+                    BNB_ST_STAMP(5)
                 issue(st[j], base + j + NS);
             }
         }
     }
+    BNB_ST_STAMP(6)
 
     // ---- combine the segment partials of every row in segment order, bias, one rounding
     __syncthreads();
+    BNB_ST_STAMP(7)
     for (int idx = tid; idx < nrows * MB; idx += THREADS) {
         const int m = idx / nrows, rl = idx - m * nrows;
         if (m0 + m >= M)
@@ -412,6 +454,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         const float b = bias ? static_cast<float>(bias[row]) : 0.0f;
         static_cast<T*>(p.mat[mi].out)[static_cast<long>(m0 + m) * p.mat[mi].N + row] = static_cast<T>(v + b);
     }
+    BNB_ST_STAMP(8)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -662,6 +705,9 @@ void gemv_4bit_stream(int dtype, const void* A, const uint8_t* B, const float* a
         return;
     if (stream_ok(A, K, blocksize) && aligned_to(B, 16)) {
         StreamArgs a;
+#ifdef BNB_PROFILING
+        a.dbg = g_dbg_buf;
+#endif
         a.A = A;
         a.code16 = code16;
         a.M = M;
@@ -694,6 +740,9 @@ bool gemv_4bit_grouped(int dtype, const void* A, int count, const uint8_t* const
     if (count < 1 || count > kMaxGroup || M < 1 || M > 4 || K <= 0 || !stream_ok(A, K, blocksize))
         return false;
     StreamArgs a;
+#ifdef BNB_PROFILING
+    a.dbg = nullptr;
+#endif
     a.A = A;
     a.code16 = nullptr;
     a.M = M;
