@@ -158,6 +158,31 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// C independent wave sums in lock step: every DPP stage runs over all C values before the next one, so the chains
+// overlap instead of paying the DPP / readlane hazards C times in a row.
+template <int C> __device__ __forceinline__ void wave_sum_n(float (&v)[C]) {
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        v[c] = dpp_add<0xB1>(v[c]);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        v[c] = dpp_add<0x4E>(v[c]);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        v[c] = dpp_add<0x141>(v[c]);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        v[c] = dpp_add<0x140>(v[c]);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[c]), 0));
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[c]), 16));
+        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[c]), 32));
+        const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[c]), 48));
+        v[c] = (r0 + r1) + (r2 + r3);
+    }
+}
+
 static inline int ilog2(int v) {
     int s = 0;
     while ((1 << s) < v)

@@ -56,7 +56,8 @@ enum StreamFlags : int {
     kCodePtr = 2, // code values from a caller-supplied device table (legacy gemv_4bit op) instead of literals
     kFp4 = 4,     // literal table = FP4 (else NF4)
     kNT = 8,      // non-temporal weight loads
-    kGrouped = 16 // several matrices over one concatenated row space
+    kGrouped = 16, // several matrices over one concatenated row space
+    kMulti = 32    // rows longer than the workgroup's segment columns: several phases (a loop around the whole body)
 };
 
 // One weight matrix of a launch.
@@ -134,44 +135,63 @@ template <> __device__ __forceinline__ void unpack16<float>(const u32x4& v, floa
 
 // T in {bf16, f16, float}; MB = activation rows held in registers; WAVES = wavefronts per workgroup (16 at MB = 1,
 // 8 above: 32 MB fp32 activation registers per lane); NS = depth of the weight ring.
+//
+// One CU has ONE scalar unit: with 16 wavefronts resident every scalar instruction of the kernel costs the CU 16
+// issue slots (the first version spent 2300 cycles between its first two stamps on integer divisions and descriptor
+// arithmetic, profiles/r2_timeline_stream.txt). Everything that depends only on the problem is therefore computed on
+// the host and arrives in preloaded SGPRs; what remains per item is a handful of scalar operations.
 template <typename T, int MB, int WAVES, int NS, int FLAGS>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES / 4, WAVES / 4))) void gemv4_stream_kernel(
-    // hot arguments as separate scalars: the command processor preloads them into SGPRs (kernarg preload), so a
-    // wavefront does not start with a dependent s_load from a cold kernarg buffer
-    const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, const float* hot_code16,
-    int hot_N, int hot_K, int hot_packed /* M | bs_shift << 24 */, int hot_geom /* R | SW << 16 | G << 21 */,
-    const StreamArgs p) {
+    // hot arguments as separate scalars: the command processor preloads them into SGPRs (kernarg preload, 14 dwords),
+    // so a wavefront does not start with a dependent s_load from a cold kernarg buffer
+    const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, int hot_N, int hot_K,
+    int hot_packed /* M | bs_shift << 18 | P << 23 */, int hot_geom /* R | SW << 16 | G << 21 */,
+    int hot_inv /* ceil(256 / SW) */, const StreamArgs p) {
     constexpr bool NESTED = FLAGS & kNested, CODEPTR = FLAGS & kCodePtr, NT = FLAGS & kNT, GROUPED = FLAGS & kGrouped;
+    constexpr bool MULTI = FLAGS & kMulti;
     constexpr int THREADS = WAVES * 64;
     constexpr int TB = TypeInfo<T>::bytes;
     constexpr int CH = 2 * TB;  // 16-byte chunks of activations per lane and segment (= 1-KiB DMA pieces per segment)
     constexpr int EPC = 16 / TB; // elements per chunk
     constexpr int LPS = NESTED ? 3 : 2; // vector loads per ring stage
+    // The wavefronts of a workgroup start ~90 cycles apart (the last of 16 about 1400 cycles after the first, measured
+    // with s_memtime): everything that has to be finished before the first barrier - activation copy, decode table -
+    // is given to the first half of them, which have that time to spare; the late ones only issue their loads.
+    constexpr int BUILDERS = (WAVES >= 16) ? WAVES / 2 : WAVES; // (an 8-wavefront workgroup starts within ~130 cycles)
+    constexpr int IL = (NS % 2 == 0 && WAVES < 16 && MB <= 2) ? 2 : 1; // ring stages decoded together
+    static_assert(NS % IL == 0, "the ring is consumed IL stages at a time");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = hot_K;
-    const int M = hot_packed & 0xFFFFFF, bs_shift = (hot_packed >> 24) & 31;
+    // Single-phase instances have no loop around the body: in the looped form LLVM hoists every phase-invariant
+    // address computation in front of the loop - i.e. in front of the first loads.
+    const int M = hot_packed & 0x3FFFF, bs_shift = (hot_packed >> 18) & 31, P = MULTI ? (hot_packed >> 23) & 511 : 1;
     const int R = hot_geom & 0xFFFF, SW = (hot_geom >> 16) & 31, G = (hot_geom >> 21) & 31;
-    const int S = (K + kSegK - 1) / kSegK;
-    const int P = (S + SW - 1) / SW;
+    const int S = (K + kSegK - 1) >> 11;
     const int rows_total = GROUPED ? p.rows_total : hot_N;
     const int row_begin = blockIdx.x * R;
     if (row_begin >= rows_total)
         return;
     const int nrows = (rows_total - row_begin < R) ? rows_total - row_begin : R;
     const int m0 = blockIdx.y * MB;
-    const int sw = wave % SW, g = wave / SW;
+    // wave -> (segment column sw, row group g): g = wave / SW by a host-made reciprocal (exact for wave < 16 <= 256 / SW)
+    const int g = (wave * hot_inv) >> 8;
+    const int sw = wave - g * SW;
+#ifdef BNB_PROFILING
+    if (p.dbg && lane == 0)
+        p.dbg[(static_cast<long>(blockIdx.x) * WAVES + wave) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+#endif
     BNB_ST_STAMP(0)
 
-    // LDS map: table | nested code(s) (1 KiB per matrix) | segment partials [R][S][MB] | activation image [MB][SW][2048] T
+    // LDS map: table | nested code(s) (1 KiB per matrix) | activation image [MB][SW][2048] T | segment partials [R][S][MB]
+    // (the image sits at a compile-time offset: its address is needed before the first loads go out)
     constexpr int kCode2Bytes = (GROUPED ? kMaxGroup : 1) * 1024;
     float* const code2 = reinterpret_cast<float*>(smem + kLutBytes);
-    float* const part = reinterpret_cast<float*>(smem + kLutBytes + kCode2Bytes);
-    const int part_bytes = (R * S * MB * 4 + 15) & ~15;
-    unsigned char* const ximg = smem + kLutBytes + kCode2Bytes + part_bytes;
+    unsigned char* const ximg = smem + kLutBytes + kCode2Bytes;
+    float* const part = reinterpret_cast<float*>(ximg + MB * SW * kSegK * TB);
 
     const T* __restrict__ A = static_cast<const T*>(hot_A);
 
@@ -189,9 +209,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         }
     }
     if constexpr (CODEPTR)
-        cv = hot_code16[lane & 15];
-    else
-        cv = code_literal<(FLAGS & kFp4) != 0>(lane & 15);
+        cv = p.code16[lane & 15];
 
     // ---- activation image of phase ph: LDS-DMA, one 1-KiB piece per instruction. The image is lane-linear per
     // piece (hardware), so the bank swizzle is applied on the SOURCE side: slot s = CH l' + j of a segment row
@@ -201,9 +219,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     // compiler sees DMA and ordinary loads on one counter and turns every later register wait into vmcnt(0).
     auto swz = [](int l) -> int { return (CH == 4) ? ((l >> 2) & 3) : ((l >> 1) & 7); };
     auto issue_x = [&](int ph) {
+        if (wave >= BUILDERS)
+            return;
         const int segs = (S - ph * SW < SW) ? S - ph * SW : SW;
         const int pieces = MB * segs * CH;
-        for (int piece = wave; piece < pieces; piece += WAVES) {
+        for (int piece = wave; piece < pieces; piece += BUILDERS) {
             const int t = piece / CH, pc = piece - t * CH; // CH is a power of two
             const int m = (MB == 1) ? 0 : t / segs;
             const int sg = t - m * segs;
@@ -218,6 +238,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory", "m0");
         }
     };
+
     // ---- weight ring. Loads go through buffer descriptors so that EVERY issue is unconditional: an item past the
     // end of the wavefront's list (and a lane past the end of the row) is an out-of-range access - the hardware
     // bounds check returns zeros without touching memory - and the number of vector-memory operations in flight is
@@ -230,8 +251,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         float s2; // nested: second-level absmax
     };
     Stage st[NS];
-    constexpr uint32_t kOob = 0xFFFFFFF0u; // beyond any num_records (packed weights of < 2^31 elements are < 2^30 bytes)
+    constexpr uint32_t kOob = 0xFFFFFFF0u; // beyond num_records
     constexpr int kRsrcFlags = 0x00020000;
+    constexpr int kRecords = 0x7FFFFFFF;   // the descriptors only exist for the out-of-range trick: valid offsets are < 2^30
     constexpr int kWeightAux = NT ? 2 : 0; // nt: streamed once, read by one CU
 
     // matrix of a concatenated row (grouped launches): wave-uniform scan over <= kMaxGroup descriptors
@@ -246,49 +268,44 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     };
 
     int seg = sw;
-    int n_items = 0;
-    auto items_of = [&](int sg) -> int { return (g < G && sg < S && g < nrows) ? (nrows - g + G - 1) / G : 0; };
+    int rl_end = 0;       // items of this wavefront: local rows g, g + G, ... < rl_end (0: nothing to do in this phase)
+    uint32_t k0 = 0;      // first k of this lane in the current segment
+    bool k_ok = false;    // ... and whether it lies inside the row
 
+    // Offsets of an item's loads: a per-phase lane part (k0, or kOob for lanes past the end of the row) OR-ed with a
+    // wave-uniform mask that is all-ones-ish for an item past the end of the list - branch-free (written as selects,
+    // hipcc turned the predicate into two exec-masked copies of every load).
+    uint32_t lane_mask = kOob; // 0 for lanes inside the row, kOob otherwise
     auto issue = [&](Stage& s, int i) {
-        const bool valid = i < n_items; // wave-uniform
-        const int grow = row_begin + g + i * G;
+        const bool valid = g + i * G < rl_end; // wave-uniform
+        const int grow = valid ? row_begin + g + i * G : 0;
+        const uint32_t inval = (valid ? 0u : kOob) | lane_mask;
         const uint8_t* Bp = hot_B;
         const float* am = hot_absmax;
         const uint8_t* am8 = hot_absmax8;
-        int row = grow, nmat_rows = hot_N;
+        int row = grow;
         if constexpr (GROUPED) {
-            const int mi = mat_of(valid ? grow : 0);
+            const int mi = mat_of(grow);
             Bp = p.mat[mi].B;
             am = p.mat[mi].absmax;
             am8 = p.mat[mi].absmax8;
-            row = grow - p.mat[mi].row_start;
-            nmat_rows = p.mat[mi].N;
+            row = valid ? grow - p.mat[mi].row_start : 0;
         }
-        row = valid ? row : 0;
-        const long elems = static_cast<long>(nmat_rows) * K;
-        const long blocks = (elems + (1L << bs_shift) - 1) >> bs_shift;
-        const int k0 = seg * kSegK + lane * 32;
-        const bool lane_ok = valid && (k0 < K);
-        const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(Bp), 0, static_cast<int>(elems >> 1), kRsrcFlags);
+        const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(Bp), 0, kRecords, kRsrcFlags);
         s.w = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                            rs_w, lane_ok ? static_cast<uint32_t>(k0 >> 1) : kOob,
+                                            rs_w, (k0 >> 1) | inval,
                                             static_cast<uint32_t>(row) * static_cast<uint32_t>(K >> 1), kWeightAux));
-        const uint32_t blk = static_cast<uint32_t>((static_cast<uint32_t>(row) * static_cast<uint32_t>(K) + static_cast<uint32_t>(k0)) >> bs_shift);
+        const uint32_t blk = (static_cast<uint32_t>(row) * static_cast<uint32_t>(K) + k0) >> bs_shift;
         if constexpr (NESTED) {
-            const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(am8), 0, static_cast<int>(blocks), kRsrcFlags);
-            const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(am), 0, static_cast<int>(((blocks + 255) >> 8) * 4), kRsrcFlags);
-            s.s = __builtin_bit_cast(float, static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b8(rs_q, lane_ok ? blk : kOob, 0, 0)));
-            s.s2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, lane_ok ? (blk >> 8) * 4u : kOob, 0, 0));
+            const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(am8), 0, kRecords, kRsrcFlags);
+            const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(am), 0, kRecords, kRsrcFlags);
+            s.s = __builtin_bit_cast(float, static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b8(rs_q, blk | inval, 0, 0)));
+            s.s2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, ((blk >> 8) * 4u) | inval, 0, 0));
         } else {
-            const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(am), 0, static_cast<int>(blocks * 4), kRsrcFlags);
-            s.s = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, lane_ok ? blk * 4u : kOob, 0, 0));
+            const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(am), 0, kRecords, kRsrcFlags);
+            s.s = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, (blk * 4u) | inval, 0, 0));
         }
     };
-
-    // The table is addressed with the raw v_perm_b32 result: it must sit at LDS address 0 (this kernel has no static
-    // LDS, so the dynamic segment starts there).
-    if (reinterpret_cast<uintptr_t>((lds_ptr)smem) != 0)
-        __builtin_trap();
 
     uint32_t perm_sel = 0x0C0C0400u; // v_perm_b32 selector {lane offset, weight byte j, 0, 0}
     const uint32_t lane_off = static_cast<uint32_t>(lane & 31) * 8u;
@@ -296,8 +313,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     float xr[MB][32];
 
     auto load_slice = [&]() {
-        const int k0 = seg * kSegK + lane * 32;
-        const bool act = (seg < S) && (k0 < K);
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
 #pragma unroll
@@ -306,57 +321,78 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
                 const u32x4 v = *reinterpret_cast<const u32x4*>(ximg + ((m * SW + sw) * CH * 64 + slot) * 16);
                 unpack16<T>(v, &xr[m][q * EPC]);
             }
-            // lanes past the end of the row hold zeros (their weight loads are out of range, their scale is forced to 0)
+            // lanes past the end of the row hold zeros (their weight loads are out of range, their scale is forced to 0);
+            // only the last segment of a row whose length is not a multiple of 2048 has such lanes
+            if ((seg + 1) * kSegK > K) {
 #pragma unroll
-            for (int e = 0; e < 32; ++e)
-                xr[m][e] = act ? xr[m][e] : 0.0f;
+                for (int e = 0; e < 32; ++e)
+                    xr[m][e] = k_ok ? xr[m][e] : 0.0f;
+            }
         }
     };
 
-    auto compute = [&](const Stage& s, int i) {
-        // all 16 look-ups of the item first (one v_perm_b32 + one ds_read_b64 per packed byte), then the FMAs: the
-        // LDS round trip is paid once per item, not once per byte (left alone, the scheduler serialises them)
-        f32x2 pr[16];
+    // Decode of IL consecutive ring stages at once (IL = 1 with 16 wavefronts per CU, 2 with 8: half as many
+    // wavefronts repeat the per-wavefront work - prologue, table, slice - but each needs its own instruction-level
+    // parallelism): all look-ups of the IL items first (one v_perm_b32 + one ds_read_b64 per packed byte), then the
+    // FMAs, then IL x MB wave reductions in lock step. The LDS round trip is paid once per group, not once per byte
+    // (left alone, the scheduler serialises look-up and use).
+    auto compute = [&](int j0, int i0) {
+        f32x2 pr[IL][16];
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+        for (int u = 0; u < IL; ++u)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t addr = __builtin_amdgcn_perm(s.w[d], lane_off, perm_sel + (j << 8));
-                pr[4 * d + j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>(addr);
-            }
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t addr = __builtin_amdgcn_perm(st[j0 + u].w[d], lane_off, perm_sel + (j << 8));
+                    pr[u][4 * d + j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>(addr);
+                }
         __builtin_amdgcn_sched_barrier(0);
-        float acc[MB][4];
+        float acc[IL][MB][4];
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
-            acc[m][0] = acc[m][1] = acc[m][2] = acc[m][3] = 0.0f;
+        for (int u = 0; u < IL; ++u)
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                acc[u][m][0] = acc[u][m][1] = acc[u][m][2] = acc[u][m][3] = 0.0f;
 #pragma unroll
         for (int b = 0; b < 16; ++b)
 #pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                acc[m][(b & 1) * 2] = fmaf(pr[b][0], xr[m][2 * b], acc[m][(b & 1) * 2]);
-                acc[m][(b & 1) * 2 + 1] = fmaf(pr[b][1], xr[m][2 * b + 1], acc[m][(b & 1) * 2 + 1]);
-            }
-        const int grow = row_begin + g + i * G;
-        float scale;
-        if constexpr (NESTED) {
-            const uint32_t q8 = __builtin_bit_cast(uint32_t, s.s);
-            if constexpr (GROUPED) {
-                const int mi = mat_of(grow);
-                scale = __fadd_rn(__fmul_rn(code2[mi * 256 + q8], s.s2), p.mat[mi].absmax_offset[0]);
-            } else {
-                scale = __fadd_rn(__fmul_rn(code2[q8], s.s2), offset);
-            }
-        } else {
-            scale = s.s;
-        }
-        const int k0 = seg * kSegK + lane * 32;
-        scale = (k0 < K) ? scale : 0.0f;
-        const int rl = g + i * G;
+            for (int u = 0; u < IL; ++u)
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const float v = wave_sum(((acc[m][0] + acc[m][1]) + (acc[m][2] + acc[m][3])) * scale);
-            if (lane == 0)
-                part[(rl * S + seg) * MB + m] = v;
+                for (int m = 0; m < MB; ++m) {
+                    acc[u][m][(b & 1) * 2] = fmaf(pr[u][b][0], xr[m][2 * b], acc[u][m][(b & 1) * 2]);
+                    acc[u][m][(b & 1) * 2 + 1] = fmaf(pr[u][b][1], xr[m][2 * b + 1], acc[u][m][(b & 1) * 2 + 1]);
+                }
+        float v[IL * MB];
+#pragma unroll
+        for (int u = 0; u < IL; ++u) {
+            const Stage& s = st[j0 + u];
+            float scale;
+            if constexpr (NESTED) {
+                const uint32_t q8 = __builtin_bit_cast(uint32_t, s.s);
+                if constexpr (GROUPED) {
+                    const int mi = mat_of(row_begin + g + (i0 + u) * G);
+                    scale = __fadd_rn(__fmul_rn(code2[mi * 256 + q8], s.s2), p.mat[mi].absmax_offset[0]);
+                } else {
+                    scale = __fadd_rn(__fmul_rn(code2[q8], s.s2), offset);
+                }
+            } else {
+                scale = s.s;
+            }
+            scale = k_ok ? scale : 0.0f;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                v[u * MB + m] = ((acc[u][m][0] + acc[u][m][1]) + (acc[u][m][2] + acc[u][m][3])) * scale;
+        }
+        wave_sum_n<IL * MB>(v);
+#pragma unroll
+        for (int u = 0; u < IL; ++u) {
+            const int rl = g + (i0 + u) * G;
+            if (lane == 0 && rl < rl_end) {
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+                    part[(rl * S + seg) * MB + m] = v[u * MB + m];
+            }
         }
     };
 
@@ -370,32 +406,47 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         if (ph == 0)
             BNB_ST_STAMP(10)
         seg = ph * SW + sw;
-        n_items = items_of(seg);
+        rl_end = (g < G && seg < S) ? nrows : 0;
+        k0 = static_cast<uint32_t>(seg * kSegK + lane * 32);
+        k_ok = (seg < S) && (k0 < static_cast<uint32_t>(K));
+        lane_mask = k_ok ? 0u : kOob;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             issue(st[j], j);
             __builtin_amdgcn_sched_barrier(0); // keep the queue in stage order: (weights, scale) of stage 0, of stage 1, ...
-            if (ph == 0 && j == 0)
-                BNB_ST_STAMP(11)
-            if (ph == 0 && j == 1)
-                BNB_ST_STAMP(12)
         }
         if (ph == 0)
             BNB_ST_STAMP(1)
         if (ph == 0) {
+            // everything below is written AFTER the first loads in program order and fenced there: the scalar unit
+            // is shared by the CU's 16 wavefronts, so nothing that is not needed for the loads may run before them
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ph == 0 && wave < BUILDERS) {
+            if constexpr (!CODEPTR)
+                cv = code_literal<(FLAGS & kFp4) != 0>((lane & 15) + opaque_zero()); // (opaque: not hoisted above the loads)
             // (2) decode table, built while the loads fly: entry e (a packed byte) = 32 copies of
             // (code[e >> 4], code[e & 15]) in fp32, 256 B per entry, copy c at byte 8 c. Chunk c16 of the table
             // (16 B = two copies) is written by thread c16 % THREADS: every ds_write_b128 of a wavefront covers 1 KiB
             // contiguous, conflict-free. The two code values come from lanes (e >> 4) and (e & 15) of `cv`.
-            static_assert((kLutBytes / 16) % THREADS == 0, "whole passes over the table");
+            constexpr int BT = BUILDERS * 64;
+            constexpr int ITERS = kLutBytes / 16 / BT;
+            static_assert((kLutBytes / 16) % BT == 0 && BT % 256 == 0, "whole passes over the table");
+            // chunk c16 = it * BT + tid: entry e = c16 >> 4, so code[e & 15] is the same in every pass of a thread and
+            // code[e >> 4] = code[c16 >> 8]. All cross-lane fetches are issued before the first store: written as
+            // fetch-fetch-store per pass the build is a chain of LDS round trips (measured: 2400 cycles for 16 passes).
+            const int cvb = __builtin_bit_cast(int, cv);
+            const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((tid >> 4) & 15) * 4, cvb));
+            float hi[ITERS];
 #pragma unroll
-            for (int it = 0; it < kLutBytes / 16 / THREADS; ++it) {
-                const int c16 = it * THREADS + tid;
-                const int e = c16 >> 4;
-                const float hi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e >> 4) * 4, __builtin_bit_cast(int, cv)));
-                const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e & 15) * 4, __builtin_bit_cast(int, cv)));
-                *reinterpret_cast<f32x4*>(smem + c16 * 16) = f32x4{hi, lo, hi, lo};
-            }
+            for (int it = 0; it < ITERS; ++it)
+                hi[it] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((it * BT + tid) >> 8) * 4, cvb));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it)
+                *reinterpret_cast<f32x4*>(smem + (it * BT + tid) * 16) = f32x4{hi[it], lo, hi[it], lo};
+        }
+        if (ph == 0) {
             if constexpr (NESTED) {
 #pragma unroll
                 for (int i = 0; i < C2PASS; ++i) {
@@ -420,25 +471,45 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         load_slice();
         if (ph == 0)
             BNB_ST_STAMP(4)
-        // (4) rounds of NS items; the refill of a stage is issued right after the stage was consumed, valid or not
-        for (int base = 0; base < n_items; base += NS) {
+#ifdef BNB_PROFILING
+        if (ph == 0 && p.dbg) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS * LPS - 1) : "memory");
+            BNB_ST_STAMP(15)
+        }
+#endif
+        // (4) rounds of NS items, IL at a time. While another round follows, the refill of a stage is issued right
+        // after the stage was consumed - valid or not, see above; the last round (peeled) consumes without refilling.
+        int base = 0;
+        for (; g + (base + NS) * G < rl_end; base += NS) {
 #pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                if (base + j < n_items)
-                    compute(st[j], base + j);
+            for (int j = 0; j < NS; j += IL) {
+                compute(j, base + j);
                 if (ph == 0 && base == 0 && j == 0)
                     BNB_ST_STAMP(5)
-                issue(st[j], base + j + NS);
+#pragma unroll
+                for (int u = 0; u < IL; ++u)
+                    issue(st[j + u], base + j + u + NS);
             }
+        }
+#pragma unroll
+        for (int j = 0; j < NS; j += IL) {
+            if (g + (base + j) * G < rl_end)
+                compute(j, base + j);
+            if (ph == 0 && base == 0 && j == 0)
+                BNB_ST_STAMP(5)
         }
     }
     BNB_ST_STAMP(6)
+    // The table is addressed with the raw v_perm_b32 result: it must sit at LDS address 0 (this kernel has no static
+    // LDS, so the dynamic segment starts there).
+    if (reinterpret_cast<uintptr_t>((lds_ptr)smem) != 0)
+        __builtin_trap();
 
     // ---- combine the segment partials of every row in segment order, bias, one rounding
     __syncthreads();
     BNB_ST_STAMP(7)
     for (int idx = tid; idx < nrows * MB; idx += THREADS) {
-        const int m = idx / nrows, rl = idx - m * nrows;
+        const int m = (MB == 1) ? 0 : idx / nrows, rl = idx - m * nrows;
         if (m0 + m >= M)
             continue;
         float v = 0.0f;
@@ -455,6 +526,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         static_cast<T*>(p.mat[mi].out)[static_cast<long>(m0 + m) * p.mat[mi].N + row] = static_cast<T>(v + b);
     }
     BNB_ST_STAMP(8)
+#ifdef BNB_PROFILING
+    if (p.dbg && lane == 0)
+        p.dbg[(static_cast<long>(blockIdx.x) * WAVES + wave) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -541,7 +616,7 @@ int device_cu_count() {
 constexpr size_t kLdsBudget = 156 * 1024; // largest dynamic allocation that launches (157 KiB is refused)
 
 struct Geometry {
-    int R, SW, G, grid_x;
+    int R, SW, G, P, grid_x;
     size_t lds;
 };
 
@@ -576,6 +651,7 @@ Geometry make_geometry(int rows_total, int K, int mb, int waves, int tbytes, boo
     if (R < 1)
         R = 1;
     ge.R = R;
+    ge.P = (S + sw - 1) / sw;
     ge.grid_x = (rows_total + R - 1) / R;
     ge.lds = fixed + ((static_cast<size_t>(R) * S * mb * 4 + 15) & ~size_t(15)) + ximg;
     return ge;
@@ -586,44 +662,65 @@ struct StreamTuning {
 };
 StreamTuning g_tune;
 
+// Production ring depth: 2 stages with 16 wavefronts per CU (2 KiB x 16 in flight already cover bandwidth x latency;
+// deeper rings only add refill work at the end of a row list), 4 stages - decoded two at a time - with 8.
+constexpr int kRing = 2;
+constexpr int ring_depth(int mb, int waves) { return (mb == 1 && waves == 8) ? 4 : kRing; }
+
 template <typename T, int MB, int WAVES, int NS, int FLAGS> void launch_one(const StreamArgs& a, hipStream_t stream) {
     const Geometry ge = make_geometry(a.rows_total, a.K, MB, WAVES, TypeInfo<T>::bytes, (FLAGS & kGrouped) != 0, g_tune.sw.load(std::memory_order_relaxed),
                                       g_tune.rows.load(std::memory_order_relaxed));
+    dim3 grid(ge.grid_x, (a.M + MB - 1) / MB);
+    const StreamMat& m0 = a.mat[0];
+    if constexpr (!(FLAGS & kGrouped) && NS == ring_depth(MB, WAVES) && !(MB == 2 && WAVES == 16)) {
+        if (ge.P > 1) {
+            auto kern = gemv4_stream_kernel<T, MB, WAVES, NS, FLAGS | kMulti>;
+            static LdsLimit lds_limit;
+            ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), ge.lds);
+            hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), ge.lds, stream, a.A, m0.B, m0.absmax, m0.absmax8, m0.N, a.K,
+                               (a.M & 0x3FFFF) | (a.bs_shift << 18) | (ge.P << 23), ge.R | (ge.SW << 16) | (ge.G << 21),
+                               (256 + ge.SW - 1) / ge.SW, a);
+            return;
+        }
+    }
+    if (ge.P > 1) {
+        // sweep-only instances exist single-phase only; grouped launches are refused earlier (grouped_fits)
+        if constexpr (!(FLAGS & kGrouped) && (NS != ring_depth(MB, WAVES) || (MB == 2 && WAVES == 16)))
+            return launch_one<T, MB, (MB == 1 ? 16 : 8), kRing, FLAGS | kNT>(a, stream);
+        fprintf(stderr, "bitsandbytes_amd: gemv_4bit: internal error, multi-phase geometry on a single-phase instance\n");
+        exit(1);
+    }
     auto kern = gemv4_stream_kernel<T, MB, WAVES, NS, FLAGS>;
     static LdsLimit lds_limit;
     ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), ge.lds);
-    dim3 grid(ge.grid_x, (a.M + MB - 1) / MB);
-    const StreamMat& m0 = a.mat[0];
-    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), ge.lds, stream, a.A, m0.B, m0.absmax, m0.absmax8, a.code16, m0.N, a.K,
-                       (a.M & 0xFFFFFF) | (a.bs_shift << 24), ge.R | (ge.SW << 16) | (ge.G << 21), a);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), ge.lds, stream, a.A, m0.B, m0.absmax, m0.absmax8, m0.N, a.K,
+                       (a.M & 0x3FFFF) | (a.bs_shift << 18) | (ge.P << 23), ge.R | (ge.SW << 16) | (ge.G << 21),
+                       (256 + ge.SW - 1) / ge.SW, a);
 }
 
-// Production instances: ring depth kRing, non-temporal weight loads, 16 wavefronts at MB = 1 and 8 above.
-// The sweep-only variants (other ring depths, default cache policy, 8 wavefronts) exist for ONE configuration -
-// bf16, one activation row, fp32 absmax, literal NF4 table - so that tools/ can A/B them without multiplying the
-// instance count of the library.
-constexpr int kRing = 4;
-
+// The sweep-only variants (other ring depths, default cache policy) exist for ONE configuration - bf16, one activation
+// row, fp32 absmax, literal NF4 table - so that tools/ can A/B them without multiplying the instance count of the library.
 template <typename T, int MB, int WAVES, int FLAGS> void launch_tuned(const StreamArgs& a, hipStream_t stream) {
     if constexpr (std::is_same<T, bf16>::value && MB == 1 && FLAGS == 0) {
         const int ns = g_tune.ns.load(std::memory_order_relaxed);
         const int nt = g_tune.nt.load(std::memory_order_relaxed);
-        const int tw = g_tune.waves.load(std::memory_order_relaxed);
-        if (tw == 8) {
+        if constexpr (WAVES == 8) {
+            if (ns == 2)
+                return launch_one<T, 1, 8, 2, kNT>(a, stream);
             if (nt == 0)
-                return launch_one<T, 1, 8, kRing, 0>(a, stream);
-            return launch_one<T, 1, 8, kRing, kNT>(a, stream);
+                return launch_one<T, 1, 8, 4, 0>(a, stream);
+        } else {
+            if (ns == 4)
+                return launch_one<T, 1, 16, 4, kNT>(a, stream);
+            if (ns == 3)
+                return launch_one<T, 1, 16, 3, kNT>(a, stream);
+            if (ns == 6)
+                return launch_one<T, 1, 16, 6, kNT>(a, stream);
+            if (nt == 0)
+                return launch_one<T, 1, 16, kRing, 0>(a, stream);
         }
-        if (ns == 2)
-            return launch_one<T, 1, 16, 2, kNT>(a, stream);
-        if (ns == 3)
-            return launch_one<T, 1, 16, 3, kNT>(a, stream);
-        if (ns == 6)
-            return launch_one<T, 1, 16, 6, kNT>(a, stream);
-        if (nt == 0)
-            return launch_one<T, 1, 16, kRing, 0>(a, stream);
     }
-    launch_one<T, MB, WAVES, kRing, FLAGS | kNT>(a, stream);
+    launch_one<T, MB, WAVES, ring_depth(MB, WAVES), FLAGS | kNT>(a, stream);
 }
 
 template <typename T, int MB, int WAVES> void launch_flags(const StreamArgs& a, int quant_type, bool grouped, hipStream_t stream) {
@@ -633,7 +730,7 @@ template <typename T, int MB, int WAVES> void launch_flags(const StreamArgs& a, 
         // caller-supplied code table (legacy gemv_4bit op): one activation row, un-nested absmax by construction
         if constexpr (MB == 1) {
             if (!nested && !grouped)
-                return launch_one<T, 1, WAVES, kRing, kCodePtr | kNT>(a, stream);
+                return launch_one<T, 1, WAVES, ring_depth(1, WAVES), kCodePtr | kNT>(a, stream);
         }
         fprintf(stderr, "bitsandbytes_amd: gemv_4bit: a caller-supplied code table needs fp32 absmax\n");
         exit(1);
@@ -655,10 +752,27 @@ template <typename T> void launch_mb(const StreamArgs& a, int quant_type, bool g
     // rows of A held in registers per pass: 1, 2 or 4 (M = 3 runs the 4-row instance, its fourth row a duplicate
     // that is never stored); larger M - only reached for shapes the MFMA kernels do not take - loops passes of 4
     // over grid.y. A caller-supplied code table (legacy op) always runs row by row.
-    if (a.M == 1 || a.code16 != nullptr)
+    if (a.M == 1 || a.code16 != nullptr) {
+        // 16 wavefronts (ring of 2) or 8 (ring of 4, decoded two stages at a time). Eight repeat the per-wavefront work
+        // half as often and win once a CU has enough row segments to amortise their longer dependency chains
+        // (measured on MI355X, profiles/r2_stream_ab.txt: 8192^2 9.5 vs 10.7 us, 14336 x 4096 8.8 vs 9.8; but 4096^2 4.44
+        // vs 4.25 and, with 6 or 7 segments per row that leave wavefronts idle, 4096 x 11008 8.8 vs 7.8)
+        const int S = (a.K + kSegK - 1) / kSegK;
+        const long items_per_cu = static_cast<long>((a.rows_total + device_cu_count() - 1) / device_cu_count()) * S;
+        const int tw = g_tune.waves.load(std::memory_order_relaxed);
+        const bool eight = tw == 8 || (tw == 0 && a.code16 == nullptr && (8 % S) == 0 && items_per_cu >= 64);
+        if (eight)
+            return launch_flags<T, 1, 8>(a, quant_type, grouped, stream);
         return launch_flags<T, 1, 16>(a, quant_type, grouped, stream);
-    if (a.M == 2)
+    }
+    if (a.M == 2) {
+        // two rows still fit the 128-register budget of 16 wavefronts when the row is one phase long (measured: equal at
+        // 4096^2, 13 % faster at 8192^2 and 11008 x 4096); the multi-phase form spills there and keeps 8 wavefronts
+        if (g_tune.waves.load(std::memory_order_relaxed) != 8 &&
+            make_geometry(a.rows_total, a.K, 2, 16, TypeInfo<T>::bytes, grouped, 0, 0).P == 1)
+            return launch_flags<T, 2, 16>(a, quant_type, grouped, stream);
         return launch_flags<T, 2, 8>(a, quant_type, grouped, stream);
+    }
     return launch_flags<T, 4, 8>(a, quant_type, grouped, stream);
 }
 
@@ -670,8 +784,9 @@ template <typename T> void launch_generic(const GenericArgs& p, hipStream_t stre
         hipLaunchKernelGGL((gemv4_generic_kernel<T, false>), grid, dim3(256), 0, stream, p);
 }
 
-bool stream_ok(const void* A, int K, int blocksize) {
-    return (K % 32 == 0) && blocksize >= 32 && is_pow2(blocksize) && aligned_to(A, 16);
+bool stream_ok(const void* A, int M, int K, int blocksize) {
+    // (the phase count travels in 9 bits and grid.y in 16: far beyond any real layer, the generic kernel takes the rest)
+    return (K % 32 == 0) && K <= 511 * kSegK && M <= 65535 && blocksize >= 32 && is_pow2(blocksize) && aligned_to(A, 16);
 }
 
 void launch_stream_any(int dtype, const StreamArgs& a, int quant_type, bool grouped, hipStream_t stream) {
@@ -703,7 +818,7 @@ void gemv_4bit_stream(int dtype, const void* A, const uint8_t* B, const float* a
                    const void* bias, int M, int N, int K, int blocksize, int quant_type, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0)
         return;
-    if (stream_ok(A, K, blocksize) && aligned_to(B, 16)) {
+    if (stream_ok(A, M, K, blocksize) && aligned_to(B, 16)) {
         StreamArgs a;
 #ifdef BNB_PROFILING
         a.dbg = g_dbg_buf;
@@ -737,7 +852,7 @@ bool gemv_4bit_grouped(int dtype, const void* A, int count, const uint8_t* const
                        const uint8_t* const* absmax8, const float* const* absmax_code, const float* const* absmax_offset,
                        void* const* out, const void* const* bias, const int* N, int M, int K, int blocksize, int quant_type,
                        hipStream_t stream) {
-    if (count < 1 || count > kMaxGroup || M < 1 || M > 4 || K <= 0 || !stream_ok(A, K, blocksize))
+    if (count < 1 || count > kMaxGroup || M < 1 || M > 4 || K <= 0 || !stream_ok(A, M, K, blocksize))
         return false;
     StreamArgs a;
 #ifdef BNB_PROFILING
@@ -767,6 +882,10 @@ bool gemv_4bit_grouped(int dtype, const void* A, int count, const uint8_t* const
         a.mat[i].row_start = 0x7FFFFFFF;
     }
     a.rows_total = static_cast<int>(rows);
+    const int mb = M >= 3 ? 4 : M;
+    if (make_geometry(a.rows_total, K, mb, mb <= 2 ? 16 : 8, dtype == 0 ? 4 : 2, true, 0, 0).P > 1 ||
+        make_geometry(a.rows_total, K, mb, 8, dtype == 0 ? 4 : 2, true, 0, 0).P > 1)
+        return false; // rows longer than one workgroup's segment columns: the single-matrix path has the phase loop
     launch_stream_any(dtype, a, quant_type, true, stream);
     return true;
 }

@@ -53,19 +53,27 @@ t = buf.view(NW, 16).cpu().double()
 live = t[:, 0] > 0
 # s_memtime counters are per XCD: normalise every wavefront to the earliest start on ITS XCD (workgroup b runs on XCD b % 8)
 waves_per_wg = 16 if M == 1 and a.tune[4] != 8 else 8
-xcd = (torch.arange(NW) // waves_per_wg) % 8
-for xc in range(8):
-    sel = live & (xcd == xc)
+rt = t[:, 13:15].clone()  # s_memrealtime (100 MHz, chip-wide) at wavefront start / end
+wg = torch.arange(NW) // waves_per_wg
+nwg = int(wg[live].max().item()) + 1
+for b in range(nwg):  # s_memtime domains are not chip-wide: normalise every wavefront to ITS workgroup's first start
+    sel = live & (wg == b)
     if sel.any():
         base = t[sel, 0].min()
-        t[sel] = torch.where(t[sel] > 0, t[sel] - base + 1, t[sel])
+        t[sel, :13] = torch.where(t[sel, :13] > 0, t[sel, :13] - base + 1, t[sel, :13])
+        t[sel, 15] = torch.where(t[sel, 15] > 0, t[sel, 15] - base + 1, t[sel, 15])
+rt = rt[live]
 t = t[live]
+r0 = rt[:, 0].min()
+print(f"# realtime (10 ns ticks): wavefront starts span {(rt[:, 0].max() - r0).item() * 10:.0f} ns, last end at "
+      f"{(rt[:, 1].max() - r0).item() * 10:.0f} ns after the first start; per-workgroup first start: median "
+      f"{(rt[:, 0].view(-1, waves_per_wg).min(1).values - r0).median().item() * 10:.0f} ns")
 t0 = 1.0
-order = [0, 9, 10, 11, 12, 1, 2, 3, 4, 5, 6, 7, 8]
+order = [0, 9, 10, 1, 2, 3, 4, 15, 5, 6, 7, 8]
 names = {0: "start", 9: "before x DMA", 10: "x DMA issued", 11: "stage 0 issued", 12: "stage 1 issued", 1: "ring issued",
-         2: "table written", 3: "past barrier", 4: "x slice in regs", 5: "item 0 decoded", 6: "items done",
+         2: "table written", 3: "past barrier", 4: "x slice in regs", 15: "stage-0 weights landed", 5: "item 0 decoded", 6: "items done",
          7: "past final barrier", 8: "end"}
-print(f"# M={M} N={N} K={K} tune={a.tune}: {t.shape[0]} wavefronts; s_memtime ticks relative to the first wavefront's start")
+print(f"# M={M} N={N} K={K} tune={a.tune}: {t.shape[0]} wavefronts; s_memtime ticks relative to the first wavefront start of the SAME workgroup")
 print(f"{'stamp':20s} {'min':>8s} {'median':>8s} {'p90':>8s} {'max':>8s}   median delta to previous stamp")
 prev = None
 for i in order:
