@@ -59,7 +59,11 @@ bool route_to_mfma(int kernel, int dtype, const void* A, const uint8_t* B, int M
         return false;
     if (kernel == 2)
         return gemm_4bit_mfma_supported(dtype, A, B, M, N, K, blocksize);
-    return (M > kStreamMaxM) && gemm_4bit_mfma_supported(dtype, A, B, M, N, K, blocksize);
+    // three or four rows: the streaming kernel's FMA count grows with M while the MFMA kernel's does not - on matrices that
+    // fill the chip with 16-column workgroups the MFMA kernel is ahead from M = 3 (4096^2 6.5 vs 6.9 us, 4096 x 11008 10.8 vs
+    // 26.7), on small ones the streaming kernel's cheaper launch still wins (1376 x 4096 4.9 vs 5.3)
+    const bool big = static_cast<long>(N) * K >= (12L << 20);
+    return (M > kStreamMaxM || (M >= 3 && big)) && gemm_4bit_mfma_supported(dtype, A, B, M, N, K, blocksize);
 }
 
 void gemm_4bit_dispatch(int kernel, int dtype, const void* A, const uint8_t* B, const float* absmax,

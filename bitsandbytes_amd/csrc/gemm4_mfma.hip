@@ -1047,6 +1047,58 @@ template <typename T> void dispatch_mfma(GemmArgs& p, float* ws, size_t ws_bytes
 
 } // namespace
 
+// gemm4_mfma_rt.hip (the register-transposed kernel for small batches on small / medium matrices)
+bool gemm_4bit_rt_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize);
+size_t gemm_4bit_rt_workspace_bytes(int M, int N, int K, int force_ks);
+void gemm_4bit_rt(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
+                  const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
+                  int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int force_waves,
+                  hipStream_t stream);
+
+// shared with gemm4_mfma_rt.hip: the slab finalize launch and the library-owned workspace
+void gemm_4bit_finalize(int dtype, const float* ws, const void* bias, void* out, int M, int N, int kslices, hipStream_t stream) {
+    const long total = static_cast<long>(M) * N;
+    const long threads = (total + 3) / 4;
+    const dim3 grid(static_cast<unsigned>((threads + 255) / 256));
+    if (dtype == 2)
+        hipLaunchKernelGGL((gemm4_finalize_kernel<bf16>), grid, dim3(256), 0, stream, ws, static_cast<const bf16*>(bias),
+                           static_cast<bf16*>(out), total, N, kslices);
+    else
+        hipLaunchKernelGGL((gemm4_finalize_kernel<f16>), grid, dim3(256), 0, stream, ws, static_cast<const f16*>(bias),
+                           static_cast<f16*>(out), total, N, kslices);
+    BNB_CHECK_LAUNCH();
+}
+float* gemm_4bit_internal_workspace(size_t bytes, hipStream_t stream) { return get_internal_workspace(bytes, stream); }
+
+namespace {
+// Which problems go to the register-transposed kernel (tuning knob cfg 20 / 21 / 22 forces it: built-in / 8 / 16 wavefronts).
+// Calibrated on MI355X - see DESIGN.md: batches of at most one row tile on matrices small enough that N / 16 workgroups
+// need no (or few) K slices.
+bool rt_selected(int M, int N, int K, int* force_ks, int* force_waves) {
+    const int cfg = g_mfma_knob1 / 100;
+    *force_ks = 0;
+    *force_waves = 0;
+    if (cfg >= 20 && cfg <= 22) {
+        *force_ks = g_mfma_knob1 % 100;
+        *force_waves = cfg == 21 ? 8 : cfg == 22 ? 16 : 0;
+        return true;
+    }
+    if (cfg != 0)
+        return false;
+    // measured on MI355X (profiles/r2_mfma_ab.txt), us per launch, register-transposed vs producer/consumer kernel:
+    // M <= 16: 4096^2 6.5 vs 8.4, 11008 x 4096 11.2 vs 14.7, 8192^2 14.2-15.6 vs 16.3-16.6; M = 32: 4096^2 8.6 vs 10.7 but
+    // 11008 x 4096 19.2 vs 17.4; M = 64: 1376 x 4096 7.8 vs 9.5, 4096^2 equal, 8192^2 43 vs 23
+    const long weights = static_cast<long>(N) * K;
+    if (M <= 16)
+        return weights <= (96L << 20);
+    if (M <= 32)
+        return weights <= (20L << 20);
+    if (M <= 64)
+        return weights <= (8L << 20);
+    return false;
+}
+} // namespace
+
 // Preconditions of the MFMA kernel: 16-bit activations, K a multiple of 256, blocksize >= 64
 // (so that a 64-k MFMA pair stays inside one quantization block), 16-byte aligned A, 8-byte aligned B.
 bool gemm_4bit_mfma_supported(int dtype, const void* A, const uint8_t* B, int M, int N, int K, int blocksize) {
@@ -1058,6 +1110,9 @@ bool gemm_4bit_mfma_supported(int dtype, const void* A, const uint8_t* B, int M,
 size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K) {
     if (M < 1 || N < 1 || K < kKC)
         return 0;
+    int fks, fw;
+    if (rt_selected(M, N, K, &fks, &fw))
+        return gemm_4bit_rt_workspace_bytes(M, N, K, fks);
     const Plan pl = make_plan(M, N, K);
     return pl.ks > 1 ? static_cast<size_t>(pl.ks) * M * N * sizeof(float) : 0;
 }
@@ -1066,6 +1121,10 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
                     const float* absmax_code, const float* absmax_offset, const float* code16, void* out,
                     const void* bias, int M, int N, int K, int blocksize, int quant_type, void* workspace,
                     size_t workspace_bytes, hipStream_t stream) {
+    int fks, fw;
+    if (rt_selected(M, N, K, &fks, &fw) && gemm_4bit_rt_supported(dtype, A, B, code16, M, N, K, blocksize))
+        return gemm_4bit_rt(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize,
+                            quant_type, workspace, workspace_bytes, fks, fw, stream);
     GemmArgs p;
     p.A = A;
     p.B = B;

@@ -1,0 +1,462 @@
+// gemm4_mfma_rt.hip — "register-transposed" MFMA kernel ("v6" in profiles/) for small batches on small and medium
+// matrices:  out[m, n] = sum_k A[m, k] * code[B[n, k]] * scale[n, k / bs]  (+ bias[n]),  bf16 / fp16, K % 256 == 0.
+//
+// Fills, on MI355X, the tensor-core capability the reference only has on CUDA (csrc/gemm_4bit_sm80.cu:127-457) for the
+// batch sizes between the streaming dot kernel (gemv4_stream.hip, M <= 2) and the producer/consumer MFMA kernel
+// (gemm4_mfma.hip, large matrices / tall tiles). What round 1's LDS-DMA kernel measured (profiles/r1_timeline_mfma_v3_*):
+// a wavefront spent ~5500 of its ~11000 cycles before its loads were even issued (a dependent global load in front of the
+// decode table, integer divisions and per-lane address arithmetic on a scalar unit shared by 16 wavefronts, ~150 cycles per
+// LDS-DMA issue) and ~2600 in a serial reduction. This kernel is built the way the streaming kernel was:
+//
+//  * ONE workgroup of 16 wavefronts per 16 output columns, no split-K between workgroups when N / 16 fills the chip (no
+//    slab round trip, no second launch); the wavefronts split K in 256-k chunks and combine once through LDS.
+//  * Every global load is a plain, fully coalesced 16-byte-per-lane load whose four neighbouring lanes cover 64 contiguous
+//    bytes of ONE row (lane 4r + p: row r, piece p): 16 L1 tag look-ups per instruction. The MFMA operand layout wants the
+//    row index in the LOW lane bits (lane r + 16 g) - loading in that shape costs 64 tag look-ups per instruction (four
+//    different rows per lane quad), which is what made round 1's fragment-shaped loads crawl. The transposition
+//    (4r + p -> r + 16p) is a ds_write_b128 / ds_read_b128 pair through a 1-KiB tile private to the wavefront: same
+//    wavefront, in-order LDS, no barrier, bank-conflict-free both ways (slot 16p + ((r + 2p) & 15)).
+//  * K order inside an MFMA is free as long as both operands agree. A lane's 16 weight bytes are 32 consecutive k; after
+//    the transposition the four lane groups of a column hold 128 consecutive k = two quantization blocks. One
+//    v_permlane32_swap per dword pair regroups them so that every MFMA consumes k from ONE block (dwords 0/1 of groups 0,1
+//    + dwords 2/3 of groups 0,1 seen from groups 2,3), i.e. the fp32 absmax is applied exactly, per lane, to the partial
+//    tile of each 64-k block. The activation loads fetch the matching k (16-byte pieces at a 32-byte stride inside one
+//    128-byte line), so no data is ever permuted on the A side.
+//  * The decode table (byte -> the pair (code[hi], code[lo]) in T, 32 bank-private copies) is built from compile-time
+//    literals while the loads fly: no memory dependency in front of it. Loads are issued before anything else.
+//  * No LDS-DMA and no inline-asm waits: every wait is the compiler's counted vmcnt on ordinary loads.
+//
+// Results are bit-reproducible: partial tiles are combined in wavefront order, K slices (only when N / 16 workgroups would
+// leave most of the chip idle) through fp32 slabs added in slice order by gemm4_finalize (gemm4_mfma.hip).
+#include "bnb_common.h"
+
+namespace bnb {
+
+#ifdef BNB_PROFILING
+extern unsigned long long* g_dbg_buf;
+#endif
+
+// gemm4_mfma.hip
+void gemm_4bit_finalize(int dtype, const float* ws, const void* bias, void* out, int M, int N, int kslices, hipStream_t stream);
+float* gemm_4bit_internal_workspace(size_t bytes, hipStream_t stream);
+
+namespace {
+
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <typename T> struct RtMma;
+template <> struct RtMma<bf16> {
+    using frag = __attribute__((ext_vector_type(8))) bf16;
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(frag, a), __builtin_bit_cast(frag, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t pack(float first, float second) {
+        using V = __attribute__((ext_vector_type(2))) bf16;
+        V v;
+        v[0] = static_cast<bf16>(first);
+        v[1] = static_cast<bf16>(second);
+        return __builtin_bit_cast(uint32_t, v);
+    }
+};
+template <> struct RtMma<f16> {
+    using frag = __attribute__((ext_vector_type(8))) f16;
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(frag, a), __builtin_bit_cast(frag, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t pack(float first, float second) {
+        using V = __attribute__((ext_vector_type(2))) f16;
+        V v;
+        v[0] = static_cast<f16>(first);
+        v[1] = static_cast<f16>(second);
+        return __builtin_bit_cast(uint32_t, v);
+    }
+};
+
+constexpr int kRtLut = 32768;            // 256 entries x 32 copies x 4 B, at LDS address 0
+constexpr int kRtScratch = 2 * 1024 + 256; // per wavefront: two transposition tiles + the scale tile (16 x 16 B)
+constexpr int kRtChunk = 256;            // k per wavefront step: four 64-k MFMA pairs
+
+struct RtArgs {
+#ifdef BNB_PROFILING
+    unsigned long long* dbg;
+#endif
+    const float* absmax_code;
+    const float* absmax_offset;
+    void* out;
+    const void* bias;
+    float* ws; // fp32 [kslices][M][N] partial slabs when kslices > 1
+};
+
+#ifdef BNB_PROFILING
+#define BNB_RT_STAMP(i)                                                                            \
+    {                                                                                              \
+        if (p.dbg && lane == 0)                                                                    \
+            p.dbg[((static_cast<long>(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * WAVES * 16 + wave * 16 + (i)] = \
+                __builtin_amdgcn_s_memtime();                                                      \
+    }
+#else
+#define BNB_RT_STAMP(i) {}
+#endif
+
+__device__ __forceinline__ float rt_code_literal(int i, bool fp4) {
+    // compare/select over literals: no memory access (the inner select is scalar)
+    constexpr float nf4[16] = {BNB_NF4_VALUES};
+    constexpr float fp4v[16] = {BNB_FP4_VALUES};
+    float v = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        v = (i == j) ? (fp4 ? fp4v[j] : nf4[j]) : v;
+    return v;
+}
+
+// T in {bf16, f16}; WAVES wavefronts split the workgroup's K range chunk by chunk (chunk c of the slice goes to
+// wavefront c % WAVES). grid = (ceil(N / 16), kslices, ceil(M / 16)).
+template <typename T, int WAVES, bool NESTED>
+__global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
+    // hot arguments as separate scalars: preloaded into SGPRs by the command processor (14 dwords)
+    const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, int hot_M, int hot_N,
+    int hot_K, int hot_flags /* bs_shift | fp4 << 8 */, int hot_cps /* chunks per K slice */, int hot_kslices,
+    const RtArgs p) {
+    constexpr int THREADS = WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    BNB_RT_STAMP(0)
+    const int r = lane >> 2, pp = lane & 3; // load roles: row r of the 16-row tile, 16-byte piece pp of its 64 bytes
+    const int ln = lane & 15, lg = lane >> 4; // MFMA roles: row / column ln, k group lg
+    const int M = hot_M, N = hot_N, K = hot_K;
+    const int bs_shift = hot_flags & 31;
+    const bool fp4 = (hot_flags >> 8) & 1;
+    const int col0 = blockIdx.x * 16;
+    const int m_base = blockIdx.z * 16;
+    const int cb = blockIdx.y * hot_cps;
+    int ce = cb + hot_cps;
+    ce = (ce < (K >> 8)) ? ce : (K >> 8);
+
+    // LDS map: table | per-wavefront scratch (tile 0, tile 1, scale tile) | nested absmax code (1 KiB)
+    unsigned char* const sc = smem + kRtLut + wave * kRtScratch;
+    u32x4* const tile0 = reinterpret_cast<u32x4*>(sc);
+    u32x4* const tile1 = reinterpret_cast<u32x4*>(sc + 1024);
+    u32x4* const stile = reinterpret_cast<u32x4*>(sc + 2048);
+    float* const code2 = reinterpret_cast<float*>(smem + kRtLut + WAVES * kRtScratch);
+
+    // ---- sources. Rows past the end (ragged N or M) re-read the last row: MFMA rows / columns are independent and those
+    // results are never stored, so no masking instructions are needed.
+    int wrow = col0 + r;
+    wrow = (wrow < N) ? wrow : N - 1;
+    int arow = m_base + r;
+    const bool a_valid = arow < M;
+    arow = a_valid ? arow : M - 1;
+    const uint8_t* const wsrc = hot_B + static_cast<long>(wrow) * (K >> 1) + pp * 16;
+    const T* const asrc = static_cast<const T*>(hot_A) + static_cast<long>(arow) * K + (pp & 1) * 32 + (pp >> 1) * 16;
+    const long e0 = static_cast<long>(wrow) * K; // flat element index of the row start
+
+    struct Raw {
+        u32x4 w[2]; // 128 k each: lane (r, pp) holds k [128 h + 32 pp, + 32) of row r
+        u32x4 s;    // the row's scales of the chunk's four 64-k sub-blocks (nested: {4 x uint8, second-level absmax})
+        u32x4 a[8]; // step (h, j): lane (r, pp) holds A[r][128 h + 64 (j >> 1) + 8 (j & 1) + 32 (pp & 1) + 16 (pp >> 1) + 0..7]
+    };
+    auto issue = [&](Raw& raw, int c) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            raw.w[h] = *reinterpret_cast<const u32x4*>(wsrc + static_cast<long>(c) * 128 + h * 64);
+        const long e = e0 + (static_cast<long>(c) << 8);
+        if (bs_shift == 6) {
+            if constexpr (NESTED) {
+                raw.s[0] = *reinterpret_cast<const uint32_t*>(hot_absmax8 + (e >> 6));
+                raw.s[1] = __builtin_bit_cast(uint32_t, hot_absmax[e >> 14]);
+                raw.s[2] = raw.s[3] = 0;
+            } else {
+                raw.s = *reinterpret_cast<const u32x4*>(hot_absmax + (e >> 6));
+            }
+        } else {
+            if constexpr (NESTED) {
+                uint32_t q = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    q |= static_cast<uint32_t>(hot_absmax8[(e + b * 64) >> bs_shift]) << (8 * b);
+                raw.s[0] = q;
+                raw.s[1] = __builtin_bit_cast(uint32_t, hot_absmax[(e >> bs_shift) >> 8]);
+                raw.s[2] = raw.s[3] = 0;
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    raw.s[b] = __builtin_bit_cast(uint32_t, hot_absmax[(e + b * 64) >> bs_shift]);
+            }
+        }
+        // activation rows past the end of the batch are not fetched at all (exec-masked: the loads then cost the L1 M / 16 of a
+        // full tile); those lanes hold zeros and the MFMA rows they feed are never stored
+        if (a_valid) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                raw.a[s] = *reinterpret_cast<const u32x4*>(asrc + static_cast<long>(c) * kRtChunk + 128 * (s >> 2) +
+                                                           64 * ((s >> 1) & 1) + 8 * (s & 1));
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                raw.a[s] = u32x4{0, 0, 0, 0};
+        }
+    };
+
+    Raw raw;
+    int c = cb + wave;
+    if (c < ce)
+        issue(raw, c);
+    BNB_RT_STAMP(1)
+    __builtin_amdgcn_sched_barrier(0); // nothing that is not needed for the loads runs before them
+
+    // ---- decode table, built while the loads fly: entry e (a packed byte) = 32 copies of (T(code[e >> 4]), T(code[e & 15])),
+    // 128 B per entry. Thread idx writes chunks (2 sub) ^ (e & 1) and (2 sub + 1) ^ (e & 1) of entry e = idx >> 2: the eight
+    // lanes one ds_write_b128 services together land in eight different bank quads.
+    {
+        // (literals only: a caller-supplied code table would put a load - and at the join of the two paths a vmcnt(0)
+        // that drains the weight loads - in front of the table; such calls go to the LDS-DMA kernels)
+        const float cv = rt_code_literal((lane & 15) + opaque_zero(), fp4);
+        const int cvb = __builtin_bit_cast(int, cv);
+        u32x4* const lut = reinterpret_cast<u32x4*>(smem);
+#pragma unroll
+        for (int idx = tid; idx < 1024; idx += THREADS) {
+            const int e = idx >> 2, sub = idx & 3;
+            const float hi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e >> 4) * 4, cvb));
+            const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e & 15) * 4, cvb));
+            const uint32_t pr = RtMma<T>::pack(hi, lo);
+            const u32x4 v = {pr, pr, pr, pr};
+            lut[e * 8 + ((2 * sub) ^ (e & 1))] = v;
+            lut[e * 8 + ((2 * sub + 1) ^ (e & 1))] = v;
+        }
+    }
+    float offset = 0.0f;
+    if constexpr (NESTED) {
+        for (int i = tid; i < 256; i += THREADS)
+            code2[i] = p.absmax_code[i];
+        offset = p.absmax_offset[0];
+    }
+    BNB_RT_STAMP(2)
+    __syncthreads();
+    BNB_RT_STAMP(3)
+
+    const int wslot = 16 * pp + ((r + 2 * pp) & 15);  // where lane (r, pp) puts its 16 bytes ...
+    const int rslot = 16 * lg + ((ln + 2 * lg) & 15); // ... and where lane (ln, lg) finds those of lane (r = ln, pp = lg)
+    const uint32_t lane_off = static_cast<uint32_t>(lane & 31) * 4u + static_cast<uint32_t>(opaque_zero());
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (; c < ce; c += WAVES) {
+        // weights: transpose, then regroup so that dwords 0/1 (2/3) of every lane group belong to block 2h (2h + 1)
+        u32x4 wt[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4* const tile = h ? tile1 : tile0;
+            tile[wslot] = raw.w[h];
+            wt[h] = tile[rslot];
+        }
+        if (pp == 0)
+            stile[r] = raw.s;
+        const u32x4 sraw = stile[ln];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const auto s02 = __builtin_amdgcn_permlane32_swap(wt[h][0], wt[h][2], false, false);
+            const auto s13 = __builtin_amdgcn_permlane32_swap(wt[h][1], wt[h][3], false, false);
+            wt[h][0] = s02[0];
+            wt[h][2] = s02[1];
+            wt[h][1] = s13[0];
+            wt[h][3] = s13[1];
+        }
+        float scale[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            // (copies first: __builtin_bit_cast applied to a vector-element lvalue reads element 0 - hipcc 7.2)
+            const uint32_t sb = sraw[b], s0 = sraw[0], s1 = sraw[1];
+            if constexpr (NESTED)
+                scale[b] = __fadd_rn(__fmul_rn(code2[(s0 >> (8 * b)) & 0xFFu], __builtin_bit_cast(float, s1)), offset);
+            else
+                scale[b] = __builtin_bit_cast(float, sb);
+        }
+        if (c == cb + wave)
+            BNB_RT_STAMP(4)
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            f32x4 part = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int h = blk >> 1, j = 2 * (blk & 1) + i, s = 4 * h + j;
+                u32x4* const tile = (s & 1) ? tile1 : tile0;
+                tile[wslot] = raw.a[s];
+                const u32x4 af = tile[rslot];
+                const uint32_t w = wt[h][j];
+                u32x4 bf;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t byte = __builtin_amdgcn_ubfe(w, 8u * q, 8u);
+                    bf[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((byte << 7) + lane_off);
+                }
+                part = RtMma<T>::run(af, bf, part);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                acc[q] = fmaf(scale[blk], part[q], acc[q]);
+        }
+        if (c + WAVES < ce)
+            issue(raw, c + WAVES);
+    }
+    BNB_RT_STAMP(5)
+    // The table is addressed with raw LDS offsets: it must sit at LDS address 0 (no static LDS in this kernel).
+    if (reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem) != 0)
+        __builtin_trap();
+
+    // ---- combine the wavefronts' partial tiles in wavefront order (each wavefront parks its tile in its own scratch)
+    *reinterpret_cast<f32x4*>(sc + lane * 16) = acc;
+    __syncthreads();
+    BNB_RT_STAMP(6)
+    if (tid < 256) {
+        const int col = tid & 15, row = tid >> 4;
+        const int src = (col + 16 * (row >> 2)) * 4 + (row & 3);
+        float pv[WAVES];
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w)
+            pv[w] = reinterpret_cast<const float*>(smem + kRtLut + w * kRtScratch)[src];
+        __builtin_amdgcn_sched_barrier(0); // all look-ups in flight before the first add (the adds stay in wavefront order)
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w)
+            v += pv[w];
+        const int m = m_base + row, n = col0 + col;
+        if (m < M && n < N) {
+            const long o = static_cast<long>(m) * N + n;
+            if (hot_kslices == 1) {
+                const T* bias = static_cast<const T*>(p.bias);
+                const float b = bias ? static_cast<float>(bias[n]) : 0.0f;
+                static_cast<T*>(p.out)[o] = static_cast<T>(v + b);
+            } else {
+                p.ws[static_cast<long>(blockIdx.y) * M * N + o] = v;
+            }
+        }
+    }
+    BNB_RT_STAMP(7)
+}
+
+int rt_cu_count() {
+    static std::atomic<int> cached{0};
+    int v = cached.load(std::memory_order_relaxed);
+    if (v == 0) {
+        int dev = 0;
+        BNB_HIP_CHECK(hipGetDevice(&dev));
+        BNB_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        v = v > 0 ? v : 256;
+        cached.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+struct RtPlan {
+    int ks, cps, waves;
+};
+
+// K slices only when the column tiles alone would leave nearly all of the chip idle (a second launch and a slab round trip
+// cost more than a half-empty chip gains: 1376 x 4096 measured 5.3 us un-split against 6.3 us with two slices); every
+// wavefront keeps at least one chunk.
+RtPlan rt_plan(int M, int N, int K, int force_ks) {
+    RtPlan pl;
+    const int chunks = K / kRtChunk;
+    const int wgs = ((N + 15) / 16) * ((M + 15) / 16);
+    const int cus = rt_cu_count();
+    int ks = 1;
+    if (force_ks > 0)
+        ks = force_ks;
+    else if (wgs * 8 <= cus)
+        ks = cus / (2 * wgs);
+    const int max_ks = chunks / 8 > 0 ? chunks / 8 : 1;
+    ks = ks > max_ks ? max_ks : ks;
+    ks = ks < 1 ? 1 : ks;
+    pl.cps = (chunks + ks - 1) / ks;
+    pl.ks = (chunks + pl.cps - 1) / pl.cps;
+    // Sixteen wavefronts (one workgroup per CU) only when the launch is a single round of workgroups with long rows;
+    // otherwise eight, two workgroups per CU (measured on MI355X, profiles/r2_mfma_ab.txt: 4096^2 6.45 vs 6.7 us,
+    // 11008 x 4096 11.2 vs 16.0; 4096 x 11008 11.5 vs 10.8)
+    pl.waves = (wgs * pl.ks <= cus && pl.cps > 16) ? 16 : 8;
+    return pl;
+}
+
+template <typename T, int WAVES> void rt_launch(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
+                                                int M, int N, int K, int flags, const RtPlan& pl, const RtArgs& a,
+                                                hipStream_t stream) {
+    const size_t lds = kRtLut + static_cast<size_t>(WAVES) * kRtScratch + 1024;
+    dim3 grid((N + 15) / 16, pl.ks, (M + 15) / 16);
+    if (absmax8 != nullptr) {
+        auto kern = gemm4_mfma_rt_kernel<T, WAVES, true>;
+        static LdsLimit lim;
+        ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
+        hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, M, N, K, flags, pl.cps, pl.ks, a);
+    } else {
+        auto kern = gemm4_mfma_rt_kernel<T, WAVES, false>;
+        static LdsLimit lim;
+        ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
+        hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, M, N, K, flags, pl.cps, pl.ks, a);
+    }
+}
+
+} // namespace
+
+bool gemm_4bit_rt_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize) {
+    return dtype != 0 && code16 == nullptr && M >= 1 && N >= 1 && K >= kRtChunk && (K % kRtChunk) == 0 && blocksize >= 64 && is_pow2(blocksize) &&
+           aligned_to(A, 16) && aligned_to(B, 16);
+}
+
+size_t gemm_4bit_rt_workspace_bytes(int M, int N, int K, int force_ks) {
+    if (M < 1 || N < 1 || K < kRtChunk)
+        return 0;
+    const RtPlan pl = rt_plan(M, N, K, force_ks);
+    return pl.ks > 1 ? static_cast<size_t>(pl.ks) * M * N * sizeof(float) : 0;
+}
+
+// dtype: 1 = f16, 2 = bf16. force_ks / force_waves: sweeps and tests (0 = built-in choice).
+void gemm_4bit_rt(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
+                  const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
+                  int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int force_waves,
+                  hipStream_t stream) {
+    RtPlan pl = rt_plan(M, N, K, force_ks);
+    if (force_waves == 8 || force_waves == 16)
+        pl.waves = force_waves;
+    float* ws = static_cast<float*>(workspace);
+    const size_t slab = static_cast<size_t>(M) * N * sizeof(float);
+    if (pl.ks > 1) {
+        if (ws == nullptr) {
+            ws = gemm_4bit_internal_workspace(slab * pl.ks, stream);
+            workspace_bytes = ws ? slab * pl.ks : 0;
+        }
+        if (workspace_bytes < slab * pl.ks) {
+            const int fit = static_cast<int>(workspace_bytes / slab);
+            const int chunks = K / kRtChunk;
+            const int ks = fit >= 2 ? fit : 1;
+            pl.cps = (chunks + ks - 1) / ks;
+            pl.ks = (chunks + pl.cps - 1) / pl.cps;
+        }
+    }
+    RtArgs a;
+#ifdef BNB_PROFILING
+    a.dbg = g_dbg_buf;
+#endif
+    a.absmax_code = absmax_code;
+    a.absmax_offset = absmax_offset;
+    a.out = out;
+    a.bias = bias;
+    a.ws = ws;
+    const int flags = ilog2(blocksize) | ((quant_type == kFP4) ? 256 : 0);
+    if (dtype == 2) {
+        if (pl.waves == 16)
+            rt_launch<bf16, 16>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+        else
+            rt_launch<bf16, 8>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+    } else {
+        if (pl.waves == 16)
+            rt_launch<f16, 16>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+        else
+            rt_launch<f16, 8>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+    }
+    BNB_CHECK_LAUNCH();
+    if (pl.ks > 1)
+        gemm_4bit_finalize(dtype, ws, bias, out, M, N, pl.ks, stream);
+}
+
+} // namespace bnb

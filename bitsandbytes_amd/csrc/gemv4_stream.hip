@@ -310,24 +310,31 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     uint32_t perm_sel = 0x0C0C0400u; // v_perm_b32 selector {lane offset, weight byte j, 0, 0}
     const uint32_t lane_off = static_cast<uint32_t>(lane & 31) * 8u;
     float offset = 0.0f;
-    float xr[MB][32];
+    // the lane's 32 activations of each row as 16 fp32 PAIRS (k, k + 1): a packed byte decodes to the pair (code[hi],
+    // code[lo]) and one v_pk_fma_f32 multiplies pair by pair - half the VALU issue slots of two v_fma_f32 (the decode is
+    // VALU-bound at streaming rate: ~80 wave-instructions per KiB of weights against ~1 per cycle and CU)
+    f32x2 xr[MB][16];
 
     auto load_slice = [&]() {
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
+            float xs[32];
 #pragma unroll
             for (int q = 0; q < CH; ++q) {
                 const int slot = CH * lane + (q ^ swz(lane));
                 const u32x4 v = *reinterpret_cast<const u32x4*>(ximg + ((m * SW + sw) * CH * 64 + slot) * 16);
-                unpack16<T>(v, &xr[m][q * EPC]);
+                unpack16<T>(v, &xs[q * EPC]);
             }
             // lanes past the end of the row hold zeros (their weight loads are out of range, their scale is forced to 0);
             // only the last segment of a row whose length is not a multiple of 2048 has such lanes
             if ((seg + 1) * kSegK > K) {
 #pragma unroll
                 for (int e = 0; e < 32; ++e)
-                    xr[m][e] = k_ok ? xr[m][e] : 0.0f;
+                    xs[e] = k_ok ? xs[e] : 0.0f;
             }
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                xr[m][b] = f32x2{xs[2 * b], xs[2 * b + 1]};
         }
     };
 
@@ -348,21 +355,21 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
                     pr[u][4 * d + j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>(addr);
                 }
         __builtin_amdgcn_sched_barrier(0);
-        float acc[IL][MB][4];
+        // two independent chains of packed FMAs per (item, row): [chain][even k, odd k] - the same four partial sums, in
+        // the same order, as four scalar chains
+        f32x2 acc[IL][MB][2];
 #pragma unroll
         for (int u = 0; u < IL; ++u)
 #pragma unroll
             for (int m = 0; m < MB; ++m)
-                acc[u][m][0] = acc[u][m][1] = acc[u][m][2] = acc[u][m][3] = 0.0f;
+                acc[u][m][0] = acc[u][m][1] = f32x2{0.0f, 0.0f};
 #pragma unroll
         for (int b = 0; b < 16; ++b)
 #pragma unroll
             for (int u = 0; u < IL; ++u)
 #pragma unroll
-                for (int m = 0; m < MB; ++m) {
-                    acc[u][m][(b & 1) * 2] = fmaf(pr[u][b][0], xr[m][2 * b], acc[u][m][(b & 1) * 2]);
-                    acc[u][m][(b & 1) * 2 + 1] = fmaf(pr[u][b][1], xr[m][2 * b + 1], acc[u][m][(b & 1) * 2 + 1]);
-                }
+                for (int m = 0; m < MB; ++m)
+                    acc[u][m][b & 1] = __builtin_elementwise_fma(pr[u][b], xr[m][b], acc[u][m][b & 1]);
         float v[IL * MB];
 #pragma unroll
         for (int u = 0; u < IL; ++u) {
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             scale = k_ok ? scale : 0.0f;
 #pragma unroll
             for (int m = 0; m < MB; ++m)
-                v[u * MB + m] = ((acc[u][m][0] + acc[u][m][1]) + (acc[u][m][2] + acc[u][m][3])) * scale;
+                v[u * MB + m] = ((acc[u][m][0][0] + acc[u][m][0][1]) + (acc[u][m][1][0] + acc[u][m][1][1])) * scale;
         }
         wave_sum_n<IL * MB>(v);
 #pragma unroll

@@ -740,6 +740,62 @@ def test_mfma_kernel_variants(cfg, M, N, K, ks):
             assert torch.equal(y1, y2)
 
 
+@pytest.mark.parametrize("cfg,ks", [(20, 0), (21, 0), (22, 0), (20, 2), (22, 3)])
+@pytest.mark.parametrize("M,N,K", [(3, 256, 1024), (5, 200, 2048), (8, 4096, 4096), (13, 96, 4352), (16, 1376, 4096),
+                                   (16, 512, 11008 - 11008 % 256), (33, 384, 1024), (64, 512, 4096), (100, 130, 512)])
+def test_mfma_rt_kernel_geometries(cfg, ks, M, N, K):
+    """The register-transposed MFMA kernel (csrc/gemm4_mfma_rt.hip) in every launch geometry - built-in / 8 / 16
+    wavefronts, forced K slices, ragged N and M, wavefronts with no / one / several chunks - against the oracle,
+    for fp32 and nested absmax, NF4 and FP4, blocksize 64 and 128, bf16 and fp16; bit-reproducible run to run."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    for dtype, qt, bs, dq in ((torch.bfloat16, "nf4", 64, False), (torch.bfloat16, "nf4", 64, True),
+                              (torch.float16, "fp4", 128, True), (torch.float16, "nf4", 256, False)):
+        W = (torch.randn(N, K) / K**0.5).to(dtype)
+        x = torch.randn(M, K).to(dtype)
+        bias = torch.randn(N).to(dtype)
+        q, st = F.quantize_4bit(W.to(DEV), blocksize=bs, quant_type=qt, compress_statistics=dq)
+        y_ref = _oracle_y(x, q, st, bias)
+        try:
+            bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, cfg * 100 + ks)
+            y1 = _run_kernel(2, x.to(DEV), q, st, bias.to(DEV))
+            y2 = _run_kernel(2, x.to(DEV), q, st, bias.to(DEV))
+            y3 = _run_kernel(2, x.to(DEV), q, st, None)
+        finally:
+            bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+        assert rel_err(y1.cpu(), y_ref) < REL_TOL, (dtype, qt, bs, dq)
+        assert torch.equal(y1, y2)
+        assert rel_err(y3.cpu(), _oracle_y(x, q, st, None)) < REL_TOL
+
+
+def test_mfma_rt_kernel_exact_on_representable_inputs():
+    """Activations that are small integers and weights whose codes / scales are exactly representable make every product
+    and every partial sum exact in fp32: the kernel must then equal the oracle bit for bit - a k that is paired with the
+    wrong weight, or a block that gets its neighbour's scale, cannot hide inside the 1e-2 tolerance."""
+    F = _F()
+    M, N, K = 16, 64, 1024
+    g = torch.Generator().manual_seed(5)
+    # FP4 codes that bf16 holds exactly: 0, 1, 0.5, 0.25 and their negatives (indices 0, 3, 5, 7, 8, 11, 13, 15); with a
+    # power-of-two absmax per block (first element of every block = code 1.0) quantization reproduces the indices exactly
+    fp4 = F.get_4bit_type("fp4", device="cpu")
+    allowed = torch.tensor([0, 3, 5, 7, 11, 13, 15])
+    idx = allowed[torch.randint(0, len(allowed), (N, K), generator=g)]
+    idx[:, ::64] = 3
+    scale = 2.0 ** torch.randint(-2, 3, (N, K // 64), generator=g)
+    W = (fp4[idx] * scale.repeat_interleave(64, dim=1)).to(torch.bfloat16)
+    x = torch.randint(-4, 5, (M, K), generator=g).to(torch.bfloat16)
+    q, st = F.quantize_4bit(W.to(DEV), blocksize=64, quant_type="fp4")
+    y_ref = _oracle_y(x, q, st, None)
+    import bitsandbytes_amd as bnb
+    try:
+        bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 2000)
+        y = _run_kernel(2, x.to(DEV), q, st, None)
+    finally:
+        bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+    assert torch.equal(y.float().cpu(), y_ref.to(torch.bfloat16).float())
+
+
 # ------------------------------------------------------------------------------------------ callers of dequantize_4bit
 @pytest.mark.parametrize("quant_type", ["nf4", "fp4"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32], ids=["fp16", "bf16", "fp32"])

@@ -381,3 +381,19 @@ def test_state_dict_travels_through_safetensors(tmp_path, double_quant):
     y_ref = layer(x)
     y = bnb.matmul_4bit(x, w, bias=loaded["bias"].to(x.dtype), quant_state=w.quant_state)
     assert torch.equal(y, y_ref)
+
+
+def test_rt_mfma_lane_algebra_emulation():
+    """The index algebra of csrc/gemm4_mfma_rt.hip (coalesced "4r + p" loads, LDS transposition slots, permlane32_swap
+    regrouping, activation k order) replayed lane by lane against the hardware semantics of the MFMA - see
+    tests/checks/emulate_rt_mfma.py."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location(
+        "emulate_rt_mfma", os.path.join(os.path.dirname(__file__), "checks", "emulate_rt_mfma.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for M in (1, 7, 16):
+        assert mod.emulate(M=M, K=512, seed=M) < 1e-12
+    assert mod.final_sum_mapping_ok()
