@@ -29,6 +29,7 @@ _QT_CODE = {"fp4": 1, "nf4": 2}
 # Largest M routed to the fused kernels; above it one dequantize + hipBLASLt GEMM moves fewer bytes
 # per FLOP than re-streaming the packed weight per 64-row slab. Calibrated on MI355X.
 FUSED_MAX_M = 128
+_REFERENCE_CUSTOM_MAX_M = 256  # reference backends/cuda/ops.py:816 (_gemm_4bit_custom_max_m on ROCm)
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -243,14 +244,18 @@ def _gemm_4bit_route(dtype: torch.dtype, M: int, N: int, K: int, blocksize: int)
     """MI355X routing: 'fused' (HIP dot / MFMA kernels, chosen inside the library by M) or 'unfused'
     (dequantize + hipBLASLt). Replaces reference backends/cuda/ops.py:814-843,921-962."""
     if K % blocksize != 0:
-        warn(
-            f"inner dimension ({K}) is not aligned for fast kernel with blocksize={blocksize}, "
-            "falling back to slower implementation.",
-            UserWarning,
-        )
+        # the reference only warns where its custom kernel could have run (M <= 256 on ROCm,
+        # backends/cuda/ops.py:956-962): larger batches take dequantize + linear silently
+        if M <= _REFERENCE_CUSTOM_MAX_M:
+            warn(
+                f"inner dimension ({K}) is not aligned for fast kernel with blocksize={blocksize}, "
+                "falling back to slower implementation.",
+                UserWarning,
+            )
         return "unfused"
     if dtype == torch.float32:
-        # no fp32 MFMA fast path worth having here (1/16 of the bf16 rate): dot kernel for tiny M only
+        # fp32 activations: the streaming kernel (fp32 FMA decode, same code path as bf16/fp16) for decode-sized batches;
+        # no fp32 MFMA path worth having above that (1/16 of the bf16 matrix rate)
         return "fused" if M <= 4 else "unfused"
     return "fused" if M <= FUSED_MAX_M else "unfused"
 

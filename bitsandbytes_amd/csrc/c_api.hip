@@ -1,6 +1,6 @@
 // c_api.hip — the extern "C" surface of libbitsandbytes_mi355x.so (declared in include/bnb_mi355x.h).
 // Thin, un-mangled wrappers over the launchers in quantize4.hip, dequantize4.hip, blockwise8.hip,
-// gemv4.hip and gemm4_mfma.hip. Mirrors the symbol set the reference exports for this path from
+// gemv4_stream.hip, gemm4_mfma.hip and gemm4_mfma_rt.hip. Mirrors the symbol set the reference exports for this path from
 // csrc/pythonInterface.cpp:343-841 and csrc/gemm_4bit.cu:136-168.
 #include "bnb_common.h"
 
@@ -23,10 +23,6 @@ void quantize_8bit_bf16(const float*, const void*, float*, uint8_t*, int, long, 
 void dequantize_8bit_f32(const float*, const uint8_t*, const float*, float*, int, long, hipStream_t);
 void dequantize_8bit_f16(const float*, const uint8_t*, const float*, void*, int, long, hipStream_t);
 void dequantize_8bit_bf16(const float*, const uint8_t*, const float*, void*, int, long, hipStream_t);
-// gemv4.hip
-void gemv_4bit_dot(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
-                   const float* absmax_code, const float* absmax_offset, const float* code16, void* out,
-                   const void* bias, int M, int N, int K, int blocksize, int quant_type, hipStream_t stream);
 // gemv4_stream.hip
 void gemv_4bit_stream(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                       const float* absmax_code, const float* absmax_offset, const float* code16, void* out,
@@ -36,8 +32,9 @@ bool gemv_4bit_grouped(int dtype, const void* A, int count, const uint8_t* const
                        void* const* out, const void* const* bias, const int* N, int M, int K, int blocksize, int quant_type,
                        hipStream_t stream);
 void gemv_4bit_stream_tuning(int ns, int sw, int rows_per_wg, int nt, int waves);
-extern int g_dot_rpw, g_dot_segs, g_dot_ablate, g_dot_flags;
-extern unsigned long long* g_dbg_buf;
+#ifdef BNB_PROFILING
+unsigned long long* g_dbg_buf = nullptr; // profiling builds only: device buffer for the kernels' s_memtime stamps
+#endif
 // gemm4_mfma.hip
 bool gemm_4bit_mfma_supported(int dtype, const void* A, const uint8_t* B, int M, int N, int K, int blocksize);
 void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
@@ -79,9 +76,6 @@ void gemm_4bit_dispatch(int kernel, int dtype, const void* A, const uint8_t* B, 
     if (route_to_mfma(kernel, dtype, A, B, M, N, K, blocksize))
         gemm_4bit_mfma(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, code16, out, bias, M, N, K, blocksize,
                        quant_type, workspace, workspace_bytes, stream);
-    else if (kernel == 1) // round 1's dot kernel, kept for A/B measurements until the streaming kernel has replaced it
-        gemv_4bit_dot(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, code16, out, bias, M, N, K, blocksize,
-                      quant_type, stream);
     else
         gemv_4bit_stream(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, code16, out, bias, M, N, K, blocksize,
                          quant_type, stream);
@@ -276,21 +270,21 @@ size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N,
         return 0;
     return gemm_4bit_mfma_workspace_bytes(M, N, K);
 }
-void bnb_mi355x_set_tuning(int dot_rows_per_wave, int dot_segments, int mfma_knob0, int mfma_knob1) {
-    g_dot_rpw = dot_rows_per_wave;
-    g_dot_segs = dot_segments;
+void bnb_mi355x_set_tuning(int reserved0, int reserved1, int mfma_knob0, int mfma_knob1) {
+    (void)reserved0;
+    (void)reserved1;
     g_mfma_knob0 = mfma_knob0;
     g_mfma_knob1 = mfma_knob1;
 }
 void bnb_mi355x_set_stream_tuning(int ring_depth, int segments, int rows_per_workgroup, int nontemporal, int waves) {
     gemv_4bit_stream_tuning(ring_depth, segments, rows_per_workgroup, nontemporal, waves);
 }
-void bnb_mi355x_set_debug(int dot_ablation, int dot_flags) {
-    g_dot_ablate = dot_ablation;
-    g_dot_flags = dot_flags;
-}
 void bnb_mi355x_set_stamp_buffer(void* device_u64_buffer) {
+#ifdef BNB_PROFILING
     g_dbg_buf = static_cast<unsigned long long*>(device_u64_buffer);
+#else
+    (void)device_u64_buffer; // the product library carries no stamp code: the call is accepted and ignored
+#endif
 }
 const char* bnb_mi355x_version(void) { return "bitsandbytes_amd 0.1.0 gfx950"; }
 

@@ -118,7 +118,9 @@ void launch_dequantize4(const uint8_t* A, const float* absmax, T* out, int block
 // Requires row_len % 8 == 0 and row_len % blocksize == 0, so a row is a whole number of packed dwords and
 // of quantization blocks. grid = (ceil(row_len / 2048), rows_out); a lane owns 8 outputs exactly as above,
 // so results are bit-identical to dequantize4_kernel on the gathered bytes. An index outside
-// [0, num_rows) yields a row of zeros (F.embedding would raise a device-side assert instead).
+// [0, num_rows) yields a row of NaN: the library has no error return and a device-side assert (what F.embedding does)
+// would take the process down mid-graph, but a silent row of zeros would turn a bad token id into a plausible
+// embedding - NaN propagates to the first consumer that looks.
 template <typename T, typename IdxT>
 __global__ __launch_bounds__(kDqThreads) void dequantize4_rows_kernel(const uint8_t* __restrict__ A,
                                                                       const float* __restrict__ absmax,
@@ -148,8 +150,8 @@ __global__ __launch_bounds__(kDqThreads) void dequantize4_rows_kernel(const uint
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const uint32_t byte = (w >> (8 * b)) & 0xFFu;
-        v[2 * b] = valid ? rounded_f32(code[byte >> 4] * s) : 0.0f;
-        v[2 * b + 1] = valid ? rounded_f32(code[byte & 0xF] * s) : 0.0f;
+        v[2 * b] = valid ? rounded_f32(code[byte >> 4] * s) : __builtin_nanf("");
+        v[2 * b + 1] = valid ? rounded_f32(code[byte & 0xF] * s) : __builtin_nanf("");
     }
     store8<T>(out, t * row_len + col, v);
 }

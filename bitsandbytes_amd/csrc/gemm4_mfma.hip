@@ -35,8 +35,9 @@
 
 namespace bnb {
 
-extern unsigned long long* g_dbg_buf; // gemv4.hip (profiling only)
-extern int g_dot_ablate;               // gemv4.hip (profiling only): 11 / 12 select the MFMA ablations
+#ifdef BNB_PROFILING
+extern unsigned long long* g_dbg_buf; // c_api.hip (profiling builds only)
+#endif
 int g_mfma_knob0 = 0; // sweeps: bits 8 / 16 select the A-image variants of the LDS-DMA kernel (launch_mfma_dma)
 int g_mfma_knob1 = 0; // K-slice count override (0 = heuristic)
 
@@ -122,14 +123,14 @@ typedef __attribute__((address_space(3))) void* dma_dst_t;
 // wavefront, so the 8-row variant goes back to the 32-copy table.
 template <typename T, int MT, bool NESTED, int kWaves, int AROWS>
 __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(
-    // hot arguments as separate scalars: eligible for kernarg preload into SGPRs (see gemv4.hip)
+    // hot arguments as separate scalars: eligible for kernarg preload into SGPRs (see gemv4_stream.hip)
     // (exactly the 14 preloadable dwords: 16 user SGPRs minus the kernarg segment pointer; the output pointer is
     // needed last and stays in the struct)
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const float* hot_code16, int hot_M, int hot_N,
     int hot_K, int hot_bs_shift, int hot_kslices, int hot_quant_type, const GemmArgs p) {
     void* const hot_out = p.out;
     // 64 table copies, 256 B per entry: the look-up address byte * 256 + lane * 4 is one v_perm_b32 (see
-    // gemv4.hip); this kernel runs one workgroup per CU, so the 64 KiB are free
+    // gemv4_stream.hip); this kernel runs one workgroup per CU, so the 64 KiB are free
     static_assert(AROWS == 0 || (MT == 1 && (AROWS == 4 || AROWS == 8)), "A image: 4 or 8 rows, one M tile");
     constexpr int COPIES = (AROWS == 8) ? 32 : 64;
     constexpr int kLutBytes = 256 * COPIES * 4;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(
     {
         const uint32_t pr = Mma<T>::pack(code_hi, code_lo);
         const u32x4 v = {pr, pr, pr, pr};
-        // chunk order rotated by the entry's index in the wavefront: conflict-free ds_write_b128 (see gemv4.hip)
+        // chunk order rotated by the entry's index in the wavefront: conflict-free ds_write_b128 (see gemv4_stream.hip)
         constexpr int NCH = COPIES / 4 / TPE;
         u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * COPIES]) + (tid % TPE) * NCH;
         const int rot = (NCH >= 8) ? (tid & 63) : (tid & 63) * NCH / 8; // distinct bank quads within 8 lanes
@@ -438,7 +439,7 @@ constexpr int kPcProducers = 4;
 
 template <typename T, int MT, bool NESTED, int CW, int NTW, int D>
 __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel(
-    // hot arguments as separate scalars: eligible for kernarg preload into SGPRs (see gemv4.hip)
+    // hot arguments as separate scalars: eligible for kernarg preload into SGPRs (see gemv4_stream.hip)
     // (exactly the 14 preloadable dwords: 16 user SGPRs minus the kernarg segment pointer; the output pointer is
     // needed last and stays in the struct)
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const float* hot_code16, int hot_M, int hot_N,
@@ -515,7 +516,7 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
             u32x4* dst = reinterpret_cast<u32x4*>(&lut[e * 32]);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                dst[(j + e) & 7] = v; // rotated chunk order: conflict-free ds_write_b128 (see gemv4.hip)
+                dst[(j + e) & 7] = v; // rotated chunk order: conflict-free ds_write_b128 (see gemv4_stream.hip)
             if constexpr (NESTED)
                 code2[e] = code2_v;
         }
@@ -812,8 +813,11 @@ __global__ __launch_bounds__(256) void gemm4_finalize_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------
 // Library-owned split-K workspace, used only when the caller passes none (the reference ABI has no
 // workspace argument): one buffer per (device, stream) so concurrent streams never share slabs;
-// created on first use; never created while the stream is being captured (hipMalloc would
-// invalidate the capture) - in that case the call simply runs with a single K slice. Never freed.
+// created on first use with the stream-ordered allocator (hipMallocAsync: no device-wide synchronisation inside a
+// launch call); when a larger one is needed the old buffer is returned with hipFreeAsync ON THE SAME STREAM, i.e. after
+// every kernel already enqueued on it - nothing leaks, nothing is freed under a running kernel. Never allocated while
+// the stream is being captured (it would invalidate the capture): such a call runs with a single K slice; callers that
+// capture graphs pass their own workspace (bnb_mi355x_gemm_4bit, what the Python host does).
 // ---------------------------------------------------------------------------------------------
 struct WsKey {
     int dev;
@@ -845,11 +849,13 @@ float* get_internal_workspace(size_t bytes, hipStream_t stream) {
         }
         size_t want = bytes < (size_t(16) << 20) ? (size_t(16) << 20) : bytes;
         float* np = nullptr;
-        if (hipMalloc(reinterpret_cast<void**>(&np), want) != hipSuccess) {
+        if (hipMallocAsync(reinterpret_cast<void**>(&np), want, stream) != hipSuccess) {
             (void)hipGetLastError();
             return nullptr;
         }
-        b.p = np; // an older, smaller buffer stays allocated: kernels already enqueued may still use it
+        if (b.p != nullptr && hipFreeAsync(b.p, stream) != hipSuccess) // stream-ordered: after the kernels that still use it
+            (void)hipGetLastError();
+        b.p = np;
         b.bytes = want;
     }
     return b.p;
@@ -1136,8 +1142,12 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
     p.out = out;
     p.bias = bias;
     p.ws = nullptr;
+#ifdef BNB_PROFILING
     p.dbg = g_dbg_buf;
-    p.ablate = g_dot_ablate >= 10 ? g_dot_ablate - 10 : 0;
+#else
+    p.dbg = nullptr;
+#endif
+    p.ablate = 0;
     p.M = M;
     p.N = N;
     p.K = K;

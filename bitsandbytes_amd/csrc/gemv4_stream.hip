@@ -36,7 +36,7 @@
 namespace bnb {
 
 #ifdef BNB_PROFILING
-extern unsigned long long* g_dbg_buf; // gemv4.hip (profiling builds)
+extern unsigned long long* g_dbg_buf; // c_api.hip (profiling builds)
 #endif
 
 namespace {

@@ -367,6 +367,12 @@ class Embedding4bit(nn.Embedding):
                 rows, scales, state.blocksize, state.quant_type, (*input.shape, self.embedding_dim), state.dtype
             )
             return out.to(self.dtype)
+        packed_rows = (self.weight.data.numel() * self.weight.data.element_size() * 2) // self.embedding_dim
+        if packed_rows != self.num_embeddings or tuple(state.shape) != (self.num_embeddings, self.embedding_dim):
+            raise RuntimeError(
+                f"Embedding4bit: packed weight holds {packed_rows} rows of {self.embedding_dim}, quant_state.shape is "
+                f"{tuple(state.shape)}, module expects ({self.num_embeddings}, {self.embedding_dim})"
+            )
         out = torch.ops.bitsandbytes_amd.dequantize_4bit_rows.default(
             self.weight.data, absmax, input, self.embedding_dim, state.blocksize, state.quant_type, state.dtype
         )

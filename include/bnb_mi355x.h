@@ -128,26 +128,20 @@ size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N,
  * matrices are launched one by one. Results are bit-identical to `count` separate cgemm_4bit_* calls. */
 void bnb_mi355x_gemm_4bit_grouped(int dtype, const void* A, int count, const uint8_t* const* B, const float* const* absmax, const uint8_t* const* absmax_8bit, const float* const* absmax_code, const float* const* absmax_offset, void* const* out, const void* const* bias, const int* N, int M, int K, int blocksize, int quant_type, bnb_stream_t stream);
 
-/* Tuning overrides for sweeps (0 = built-in heuristic): rows per wavefront and 2048-k segments per
- * iteration of the dot kernel; MFMA kernels: knob0 = A-image variant bits of the LDS-DMA kernel, knob1 =
- * 100 * cfg + K-slice count (cfg 5/6 LDS-DMA, 11-14 producer/consumer geometries). Not thread-safe; bench/test use only. */
-void bnb_mi355x_set_tuning(int dot_rows_per_wave, int dot_segments, int mfma_knob0, int mfma_knob1);
+/* Tuning overrides of the MFMA kernels for sweeps and tests (0 = built-in heuristic; the first two arguments are reserved):
+ * knob0 = A-image variant bits of the LDS-DMA kernel, knob1 = 100 * cfg + K-slice count (cfg 5/6 LDS-DMA, 11-14
+ * producer/consumer geometries, 20/21/22 register-transposed kernel with built-in / 8 / 16 wavefronts). Every setting
+ * computes correct results - the knobs only choose a launch geometry. Not thread-safe; bench/test use only. */
+void bnb_mi355x_set_tuning(int reserved0, int reserved1, int mfma_knob0, int mfma_knob1);
 
 /* Sweep-only overrides of the streaming kernel (0 / -1 = built-in choice): ring depth (2, 3, 6; bf16 M = 1 fp32-absmax
  * NF4 only), 2048-k segments side by side, rows per workgroup, non-temporal weight loads (0 / 1, -1 = default on),
  * wavefronts per workgroup (8; same restriction as ring depth). Every setting computes the same results. Atomics. */
 void bnb_mi355x_set_stream_tuning(int ring_depth, int segments, int rows_per_workgroup, int nontemporal, int waves);
 
-/* Profiling only. dot_ablation: 0 = normal; 1..5 run ablated variants of the dot kernel (stream only /
- * no table build / no weight loads / weights only / empty) whose RESULTS ARE WRONG. dot_flags selects
- * structural variants of the dot kernel whose results stay correct (16 = EXPERIMENTAL diagonal-MFMA decode, not yet
- * validated on hardware; 32 = 32-copy decode table, 64 = 256-thread
- * workgroups, 128 = activations loaded per wavefront instead of staged in LDS, M = 1 only; bits 8..15 = KiB of
- * LDS padding for occupancy experiments). Never set outside tools/. */
-void bnb_mi355x_set_debug(int dot_ablation, int dot_flags);
-
-/* Profiling only: when non-NULL, the producer/consumer MFMA kernel writes 16 s_memtime stamps per wavefront
- * (u64) into this device buffer (tools/timeline_pc.py); the LDS-DMA MFMA kernel writes 8 (tools/timeline_v3.py). NULL switches it off. */
+/* Profiling builds only (libbitsandbytes_mi355x_prof.so, -DBNB_PROFILING): when non-NULL the kernels write s_memtime
+ * stamps per wavefront (u64) into this device buffer (tools/timeline_*.py). The product library contains no stamp or
+ * ablation code; there the call is accepted and ignored. */
 void bnb_mi355x_set_stamp_buffer(void* device_u64_buffer);
 
 /* Version / build identification: returns "bitsandbytes_amd <ver> gfx950". */

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of the streaming dot kernel (kernel = 3) against round 1's dot kernel (kernel = 1): per-launch time over an
-HBM-resident rotation of distinct layers, hipGraph-replayed (launch-to-launch time in a dependent stream).
+"""Per-launch time of the streaming dot kernel (kernel = 3) over an HBM-resident rotation of distinct layers,
+hipGraph-replayed (launch-to-launch time in a dependent stream). (Round 1's dot kernel, its A/B partner until round 2,
+is no longer in the library: profiles/r2_stream_ab.txt holds the last side-by-side run.)
 Sections: shapes x M, tuning sweep at the headline shape, grouped launches vs separate launches."""
 import argparse
 import os
@@ -78,7 +79,7 @@ def main():
     shapes = [(4096, 4096), (8192, 8192), (11008, 4096), (4096, 11008), (1376, 4096), (512, 11008), (28672, 8192)]
     if args.quick:
         shapes = shapes[:2]
-    print(f"\n{'N x K':>14s} {'M':>2s} {'variant':>10s} {'old us':>8s} {'new us':>8s} {'new GB/s':>9s} {'%HBM':>6s}")
+    print(f"\n{'N x K':>14s} {'M':>2s} {'variant':>10s} {'us':>8s} {'GB/s':>9s} {'%HBM':>6s}")
     for (N, K) in shapes:
         for variant, qt, bs, dq in (("nf4-64", "nf4", 64, False), ("nf4-64-dq", "nf4", 64, True)):
             if variant != "nf4-64" and (N, K) not in ((4096, 4096), (11008, 4096)):
@@ -86,17 +87,16 @@ def main():
             layers = make_layers(N, K, bs, qt, dq)
             for M in (1, 2, 4):
                 x = torch.randn(M, K, device="cuda").bfloat16()
-                t_old = run(layers, x, 1)
                 t_new = run(layers, x, 3)
                 gbs = alg_bytes(M, N, K, bs, dq) / t_new / 1e3
-                print(f"{N:>7d}x{K:<6d} {M:2d} {variant:>10s} {t_old:8.2f} {t_new:8.2f} {gbs:9.1f} {gbs / 80:6.1f}", flush=True)
+                print(f"{N:>7d}x{K:<6d} {M:2d} {variant:>10s} {t_new:8.2f} {gbs:9.1f} {gbs / 80:6.1f}", flush=True)
             del layers
 
-    print("\n-- other activation dtypes, 4096 x 4096, M = 1 (new kernel; old one ran fp32 on its scalar path)")
+    print("\n-- other activation dtypes, 4096 x 4096, M = 1")
     for dt in (torch.float16, torch.float32):
         layers = make_layers(4096, 4096, 64, "nf4", False, dtype=dt)
         x = torch.randn(1, 4096, device="cuda").to(dt)
-        print(f"   {str(dt):16s} old {run(layers, x, 1):7.2f} us   new {run(layers, x, 3):7.2f} us", flush=True)
+        print(f"   {str(dt):16s} {run(layers, x, 3):7.2f} us", flush=True)
         del layers
 
     print("\n-- tuning sweep (bf16, M = 1): ring depth / segments side by side / rows per workgroup / nt / wavefronts")

@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""GPU-side micro-benchmark sweep over kernel variants (dot kernel rows-per-wave / segments, MFMA
-NT / K-slices) and M. Prints a table; each cell = microseconds per launch measured two ways:
+"""GPU-side micro-benchmark sweep over the MFMA kernel geometries (cfg x K-slices) and M. Prints a table; each cell = microseconds per launch measured two ways:
   graph  : 10 replays of a hipGraph of 64 back-to-back launches over 64 distinct layers (HBM-resident rotation)
   evpair : mean of per-launch HIP-event brackets (eager)
 plus the implied algorithmic GB/s from `graph`. Usage: python tools/sweep.py [--n 4096 --k 4096] [--quick]"""
@@ -74,9 +73,8 @@ def main():
     ap.add_argument("--k", type=int, default=4096)
     ap.add_argument("--bs", type=int, default=64)
     ap.add_argument("--quick", action="store_true")
-    ap.add_argument("--dot-only", action="store_true")
     ap.add_argument("--mfma-only", action="store_true")
-    ap.add_argument("--cfgs", default="5,6,11,12,13,14", help="MFMA kernel geometries to sweep (cfg codes, see make_plan)")
+    ap.add_argument("--cfgs", default="5,6,11,12,13,14,20,21,22", help="MFMA kernel geometries to sweep (cfg codes, see make_plan)")
     ap.add_argument("--ms", default="", help="comma list of M values for the MFMA sweep")
     ap.add_argument("--kss", default="2,4,8,16", help="K-slice counts to sweep")
     a = ap.parse_args()
@@ -89,39 +87,10 @@ def main():
         del W
     print(f"# N={N} K={K} bs={bs} layers={L} ({L * bytes_alg(1, N, K, bs) / 1e6:.0f} MB rotated)")
     print(f"{'kernel':8s} {'M':>3s} {'knobs':>12s} {'graph_us':>9s} {'evpair_us':>9s} {'GB/s(graph)':>11s} {'TFLOP/s':>8s}")
-    x1 = torch.randn(1, K, device="cuda", generator=g).bfloat16()
-    # correctness reference for the structural variants (they must not change results beyond rounding)
-    bnb.lib.bnb_mi355x_set_debug(0, 0)
-    q0, st0 = layers[0]
-
-    def run1(xx):
-        return hip._gemm_4bit_fused(xx, q0, st0.shape, st0.absmax, st0.blocksize, st0.quant_type, None, None, None, None, kernel=1).float()
-
-    y_ref = run1(x1)
-    FLD = {0: "512thr xLDS", 64: "256thr xLDS", 128: "512thr xwave"}
-    for rpw in (() if a.mfma_only else (1, 2)):
-        for fl, name in FLD.items():
-            bnb.lib.bnb_mi355x_set_tuning(rpw, 2, 0, 0)
-            bnb.lib.bnb_mi355x_set_debug(0, fl)
-            err = float((run1(x1) - y_ref).norm() / y_ref.norm())
-            tg, te = measure(layers, x1, 1)
-            print(f"{'dot':8s} {1:3d} {f'rpw{rpw} {name}':>16s} {tg:9.2f} {te:9.2f} {bytes_alg(1, N, K, bs) / tg / 1e3:11.1f} {2 * N * K / tg / 1e6:8.2f}  relerr_vs_base={err:.1e}")
-    bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
-    bnb.lib.bnb_mi355x_set_debug(0, 0)
-    for abl, name in (() if a.mfma_only else ((5, "empty"), (4, "weights-only"), (1, "stream-only"), (3, "no-weight-loads"), (0, "full rpw2 seg2"))):
-        bnb.lib.bnb_mi355x_set_debug(abl, 0)
-        bnb.lib.bnb_mi355x_set_tuning(2, 2, 0, 0)
-        tg, te = measure(layers, x1, 1)
-        print(f"{'dot-abl':8s} {1:3d} {name:>16s} {tg:9.2f} {te:9.2f} {bytes_alg(1, N, K, bs) / tg / 1e3:11.1f}")
-    bnb.lib.bnb_mi355x_set_debug(0, 0)
-    bnb.lib.bnb_mi355x_set_debug(0, 0)
-    bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
-    if a.dot_only:
-        return
     Ms = [1, 8, 16, 64] if a.quick else [1, 4, 8, 16, 32, 64]
     if a.ms:
         Ms = [int(v) for v in a.ms.split(",")]
-    names = {5: "dma16w", 6: "dma8w", 11: "pc8x1", 12: "pc4x2", 13: "pc8x2", 14: "pc4x1"}
+    names = {5: "dma16w", 6: "dma8w", 11: "pc8x1", 12: "pc4x2", 13: "pc8x2", 14: "pc4x1", 20: "rt", 21: "rt8w", 22: "rt16w"}
     CFG = {int(c): names.get(int(c), f"cfg{c}") for c in a.cfgs.split(",")}
     KSS = tuple(int(v) for v in a.kss.split(","))
     for M in Ms:
@@ -136,7 +105,7 @@ def main():
             dma = cfg in (5, 6)
             if dma and (mt > 2 or (cfg == 5 and mt != 1)):
                 continue
-            for ks in ((1, 2) if dma else KSS):
+            for ks in ((1, 2) if dma else (0, 2) if cfg >= 20 else KSS):
                 if dma and ks == 2 and N // 16 >= 192:
                     continue
                 bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, cfg * 100 + ks)
