@@ -1100,7 +1100,7 @@ bool rt_selected(int M, int N, int K, int* force_ks, int* force_waves) {
     if (M <= 32)
         return weights <= (20L << 20);
     if (M <= 64)
-        return weights <= (8L << 20);
+        return weights <= (20L << 20);
     return false;
 }
 } // namespace

@@ -110,9 +110,11 @@ __device__ __forceinline__ float rt_code_literal(int i, bool fp4) {
     return v;
 }
 
-// T in {bf16, f16}; WAVES wavefronts split the workgroup's K range chunk by chunk (chunk c of the slice goes to
-// wavefront c % WAVES). grid = (ceil(N / 16), kslices, ceil(M / 16)).
-template <typename T, int WAVES, bool NESTED>
+// T in {bf16, f16}; MT = 16-row tiles of the batch handled by one workgroup (the weights of a chunk are loaded, transposed
+// and decoded ONCE and multiplied with MT activation tiles in turn - while tile t is transposed and multiplied, the loads of
+// tile t + 1 refill the same registers); WAVES wavefronts split the workgroup's K range chunk by chunk (chunk c of the slice
+// goes to wavefront c % WAVES). grid = (ceil(N / 16), kslices, ceil(M / (16 MT))).
+template <typename T, int MT, int WAVES, bool NESTED>
 __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     // hot arguments as separate scalars: preloaded into SGPRs by the command processor (14 dwords)
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, int hot_M, int hot_N,
@@ -130,33 +132,46 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     const int bs_shift = hot_flags & 31;
     const bool fp4 = (hot_flags >> 8) & 1;
     const int col0 = blockIdx.x * 16;
-    const int m_base = blockIdx.z * 16;
+    const int m_base = blockIdx.z * (16 * MT);
     const int cb = blockIdx.y * hot_cps;
     int ce = cb + hot_cps;
     ce = (ce < (K >> 8)) ? ce : (K >> 8);
 
-    // LDS map: table | per-wavefront scratch (tile 0, tile 1, scale tile) | nested absmax code (1 KiB)
+    // LDS map: table | per-wavefront scratch (tile 0, tile 1, scale tile) | nested absmax code (1 KiB) | parked partial tiles
     unsigned char* const sc = smem + kRtLut + wave * kRtScratch;
     u32x4* const tile0 = reinterpret_cast<u32x4*>(sc);
     u32x4* const tile1 = reinterpret_cast<u32x4*>(sc + 1024);
     u32x4* const stile = reinterpret_cast<u32x4*>(sc + 2048);
     float* const code2 = reinterpret_cast<float*>(smem + kRtLut + WAVES * kRtScratch);
+    unsigned char* const red = smem + kRtLut + WAVES * kRtScratch + 1024; // [WAVES][MT][64 lanes][16 B]
 
     // ---- sources. Rows past the end (ragged N or M) re-read the last row: MFMA rows / columns are independent and those
     // results are never stored, so no masking instructions are needed.
     int wrow = col0 + r;
     wrow = (wrow < N) ? wrow : N - 1;
-    int arow = m_base + r;
-    const bool a_valid = arow < M;
-    arow = a_valid ? arow : M - 1;
     const uint8_t* const wsrc = hot_B + static_cast<long>(wrow) * (K >> 1) + pp * 16;
-    const T* const asrc = static_cast<const T*>(hot_A) + static_cast<long>(arow) * K + (pp & 1) * 32 + (pp >> 1) * 16;
+    const T* const abase = static_cast<const T*>(hot_A) + (pp & 1) * 32 + (pp >> 1) * 16;
     const long e0 = static_cast<long>(wrow) * K; // flat element index of the row start
 
     struct Raw {
         u32x4 w[2]; // 128 k each: lane (r, pp) holds k [128 h + 32 pp, + 32) of row r
         u32x4 s;    // the row's scales of the chunk's four 64-k sub-blocks (nested: {4 x uint8, second-level absmax})
         u32x4 a[8]; // step (h, j): lane (r, pp) holds A[r][128 h + 64 (j >> 1) + 8 (j & 1) + 32 (pp & 1) + 16 (pp >> 1) + 0..7]
+    };
+    // Activation rows past the end of the batch are not fetched at all (exec-masked: the loads then cost the L1 M / 16 of a
+    // full tile); those lanes hold zeros and the MFMA rows they feed are never stored.
+    auto load_a_step = [&](Raw& raw, int c, int mt, int s) {
+        const int row = m_base + mt * 16 + r;
+        if (row < M)
+            raw.a[s] = *reinterpret_cast<const u32x4*>(abase + static_cast<long>(row) * K + static_cast<long>(c) * kRtChunk +
+                                                       128 * (s >> 2) + 64 * ((s >> 1) & 1) + 8 * (s & 1));
+        else
+            raw.a[s] = u32x4{0, 0, 0, 0};
+    };
+    auto load_a = [&](Raw& raw, int c, int mt) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            load_a_step(raw, c, mt, s);
     };
     auto issue = [&](Raw& raw, int c) {
 #pragma unroll
@@ -186,18 +201,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
                     raw.s[b] = __builtin_bit_cast(uint32_t, hot_absmax[(e + b * 64) >> bs_shift]);
             }
         }
-        // activation rows past the end of the batch are not fetched at all (exec-masked: the loads then cost the L1 M / 16 of a
-        // full tile); those lanes hold zeros and the MFMA rows they feed are never stored
-        if (a_valid) {
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-                raw.a[s] = *reinterpret_cast<const u32x4*>(asrc + static_cast<long>(c) * kRtChunk + 128 * (s >> 2) +
-                                                           64 * ((s >> 1) & 1) + 8 * (s & 1));
-        } else {
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-                raw.a[s] = u32x4{0, 0, 0, 0};
-        }
+        load_a(raw, c, 0);
     };
 
     Raw raw;
@@ -241,7 +245,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     const int rslot = 16 * lg + ((ln + 2 * lg) & 15); // ... and where lane (ln, lg) finds those of lane (r = ln, pp = lg)
     const uint32_t lane_off = static_cast<uint32_t>(lane & 31) * 4u + static_cast<uint32_t>(opaque_zero());
 
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (; c < ce; c += WAVES) {
         // weights: transpose, then regroup so that dwords 0/1 (2/3) of every lane group belong to block 2h (2h + 1)
         u32x4 wt[2];
@@ -275,27 +282,34 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
         }
         if (c == cb + wave)
             BNB_RT_STAMP(4)
+        u32x4 bfr[8]; // decoded weight fragments of the chunk: produced with the first activation tile, reused by the others
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
-            f32x4 part = {0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int h = blk >> 1, j = 2 * (blk & 1) + i, s = 4 * h + j;
-                u32x4* const tile = (s & 1) ? tile1 : tile0;
-                tile[wslot] = raw.a[s];
-                const u32x4 af = tile[rslot];
-                const uint32_t w = wt[h][j];
-                u32x4 bf;
+            for (int blk = 0; blk < 4; ++blk) {
+                f32x4 part = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t byte = __builtin_amdgcn_ubfe(w, 8u * q, 8u);
-                    bf[q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((byte << 7) + lane_off);
+                for (int i = 0; i < 2; ++i) {
+                    const int h = blk >> 1, j = 2 * (blk & 1) + i, s = 4 * h + j;
+                    u32x4* const tile = (s & 1) ? tile1 : tile0;
+                    tile[wslot] = raw.a[s];
+                    if (mt + 1 < MT)
+                        load_a_step(raw, c, mt + 1, s); // the next tile's piece refills the register just emptied
+                    const u32x4 af = tile[rslot];
+                    if (mt == 0) {
+                        const uint32_t w = wt[h][j];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const uint32_t byte = __builtin_amdgcn_ubfe(w, 8u * q, 8u);
+                            bfr[s][q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((byte << 7) + lane_off);
+                        }
+                    }
+                    part = RtMma<T>::run(af, bfr[s], part);
                 }
-                part = RtMma<T>::run(af, bf, part);
-            }
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                acc[q] = fmaf(scale[blk], part[q], acc[q]);
+                for (int q = 0; q < 4; ++q)
+                    acc[mt][q] = fmaf(scale[blk], part[q], acc[mt][q]);
+            }
         }
         if (c + WAVES < ce)
             issue(raw, c + WAVES);
@@ -305,31 +319,33 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     if (reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem) != 0)
         __builtin_trap();
 
-    // ---- combine the wavefronts' partial tiles in wavefront order (each wavefront parks its tile in its own scratch)
-    *reinterpret_cast<f32x4*>(sc + lane * 16) = acc;
+    // ---- combine the wavefronts' partial tiles in wavefront order
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        *reinterpret_cast<f32x4*>(red + ((wave * MT + mt) * 64 + lane) * 16) = acc[mt];
     __syncthreads();
     BNB_RT_STAMP(6)
-    if (tid < 256) {
-        const int col = tid & 15, row = tid >> 4;
+    for (int o = tid; o < MT * 256; o += THREADS) {
+        const int mt = o >> 8, col = o & 15, row = (o >> 4) & 15;
         const int src = (col + 16 * (row >> 2)) * 4 + (row & 3);
         float pv[WAVES];
 #pragma unroll
         for (int w = 0; w < WAVES; ++w)
-            pv[w] = reinterpret_cast<const float*>(smem + kRtLut + w * kRtScratch)[src];
+            pv[w] = reinterpret_cast<const float*>(red + (w * MT + mt) * 1024)[src];
         __builtin_amdgcn_sched_barrier(0); // all look-ups in flight before the first add (the adds stay in wavefront order)
         float v = 0.0f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w)
             v += pv[w];
-        const int m = m_base + row, n = col0 + col;
+        const int m = m_base + mt * 16 + row, n = col0 + col;
         if (m < M && n < N) {
-            const long o = static_cast<long>(m) * N + n;
+            const long o2 = static_cast<long>(m) * N + n;
             if (hot_kslices == 1) {
                 const T* bias = static_cast<const T*>(p.bias);
                 const float b = bias ? static_cast<float>(bias[n]) : 0.0f;
-                static_cast<T*>(p.out)[o] = static_cast<T>(v + b);
+                static_cast<T*>(p.out)[o2] = static_cast<T>(v + b);
             } else {
-                p.ws[static_cast<long>(blockIdx.y) * M * N + o] = v;
+                p.ws[static_cast<long>(blockIdx.y) * M * N + o2] = v;
             }
         }
     }
@@ -350,7 +366,7 @@ int rt_cu_count() {
 }
 
 struct RtPlan {
-    int ks, cps, waves;
+    int ks, cps, waves, mt;
 };
 
 // K slices only when the column tiles alone would leave nearly all of the chip idle (a second launch and a slab round trip
@@ -359,8 +375,15 @@ struct RtPlan {
 RtPlan rt_plan(int M, int N, int K, int force_ks) {
     RtPlan pl;
     const int chunks = K / kRtChunk;
-    const int wgs = ((N + 15) / 16) * ((M + 15) / 16);
+    // Row tiles per workgroup: the whole batch up to 64 rows (a chunk's weights are decoded once for all of them) when the
+    // column tiles alone fill the chip; on narrow matrices separate workgroups per row tile fill it better (measured,
+    // profiles/r2_mfma_ab.txt: 4096^2 M = 64 11.9 us with 4 tiles per workgroup vs 13.5 with one; 1376 x 4096 10.1 vs 7.8)
     const int cus = rt_cu_count();
+    const int col_tiles = (N + 15) / 16;
+    pl.mt = M > 48 ? 4 : M > 32 ? 3 : M > 16 ? 2 : 1;
+    while (pl.mt > 1 && col_tiles * ((M + 16 * pl.mt - 1) / (16 * pl.mt)) < cus)
+        --pl.mt;
+    const int wgs = col_tiles * ((M + 16 * pl.mt - 1) / (16 * pl.mt));
     int ks = 1;
     if (force_ks > 0)
         ks = force_ks;
@@ -374,25 +397,38 @@ RtPlan rt_plan(int M, int N, int K, int force_ks) {
     // Sixteen wavefronts (one workgroup per CU) only when the launch is a single round of workgroups with long rows;
     // otherwise eight, two workgroups per CU (measured on MI355X, profiles/r2_mfma_ab.txt: 4096^2 6.45 vs 6.7 us,
     // 11008 x 4096 11.2 vs 16.0; 4096 x 11008 11.5 vs 10.8)
-    pl.waves = (wgs * pl.ks <= cus && pl.cps > 16) ? 16 : 8;
+    pl.waves = (pl.mt == 1 && wgs * pl.ks <= cus && pl.cps > 16) ? 16 : 8;
     return pl;
 }
 
-template <typename T, int WAVES> void rt_launch(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
-                                                int M, int N, int K, int flags, const RtPlan& pl, const RtArgs& a,
-                                                hipStream_t stream) {
-    const size_t lds = kRtLut + static_cast<size_t>(WAVES) * kRtScratch + 1024;
-    dim3 grid((N + 15) / 16, pl.ks, (M + 15) / 16);
+template <typename T, int MT, int WAVES> void rt_launch(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
+                                                        int M, int N, int K, int flags, const RtPlan& pl, const RtArgs& a,
+                                                        hipStream_t stream) {
+    const size_t lds = kRtLut + static_cast<size_t>(WAVES) * kRtScratch + 1024 + static_cast<size_t>(WAVES) * MT * 1024;
+    dim3 grid((N + 15) / 16, pl.ks, (M + 16 * MT - 1) / (16 * MT));
     if (absmax8 != nullptr) {
-        auto kern = gemm4_mfma_rt_kernel<T, WAVES, true>;
+        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, true>;
         static LdsLimit lim;
         ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
         hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, M, N, K, flags, pl.cps, pl.ks, a);
     } else {
-        auto kern = gemm4_mfma_rt_kernel<T, WAVES, false>;
+        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, false>;
         static LdsLimit lim;
         ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
         hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, M, N, K, flags, pl.cps, pl.ks, a);
+    }
+}
+
+template <typename T> void rt_launch_mt(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N,
+                                        int K, int flags, const RtPlan& pl, const RtArgs& a, hipStream_t stream) {
+    switch (pl.mt) {
+    case 1:
+        if (pl.waves == 16)
+            return rt_launch<T, 1, 16>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+        return rt_launch<T, 1, 8>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+    case 2: return rt_launch<T, 2, 8>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+    case 3: return rt_launch<T, 3, 8>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+    default: return rt_launch<T, 4, 8>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
     }
 }
 
@@ -416,7 +452,7 @@ void gemm_4bit_rt(int dtype, const void* A, const uint8_t* B, const float* absma
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int force_waves,
                   hipStream_t stream) {
     RtPlan pl = rt_plan(M, N, K, force_ks);
-    if (force_waves == 8 || force_waves == 16)
+    if (force_waves == 8 || (force_waves == 16 && pl.mt == 1))
         pl.waves = force_waves;
     float* ws = static_cast<float*>(workspace);
     const size_t slab = static_cast<size_t>(M) * N * sizeof(float);
@@ -443,17 +479,10 @@ void gemm_4bit_rt(int dtype, const void* A, const uint8_t* B, const float* absma
     a.bias = bias;
     a.ws = ws;
     const int flags = ilog2(blocksize) | ((quant_type == kFP4) ? 256 : 0);
-    if (dtype == 2) {
-        if (pl.waves == 16)
-            rt_launch<bf16, 16>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
-        else
-            rt_launch<bf16, 8>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
-    } else {
-        if (pl.waves == 16)
-            rt_launch<f16, 16>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
-        else
-            rt_launch<f16, 8>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
-    }
+    if (dtype == 2)
+        rt_launch_mt<bf16>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+    else
+        rt_launch_mt<f16>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
     BNB_CHECK_LAUNCH();
     if (pl.ks > 1)
         gemm_4bit_finalize(dtype, ws, bias, out, M, N, pl.ks, stream);

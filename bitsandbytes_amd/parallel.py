@@ -69,8 +69,11 @@ class ShardedLinear4bit(nn.Module):
     """This rank's row-shard of a 4-bit linear layer; ``forward`` returns the full ``[*, N]`` output."""
 
     def __init__(self, packed_shard: torch.Tensor, quant_state: QuantState, out_features: int,
-                 bias_shard: Optional[torch.Tensor] = None, group=None, gather_output: bool = True):
+                 bias_shard: Optional[torch.Tensor] = None, group=None, gather_output: bool = True,
+                 always_gather: bool = False):
         super().__init__()
+        # always_gather: issue the collective even in a group of one (a single-GPU smoke test of the RCCL path)
+        self.always_gather = always_gather
         self.register_buffer("weight", packed_shard, persistent=False)
         self.quant_state = quant_state
         self.bias = bias_shard
@@ -83,12 +86,15 @@ class ShardedLinear4bit(nn.Module):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
     def local_forward(self, x: torch.Tensor) -> torch.Tensor:
-        return matmul_4bit(x, self.weight, bias=self.bias, quant_state=self.quant_state)
+        bias = self.bias
+        if bias is not None and bias.dtype != x.dtype:  # Linear4bit.forward casts its bias the same way
+            bias = bias.to(x.dtype)
+        return matmul_4bit(x, self.weight, bias=bias, quant_state=self.quant_state)
 
     def gather(self, y_local: torch.Tensor) -> torch.Tensor:
         """One all-gather: rank-major buffer [G, M, N/G] -> [*, N]."""
         G = self.world_size
-        if G == 1:
+        if G == 1 and not (self.always_gather and dist.is_initialized()):
             return y_local
         lead = y_local.shape[:-1]
         ns = y_local.shape[-1]
@@ -106,7 +112,7 @@ class ShardedLinear4bit(nn.Module):
 
 
 def shard_linear4bit(layer, rank: Optional[int] = None, world_size: Optional[int] = None, group=None,
-                     gather_output: bool = True) -> ShardedLinear4bit:
+                     gather_output: bool = True, always_gather: bool = False) -> ShardedLinear4bit:
     """Build this rank's :class:`ShardedLinear4bit` from an already-quantised ``Linear4bit``."""
     if rank is None:
         rank = dist.get_rank(group)
@@ -121,4 +127,5 @@ def shard_linear4bit(layer, rank: Optional[int] = None, world_size: Optional[int
     bias = None
     if layer.bias is not None:
         bias = layer.bias.data[rank * ns : (rank + 1) * ns].clone()
-    return ShardedLinear4bit(packed_shard, shard_state, N, bias, group=group, gather_output=gather_output)
+    return ShardedLinear4bit(packed_shard, shard_state, N, bias, group=group, gather_output=gather_output,
+                             always_gather=always_gather)

@@ -1063,3 +1063,59 @@ def test_config5_fp4_nested_bs128_full():
     q, st = F.quantize_4bit(W, blocksize=128, quant_type="fp4", compress_statistics=True)
     y = bnb.matmul_4bit(x, q, st)
     assert rel_err(y.cpu(), _oracle_y_full(x, q, st)) < REL_TOL
+
+
+# ------------------------------------------------------------------------------------------ multi-GPU path on one GPU
+@pytest.mark.parametrize("N,K", [(11008, 4096), (4096, 11008)])
+@pytest.mark.parametrize("M", [1, 2, 64])
+def test_config4_eight_row_shards_equal_the_full_layer(N, K, M):
+    """BASELINE.json configs[3] as the sharded path computes it: the 8 row shards parallel.shard_linear4bit hands to the 8
+    ranks (1376 x 4096, 512 x 11008; nested absmax, so the second-level slicing is exercised), each run on this GPU,
+    concatenated = the un-sharded layer. Bit for bit at M <= 2 (the streaming kernel's result does not depend on the launch
+    geometry), within the matmul tolerance of the oracle above (the MFMA geometry follows N)."""
+    import bitsandbytes_amd.nn as bnn
+    from bitsandbytes_amd.parallel import shard_linear4bit
+
+    torch.manual_seed(3)
+    layer = bnn.Linear4bit(K, N, bias=True, compute_dtype=torch.bfloat16, compress_statistics=True, quant_type="nf4").to(DEV)
+    x = torch.randn(M, K, device=DEV, dtype=torch.bfloat16)
+    y_full = layer(x)
+    parts = [shard_linear4bit(layer, rank=r, world_size=8, gather_output=False)(x) for r in range(8)]
+    y_cat = torch.cat(parts, dim=-1)
+    assert y_cat.shape == y_full.shape
+    if M <= 2:
+        assert torch.equal(y_cat, y_full)
+    else:
+        assert rel_err(y_cat.cpu(), y_full.cpu()) < 3e-3
+
+
+def test_sharded_linear4bit_over_rccl_world_size_one():
+    """parallel.ShardedLinear4bit with torch.distributed backend "nccl" (= RCCL on ROCm) in a group of one: process-group
+    initialisation on the device, the kernel on the shard, and the all_gather_into_tensor collective actually issued
+    (always_gather) - the single-GPU rehearsal of BASELINE.json configs[3]; the 2-rank exchange is covered on CPU (gloo)."""
+    import socket
+
+    import torch.distributed as dist
+
+    import bitsandbytes_amd.nn as bnn
+    from bitsandbytes_amd.parallel import shard_linear4bit
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this interpreter")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    try:
+        torch.manual_seed(4)
+        for (N, K, M) in ((1376, 4096, 1), (512, 11008, 1), (1376, 4096, 64)):
+            layer = bnn.Linear4bit(K, N, bias=True, compute_dtype=torch.bfloat16, quant_type="nf4").to(DEV)
+            x = torch.randn(M, K, device=DEV, dtype=torch.bfloat16)
+            sharded = shard_linear4bit(layer, always_gather=True)
+            y = sharded(x)
+            torch.cuda.synchronize()
+            assert y.shape == (M, N)
+            assert torch.equal(y, layer(x))
+    finally:
+        dist.destroy_process_group()
