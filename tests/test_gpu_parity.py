@@ -760,12 +760,13 @@ def test_mfma_rt_kernel_exact_on_representable_inputs():
     q, st = F.quantize_4bit(W.to(DEV), blocksize=64, quant_type="fp4")
     y_ref = _oracle_y(x, q, st, None)
     import bitsandbytes_amd as bnb
-    try:
-        bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 2000)
-        y = _run_kernel(2, x.to(DEV), q, st, None)
-    finally:
-        bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
-    assert torch.equal(y.float().cpu(), y_ref.to(torch.bfloat16).float())
+    for knob in (2000, 2002, 1100):  # register-transposed kernel (one / two K slices), producer/consumer kernel
+        try:
+            bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, knob)
+            y = _run_kernel(2, x.to(DEV), q, st, None)
+        finally:
+            bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+        assert torch.equal(y.float().cpu(), y_ref.to(torch.bfloat16).float()), knob
 
 
 # ------------------------------------------------------------------------------------------ callers of dequantize_4bit

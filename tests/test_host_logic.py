@@ -397,3 +397,4 @@ def test_rt_mfma_lane_algebra_emulation():
     for M in (1, 7, 16):
         assert mod.emulate(M=M, K=512, seed=M) < 1e-12
     assert mod.final_sum_mapping_ok()
+

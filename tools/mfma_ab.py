@@ -25,25 +25,28 @@ def timed(layers, x, kernel, knob1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--big", action="store_true", help="only the large-matrix / tall-batch cases")
     args = ap.parse_args()
     print(torch.cuda.get_device_name(0), bnb.lib.bnb_mi355x_version().decode())
     shapes = [(4096, 4096, False), (4096, 4096, True), (11008, 4096, False), (4096, 11008, False), (1376, 4096, False),
               (8192, 8192, False)]
     if args.quick:
         shapes = shapes[:1]
+    if args.big:
+        shapes = [(4096, 4096, False), (11008, 4096, False), (8192, 8192, False), (28672, 8192, False)]
     variants = [("auto", 0, 0), ("stream", 3, 0), ("v3 dma", 2, 500), ("v5 pc11", 2, 1100), ("v5 pc14", 2, 1400),
                 ("rt", 2, 2000), ("rt 8w", 2, 2100), ("rt 16w", 2, 2200)]
     print(f"{'N x K':>14s} {'dq':>2s} {'M':>3s} " + " ".join(f"{n:>9s}" for n, _, _ in variants) + "   best GB/s (%HBM)")
     for (N, K, dq) in shapes:
         layers = make_layers(N, K, 64, "nf4", dq)
-        for M in (3, 4, 5, 8, 16, 32, 64):
+        for M in ((8, 16, 32, 64, 128) if args.big else (3, 4, 5, 8, 16, 32, 64)):
             x = torch.randn(M, K, device="cuda").bfloat16()
             row = []
             for name, kernel, knob1 in variants:
                 if kernel == 3 and M > 8:
                     row.append(float("nan"))
                     continue
-                if name.startswith("v3") and M > 32:
+                if (name.startswith("v3") and M > 32) or (name == "rt" and M > 64):
                     row.append(float("nan"))
                     continue
                 row.append(timed(layers, x, kernel, knob1))
