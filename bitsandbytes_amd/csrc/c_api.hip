@@ -42,7 +42,7 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
                     const void* bias, int M, int N, int K, int blocksize, int quant_type, void* workspace,
                     size_t workspace_bytes, hipStream_t stream);
 size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K);
-extern int g_mfma_knob0, g_mfma_knob1;
+extern std::atomic<int> g_mfma_knob0, g_mfma_knob1;
 
 namespace {
 
@@ -273,8 +273,8 @@ size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N,
 void bnb_mi355x_set_tuning(int reserved0, int reserved1, int mfma_knob0, int mfma_knob1) {
     (void)reserved0;
     (void)reserved1;
-    g_mfma_knob0 = mfma_knob0;
-    g_mfma_knob1 = mfma_knob1;
+    g_mfma_knob0.store(mfma_knob0, std::memory_order_relaxed);
+    g_mfma_knob1.store(mfma_knob1, std::memory_order_relaxed);
 }
 void bnb_mi355x_set_stream_tuning(int ring_depth, int segments, int rows_per_workgroup, int nontemporal, int waves) {
     gemv_4bit_stream_tuning(ring_depth, segments, rows_per_workgroup, nontemporal, waves);

@@ -38,8 +38,10 @@ namespace bnb {
 #ifdef BNB_PROFILING
 extern unsigned long long* g_dbg_buf; // c_api.hip (profiling builds only)
 #endif
-int g_mfma_knob0 = 0; // sweeps: bits 8 / 16 select the A-image variants of the LDS-DMA kernel (launch_mfma_dma)
-int g_mfma_knob1 = 0; // K-slice count override (0 = heuristic)
+// Sweep / test overrides (bnb_mi355x_set_tuning). Atomics, and every call takes ONE snapshot of them: a sweep thread can
+// never corrupt a concurrent launch, it can only change which (always correct) geometry that launch uses.
+std::atomic<int> g_mfma_knob0{0}; // bits 8 / 16 select the A-image variants of the LDS-DMA kernel (launch_mfma_dma)
+std::atomic<int> g_mfma_knob1{0}; // 100 * cfg + K-slice count (0 = heuristic)
 
 namespace {
 
@@ -93,6 +95,7 @@ struct GemmArgs {
     int quant_type;
     unsigned long long* dbg; // profiling only: s_memtime stamps, 8 per wavefront (NULL in production)
     int ablate;              // profiling only: 1 = skip decode + MFMA (stream only), 2 = also skip the A loads
+    int knob0;               // host only: snapshot of g_mfma_knob0 for this call
     int kslices;     // number of K slices (grid.y)
     int steps_total; // K / 256
 };
@@ -845,6 +848,11 @@ float* get_internal_workspace(size_t bytes, hipStream_t stream) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
             (void)hipGetLastError();
+            static std::atomic<bool> warned{false};
+            if (!warned.exchange(true))
+                fprintf(stderr, "bitsandbytes_amd: cgemm_4bit_* called inside a stream capture without a workspace: the split-K "
+                                "scratch cannot be allocated there, this launch runs with a single K slice (slower on small N). "
+                                "Warm the stream up once before capturing, or pass a workspace (bnb_mi355x_gemm_4bit).\n");
             return nullptr;
         }
         size_t want = bytes < (size_t(16) << 20) ? (size_t(16) << 20) : bytes;
@@ -877,13 +885,13 @@ constexpr int cfg_waves(int cfg) { return cfg == 5 ? 16 : 8; } // wavefronts tha
 
 // Kernel, tile shape and K-slice count for a problem: a pure function of (M, N, K) and the tuning knobs,
 // shared by the launch and by the workspace-size query.
-Plan make_plan(int M, int N, int K) {
+Plan make_plan(int M, int N, int K, int knob1) {
     Plan pl;
     pl.mt = (M > 48) ? 4 : (M > 32) ? 3 : (M > 16) ? 2 : 1;
     const int groups = K / kKC; // units of 4 blocks
     const int gz = (M + pl.mt * 16 - 1) / (pl.mt * 16);
-    int ks = g_mfma_knob1 % 100;
-    int cfg = g_mfma_knob1 / 100;
+    int ks = knob1 % 100;
+    int cfg = knob1 / 100;
     if (!cfg_is_dma(cfg) && !cfg_is_pc(cfg)) {
         // Calibrated on MI355X (profiles/r1_sweep_mfma_variants.txt): the producer/consumer kernel (A shared
         // through LDS by 64-128 columns) wins once the A tile is big (M > 16) or the weight matrix is large; the
@@ -942,9 +950,9 @@ template <typename T, int MT, int WAVES, int AROWS> void launch_mfma_dma_one(Gem
 template <typename T, int MT, int WAVES> void launch_mfma_dma(GemmArgs& p, hipStream_t stream) {
     if constexpr (MT == 1) {
         // the whole batch fits a 4- or 8-row A image (p.M rows at grid.z = 1)
-        if (p.M <= 4 && !(g_mfma_knob0 & 8))
+        if (p.M <= 4 && !(p.knob0 & 8))
             return launch_mfma_dma_one<T, MT, WAVES, 4>(p, stream);
-        if (p.M <= ((g_mfma_knob0 & 16) ? 8 : 16) && !(g_mfma_knob0 & 8))
+        if (p.M <= ((p.knob0 & 16) ? 8 : 16) && !(p.knob0 & 8))
             return launch_mfma_dma_one<T, MT, WAVES, 8>(p, stream); // rows 8..15 by register loads (hybrid)
     }
     launch_mfma_dma_one<T, MT, WAVES, 0>(p, stream);
@@ -1007,8 +1015,8 @@ template <typename T, int MT> void launch_mfma(GemmArgs& p, int cfg, hipStream_t
     return launch_mfma_pc<T, MT, 8, 1>(p, stream); // cfg 11
 }
 
-template <typename T> void dispatch_mfma(GemmArgs& p, float* ws, size_t ws_bytes, hipStream_t stream) {
-    Plan pl = make_plan(p.M, p.N, p.K);
+template <typename T> void dispatch_mfma(GemmArgs& p, float* ws, size_t ws_bytes, int knob1, hipStream_t stream) {
+    Plan pl = make_plan(p.M, p.N, p.K, knob1);
     const size_t slab = static_cast<size_t>(p.M) * p.N * sizeof(float);
     if (pl.ks > 1) {
         if (ws == nullptr) {
@@ -1080,12 +1088,12 @@ namespace {
 // Which problems go to the register-transposed kernel (tuning knob cfg 20 / 21 / 22 forces it: built-in / 8 / 16 wavefronts).
 // Calibrated on MI355X - see DESIGN.md: batches of at most one row tile on matrices small enough that N / 16 workgroups
 // need no (or few) K slices.
-bool rt_selected(int M, int N, int K, int* force_ks, int* force_waves) {
-    const int cfg = g_mfma_knob1 / 100;
+bool rt_selected(int M, int N, int K, int knob1, int* force_ks, int* force_waves) {
+    const int cfg = knob1 / 100;
     *force_ks = 0;
     *force_waves = 0;
     if (cfg >= 20 && cfg <= 22) {
-        *force_ks = g_mfma_knob1 % 100;
+        *force_ks = knob1 % 100;
         *force_waves = cfg == 21 ? 8 : cfg == 22 ? 16 : 0;
         return true;
     }
@@ -1117,9 +1125,10 @@ size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K) {
     if (M < 1 || N < 1 || K < kKC)
         return 0;
     int fks, fw;
-    if (rt_selected(M, N, K, &fks, &fw))
+    const int knob1 = g_mfma_knob1.load(std::memory_order_relaxed);
+    if (rt_selected(M, N, K, knob1, &fks, &fw))
         return gemm_4bit_rt_workspace_bytes(M, N, K, fks);
-    const Plan pl = make_plan(M, N, K);
+    const Plan pl = make_plan(M, N, K, knob1);
     return pl.ks > 1 ? static_cast<size_t>(pl.ks) * M * N * sizeof(float) : 0;
 }
 
@@ -1128,7 +1137,8 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
                     const void* bias, int M, int N, int K, int blocksize, int quant_type, void* workspace,
                     size_t workspace_bytes, hipStream_t stream) {
     int fks, fw;
-    if (rt_selected(M, N, K, &fks, &fw) && gemm_4bit_rt_supported(dtype, A, B, code16, M, N, K, blocksize))
+    const int knob0 = g_mfma_knob0.load(std::memory_order_relaxed), knob1 = g_mfma_knob1.load(std::memory_order_relaxed);
+    if (rt_selected(M, N, K, knob1, &fks, &fw) && gemm_4bit_rt_supported(dtype, A, B, code16, M, N, K, blocksize))
         return gemm_4bit_rt(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize,
                             quant_type, workspace, workspace_bytes, fks, fw, stream);
     GemmArgs p;
@@ -1148,6 +1158,7 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
     p.dbg = nullptr;
 #endif
     p.ablate = 0;
+    p.knob0 = knob0;
     p.M = M;
     p.N = N;
     p.K = K;
@@ -1156,9 +1167,9 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
     p.kslices = 1;
     p.steps_total = K / kKC;
     if (dtype == 2)
-        dispatch_mfma<bf16>(p, static_cast<float*>(workspace), workspace_bytes, stream);
+        dispatch_mfma<bf16>(p, static_cast<float*>(workspace), workspace_bytes, knob1, stream);
     else
-        dispatch_mfma<f16>(p, static_cast<float*>(workspace), workspace_bytes, stream);
+        dispatch_mfma<f16>(p, static_cast<float*>(workspace), workspace_bytes, knob1, stream);
 }
 
 } // namespace bnb

@@ -161,6 +161,11 @@ def main():
         ("nf4", torch.float32, 64, 2, 32, 256, False, False),
         ("fp4", torch.float16, 64, 33, 48, 256, False, True),
         ("nf4", torch.bfloat16, 32, 1, 32, 128, False, False),
+        # MFMA-sized: tall tiles and enough K for cross-workgroup K slices (reach the producer/consumer kernel and the
+        # multi-row-tile register-transposed kernel with reference-generated vectors)
+        ("nf4", torch.bfloat16, 64, 64, 256, 4096, False, True),
+        ("nf4", torch.bfloat16, 64, 64, 384, 2048, True, True),
+        ("fp4", torch.float16, 128, 16, 128, 4096, True, False),
     ]
     for i, (qt, dt, bs, M, N, K, dqf, use_bias) in enumerate(gemm_cases):
         W = (make_input(N * K, torch.float32, 4000 + i, "randn").reshape(N, K) / (K**0.5)).to(dt)
@@ -176,7 +181,8 @@ def main():
         store[f"{p}/meta"] = np.array([{"nf4": 2, "fp4": 1}[qt], {"fp32": 0, "fp16": 1, "bf16": 2}[_DT_NAME[dt]], bs, M, N,
                                       K, int(dqf), int(use_bias)])
         store[f"{p}/x"] = bits(x)
-        store[f"{p}/W"] = bits(W)
+        if N * K <= 262144:  # (the MFMA-sized cases do not store their dense weight: no test reads it)
+            store[f"{p}/W"] = bits(W)
         if bias is not None:
             store[f"{p}/bias"] = bits(bias)
         store[f"{p}/packed"] = packed.numpy().reshape(-1).copy()

@@ -442,6 +442,42 @@ def test_gemm_4bit_golden(i):
         assert rel_err(y.cpu(), y32_ref) < max(2.5 * rel_err(y_ref, y32_ref), 3e-3)
 
 
+@pytest.mark.parametrize("i", [8, 9, 10])
+@pytest.mark.parametrize("knob", [0, 1104, 1402, 1204, 506, 2000, 2002, 2100])
+def test_gemm_4bit_golden_mfma_geometries(i, knob):
+    """The MFMA-sized reference-generated vectors (tests/golden/make_golden.py: M = 64 / 16, K up to 4096) through every MFMA
+    kernel family and cross-workgroup K slices: producer/consumer (cfg 11 / 12 / 14), LDS-DMA (cfg 5/6), register-transposed
+    (cfg 20 / 21), and the production routing (knob 0)."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    qt_c, dt_c, bs, M, N, K, dqf, has_bias = (int(v) for v in G[f"gemm/{i}/meta"])
+    x = from_bits(G[f"gemm/{i}/x"], dt_c).reshape(M, K).to(DEV)
+    packed = torch.from_numpy(G[f"gemm/{i}/packed"]).reshape(-1, 1).to(DEV)
+    bias = from_bits(G[f"gemm/{i}/bias"], dt_c).to(DEV) if has_bias else None
+    code = F.get_4bit_type(QT[qt_c], device=DEV)
+    if dqf:
+        s2 = F.QuantState(absmax=from_bits(G[f"gemm/{i}/absmax2"], 0).to(DEV), code=from_bits(G["code/dynamic"], 0).to(DEV),
+                          blocksize=256, dtype=torch.float32)
+        st = F.QuantState(absmax=torch.from_numpy(G[f"gemm/{i}/absmax8"]).to(DEV), shape=torch.Size((N, K)), code=code,
+                          blocksize=bs, quant_type=QT[qt_c], dtype=DT[dt_c],
+                          offset=from_bits(G[f"gemm/{i}/offset"], 0).reshape(()).to(DEV), state2=s2)
+    else:
+        st = F.QuantState(absmax=from_bits(G[f"gemm/{i}/absmax"], 0).to(DEV), shape=torch.Size((N, K)), code=code,
+                          blocksize=bs, quant_type=QT[qt_c], dtype=DT[dt_c])
+    if knob // 100 == 5 and M > 32:
+        pytest.skip("the LDS-DMA kernel holds at most a 32-row tile")
+    try:
+        bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, knob)
+        y = _run_kernel(2 if knob else 0, x, packed, st, bias)
+    finally:
+        bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+    y32_ref = from_bits(G[f"gemm/{i}/y_fp32"], 0).reshape(M, N)
+    y_ref = from_bits(G[f"gemm/{i}/y"], dt_c).reshape(M, N)
+    assert rel_err(y.cpu(), y32_ref) < REL_TOL
+    assert rel_err(y.cpu(), y32_ref) < max(2.5 * rel_err(y_ref, y32_ref), 3e-3)
+
+
 SHAPES = [  # (M, N, K)
     (1, 4096, 4096),   # BASELINE config 2
     (1, 1000, 2048), (1, 31, 96), (1, 512, 11008 // 4), (2, 256, 4096), (3, 130, 1024), (4, 4096, 1024),
@@ -612,6 +648,70 @@ def test_c_abi_direct_calls():
                                         code.data_ptr(), y.data_ptr(), N, K // 2, N, bs, stream)
     assert rel_err(y.cpu(), O.gemm_4bit(x[:1], q_o, (N, K), am_o, bs, "nf4")[1]) < REL_TOL
     assert lib.get_context() is not None
+
+
+def test_c_abi_reentrant_from_two_threads_on_two_streams():
+    """the C entry points must be re-entrant from several Python threads (ctypes drops the GIL). Two threads, each
+    on its own stream, hammer cgemm_4bit_bf16 - one in the streaming kernel's range (M = 1), one in the MFMA range with K
+    slices (M = 24 on a narrow matrix: library-owned workspace, one per stream) - while a third flips the tuning knobs;
+    every result must equal the single-threaded result bit for bit."""
+    import threading
+
+    from bitsandbytes_amd.cextension import lib
+
+    F = _F()
+    N, K, bs = 320, 4096, 64
+    W = (torch.randn(N, K, device=DEV) / K**0.5).bfloat16()
+    q, st = F.quantize_4bit(W, blocksize=bs, quant_type="nf4")
+    xs = {1: torch.randn(1, K, device=DEV).bfloat16(), 24: torch.randn(24, K, device=DEV).bfloat16()}
+    ref = {}
+    for M, x in xs.items():
+        y = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        lib.cgemm_4bit_bf16(x.data_ptr(), q.data_ptr(), st.absmax.data_ptr(), None, None, None, y.data_ptr(), None, M, N, K, bs,
+                            2, torch._C._cuda_getCurrentRawStream(0))
+        torch.cuda.synchronize()
+        ref[M] = y.clone()
+    errors = []
+    stop = threading.Event()
+
+    def worker(M):
+        try:
+            s = torch.cuda.Stream()
+            x = xs[M]
+            outs = [torch.empty(M, N, device=DEV, dtype=torch.bfloat16) for _ in range(8)]
+            with torch.cuda.stream(s):
+                for it in range(300):
+                    y = outs[it % 8]
+                    lib.cgemm_4bit_bf16(x.data_ptr(), q.data_ptr(), st.absmax.data_ptr(), None, None, None, y.data_ptr(), None,
+                                        M, N, K, bs, 2, s.cuda_stream)
+                    if it % 50 == 49:
+                        s.synchronize()
+                        for o in outs:
+                            if not torch.equal(o, ref[M]):
+                                errors.append(f"M={M} iteration {it}: result differs")
+                s.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def knob_flipper():
+        # production geometry <-> forced K slices of the same kernels: every setting is a correct geometry and, for a given
+        # kernel family, the same summation order is NOT guaranteed across slice counts - so only flip the LDS-DMA A-image
+        # knob (results identical by construction)
+        while not stop.is_set():
+            lib.bnb_mi355x_set_tuning(0, 0, 8, 0)
+            lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+
+    threads = [threading.Thread(target=worker, args=(M,)) for M in (1, 24)]
+    flip = threading.Thread(target=knob_flipper)
+    flip.start()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    stop.set()
+    flip.join()
+    lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+    assert not errors, errors[:3]
 
 
 @pytest.mark.parametrize("M", [1, 32])
