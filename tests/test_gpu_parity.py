@@ -660,10 +660,11 @@ def test_c_abi_reentrant_from_two_threads_on_two_streams():
     from bitsandbytes_amd.cextension import lib
 
     F = _F()
-    N, K, bs = 320, 4096, 64
+    N, K, bs = 128, 4096, 64  # 8 column tiles: the MFMA launch splits K over two workgroups -> slabs in the library workspace
     W = (torch.randn(N, K, device=DEV) / K**0.5).bfloat16()
     q, st = F.quantize_4bit(W, blocksize=bs, quant_type="nf4")
     xs = {1: torch.randn(1, K, device=DEV).bfloat16(), 24: torch.randn(24, K, device=DEV).bfloat16()}
+    assert lib.bnb_mi355x_gemm_4bit_workspace_bytes(0, 2, 24, N, K, bs) > 0
     ref = {}
     for M, x in xs.items():
         y = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
