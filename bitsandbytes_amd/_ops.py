@@ -258,3 +258,24 @@ def _(A, absmax, indices, row_len: int, blocksize: int, quant_type: str, dtype: 
     torch._check(indices.dtype in (torch.int32, torch.int64), lambda: f"indices must be int32/int64, got {indices.dtype}")
     torch._check(row_len % blocksize == 0 and row_len % 8 == 0, lambda: "row_len must be a multiple of blocksize and of 8")
     return torch.empty((*indices.shape, row_len), dtype=dtype, device=A.device)
+
+
+# ---------------------------------------------------------------------------------------------- gemm_4bit_grad_input
+# Not a reference op: the fused backward of gemm_4bit with respect to its activations,
+#   grad_A[*, K] = grad_out[*, N] @ dequantize_4bit(B)[N, K]
+# (the reference dequantizes the whole weight and calls a dense matmul, autograd/_functions.py:365-386). Own namespace,
+# like dequantize_4bit_rows. Argument meaning of the weight side as in bitsandbytes::gemm_4bit.
+torch.library.define(
+    "bitsandbytes_amd::gemm_4bit_grad_input",
+    "(Tensor grad_out, Tensor B, int[] shapeB, Tensor absmax, int blocksize, str quant_type, Tensor? absmax_8bit=None, "
+    "Tensor? absmax_code=None, Tensor? absmax_offset=None) -> Tensor",
+)
+
+
+@register_fake("bitsandbytes_amd::gemm_4bit_grad_input")
+def _(grad_out, B, shapeB: Sequence[int], absmax, blocksize: int, quant_type: str, absmax_8bit=None, absmax_code=None,
+      absmax_offset=None):
+    _check_4bit_common(blocksize, quant_type)
+    torch._check(len(shapeB) == 2, lambda: "shapeB must be [N, K]")
+    torch._check(grad_out.shape[-1] == shapeB[0], lambda: f"grad_out inner dim ({grad_out.shape[-1]}) must equal N ({shapeB[0]})")
+    return torch.empty((*grad_out.shape[:-1], shapeB[1]), dtype=grad_out.dtype, device=grad_out.device)

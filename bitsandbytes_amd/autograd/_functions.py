@@ -1,7 +1,8 @@
 """``matmul_4bit`` and its autograd function — reference ``bitsandbytes/autograd/_functions.py:300-491``.
 
 Forward is one ``bitsandbytes::gemm_4bit`` op call for every M (the op's MI355X kernel picks the
-wave64 dot kernel or the MFMA kernel); backward is ``grad_A = grad_out @ dequantize_4bit(B)``.
+streaming dot kernel or an MFMA kernel); backward is ``grad_A = grad_out @ dequantize_4bit(B)`` - fused into one
+launch on the HIP device for batches up to 256 rows (``bitsandbytes_amd::gemm_4bit_grad_input``).
 Double-quantised states pass their pieces straight into the op so the absmax reconstruction is
 fused into the GEMM kernel.
 """
@@ -41,6 +42,26 @@ def _gemm_4bit_from_state(A: torch.Tensor, B: torch.Tensor, quant_state: F.Quant
     )
 
 
+def _grad_input_from_state(grad_output: torch.Tensor, B: torch.Tensor, state: F.QuantState) -> torch.Tensor:
+    fused = (
+        grad_output.is_cuda
+        and grad_output.dtype in (torch.float16, torch.bfloat16)
+        and len(state.shape) == 2
+        and grad_output.shape[-1] == state.shape[0]
+        and (not state.nested or state.state2.blocksize == 256)
+    )
+    if not fused:
+        return torch.matmul(grad_output, F.dequantize_4bit(B, state).to(grad_output.dtype))
+    if state.nested:
+        return torch.ops.bitsandbytes_amd.gemm_4bit_grad_input.default(
+            grad_output, B, state.shape, state.state2.absmax, state.blocksize, state.quant_type,
+            absmax_8bit=state.absmax, absmax_code=state.state2.code, absmax_offset=state.offset,
+        )
+    return torch.ops.bitsandbytes_amd.gemm_4bit_grad_input.default(
+        grad_output, B, state.shape, state.absmax, state.blocksize, state.quant_type
+    )
+
+
 class MatMul4Bit(torch.autograd.Function):
     @staticmethod
     def forward(ctx, A, B, out=None, bias=None, quant_state: Optional[F.QuantState] = None):
@@ -75,8 +96,10 @@ class MatMul4Bit(torch.autograd.Function):
         if need_bias:
             grad_bias = grad_output.sum(0, dtype=ctx.dtype_bias)
         if need_A:
-            # dequantize gives [N, K]; grad_out[M, N] @ W[N, K] = grad_A[M, K]
-            grad_A = torch.matmul(grad_output, F.dequantize_4bit(B, ctx.state).to(grad_output.dtype))
+            # grad_out[M, N] @ dequantize(B)[N, K] = grad_A[M, K]. On the HIP device this is one fused launch for small and
+            # medium batches (bitsandbytes_amd::gemm_4bit_grad_input: the weight tile is dequantized into LDS and never
+            # written to HBM); the op itself falls back to dequantize + matmul for the rest - the reference's formulation.
+            grad_A = _grad_input_from_state(grad_output, B, ctx.state)
         return grad_A, None, None, grad_bias, None
 
 

@@ -300,6 +300,57 @@ def _gemm_4bit_fused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8
     return out
 
 
+# ------------------------------------------------------------------------------------------ gemm_4bit backward
+# Largest batch the fused backward is used for: the kernel dequantizes the weight tile once per 64-row pass, so above two
+# passes one dequantize_4bit + hipBLASLt GEMM is cheaper (measured on MI355X, profiles/r2_backward_bench.txt: 4096^2 M = 64
+# 19 vs 32 us, 11008 x 4096 37 vs 100 us, but M = 256 48 vs 33 us).
+FUSED_BACKWARD_MAX_M = 128
+
+
+def grad_input_fused_ok(dtype: torch.dtype, M: int, N: int, K: int, blocksize: int) -> bool:
+    """Whether ``bitsandbytes_amd::gemm_4bit_grad_input`` runs the fused kernel for this problem."""
+    if dtype not in (torch.float16, torch.bfloat16) or M < 1 or M > FUSED_BACKWARD_MAX_M:
+        return False
+    return bool(lib.bnb_mi355x_gemm_4bit_grad_input_supported(_DT_CODE[dtype], M, N, K, blocksize))
+
+
+@register_kernel("bitsandbytes_amd::gemm_4bit_grad_input", "cuda")
+def _(grad_out, B, shapeB: Sequence[int], absmax, blocksize: int, quant_type: str, absmax_8bit=None, absmax_code=None,
+      absmax_offset=None):
+    N, K = int(shapeB[0]), int(shapeB[1])
+    if grad_out.shape[-1] != N:
+        raise RuntimeError(f"grad_out inner dim ({grad_out.shape[-1]}) does not match weight rows ({N})")
+    if quant_type not in _QT_CODE:
+        raise ValueError(f"quant_type must be 'nf4' or 'fp4', got {quant_type!r}")
+    if absmax.dtype != torch.float32:
+        raise RuntimeError(f"absmax must be float32, got {absmax.dtype}")
+    M = grad_out.numel() // N if N else 0
+    G = grad_out.contiguous()
+    if M == 0 or not grad_input_fused_ok(G.dtype, M, N, K, blocksize) or G.data_ptr() % 16 or B.data_ptr() % 16:
+        # unfused, like the reference: dequantize the weight, dense matmul (also the path for fp32 gradients and odd shapes)
+        scales = absmax
+        if absmax_8bit is not None:
+            scales = torch.ops.bitsandbytes.dequantize_blockwise.default(absmax_8bit, absmax, absmax_code, 256, torch.float32)
+            scales = scales + absmax_offset
+        W = torch.ops.bitsandbytes.dequantize_4bit.default(B, scales.float(), blocksize, quant_type, (N, K), G.dtype)
+        return torch.matmul(G, W)
+    out = torch.empty((*G.shape[:-1], K), dtype=G.dtype, device=G.device)
+    B = B.contiguous()
+    offset32 = absmax_offset.to(dtype=torch.float32) if absmax_offset is not None else None
+    ws = None
+    ws_bytes = lib.bnb_mi355x_gemm_4bit_grad_input_workspace_bytes(M, N, K)
+    if ws_bytes:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=G.device)  # stream-ordered, legal under graph capture
+    with _device_of(G):
+        lib.bnb_mi355x_gemm_4bit_grad_input(
+            _DT_CODE[G.dtype], G.data_ptr(), B.data_ptr(), absmax.contiguous().data_ptr(),
+            _ptr(absmax_8bit if absmax_8bit is None else absmax_8bit.contiguous()),
+            _ptr(absmax_code if absmax_code is None else absmax_code.contiguous()), _ptr(offset32), out.data_ptr(),
+            M, N, K, blocksize, _QT_CODE[quant_type], _ptr(ws), ws_bytes, _stream(G),
+        )
+    return out
+
+
 def gemm_4bit_grouped(A: torch.Tensor, mats, blocksize: int, quant_type: str):
     """``[A @ dequant(B_i).T (+ bias_i) for i]`` for several packed weights that share the activations, in ONE launch
     of the streaming kernel when M <= 4 (``bnb_mi355x_gemm_4bit_grouped``; larger M and odd shapes are issued matrix

@@ -183,6 +183,27 @@ template <int C> __device__ __forceinline__ void wave_sum_n(float (&v)[C]) {
     }
 }
 
+// Compute units of the current device (cached per device); 256 (MI355X) when no device can be queried - the launch-plan
+// functions that use it are also reachable from pure size queries (workspace bytes) on a host without a GPU.
+inline int device_cu_count_or_default() {
+    static std::atomic<int> cached[LdsLimit::kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    const int slot = (dev >= 0 && dev < LdsLimit::kMaxDevices) ? dev : 0;
+    int v = cached[slot].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) {
+            (void)hipGetLastError();
+            v = 256;
+        }
+        cached[slot].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 static inline int ilog2(int v) {
     int s = 0;
     while ((1 << s) < v)

@@ -43,6 +43,12 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
                     size_t workspace_bytes, hipStream_t stream);
 size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K);
 extern std::atomic<int> g_mfma_knob0, g_mfma_knob1;
+// gemm4_grad_input.hip
+bool gemm_4bit_grad_input_supported(int dtype, const void* G, const uint8_t* B, int M, int N, int K, int blocksize);
+size_t gemm_4bit_grad_input_workspace_bytes(int M, int N, int K);
+void gemm_4bit_grad_input(int dtype, const void* G, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
+                          const float* absmax_code, const float* absmax_offset, void* out, int M, int N, int K, int blocksize,
+                          int quant_type, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 namespace {
 
@@ -269,6 +275,22 @@ size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N,
     if (!route_to_mfma(kernel, dtype, a, reinterpret_cast<const uint8_t*>(a), M, N, K, blocksize))
         return 0;
     return gemm_4bit_mfma_workspace_bytes(M, N, K);
+}
+void bnb_mi355x_gemm_4bit_grad_input(int dtype, const void* grad_out, const uint8_t* B, const float* absmax,
+                                     const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, void* grad_A,
+                                     int M, int N, int K, int blocksize, int quant_type, void* workspace, size_t workspace_bytes,
+                                     bnb_stream_t s) {
+    if (quant_type != kFP4 && quant_type != kNF4) {
+        fprintf(stderr, "bitsandbytes_amd: gemm_4bit_grad_input: quant_type must be 1 (FP4) or 2 (NF4), got %d\n", quant_type);
+        exit(1);
+    }
+    gemm_4bit_grad_input(dtype, grad_out, B, absmax, absmax_8bit, absmax_code, absmax_offset, grad_A, M, N, K, blocksize,
+                         quant_type, workspace, workspace_bytes, S(s));
+}
+size_t bnb_mi355x_gemm_4bit_grad_input_workspace_bytes(int M, int N, int K) { return gemm_4bit_grad_input_workspace_bytes(M, N, K); }
+int bnb_mi355x_gemm_4bit_grad_input_supported(int dtype, int M, int N, int K, int blocksize) {
+    static const int dummy_aligned[4] __attribute__((aligned(16))) = {0, 0, 0, 0};
+    return gemm_4bit_grad_input_supported(dtype, dummy_aligned, reinterpret_cast<const uint8_t*>(dummy_aligned), M, N, K, blocksize) ? 1 : 0;
 }
 void bnb_mi355x_set_tuning(int reserved0, int reserved1, int mfma_knob0, int mfma_knob1) {
     (void)reserved0;

@@ -352,18 +352,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     BNB_RT_STAMP(7)
 }
 
-int rt_cu_count() {
-    static std::atomic<int> cached{0};
-    int v = cached.load(std::memory_order_relaxed);
-    if (v == 0) {
-        int dev = 0;
-        BNB_HIP_CHECK(hipGetDevice(&dev));
-        BNB_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-        v = v > 0 ? v : 256;
-        cached.store(v, std::memory_order_relaxed);
-    }
-    return v;
-}
+int rt_cu_count() { return device_cu_count_or_default(); }
 
 struct RtPlan {
     int ks, cps, waves, mt;

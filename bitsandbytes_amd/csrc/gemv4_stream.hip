@@ -606,19 +606,7 @@ template <typename T, bool NESTED> __global__ __launch_bounds__(256) void gemv4_
 // ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
-int device_cu_count() {
-    static std::atomic<int> cached[LdsLimit::kMaxDevices] = {};
-    int dev = 0;
-    BNB_HIP_CHECK(hipGetDevice(&dev));
-    const int slot = (dev >= 0 && dev < LdsLimit::kMaxDevices) ? dev : 0;
-    int v = cached[slot].load(std::memory_order_relaxed);
-    if (v == 0) {
-        BNB_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-        v = v > 0 ? v : 256;
-        cached[slot].store(v, std::memory_order_relaxed);
-    }
-    return v;
-}
+int device_cu_count() { return device_cu_count_or_default(); }
 
 constexpr size_t kLdsBudget = 156 * 1024; // largest dynamic allocation that launches (157 KiB is refused)
 

@@ -107,11 +107,11 @@ void bnb_mi355x_quantize_8bit(const float* code, const void* A, int dtype, float
  * F.embedding on the packed bytes, F.embedding on absmax, dequantize_4bit). A is the packed
  * [num_rows, row_len] table, absmax its fp32 scales (un-nested); row_len % 8 == 0 and
  * row_len % blocksize == 0; indices are int32 (index_bytes 4) or int64 (8). Values are bit-identical to
- * cdequantize_blockwise_* applied to the gathered rows. An index outside [0, num_rows) gives a zero row. */
+ * cdequantize_blockwise_* applied to the gathered rows. An index outside [0, num_rows) gives a row of NaN. */
 void bnb_mi355x_dequantize_4bit_rows(int dtype, const unsigned char* A, const float* absmax, const void* indices, int index_bytes, void* out, long rows_out, long num_rows, int row_len, int blocksize, int quant_type, bnb_stream_t stream);
 
 /* gemm_4bit with an explicit kernel choice and a caller-owned split-K workspace:
- * kernel = 0 auto, 1 round-1 wave64 dot kernel (A/B measurements), 2 MFMA kernel, 3 streaming dot kernel. dtype as above; code16 may be NULL.
+ * kernel = 0 auto, 1 / 3 streaming dot kernel, 2 MFMA kernels. dtype as above; code16 may be NULL.
  * workspace: device buffer of bnb_mi355x_gemm_4bit_workspace_bytes(...) bytes (may be NULL / smaller:
  * the MFMA kernel then uses fewer K slices, or a library-owned per-stream buffer when NULL and the
  * stream is not being captured). Its contents are scratch; no initialisation is required. */
@@ -127,6 +127,17 @@ size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N,
  * concatenated rows (one kernel boundary, one decode-table build, one activation copy per CU); otherwise the
  * matrices are launched one by one. Results are bit-identical to `count` separate cgemm_4bit_* calls. */
 void bnb_mi355x_gemm_4bit_grouped(int dtype, const void* A, int count, const uint8_t* const* B, const float* const* absmax, const uint8_t* const* absmax_8bit, const float* const* absmax_code, const float* const* absmax_offset, void* const* out, const void* const* bias, const int* N, int M, int K, int blocksize, int quant_type, bnb_stream_t stream);
+
+/* Fused backward of the 4-bit linear layer (MatMul4Bit.backward, reference bitsandbytes/autograd/_functions.py:365-386, which
+ * dequantizes the whole weight and calls a dense matmul):
+ *   grad_A[M, K] = grad_out[M, N] * dequant(B)[N, K]      dequant = T(code * scale), exactly dequantize_4bit's arithmetic
+ * dtype 1 = fp16, 2 = bf16; argument meaning of the weight side as in cgemm_4bit_*. Requires N % 64 == 0, K % 128 == 0,
+ * blocksize >= 64, 16-byte aligned grad_out / B (bnb_mi355x_gemm_4bit_grad_input_supported; an unsupported call is a fatal
+ * error like a failed launch). workspace: device scratch of bnb_mi355x_gemm_4bit_grad_input_workspace_bytes(M, N, K) bytes
+ * (fp32 slabs of the N slices; contents need no initialisation; with less the launch uses fewer slices). */
+void bnb_mi355x_gemm_4bit_grad_input(int dtype, const void* grad_out, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, void* grad_A, int M, int N, int K, int blocksize, int quant_type, void* workspace, size_t workspace_bytes, bnb_stream_t stream);
+size_t bnb_mi355x_gemm_4bit_grad_input_workspace_bytes(int M, int N, int K);
+int bnb_mi355x_gemm_4bit_grad_input_supported(int dtype, int M, int N, int K, int blocksize);
 
 /* Tuning overrides of the MFMA kernels for sweeps and tests (0 = built-in heuristic; the first two arguments are reserved):
  * knob0 = A-image variant bits of the LDS-DMA kernel, knob1 = 100 * cfg + K-slice count (cfg 5/6 LDS-DMA, 11-14

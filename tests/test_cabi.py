@@ -147,7 +147,7 @@ def test_no_kernel_spills_to_scratch():
 
 
 def test_launch_plan_workspace_query_is_pure_host_logic():
-    """bnb_mi355x_gemm_4bit_workspace_bytes runs make_plan() on the host (no GPU call): for every BASELINE
+    """bnb_mi355x_gemm_4bit_workspace_bytes runs the launch plans on the host (no GPU needed): for every BASELINE
     shape the split-K workspace is a whole number of fp32 [M, N] slabs, bounded by one slab per 512 k of K
     (>= 2 chunks of 256 k per slice), zero where no MFMA split-K launch can happen, and the query is a pure
     function (same answer twice)."""
@@ -172,9 +172,11 @@ def test_launch_plan_workspace_query_is_pure_host_logic():
         assert q(1, BF16, 64, N, K, 64) == 0, "explicit dot kernel never needs a workspace"
         assert q(0, 0, 64, N, K, 64) == 0, "fp32 activations never take the MFMA path"
         assert q(0, BF16, 64, N, K, 32) == 0, "blocksize 32 is outside the MFMA kernels' preconditions"
-    # headline shape: single-launch plans (no finalize pass) up to M = 16, split-K above
+    # headline shape: single-launch plans (no finalize pass) for every batch up to 64 rows (the register-transposed kernel:
+    # 256 column tiles fill the chip without K slices); large matrices with tall tiles split K
     assert q(0, BF16, 16, 4096, 4096, 64) == 0
-    assert q(0, BF16, 64, 4096, 4096, 64) > 0
+    assert q(0, BF16, 64, 4096, 4096, 64) == 0
+    assert q(0, BF16, 64, 8192, 8192, 64) > 0
     assert q(0, BF16, 64, 4096, 4100, 64) == 0, "K % 256 != 0 falls back to the dot kernel"
 
 

@@ -771,18 +771,82 @@ def test_linear4bit_module_gpu(double_quant, storage):
     assert torch.equal(new(x), layer(x))
 
 
-def test_backward_through_matmul_4bit_gpu():
+def _oracle_grad_input(g, q, st):
+    """grad_out @ dequantize_4bit(B) with the oracle's dequantize (rounded to the gradient dtype, like the reference's
+    backward, autograd/_functions.py:384) and an fp64 product."""
+    N, K = int(st.shape[0]), int(st.shape[1])
+    if st.nested:
+        absmax = O.dequantize_blockwise(st.absmax.cpu(), st.state2.absmax.cpu(), st.state2.code.cpu(), 256, torch.float32)
+        absmax = absmax + st.offset.cpu()
+    else:
+        absmax = st.absmax.cpu()
+    Wd = O.dequantize_4bit(q.cpu(), absmax.float(), st.blocksize, st.quant_type, (N, K), g.dtype)
+    return (g.cpu().double() @ Wd.double()).float()
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 64, 128), (8, 256, 512), (64, 4096, 4096), (100, 1024, 11008), (200, 192, 384),
+                                   (300, 128, 256)])
+@pytest.mark.parametrize("variant", ["nf4-bs64", "nf4-bs64-nested", "fp4-bs128-nested-fp16", "nf4-bs256"])
+def test_gemm_4bit_grad_input_fused_vs_oracle(M, N, K, variant):
+    """The fused backward kernel (csrc/gemm4_grad_input.hip): grad_A = grad_out @ dequantize_4bit(B), every output against the
+    oracle's dequantize + an fp64 product; several N slices, several 64-row passes, ragged M, batches above the fused range
+    (the op's own dequantize + matmul fallback); bit-reproducible run to run."""
+    F = _F()
+    qt = "fp4" if variant.startswith("fp4") else "nf4"
+    bs = 128 if "bs128" in variant else 256 if "bs256" in variant else 64
+    dt = torch.float16 if "fp16" in variant else torch.bfloat16
+    W = (torch.randn(N, K) / K**0.5).to(dt)
+    g = torch.randn(M, N).to(dt)
+    q, st = F.quantize_4bit(W.to(DEV), blocksize=bs, quant_type=qt, compress_statistics="nested" in variant)
+    ref = _oracle_grad_input(g, q, st)
+    if st.nested:
+        args = (g.to(DEV), q, st.shape, st.state2.absmax, bs, qt, st.absmax, st.state2.code, st.offset)
+    else:
+        args = (g.to(DEV), q, st.shape, st.absmax, bs, qt)
+    y1 = torch.ops.bitsandbytes_amd.gemm_4bit_grad_input.default(*args)
+    y2 = torch.ops.bitsandbytes_amd.gemm_4bit_grad_input.default(*args)
+    assert y1.shape == (M, K) and y1.dtype == dt
+    assert rel_err(y1.cpu(), ref) < 4e-3   # one rounding of the result to 16 bits (the operands are the oracle's)
+    assert torch.equal(y1, y2)
+
+
+def test_gemm_4bit_grad_input_exact_on_representable_inputs():
+    """Gradients that are small integers and weights whose codes / scales are exactly representable: every product and sum
+    is exact, so the fused kernel must equal the oracle bit for bit - an n paired with the wrong weight row, or a scale taken
+    from a neighbouring block, cannot hide."""
+    F = _F()
+    M, N, K = 48, 256, 256
+    g_ = torch.Generator().manual_seed(7)
+    fp4 = F.get_4bit_type("fp4", device="cpu")
+    allowed = torch.tensor([0, 3, 5, 7, 11, 13, 15])
+    idx = allowed[torch.randint(0, len(allowed), (N, K), generator=g_)]
+    idx[:, ::64] = 3
+    scale = 2.0 ** torch.randint(-2, 3, (N, K // 64), generator=g_)
+    W = (fp4[idx] * scale.repeat_interleave(64, dim=1)).to(torch.bfloat16)
+    g = torch.randint(-4, 5, (M, N), generator=g_).to(torch.bfloat16)
+    q, st = F.quantize_4bit(W.to(DEV), blocksize=64, quant_type="fp4")
+    ref = _oracle_grad_input(g, q, st)
+    y = torch.ops.bitsandbytes_amd.gemm_4bit_grad_input.default(g.to(DEV), q, st.shape, st.absmax, 64, "fp4")
+    assert torch.equal(y.float().cpu(), ref.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("M,N,K", [(8, 256, 512), (40, 200, 300)])
+def test_backward_through_matmul_4bit_gpu(M, N, K):
+    """MatMul4Bit.backward end to end (fused kernel for the first shape, the reference's dequantize + matmul formulation for
+    the second, whose N and K are not whole tiles) against the oracle."""
     import bitsandbytes_amd as bnb
 
     F = _F()
-    W = (torch.randn(256, 512, device=DEV) / 512**0.5).bfloat16()
-    q, st = F.quantize_4bit(W, quant_type="nf4")
-    x = torch.randn(8, 512, device=DEV, dtype=torch.bfloat16, requires_grad=True)
-    y = bnb.matmul_4bit(x, q, st)
-    y.float().pow(2).sum().backward()
-    Wd = F.dequantize_4bit(q, st).float()
-    g_ref = (2 * y.detach().float()) @ Wd
-    assert rel_err(x.grad.float().cpu(), g_ref.cpu()) < 2e-2
+    W = (torch.randn(N, K, device=DEV) / K**0.5).bfloat16()
+    q, st = F.quantize_4bit(W, quant_type="nf4", blocksize=64)
+    x = torch.randn(M, K, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # (K = 300 is not a multiple of the blocksize: the documented slow-path warning)
+        y = bnb.matmul_4bit(x, q, st)
+    g = torch.randn_like(y)
+    y.backward(g)
+    assert x.grad.shape == x.shape and x.grad.dtype == x.dtype
+    assert rel_err(x.grad.detach().cpu(), _oracle_grad_input(g, q, st)) < 4e-3
 
 
 @pytest.mark.parametrize("cfg", [5, 6, 11, 12, 13, 14])
