@@ -127,7 +127,10 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
         uint32_t s, s2;
         u32x4 g[2];
     };
-    auto issue = [&](Stage& st, int step) {
+    // (the step index is clamped to the slice: a harmless re-read at the tail instead of a branch around the loads, so the
+    // compiler's counted waits stay exact)
+    auto issue = [&](Stage& st, int step_unclamped) {
+        const int step = step_unclamped < se ? step_unclamped : se - 1;
         const long n0 = static_cast<long>(step) * kGiStep;
         st.w = *reinterpret_cast<const u32x4*>(wsrc + n0 * (K >> 1));
         const long e = we0 + n0 * K;
@@ -142,9 +145,15 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
         st.g[1] = *reinterpret_cast<const u32x4*>(gsrc + n0 + 8);
     };
 
-    Stage st;
-    if (sb < se)
-        issue(st, sb);
+    // a three-deep register ring: the loads of step s + 3 are issued while step s is multiplied (one step of compute is far
+    // shorter than an HBM round trip)
+    constexpr int D = 3;
+    if (sb >= se)
+        return; // (never: the host makes every N slice non-empty)
+    Stage st[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+        issue(st[j], sb + j);
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- decode table, built while the first loads fly: entry e (a packed byte) = 32 copies of (code[e >> 4], code[e & 15])
@@ -184,16 +193,35 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
             scale = __builtin_bit_cast(float, sv);
         }
         unsigned char* const wrow = wtiles + buf * kGiWTile + wr * kGiWStride + wp * 64;
+        // all 16 look-ups in flight before the first product (left alone, hipcc waits for each group of four: with one
+        // wavefront per SIMD that is four exposed LDS round trips per thread and step)
+        f32x2 pr[16];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const uint32_t w = s.w[d];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                pr[4 * d + q] = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>(
+                    __builtin_amdgcn_perm(w, lane_off, perm_sel + (q << 8)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
             u32x4 o;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x2 pr = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>(
-                    __builtin_amdgcn_perm(w, lane_off, perm_sel + (q << 8)));
-                // the reference's dequantize rounds the fp32 product to T once (csrc/cpu_ops.cpp:419-431)
-                o[q] = GiMma<T>::pack(rounded_f32(pr[0] * scale), rounded_f32(pr[1] * scale));
+                // the reference's dequantize rounds the fp32 product to T once (csrc/cpu_ops.cpp:419-431). bf16 has no fused
+                // multiply-convert on gfx950, so the plain expression already is "product in fp32, then one rounding"; for fp16
+                // hipcc would fuse it into v_fma_mix*_f16 (one rounding of the exact product): an opaque (non-volatile: it may
+                // be scheduled freely) register copy keeps the two steps apart
+                f32x2 pv = pr[4 * d + q] * f32x2{scale, scale};
+                if constexpr (sizeof(T) == 2 && !__is_same(T, bf16)) {
+                    float p0 = pv[0], p1 = pv[1];
+                    asm("" : "+v"(p0));
+                    asm("" : "+v"(p1));
+                    pv = f32x2{p0, p1};
+                }
+                o[q] = GiMma<T>::pack(pv[0], pv[1]);
             }
             *reinterpret_cast<u32x4*>(wrow + d * 16) = o;
         }
@@ -214,12 +242,11 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
     const uint32_t tr_lane = static_cast<uint32_t>((8 * lg + (ln >> 2)) * kGiWStride + (ln & 3) * 8 + wave * 64);
     const uint32_t a_lane = static_cast<uint32_t>(ln * kGiGStride + lg * 16);
 
-    for (int step = sb; step < se; ++step) {
+    auto do_step = [&](Stage& stg, int step) {
         const int buf = (step - sb) & 1;
-        stage_to_lds(st, buf);
+        stage_to_lds(stg, buf);
         __syncthreads();
-        if (step + 1 < se)
-            issue(st, step + 1);
+        issue(stg, step + D);
         const uint32_t wbase = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)(wtiles + buf * kGiWTile)));
         const unsigned char* const gb = gtiles + buf * kGiGTile;
 #pragma unroll
@@ -246,6 +273,12 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
                 for (int mt = 0; mt < 4; ++mt)
                     acc[ct][mt] = GiMma<T>::run(af[mt], bf[ct], acc[ct][mt]);
         }
+    };
+    for (int base = sb; base < se; base += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (base + j < se)
+                do_step(st[j], base + j);
     }
 
     // ---- store: lane (i = ln, lg) of tile (ct, mt) holds rows m_base + 16 mt + 4 lg + q of column k0 + 32 wave + 16 ct + i

@@ -20,14 +20,11 @@
 //    in slice order, adds the bias and rounds once. No atomics: results are bit-reproducible run to run
 //    (the reference's test_matmul_4bit_weight_orientation demands exact equality between calls).
 //
-// Two kernels ship (make_plan() below holds the selection rule):
-//   gemm4_mfma_dma_kernel  16 columns per workgroup, weights by LDS-DMA in full lines, K split over the
-//                          workgroup's wavefronts                                     [M <= 16, small matrices]
-//   gemm4_mfma_pc_kernel   producer / consumer wavefronts, A tile shared through LDS by 64-256 columns,
-//                          private weight rings per consumer                          [M > 16 or large matrices]
-// Three earlier generations (weights straight to registers in fragment-shaped 32-byte pieces; a 128-column
-// two-stage tile with workgroup barriers; the same with a 4-deep ring) were measured and retired - what each
-// taught is in DESIGN.md section 3.3 and their sweep record in profiles/r1_sweep_mfma_variants.txt.
+// This file holds the producer/consumer kernel (tall tiles, large matrices), the slab finalize kernel and the dispatcher;
+// the register-transposed kernel for small batches on small / medium matrices is gemm4_mfma_rt.hip. Four earlier generations
+// (weights straight to registers in fragment-shaped 32-byte pieces; a 16-column LDS-DMA kernel; a 128-column two-stage tile
+// with workgroup barriers; the same with a 4-deep ring) were measured and retired - what each taught is in DESIGN.md and their
+// sweep records in profiles/r1_sweep_mfma_variants.txt, profiles/r2_mfma_ab.txt.
 #include "bnb_common.h"
 
 #include <mutex>
@@ -40,7 +37,7 @@ extern unsigned long long* g_dbg_buf; // c_api.hip (profiling builds only)
 #endif
 // Sweep / test overrides (bnb_mi355x_set_tuning). Atomics, and every call takes ONE snapshot of them: a sweep thread can
 // never corrupt a concurrent launch, it can only change which (always correct) geometry that launch uses.
-std::atomic<int> g_mfma_knob0{0}; // bits 8 / 16 select the A-image variants of the LDS-DMA kernel (launch_mfma_dma)
+std::atomic<int> g_mfma_knob0{0}; // reserved (was: A-image variants of the retired LDS-DMA kernel)
 std::atomic<int> g_mfma_knob1{0}; // 100 * cfg + K-slice count (0 = heuristic)
 
 namespace {
@@ -102,315 +99,8 @@ struct GemmArgs {
 
 constexpr int kKC = 256;   // K granularity of the kernels: one pipeline group = 4 quantization blocks of 64
 
-// ---------------------------------------------------------------------------------------------
-// gemm4_mfma_dma_kernel ("v3" in profiles/): a workgroup owns 16 output columns, its wavefronts split the
-// K range and combine through LDS at the end; cross-workgroup K slices (grid.y) are only used when N/16
-// workgroups would not fill the chip. The weights travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4)
-// in FULL 128-byte lines: on-device ablation of the retired register-ring kernel (profiles/) showed that
-// fetching a row's line in four 32-byte pieces (what the MFMA B-fragment layout asks for) streams the same
-// bytes ~2x slower than the dot kernel's 1-KiB-per-instruction pattern. Here one DMA instruction moves 8 rows x 128 B; two of them bring the wavefront's whole
-// 256-k chunk of its 16 columns. The image is lane-linear in LDS (hardware constraint), so the
-// bank swizzle is applied on the SOURCE side: lane (r, s) fetches 16-byte chunk s ^ r of row r, which
-// permutes within one 128-B line (coalescing untouched) and makes the per-block 8-byte fragment
-// reads (ds_read_b64 at chunk (2b + g/2) ^ (n & 7)) conflict-free. The four fp32 absmax of a chunk
-// are one 16-byte load per lane; A fragments still come straight from L2.
-// ---------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) const void* dma_src_t;
 typedef __attribute__((address_space(3))) void* dma_dst_t;
-
-// AROWS > 0 (MT = 1, M <= AROWS): the wavefront's slice of A ([AROWS rows][256 k]) also travels by LDS-DMA -
-// AROWS/2 fully coalesced instructions of 2 rows x 512 B - instead of 8 fragment-shaped register loads whose
-// 64-byte pieces cost the L1 two requests per 128-B line: the s_memtime stamps showed a wavefront spending
-// 6.5 k cycles just ISSUING its loads at M = 8 (profiles/r1_timeline_mfma_v3_smemtime.txt). Source-side XOR
-// swizzle and fragment addresses as in the producer/consumer kernel. The image costs AROWS * 512 B per
-// wavefront, so the 8-row variant goes back to the 32-copy table.
-template <typename T, int MT, bool NESTED, int kWaves, int AROWS>
-__global__ __launch_bounds__(kWaves * 64) void gemm4_mfma_dma_kernel(
-    // hot arguments as separate scalars: eligible for kernarg preload into SGPRs (see gemv4_stream.hip)
-    // (exactly the 14 preloadable dwords: 16 user SGPRs minus the kernarg segment pointer; the output pointer is
-    // needed last and stays in the struct)
-    const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const float* hot_code16, int hot_M, int hot_N,
-    int hot_K, int hot_bs_shift, int hot_kslices, int hot_quant_type, const GemmArgs p) {
-    void* const hot_out = p.out;
-    // 64 table copies, 256 B per entry: the look-up address byte * 256 + lane * 4 is one v_perm_b32 (see
-    // gemv4_stream.hip); this kernel runs one workgroup per CU, so the 64 KiB are free
-    static_assert(AROWS == 0 || (MT == 1 && (AROWS == 4 || AROWS == 8)), "A image: 4 or 8 rows, one M tile");
-    constexpr int COPIES = (AROWS == 8) ? 32 : 64;
-    constexpr int kLutBytes = 256 * COPIES * 4;
-    constexpr int kABytes = AROWS * 512;                    // per wavefront
-    constexpr int kThreads = kWaves * 64;
-    constexpr int TPE = kThreads / 256;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
-    unsigned char* wring = smem + kLutBytes;                                          // [kWaves][2048]
-    unsigned char* aimg = smem + kLutBytes + kWaves * 2048;                            // [kWaves][AROWS * 512]
-    float* red = reinterpret_cast<float*>(aimg + kWaves * kABytes);                    // [kWaves-1][MT][64][4]
-    float* code2 = red + (kWaves - 1) * MT * 256;                                      // nested: [256]
-
-    const int tid = threadIdx.x;
-    // profiling only (bnb_mi355x_set_stamp_buffer): 8 s_memtime stamps per wavefront
-#define BNB_V3_STAMP(i)                                                                            \
-    if (p.dbg && (tid & 63) == 0)                                                                  \
-        p.dbg[((static_cast<long>(blockIdx.x) * gridDim.y + blockIdx.y) * kWaves + (tid >> 6)) * 16 + (i)] = \
-            __builtin_amdgcn_s_memtime();
-    BNB_V3_STAMP(0)
-    const gfloat_ptr tbl = (gfloat_ptr)(hot_code16 ? hot_code16 : (hot_quant_type == kNF4 ? kNF4Code : kFP4Code));
-    const int entry = tid / TPE;
-    const float code_hi = tbl[entry >> 4];
-    const float code_lo = tbl[entry & 15];
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ln = lane & 15, lg = lane >> 4;
-    const int N = hot_N, K = hot_K, M = hot_M;
-    const int m_base = blockIdx.z * (MT * 16);
-    const int col0 = blockIdx.x * 16;
-
-    // chunk (256 k) range of this wavefront
-    const int chunks_total = K >> 8;
-    const int per_wg = (chunks_total + hot_kslices - 1) / hot_kslices;
-    const int wg_begin = blockIdx.y * per_wg;
-    const int wg_end = (wg_begin + per_wg < chunks_total) ? wg_begin + per_wg : chunks_total;
-    const int wg_chunks = (wg_end > wg_begin) ? wg_end - wg_begin : 0;
-    const int per_wave = (wg_chunks + kWaves - 1) / kWaves;
-    const int c_begin = wg_begin + wave * per_wave;
-    const int c_end = (c_begin + per_wave < wg_end) ? c_begin + per_wave : wg_end;
-
-    // DMA source: lane (r8, s8) of instruction h fetches chunk s8 ^ r8 of row col0 + 8h + r8
-    const int r8 = lane >> 3, s8 = lane & 7;
-    const uint8_t* dsrc[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        int row = col0 + h * 8 + r8;
-        row = (row < N) ? row : N - 1;
-        dsrc[h] = hot_B + static_cast<long>(row) * (K >> 1) + ((s8 ^ r8) << 4);
-    }
-    unsigned char* wbuf = wring + wave * 2048;
-    // fragment read offsets inside the wavefront's 2 KiB image (block b adds its own chunk index)
-    const int rd_row = (ln >> 3) * 1024 + (ln & 7) * 128;
-    const int rd_sw = ln & 7;
-
-    int rown = col0 + ln;
-    rown = (rown < N) ? rown : N - 1;
-    const long rowk = static_cast<long>(rown) * K;
-    const T* __restrict__ A = static_cast<const T*>(hot_A);
-    const T* arow[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int m = m_base + mt * 16 + ln;
-        m = (m < M) ? m : M - 1;
-        arow[mt] = A + static_cast<long>(m) * K + lg * 16;
-    }
-
-    struct Stage {
-        float s[4];
-        u32x4 a[4][MT][2];
-    };
-    auto issue_chunk = [&](Stage& st, int c) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            __builtin_amdgcn_global_load_lds((dma_src_t)(dsrc[h] + static_cast<long>(c) * 128), (dma_dst_t)(wbuf + h * 1024),
-                                             16, 0, 0);
-        const long e = rowk + (static_cast<long>(c) << 8);
-        if (hot_bs_shift == 6) {
-            if constexpr (NESTED) {
-                const uint32_t q4 = *reinterpret_cast<const uint32_t*>(p.absmax8 + (e >> 6));
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    st.s[b] = __builtin_bit_cast(float, (q4 >> (8 * b)) & 0xFFu);
-            } else {
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(hot_absmax + (e >> 6));
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    st.s[b] = s4[b];
-            }
-        } else {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const long q = (e + b * 64) >> hot_bs_shift;
-                if constexpr (NESTED)
-                    st.s[b] = __builtin_bit_cast(float, static_cast<uint32_t>(p.absmax8[q]));
-                else
-                    st.s[b] = hot_absmax[q];
-            }
-        }
-        const int kb = c << 8;
-        if constexpr (AROWS > 0) {
-            const int r2 = lane >> 5, s32 = lane & 31;
-#pragma unroll
-            for (int i = 0; i < AROWS / 2; ++i) {
-                const int row = 2 * i + r2;
-                int m = m_base + row;
-                m = (m < M) ? m : M - 1;
-                const T* src = A + static_cast<long>(m) * K + kb + ((s32 ^ (row & 15)) << 3);
-                __builtin_amdgcn_global_load_lds((dma_src_t)src, (dma_dst_t)(aimg + wave * kABytes + i * 1024), 16, 0, 0);
-            }
-            // 9 <= M <= 16 with the 8-row image: rows 8.. still come as fragment-shaped register loads, but only
-            // for the lanes that own them - half the L1 requests of the all-register path
-            if (AROWS == 8 && ln >= 8 && m_base + ln < M) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    st.a[b][0][0] = *reinterpret_cast<const u32x4*>(arow[0] + kb + b * 64);
-                    st.a[b][0][1] = *reinterpret_cast<const u32x4*>(arow[0] + kb + b * 64 + 8);
-                }
-            }
-            return;
-        }
-        // A rows >= M are never stored and MFMA rows are independent, so those lanes skip the load
-        // altogether (exec-masked): the fragment loads then cost M/16 of a full tile in L1/TA time.
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (m_base + mt * 16 + ln < M) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    st.a[b][mt][0] = *reinterpret_cast<const u32x4*>(arow[mt] + kb + b * 64);
-                    st.a[b][mt][1] = *reinterpret_cast<const u32x4*>(arow[mt] + kb + b * 64 + 8);
-                }
-            }
-        }
-    };
-
-    f32x4 acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-        acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    Stage st;
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            st.a[b][mt][0] = st.a[b][mt][1] = u32x4{0, 0, 0, 0}; // rows >= M stay zero (finite) in the skipped lanes
-    if (c_begin < c_end)
-        issue_chunk(st, c_begin);
-    BNB_V3_STAMP(1)
-    {
-        const uint32_t pr = Mma<T>::pack(code_hi, code_lo);
-        const u32x4 v = {pr, pr, pr, pr};
-        // chunk order rotated by the entry's index in the wavefront: conflict-free ds_write_b128 (see gemv4_stream.hip)
-        constexpr int NCH = COPIES / 4 / TPE;
-        u32x4* dst = reinterpret_cast<u32x4*>(&lut[entry * COPIES]) + (tid % TPE) * NCH;
-        const int rot = (NCH >= 8) ? (tid & 63) : (tid & 63) * NCH / 8; // distinct bank quads within 8 lanes
-#pragma unroll
-        for (int j = 0; j < NCH; ++j)
-            dst[(j + rot) % NCH] = v;
-    }
-    float offset = 0.0f;
-    if constexpr (NESTED) {
-        if (tid < 256)
-            code2[tid] = p.absmax_code[tid];
-        offset = p.absmax_offset[0];
-    }
-    BNB_V3_STAMP(2)
-    __syncthreads();
-    BNB_V3_STAMP(3)
-    const uint32_t perm_sel = 0x0C0C0400u + static_cast<uint32_t>(opaque_zero()); // {lane offset, weight byte q, 0, 0}
-    const uint32_t lut_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((dma_dst_t)lut));
-    const uint32_t lane_off = static_cast<uint32_t>(lane) * 4u + lut_base;          // 64-copy table
-    const uint32_t lane_off32 = static_cast<uint32_t>(lane & 31) * 4u + lut_base;   // 32-copy table
-    // A image fragment address: row (clamped to the image) * 512 + ((b*8 + lg*2 + j) ^ row) * 16
-    const int arow_l = (AROWS > 0 && ln >= AROWS) ? AROWS - 1 : ln;
-    const uint32_t a_lane = static_cast<uint32_t>(arow_l * 512 + (((lg * 2) ^ arow_l) << 4));
-
-    for (int c = c_begin; c < c_end; ++c) {
-        if (c > c_begin)
-            issue_chunk(st, c);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the DMA'd image and this chunk's register loads
-        if (c == c_begin)
-            BNB_V3_STAMP(4)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int cidx = (2 * b + (lg >> 1)) ^ rd_sw;
-            const u32x2 w2 = *reinterpret_cast<const u32x2*>(wbuf + rd_row + (cidx << 4) + (lg & 1) * 8);
-            u32x4 bf[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const uint32_t w = w2[j];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if constexpr (COPIES == 64) {
-                        bf[j][q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(
-                            __builtin_amdgcn_perm(w, lane_off, perm_sel + (q << 8)));
-                    } else {
-                        const uint32_t byte = __builtin_amdgcn_ubfe(w, static_cast<uint32_t>(8 * q) + (perm_sel & 1u), 8u);
-                        bf[j][q] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(
-                            (byte << 7) + lane_off32);
-                    }
-                }
-            }
-            float scale;
-            if constexpr (NESTED) {
-                const long q = (rowk + (static_cast<long>(c) << 8) + b * 64) >> hot_bs_shift;
-                const uint32_t q8 = __builtin_bit_cast(uint32_t, st.s[b]);
-                scale = __fadd_rn(__fmul_rn(code2[q8], hot_absmax[q >> 8]), offset);
-            } else {
-                scale = st.s[b];
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                u32x4 a0, a1;
-                if constexpr (AROWS > 0) {
-                    const unsigned char* ab = aimg + wave * kABytes;
-                    a0 = *reinterpret_cast<const u32x4*>(ab + (a_lane ^ static_cast<uint32_t>((b * 8 + 0) << 4)));
-                    a1 = *reinterpret_cast<const u32x4*>(ab + (a_lane ^ static_cast<uint32_t>((b * 8 + 1) << 4)));
-                    if (AROWS == 8 && ln >= 8) { // rows beyond the image (only meaningful when M > 8; else never stored)
-                        a0 = st.a[b][mt][0];
-                        a1 = st.a[b][mt][1];
-                    }
-                } else {
-                    a0 = st.a[b][mt][0];
-                    a1 = st.a[b][mt][1];
-                }
-                f32x4 part = Mma<T>::run(a0, bf[0], f32x4{0.f, 0.f, 0.f, 0.f});
-                part = Mma<T>::run(a1, bf[1], part);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[mt][r] = fmaf(scale, part[r], acc[mt][r]);
-            }
-        }
-    }
-
-    BNB_V3_STAMP(5)
-    if (wave > 0) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            *reinterpret_cast<f32x4*>(red + (((wave - 1) * MT + mt) * 64 + lane) * 4) = acc[mt];
-    }
-    __syncthreads();
-    BNB_V3_STAMP(6)
-    if (wave != 0)
-        return;
-#pragma unroll
-    for (int w = 0; w < kWaves - 1; ++w)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(red + ((w * MT + mt) * 64 + lane) * 4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[mt][r] += o[r];
-        }
-    T* __restrict__ out = static_cast<T*>(hot_out);
-    const T* __restrict__ bias = static_cast<const T*>(p.bias);
-    const int col = col0 + ln;
-    if (col >= N)
-        return;
-    const float bv = (bias && hot_kslices == 1) ? static_cast<float>(bias[col]) : 0.0f;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m_base + mt * 16 + lg * 4 + r;
-            if (m >= M)
-                continue;
-            const long o = static_cast<long>(m) * N + col;
-            if (hot_kslices == 1)
-                out[o] = static_cast<T>(acc[mt][r] + bv);
-            else
-                p.ws[static_cast<long>(blockIdx.y) * M * N + o] = acc[mt][r];
-        }
-    }
-    BNB_V3_STAMP(7)
-#undef BNB_V3_STAMP
-}
 
 // ---------------------------------------------------------------------------------------------
 // gemm4_mfma_pc_kernel ("v5" in profiles/, "producer / consumers"). What the retired two-stage tiled kernel
@@ -871,17 +561,14 @@ float* get_internal_workspace(size_t bytes, hipStream_t stream) {
 
 struct Plan {
     int mt, ks;
-    int cfg; // LDS-DMA kernel (16 columns): 5: 16 wavefronts, 6: 8 wavefronts
-             // producer/consumer kernel: 11: 8 consumers x 1 n-tile (128 columns), 12: 4 x 2 (128), 13: 8 x 2 (256),
+    int cfg; // producer/consumer kernel: 11: 8 consumers x 1 n-tile (128 columns), 12: 4 x 2 (128), 13: 8 x 2 (256),
              // 14: 4 x 1 (64 columns)
              // (0-4 and 7-10 were the register-ring and two-stage tiled generations: retired, their sweep record is
              // profiles/r1_sweep_mfma_variants.txt)
 };
 
-constexpr bool cfg_is_dma(int cfg) { return cfg == 5 || cfg == 6; }
 constexpr bool cfg_is_pc(int cfg) { return cfg >= 11 && cfg <= 14; }
-constexpr int cfg_cols(int cfg) { return cfg == 13 ? 256 : cfg == 14 ? 64 : cfg_is_pc(cfg) ? 128 : 16; }
-constexpr int cfg_waves(int cfg) { return cfg == 5 ? 16 : 8; } // wavefronts that split a workgroup's K range (LDS-DMA kernel)
+constexpr int cfg_cols(int cfg) { return cfg == 13 ? 256 : cfg == 14 ? 64 : 128; }
 
 // Kernel, tile shape and K-slice count for a problem: a pure function of (M, N, K) and the tuning knobs,
 // shared by the launch and by the workspace-size query.
@@ -892,39 +579,21 @@ Plan make_plan(int M, int N, int K, int knob1) {
     const int gz = (M + pl.mt * 16 - 1) / (pl.mt * 16);
     int ks = knob1 % 100;
     int cfg = knob1 / 100;
-    if (!cfg_is_dma(cfg) && !cfg_is_pc(cfg)) {
-        // Calibrated on MI355X (profiles/r1_sweep_mfma_variants.txt): the producer/consumer kernel (A shared
-        // through LDS by 64-128 columns) wins once the A tile is big (M > 16) or the weight matrix is large; the
-        // 16-column LDS-DMA kernel wins for small batches on small matrices, where a second (finalize)
-        // launch would cost more than it saves.
+    if (!cfg_is_pc(cfg)) {
+        // Calibrated on MI355X (profiles/r1_sweep_mfma_variants.txt): 8 consumer wavefronts x 16 columns share one A tile;
+        // on a small matrix with a tall tile 64-column workgroups need half the K slices, i.e. half the slab traffic
+        // (4096^2 M = 64: 14.6 vs 15.4 us), on large matrices 128 columns win
         const bool big = static_cast<long>(N) * K >= (32L << 20) && N >= 1024;
-        if (pl.mt >= 2 || big) {
-            cfg = 11; // 8 consumer wavefronts x 16 columns share one A tile
-            if (pl.mt >= 3 && !big)
-                cfg = 14; // small matrix, tall tile: 64-column workgroups need half the K slices, i.e. half the
-                          // slab traffic (4096^2 M = 64: 14.6 vs 15.4 us); on large matrices 128 columns win
-        } else {
-            cfg = 5; // 16 wavefronts x 1 chunk; 8 x 2 measured +-1 % on fp32 absmax, 5 % behind on nested bs 128
-        }
+        cfg = (pl.mt >= 3 && !big) ? 14 : 11;
     }
     if (cfg == 13 && pl.mt > 2)
         cfg = 11; // 8 x 2 consumers with a > 32-row A tile do not fit the 160 KiB of LDS
-    if (cfg_is_dma(cfg) && pl.mt > 2)
-        cfg = 11; // the LDS-DMA kernel holds at most a 32-row A tile
-    if (cfg == 5 && pl.mt != 1)
-        cfg = 6;
     pl.cfg = cfg;
     const int gx = (N + cfg_cols(cfg) - 1) / cfg_cols(cfg);
-    if (ks == 0) {
-        if (cfg_is_pc(cfg))
-            ks = 256 / (gx * gz); // these kernels run one workgroup per CU: fill the 256 CUs but never spill into
-                                  // a second round (11008 x 4096: 3 slices = 258 workgroups measured 18.8 us, 2 slices 15.2)
-        else
-            ks = (gx * gz >= 192) ? 1 : (256 + gx * gz - 1) / (gx * gz); // fill the 256 CUs once
-    }
-    int max_ks = groups / cfg_waves(cfg) > 0 ? groups / cfg_waves(cfg) : 1; // keep >= 1 group per wavefront
-    if (cfg_is_pc(cfg))
-        max_ks = groups / 2 > 0 ? groups / 2 : 1;           // >= 2 chunks per workgroup so the ring has something to overlap
+    if (ks == 0)
+        ks = 256 / (gx * gz); // one workgroup per CU: fill the 256 CUs but never spill into a second round
+                              // (11008 x 4096: 3 slices = 258 workgroups measured 18.8 us, 2 slices 15.2)
+    const int max_ks = groups / 2 > 0 ? groups / 2 : 1; // >= 2 chunks per workgroup so the ring has something to overlap
     if (ks > max_ks)
         ks = max_ks;
     if (ks < 1)
@@ -932,30 +601,6 @@ Plan make_plan(int M, int N, int K, int knob1) {
     const int per = (groups + ks - 1) / ks;
     pl.ks = (groups + per - 1) / per; // every slice non-empty
     return pl;
-}
-
-template <typename T, int MT, int WAVES, int AROWS> void launch_mfma_dma_one(GemmArgs& p, hipStream_t stream) {
-    const int gx = (p.N + 15) / 16;
-    const int gz = (p.M + MT * 16 - 1) / (MT * 16);
-    constexpr size_t kLut = 256 * ((AROWS == 8) ? 32 : 64) * 4;
-    const size_t smem = kLut + static_cast<size_t>(WAVES) * 2048 + static_cast<size_t>(WAVES) * AROWS * 512 +
-                        static_cast<size_t>(WAVES - 1) * MT * 1024 + 1024;
-    dim3 grid(gx, p.kslices, gz);
-    auto kern = p.absmax8 ? gemm4_mfma_dma_kernel<T, MT, true, WAVES, AROWS> : gemm4_mfma_dma_kernel<T, MT, false, WAVES, AROWS>;
-    static LdsLimit lds_limit[2];
-    ensure_dynamic_lds(lds_limit[p.absmax8 ? 1 : 0], reinterpret_cast<const void*>(kern), smem);
-    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p.A, p.B, p.absmax, p.code16, p.M, p.N, p.K, p.bs_shift, p.kslices, p.quant_type, p);
-}
-
-template <typename T, int MT, int WAVES> void launch_mfma_dma(GemmArgs& p, hipStream_t stream) {
-    if constexpr (MT == 1) {
-        // the whole batch fits a 4- or 8-row A image (p.M rows at grid.z = 1)
-        if (p.M <= 4 && !(p.knob0 & 8))
-            return launch_mfma_dma_one<T, MT, WAVES, 4>(p, stream);
-        if (p.M <= ((p.knob0 & 16) ? 8 : 16) && !(p.knob0 & 8))
-            return launch_mfma_dma_one<T, MT, WAVES, 8>(p, stream); // rows 8..15 by register loads (hybrid)
-    }
-    launch_mfma_dma_one<T, MT, WAVES, 0>(p, stream);
 }
 
 constexpr size_t pc_smem_bytes(int MT, int CW, int NTW, int D, bool nested) {
@@ -994,15 +639,6 @@ template <typename T, int MT, int CW, int NTW> void launch_mfma_pc(GemmArgs& p, 
 }
 
 template <typename T, int MT> void launch_mfma(GemmArgs& p, int cfg, hipStream_t stream) {
-    // LDS-DMA kernel: make_plan() only selects it for MT <= 2
-    if constexpr (MT == 1) {
-        if (cfg == 5)
-            return launch_mfma_dma<T, MT, 16>(p, stream);
-    }
-    if constexpr (MT <= 2) {
-        if (cfg_is_dma(cfg))
-            return launch_mfma_dma<T, MT, 8>(p, stream);
-    }
     // producer/consumer geometries. LDS: 32 KiB table + 2 x MT*8 KiB A stages + CW*D ring slots.
     if (cfg == 12)
         return launch_mfma_pc<T, MT, 4, 2>(p, stream);

@@ -443,11 +443,11 @@ def test_gemm_4bit_golden(i):
 
 
 @pytest.mark.parametrize("i", [8, 9, 10])
-@pytest.mark.parametrize("knob", [0, 1104, 1402, 1204, 506, 2000, 2002, 2100])
+@pytest.mark.parametrize("knob", [0, 1104, 1402, 1204, 1302, 2000, 2002, 2100])
 def test_gemm_4bit_golden_mfma_geometries(i, knob):
     """The MFMA-sized reference-generated vectors (tests/golden/make_golden.py: M = 64 / 16, K up to 4096) through every MFMA
-    kernel family and cross-workgroup K slices: producer/consumer (cfg 11 / 12 / 14), LDS-DMA (cfg 5/6), register-transposed
-    (cfg 20 / 21), and the production routing (knob 0)."""
+    kernel family and cross-workgroup K slices: producer/consumer (cfg 11 / 12 / 13 / 14), register-transposed (cfg 20 / 21),
+    and the production routing (knob 0)."""
     import bitsandbytes_amd as bnb
 
     F = _F()
@@ -465,8 +465,6 @@ def test_gemm_4bit_golden_mfma_geometries(i, knob):
     else:
         st = F.QuantState(absmax=from_bits(G[f"gemm/{i}/absmax"], 0).to(DEV), shape=torch.Size((N, K)), code=code,
                           blocksize=bs, quant_type=QT[qt_c], dtype=DT[dt_c])
-    if knob // 100 == 5 and M > 32:
-        pytest.skip("the LDS-DMA kernel holds at most a 32-row tile")
     try:
         bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, knob)
         y = _run_kernel(2 if knob else 0, x, packed, st, bias)
@@ -696,10 +694,9 @@ def test_c_abi_reentrant_from_two_threads_on_two_streams():
 
     def knob_flipper():
         # production geometry <-> forced K slices of the same kernels: every setting is a correct geometry and, for a given
-        # kernel family, the same summation order is NOT guaranteed across slice counts - so only flip the LDS-DMA A-image
-        # knob (results identical by construction)
+        # kernel family, the same summation order is NOT guaranteed across slice counts - so only the reserved knob is flipped
         while not stop.is_set():
-            lib.bnb_mi355x_set_tuning(0, 0, 8, 0)
+            lib.bnb_mi355x_set_tuning(0, 0, 8, 0)  # (knob0 is reserved: same geometry, the stores race with the launches' snapshots)
             lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
 
     threads = [threading.Thread(target=worker, args=(M,)) for M in (1, 24)]
@@ -849,13 +846,12 @@ def test_backward_through_matmul_4bit_gpu(M, N, K):
     assert rel_err(x.grad.detach().cpu(), _oracle_grad_input(g, q, st)) < 4e-3
 
 
-@pytest.mark.parametrize("cfg", [5, 6, 11, 12, 13, 14])
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14])
 @pytest.mark.parametrize("M,N,K,ks", [(5, 256, 1024, 1), (16, 200, 2048, 2), (33, 384, 1024, 1), (64, 512, 4096, 4),
                                       (64, 1000, 2816, 1), (100, 128, 512, 2)])
 def test_mfma_kernel_variants(cfg, M, N, K, ks):
-    """Every geometry of the two MFMA kernels (LDS-DMA: 16 / 8 wavefronts; producer/consumer: 8x1, 4x2, 8x2,
-    4x1 consumers x n-tiles), incl. cross-workgroup K slices and ragged N / M, against the oracle; results
-    must also be bit-reproducible run to run."""
+    """Every geometry of the producer/consumer MFMA kernel (8x1, 4x2, 8x2, 4x1 consumers x n-tiles), incl. cross-workgroup K
+    slices and ragged N / M, against the oracle; results must also be bit-reproducible run to run."""
     import bitsandbytes_amd as bnb
 
     F = _F()
@@ -865,16 +861,14 @@ def test_mfma_kernel_variants(cfg, M, N, K, ks):
     for dq in (False, True):
         q, st = F.quantize_4bit(W.to(DEV), blocksize=64, quant_type="nf4", compress_statistics=dq)
         y_ref = _oracle_y(x, q, st, bias)
-        # knob0 bits 8 / 16: the LDS-DMA kernel's A-image variants (all rows by register loads / no hybrid rows)
-        for knob0 in ((0, 8, 16) if cfg in (5, 6) and M <= 16 else (0,)):
-            try:
-                bnb.lib.bnb_mi355x_set_tuning(0, 0, knob0, cfg * 100 + ks)
-                y1 = _run_kernel(2, x.to(DEV), q, st, bias.to(DEV))
-                y2 = _run_kernel(2, x.to(DEV), q, st, bias.to(DEV))
-            finally:
-                bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
-            assert rel_err(y1.cpu(), y_ref) < REL_TOL, f"knob0={knob0}"
-            assert torch.equal(y1, y2)
+        try:
+            bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, cfg * 100 + ks)
+            y1 = _run_kernel(2, x.to(DEV), q, st, bias.to(DEV))
+            y2 = _run_kernel(2, x.to(DEV), q, st, bias.to(DEV))
+        finally:
+            bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+        assert rel_err(y1.cpu(), y_ref) < REL_TOL
+        assert torch.equal(y1, y2)
 
 
 @pytest.mark.parametrize("cfg,ks", [(20, 0), (21, 0), (22, 0), (20, 2), (22, 3)])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the MFMA kernels: the register-transposed kernel (cfg 20 / 21 / 22 = built-in / 8 / 16 wavefronts) against round
-1's LDS-DMA kernel (cfg 5) and the producer/consumer kernel (cfg 11 / 14) and the streaming dot kernel (kernel 3), per launch
+"""A/B of the MFMA kernels: the register-transposed kernel (cfg 20 / 21 / 22 = built-in / 8 / 16 wavefronts) against the
+producer/consumer kernel (cfg 11 / 14) and the streaming dot kernel (kernel 3), per launch
 over an HBM-resident rotation of distinct layers, hipGraph-replayed (launch-to-launch time in a dependent stream)."""
 import argparse
 import os
@@ -34,7 +34,7 @@ def main():
         shapes = shapes[:1]
     if args.big:
         shapes = [(4096, 4096, False), (11008, 4096, False), (8192, 8192, False), (28672, 8192, False)]
-    variants = [("auto", 0, 0), ("stream", 3, 0), ("v3 dma", 2, 500), ("v5 pc11", 2, 1100), ("v5 pc14", 2, 1400),
+    variants = [("auto", 0, 0), ("stream", 3, 0), ("v5 pc11", 2, 1100), ("v5 pc14", 2, 1400),
                 ("rt", 2, 2000), ("rt 8w", 2, 2100), ("rt 16w", 2, 2200)]
     print(f"{'N x K':>14s} {'dq':>2s} {'M':>3s} " + " ".join(f"{n:>9s}" for n, _, _ in variants) + "   best GB/s (%HBM)")
     for (N, K, dq) in shapes:
@@ -46,11 +46,11 @@ def main():
                 if kernel == 3 and M > 8:
                     row.append(float("nan"))
                     continue
-                if (name.startswith("v3") and M > 32) or (name == "rt" and M > 64):
+                if name.startswith("rt") and M > 64:
                     row.append(float("nan"))
                     continue
                 row.append(timed(layers, x, kernel, knob1))
-            best = min(v for v in row[2:] if v == v)
+            best = min(v for v in row if v == v)
             gbs = alg_bytes(M, N, K, 64, dq) / best / 1e3
             print(f"{N:>7d}x{K:<6d} {int(dq):>2d} {M:>3d} " + " ".join(f"{v:9.2f}" for v in row) +
                   f"   {gbs:7.1f} ({gbs / 80:.1f})", flush=True)

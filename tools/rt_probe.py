@@ -20,7 +20,7 @@ def main():
     codes = code[idx].bfloat16().float()                                       # T-rounded code values
     scales = st.absmax.reshape(N, K // 64)
     bad = []
-    for cfg in (2000, 500):
+    for cfg in (2000, 1100):
         eff = torch.zeros(N, K, device="cuda")
         for k0 in range(0, K, 16):
             x = torch.zeros(16, K, device="cuda", dtype=torch.bfloat16)

@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--bs", type=int, default=64)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--mfma-only", action="store_true")
-    ap.add_argument("--cfgs", default="5,6,11,12,13,14,20,21,22", help="MFMA kernel geometries to sweep (cfg codes, see make_plan)")
+    ap.add_argument("--cfgs", default="11,12,13,14,20,21,22", help="MFMA kernel geometries to sweep (cfg codes, see make_plan)")
     ap.add_argument("--ms", default="", help="comma list of M values for the MFMA sweep")
     ap.add_argument("--kss", default="2,4,8,16", help="K-slice counts to sweep")
     a = ap.parse_args()
@@ -90,7 +90,7 @@ def main():
     Ms = [1, 8, 16, 64] if a.quick else [1, 4, 8, 16, 32, 64]
     if a.ms:
         Ms = [int(v) for v in a.ms.split(",")]
-    names = {5: "dma16w", 6: "dma8w", 11: "pc8x1", 12: "pc4x2", 13: "pc8x2", 14: "pc4x1", 20: "rt", 21: "rt8w", 22: "rt16w"}
+    names = {11: "pc8x1", 12: "pc4x2", 13: "pc8x2", 14: "pc4x1", 20: "rt", 21: "rt8w", 22: "rt16w"}
     CFG = {int(c): names.get(int(c), f"cfg{c}") for c in a.cfgs.split(",")}
     KSS = tuple(int(v) for v in a.kss.split(","))
     for M in Ms:
@@ -102,12 +102,7 @@ def main():
         if a.quick:
             continue
         for cfg, cname in CFG.items():
-            dma = cfg in (5, 6)
-            if dma and (mt > 2 or (cfg == 5 and mt != 1)):
-                continue
-            for ks in ((1, 2) if dma else (0, 2) if cfg >= 20 else KSS):
-                if dma and ks == 2 and N // 16 >= 192:
-                    continue
+            for ks in ((0, 2) if cfg >= 20 else KSS):
                 bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, cfg * 100 + ks)
                 tg, te = measure(layers, x, 2)
                 print(f"{'mfma':8s} {M:3d} {f'{cname} ks{ks}':>14s} {tg:9.2f} {te:9.2f} {bytes_alg(M, N, K, bs) / tg / 1e3:11.1f} {2 * M * N * K / tg / 1e6:8.2f}")
