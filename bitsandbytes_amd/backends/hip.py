@@ -12,6 +12,7 @@ dequantize once, then ``F.linear`` on hipBLASLt (reference :904-916).
 """
 from __future__ import annotations
 
+import functools
 from collections.abc import Sequence
 from math import prod
 from typing import Optional
@@ -36,6 +37,11 @@ def _stream(t: torch.Tensor) -> int:
     return torch._C._cuda_getCurrentRawStream(t.device.index)
 
 
+@functools.lru_cache(maxsize=None)
+def _DEVICE_COUNT() -> int:  # (torch.cuda.device_count() costs ~1 us per call; the count cannot change under a live process)
+    return torch.cuda.device_count()
+
+
 class _device_of:
     """Make the tensor's device current for the duration of a native call (multi-GPU processes only;
     reference functional.py:80-88)."""
@@ -45,7 +51,7 @@ class _device_of:
         self.prev = None
 
     def __enter__(self):
-        if torch.cuda.device_count() > 1:
+        if _DEVICE_COUNT() > 1:
             self.prev = torch.cuda.current_device()
             if self.prev != self.idx:
                 torch.cuda.set_device(self.idx)
@@ -287,7 +293,8 @@ def _gemm_4bit_fused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8
     # split-K scratch for the MFMA kernel comes from torch's caching allocator: stream-ordered and
     # legal under hipGraph capture (the library never has to allocate)
     ws = None
-    ws_bytes = lib.bnb_mi355x_gemm_4bit_workspace_bytes(kernel, _DT_CODE[A.dtype], M, N, K, blocksize)
+    # (M <= 2 always runs the streaming kernel, which needs no scratch: the decode hot path skips the size query)
+    ws_bytes = lib.bnb_mi355x_gemm_4bit_workspace_bytes(kernel, _DT_CODE[A.dtype], M, N, K, blocksize) if M > 2 else 0
     if ws_bytes:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device)
     with _device_of(A):
