@@ -827,6 +827,30 @@ def test_gemm_4bit_grad_input_exact_on_representable_inputs():
     assert torch.equal(y.float().cpu(), ref.to(torch.bfloat16).float())
 
 
+def test_gemm_4bit_grad_input_under_hip_graph_capture():
+    """The fused backward is capture-safe (scratch from torch's allocator, no synchronisation, no library allocation) and
+    replays to the same bits."""
+    F = _F()
+    M, N, K = 32, 512, 1024
+    W = (torch.randn(N, K, device=DEV) / K**0.5).bfloat16()
+    q, st = F.quantize_4bit(W, quant_type="nf4")
+    g = torch.randn(M, N, device=DEV, dtype=torch.bfloat16)
+    op = torch.ops.bitsandbytes_amd.gemm_4bit_grad_input.default
+    eager = op(g, q, st.shape, st.absmax, 64, "nf4")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        op(g, q, st.shape, st.absmax, 64, "nf4")
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y = op(g, q, st.shape, st.absmax, 64, "nf4")
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, eager)
+
+
 @pytest.mark.parametrize("M,N,K", [(8, 256, 512), (40, 200, 300)])
 def test_backward_through_matmul_4bit_gpu(M, N, K):
     """MatMul4Bit.backward end to end (fused kernel for the first shape, the reference's dequantize + matmul formulation for
@@ -1029,6 +1053,14 @@ def _op_samples():
         (ops.dequantize_blockwise.default, (q8, am8, code, 256, torch.float32), {}),
         (torch.ops.bitsandbytes_amd.dequantize_4bit_rows.default,
          (q, st.absmax, torch.tensor([3, 1, 3], device=DEV), 256, 64, "nf4", torch.bfloat16), {}),
+        # fused backward: the fused kernel (whole tiles), its nested form, and the op's own unfused fallback (fp32 gradients)
+        (torch.ops.bitsandbytes_amd.gemm_4bit_grad_input.default,
+         (torch.randn(9, 64, device=DEV, dtype=torch.bfloat16), q, (64, 256), st.absmax, 64, "nf4"), {}),
+        (torch.ops.bitsandbytes_amd.gemm_4bit_grad_input.default,
+         (torch.randn(2, 3, 64, device=DEV, dtype=torch.bfloat16), qd, (64, 256), std.state2.absmax, 128, "fp4", std.absmax,
+          std.state2.code, std.offset), {}),
+        (torch.ops.bitsandbytes_amd.gemm_4bit_grad_input.default,
+         (torch.randn(5, 64, device=DEV), q, (64, 256), st.absmax, 64, "nf4"), {}),
     ]
 
 
