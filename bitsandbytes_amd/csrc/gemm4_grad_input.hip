@@ -68,7 +68,7 @@ constexpr int kGiRows = 64;       // batch rows per workgroup (4 MFMA row tiles)
 constexpr int kGiStep = 64;       // n per step (two MFMA k-steps)
 constexpr int kGiLut = 65536;     // 256 entries x 32 copies x 8 B (fp32 pair), at LDS address 0
 constexpr int kGiWStride = 288;   // bytes per row of the dequantized tile: 256 + 32 (consecutive rows in different banks)
-constexpr int kGiGStride = 144;   // bytes per row of the grad_out tile: 128 + 16
+constexpr int kGiGStride = 128;   // bytes per row of the grad_out tile (16-byte chunk c of row m stored at c ^ (m & 7))
 constexpr int kGiWTile = kGiStep * kGiWStride;
 constexpr int kGiGTile = kGiRows * kGiGStride;
 constexpr int kGiLds = kGiLut + 2 * kGiWTile + 2 * kGiGTile + 1024;
@@ -192,7 +192,9 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
             const uint32_t sv = s.s;
             scale = __builtin_bit_cast(float, sv);
         }
-        unsigned char* const wrow = wtiles + buf * kGiWTile + wr * kGiWStride + wp * 64;
+        // (the 32-byte column blocks of rows 8..15 (mod 16) are stored 4 blocks away: the transpose read serves 32 lanes per
+        // pass = rows j and 8 + j of one column block, which a plain row stride puts into the same banks)
+        unsigned char* const wrow = wtiles + buf * kGiWTile + wr * kGiWStride + ((wp ^ (2 * ((wr >> 3) & 1))) * 64);
         // all 16 look-ups in flight before the first product (left alone, hipcc waits for each group of four: with one
         // wavefront per SIMD that is four exposed LDS round trips per thread and step)
         f32x2 pr[16];
@@ -225,9 +227,11 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
             }
             *reinterpret_cast<u32x4*>(wrow + d * 16) = o;
         }
-        unsigned char* const grow_p = gtiles + buf * kGiGTile + wr * kGiGStride + wp * 32;
-        *reinterpret_cast<u32x4*>(grow_p) = s.g[0];
-        *reinterpret_cast<u32x4*>(grow_p + 16) = s.g[1];
+        // grad_out tile: 16-byte chunk c of row m at position c ^ (m & 7) - conflict-free for the 8-contiguous-lane groups of
+        // ds_write_b128 here and for the 16-lane groups {0-3, 12-15, 20-27}, ... of the ds_read_b128 fragment reads below
+        unsigned char* const grow_p = gtiles + buf * kGiGTile + wr * kGiGStride;
+        *reinterpret_cast<u32x4*>(grow_p + (((2 * wp) ^ (wr & 7)) << 4)) = s.g[0];
+        *reinterpret_cast<u32x4*>(grow_p + (((2 * wp + 1) ^ (wr & 7)) << 4)) = s.g[1];
     };
 
     f32x4 acc[2][4];
@@ -239,8 +243,10 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
 
     // per-lane LDS addresses: transpose read - lane (i = ln, group lg) addresses row 8 lg + (i >> 2), 8-byte piece (i & 3) of a
     // 16-column block; A fragment - row ln of a batch tile, 16 bytes at n = 8 lg
-    const uint32_t tr_lane = static_cast<uint32_t>((8 * lg + (ln >> 2)) * kGiWStride + (ln & 3) * 8 + wave * 64);
-    const uint32_t a_lane = static_cast<uint32_t>(ln * kGiGStride + lg * 16);
+    // (column block = 2 wave + ct, stored at block ^ 4 for rows with bit 3 set, i.e. for odd lane groups)
+    const uint32_t tr_lane = static_cast<uint32_t>((8 * lg + (ln >> 2)) * kGiWStride + (ln & 3) * 8);
+    const uint32_t tr_sw = static_cast<uint32_t>((lg & 1) * 4);
+    const uint32_t a_row = static_cast<uint32_t>(ln * kGiGStride); // + ((4 ks + lg) ^ (row & 7)) << 4
 
     auto do_step = [&](Stage& stg, int step) {
         const int buf = (step - sb) & 1;
@@ -257,7 +263,8 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     u32x2 v;
-                    const uint32_t addr = wbase + tr_lane + static_cast<uint32_t>((32 * ks + 4 * h) * kGiWStride + ct * 32);
+                    const uint32_t addr = wbase + tr_lane + static_cast<uint32_t>((32 * ks + 4 * h) * kGiWStride) +
+                                          ((static_cast<uint32_t>(2 * wave + ct) ^ tr_sw) << 5);
                     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
                     bf[ct][2 * h] = v[0];
                     bf[ct][2 * h + 1] = v[1];
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
             u32x4 af[4];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
-                af[mt] = *reinterpret_cast<const u32x4*>(gb + mt * 16 * kGiGStride + a_lane + ks * 64);
+                af[mt] = *reinterpret_cast<const u32x4*>(gb + mt * 16 * kGiGStride + a_row + (((4 * ks + lg) ^ (ln & 7)) << 4));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the transpose reads are invisible to the compiler's counters
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)

@@ -15,7 +15,7 @@
 //    row index in the LOW lane bits (lane r + 16 g) - loading in that shape costs 64 tag look-ups per instruction (four
 //    different rows per lane quad), which is what made round 1's fragment-shaped loads crawl. The transposition
 //    (4r + p -> r + 16p) is a ds_write_b128 / ds_read_b128 pair through a 1-KiB tile private to the wavefront: same
-//    wavefront, in-order LDS, no barrier, bank-conflict-free both ways (slot 16p + ((r + 2p) & 15)).
+//    wavefront, in-order LDS, no barrier, bank-conflict-free both ways (slot 16p + (r ^ 2p)).
 //  * K order inside an MFMA is free as long as both operands agree. A lane's 16 weight bytes are 32 consecutive k; after
 //    the transposition the four lane groups of a column hold 128 consecutive k = two quantization blocks. One
 //    v_permlane32_swap per dword pair regroups them so that every MFMA consumes k from ONE block (dwords 0/1 of groups 0,1
@@ -241,8 +241,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     __syncthreads();
     BNB_RT_STAMP(3)
 
-    const int wslot = 16 * pp + ((r + 2 * pp) & 15);  // where lane (r, pp) puts its 16 bytes ...
-    const int rslot = 16 * lg + ((ln + 2 * lg) & 15); // ... and where lane (ln, lg) finds those of lane (r = ln, pp = lg)
+    // Where lane (r, pp) puts its 16 bytes, and where lane (ln, lg) finds those of lane (r = ln, pp = lg). The XOR makes
+    // both sides conflict-free under the hardware's lane grouping (guide, LDS table): ds_write_b128 serves 8 CONTIGUOUS lanes
+    // per pass over 32 banks - rows 2i, 2i+1 x pieces 0..3 land in 8 different 16-byte positions mod 8 - and ds_read_b128
+    // serves the 16-lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... over 64 banks: group 0 = (lg 0: ln in
+    // {0-3, 12-15}) + (lg 1: ln in 4..11) reads positions {0-3, 12-15} and {4..11} ^ 2 = {4..11}. (The first version rotated
+    // by 2 pp instead - right for contiguous 8-lane read groups, which the hardware does not use: PMC showed 16 % of the LDS
+    // cycles as bank conflicts.)
+    const int wslot = 16 * pp + (r ^ (2 * pp));
+    const int rslot = 16 * lg + (ln ^ (2 * lg));
     const uint32_t lane_off = static_cast<uint32_t>(lane & 31) * 4u + static_cast<uint32_t>(opaque_zero());
 
     f32x4 acc[MT];
