@@ -76,6 +76,7 @@ template <> struct RtMma<f16> {
 constexpr int kRtLut = 32768;            // 256 entries x 32 copies x 4 B, at LDS address 0
 constexpr int kRtScratch = 2 * 1024 + 256; // per wavefront: two transposition tiles + the scale tile (16 x 16 B)
 constexpr int kRtChunk = 256;            // k per wavefront step: four 64-k MFMA pairs
+constexpr int kRtDirectMaxM = 4;         // batches up to this many rows load their activation fragments directly (see DIRECT)
 
 struct RtArgs {
 #ifdef BNB_PROFILING
@@ -114,7 +115,12 @@ __device__ __forceinline__ float rt_code_literal(int i, bool fp4) {
 // and decoded ONCE and multiplied with MT activation tiles in turn - while tile t is transposed and multiplied, the loads of
 // tile t + 1 refill the same registers); WAVES wavefronts split the workgroup's K range chunk by chunk (chunk c of the slice
 // goes to wavefront c % WAVES). grid = (ceil(N / 16), kslices, ceil(M / (16 MT))).
-template <typename T, int MT, int WAVES, bool NESTED>
+//
+// DIRECT (M <= 4, one row tile): the activation fragments are loaded straight in MFMA shape, no transposition. Only the 16
+// lanes of rows < M fetch (the rest is exec-masked), so a load instruction touches at most 16 lines either way - the
+// fragment-shaped load is only expensive when all 64 lanes take part - and 8 ds_write_b128 + 8 ds_read_b128 per chunk and
+// wavefront disappear from the LDS store path (13 cycles per wave-instruction).
+template <typename T, int MT, int WAVES, bool NESTED, bool DIRECT>
 __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     // hot arguments as separate scalars: preloaded into SGPRs by the command processor (14 dwords)
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, int hot_M, int hot_N,
@@ -150,7 +156,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     int wrow = col0 + r;
     wrow = (wrow < N) ? wrow : N - 1;
     const uint8_t* const wsrc = hot_B + static_cast<long>(wrow) * (K >> 1) + pp * 16;
-    const T* const abase = static_cast<const T*>(hot_A) + (pp & 1) * 32 + (pp >> 1) * 16;
+    static_assert(!DIRECT || MT == 1, "direct activation fragments: one row tile");
+    // (the lane that fetches row x / k group y of a fragment: the load roles (r, pp), or - DIRECT - the MFMA roles (ln, lg))
+    const int arow_l = DIRECT ? ln : r, ag_l = DIRECT ? lg : pp;
+    const T* const abase = static_cast<const T*>(hot_A) + (ag_l & 1) * 32 + (ag_l >> 1) * 16;
     const long e0 = static_cast<long>(wrow) * K; // flat element index of the row start
 
     struct Raw {
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     // Activation rows past the end of the batch are not fetched at all (exec-masked: the loads then cost the L1 M / 16 of a
     // full tile); those lanes hold zeros and the MFMA rows they feed are never stored.
     auto load_a_step = [&](Raw& raw, int c, int mt, int s) {
-        const int row = m_base + mt * 16 + r;
+        const int row = m_base + mt * 16 + arow_l;
         if (row < M)
             raw.a[s] = *reinterpret_cast<const u32x4*>(abase + static_cast<long>(row) * K + static_cast<long>(c) * kRtChunk +
                                                        128 * (s >> 2) + 64 * ((s >> 1) & 1) + 8 * (s & 1));
@@ -299,10 +308,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
                 for (int i = 0; i < 2; ++i) {
                     const int h = blk >> 1, j = 2 * (blk & 1) + i, s = 4 * h + j;
                     u32x4* const tile = (s & 1) ? tile1 : tile0;
-                    tile[wslot] = raw.a[s];
-                    if (mt + 1 < MT)
-                        load_a_step(raw, c, mt + 1, s); // the next tile's piece refills the register just emptied
-                    const u32x4 af = tile[rslot];
+                    u32x4 af;
+                    if constexpr (DIRECT) {
+                        af = raw.a[s];
+                    } else {
+                        tile[wslot] = raw.a[s];
+                        if (mt + 1 < MT)
+                            load_a_step(raw, c, mt + 1, s); // the next tile's piece refills the register just emptied
+                        af = tile[rslot];
+                    }
                     if (mt == 0) {
                         const uint32_t w = wt[h][j];
 #pragma unroll
@@ -394,21 +408,25 @@ RtPlan rt_plan(int M, int N, int K, int force_ks) {
     // otherwise eight, two workgroups per CU (measured on MI355X, profiles/r2_mfma_ab.txt: 4096^2 6.45 vs 6.7 us,
     // 11008 x 4096 11.2 vs 16.0; 4096 x 11008 11.5 vs 10.8)
     pl.waves = (pl.mt == 1 && wgs * pl.ks <= cus && pl.cps > 16) ? 16 : 8;
+    // with directly loaded activation fragments (M <= 4) sixteen wavefronts x one chunk win from 16 chunks on
+    // (4096^2 M = 3: 6.33 vs 6.59 us)
+    if (M <= kRtDirectMaxM && wgs * pl.ks <= cus && pl.cps >= 16)
+        pl.waves = 16;
     return pl;
 }
 
-template <typename T, int MT, int WAVES> void rt_launch(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
-                                                        int M, int N, int K, int flags, const RtPlan& pl, const RtArgs& a,
-                                                        hipStream_t stream) {
+template <typename T, int MT, int WAVES, bool DIRECT = false>
+void rt_launch(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
+               const RtPlan& pl, const RtArgs& a, hipStream_t stream) {
     const size_t lds = kRtLut + static_cast<size_t>(WAVES) * kRtScratch + 1024 + static_cast<size_t>(WAVES) * MT * 1024;
     dim3 grid((N + 15) / 16, pl.ks, (M + 16 * MT - 1) / (16 * MT));
     if (absmax8 != nullptr) {
-        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, true>;
+        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, true, DIRECT>;
         static LdsLimit lim;
         ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
         hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, M, N, K, flags, pl.cps, pl.ks, a);
     } else {
-        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, false>;
+        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, false, DIRECT>;
         static LdsLimit lim;
         ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
         hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, M, N, K, flags, pl.cps, pl.ks, a);
@@ -419,6 +437,11 @@ template <typename T> void rt_launch_mt(const void* A, const uint8_t* B, const f
                                         int K, int flags, const RtPlan& pl, const RtArgs& a, hipStream_t stream) {
     switch (pl.mt) {
     case 1:
+        if (M <= kRtDirectMaxM) { // activation fragments loaded straight in MFMA shape
+            if (pl.waves == 16)
+                return rt_launch<T, 1, 16, true>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+            return rt_launch<T, 1, 8, true>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+        }
         if (pl.waves == 16)
             return rt_launch<T, 1, 16>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
         return rt_launch<T, 1, 8>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
