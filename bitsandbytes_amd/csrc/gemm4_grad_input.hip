@@ -25,6 +25,10 @@
 
 namespace bnb {
 
+#ifdef BNB_PROFILING
+extern unsigned long long* g_dbg_buf;
+#endif
+
 // gemm4_mfma.hip
 void gemm_4bit_finalize(int dtype, const float* ws, const void* bias, void* out, int M, int N, int kslices, hipStream_t stream);
 
@@ -73,7 +77,21 @@ constexpr int kGiWTile = kGiStep * kGiWStride;
 constexpr int kGiGTile = kGiRows * kGiGStride;
 constexpr int kGiLds = kGiLut + 2 * kGiWTile + 2 * kGiGTile + 1024;
 
+#ifdef BNB_PROFILING
+#define BNB_GI_STAMP(i)                                                                            \
+    {                                                                                              \
+        if (p.dbg && lane == 0)                                                                    \
+            p.dbg[((((static_cast<long>(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4) + wave) * 16 + (i)] = \
+                __builtin_amdgcn_s_memtime();                                                      \
+    }
+#else
+#define BNB_GI_STAMP(i) {}
+#endif
+
 struct GiArgs {
+#ifdef BNB_PROFILING
+    unsigned long long* dbg;
+#endif
     const float* absmax_code;
     const float* absmax_offset;
     void* out;
@@ -102,6 +120,7 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
     const int M = hot_M, N = hot_N, K = hot_K;
     const int bs_shift = hot_flags & 31;
     const bool fp4 = (hot_flags >> 8) & 1;
+    BNB_GI_STAMP(0)
     const int k0 = blockIdx.x * kGiCols;
     const int m_base = blockIdx.z * kGiRows;
     const int steps_total = N / kGiStep;
@@ -154,6 +173,7 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
 #pragma unroll
     for (int j = 0; j < D; ++j)
         issue(st[j], sb + j);
+    BNB_GI_STAMP(1)
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- decode table, built while the first loads fly: entry e (a packed byte) = 32 copies of (code[e >> 4], code[e & 15])
@@ -175,6 +195,7 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
         offset = p.absmax_offset[0];
     }
     __syncthreads();
+    BNB_GI_STAMP(2)
     if (reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem) != 0)
         __builtin_trap(); // the table is addressed with raw v_perm_b32 results: it must sit at LDS address 0
 
@@ -251,7 +272,11 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
     auto do_step = [&](Stage& stg, int step) {
         const int buf = (step - sb) & 1;
         stage_to_lds(stg, buf);
+        if (step - sb < 3)
+            BNB_GI_STAMP(3 + 3 * (step - sb))
         __syncthreads();
+        if (step - sb < 3)
+            BNB_GI_STAMP(4 + 3 * (step - sb))
         issue(stg, step + D);
         const uint32_t wbase = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)(wtiles + buf * kGiWTile)));
         const unsigned char* const gb = gtiles + buf * kGiGTile;
@@ -280,31 +305,63 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
                 for (int mt = 0; mt < 4; ++mt)
                     acc[ct][mt] = GiMma<T>::run(af[mt], bf[ct], acc[ct][mt]);
         }
+        if (step - sb < 3)
+            BNB_GI_STAMP(5 + 3 * (step - sb))
     };
-    for (int base = sb; base < se; base += D) {
+    // whole rounds of D steps with nothing conditional around the loads (a branch around a load makes the compiler merge
+    // the pending-load state of both paths at the join and wait with vmcnt(0): that drained the prefetch ring every step),
+    // then the tail
+    int base = sb;
+    for (; base + D <= se; base += D) {
 #pragma unroll
         for (int j = 0; j < D; ++j)
-            if (base + j < se)
-                do_step(st[j], base + j);
+            do_step(st[j], base + j);
     }
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+        if (base + j < se)
+            do_step(st[j], base + j);
 
-    // ---- store: lane (i = ln, lg) of tile (ct, mt) holds rows m_base + 16 mt + 4 lg + q of column k0 + 32 wave + 16 ct + i
+    BNB_GI_STAMP(12)
+    // ---- store. Lane (i = ln, lg) of tile (ct, mt) holds rows 16 mt + 4 lg + q of column 32 wave + 16 ct + i: stored as it
+    // sits, that is 32 four-byte stores per lane, 64 bytes contiguous each (measured: 4100 of the kernel's 24 k cycles). The
+    // wavefront's [64 rows][32 columns] fp32 tile goes through LDS instead (the step tiles are free now) and leaves as 16
+    // bytes per lane, 8 rows x 128 contiguous bytes per instruction.
+    __syncthreads(); // every wavefront is done reading the step tiles
+    {
+        constexpr int kOutStride = 144; // bytes per row of the staged tile: rows 4 apart land 16 banks apart
+        unsigned char* const ot = wtiles + wave * (kGiRows * kOutStride);
+        static_assert(4 * kGiRows * kOutStride <= 2 * kGiWTile, "the staged output tiles fit over the step tiles");
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = m_base + 16 * mt + 4 * lg + q;
-                const int k = k0 + 32 * wave + 16 * ct + ln;
-                if (m < M) {
-                    const long idx = static_cast<long>(m) * K + k;
-                    if (hot_nslices == 1)
-                        static_cast<T*>(p.out)[idx] = static_cast<T>(acc[ct][mt][q]);
-                    else
-                        p.ws[static_cast<long>(blockIdx.y) * M * K + idx] = acc[ct][mt][q];
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float*>(ot + (16 * mt + 4 * lg + q) * kOutStride + (16 * ct + ln) * 4) = acc[ct][mt][q];
+        // (same wavefront wrote and reads: in-order LDS, no barrier)
+        const int rr = lane >> 3, cq = lane & 7;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int row = 8 * ps + rr;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ot + row * kOutStride + cq * 16);
+            const int m = m_base + row;
+            if (m < M) {
+                const long idx = static_cast<long>(m) * K + k0 + 32 * wave + 4 * cq;
+                if (hot_nslices == 1) {
+                    using T4 = __attribute__((ext_vector_type(4))) T;
+                    T4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o[e] = static_cast<T>(v[e]);
+                    *reinterpret_cast<T4*>(static_cast<T*>(p.out) + idx) = o;
+                } else {
+                    *reinterpret_cast<f32x4*>(p.ws + static_cast<long>(blockIdx.y) * M * K + idx) = v;
                 }
             }
+        }
+    }
+    BNB_GI_STAMP(13)
 }
 
 int gi_cu_count() { return device_cu_count_or_default(); }
@@ -380,6 +437,9 @@ void gemm_4bit_grad_input(int dtype, const void* G, const uint8_t* B, const floa
         pl.ns = (steps + pl.sps - 1) / pl.sps;
     }
     GiArgs a;
+#ifdef BNB_PROFILING
+    a.dbg = g_dbg_buf;
+#endif
     a.absmax_code = absmax_code;
     a.absmax_offset = absmax_offset;
     a.out = out;
