@@ -13,13 +13,14 @@
 // exactly that from a row-major LDS image (semantics probed on the device, tools/ubench/tr_probe.hip: inside a 16-lane
 // group lane 4 j + q addresses the 8-byte piece q of row j, and lane i receives column i of the resulting 4 x 16 block).
 //
-//  * A workgroup (4 wavefronts) owns 128 k-columns x 64 batch rows x a slice of N and walks it in steps of 64 n.
-//  * Per step every thread loads 16 packed bytes (32 k of one weight row; four threads cover a row's 64 bytes) and its
+//  * A workgroup (8 wavefronts, two per SIMD: the decode phase of one overlaps the LDS / MFMA latencies of the other) owns
+//    128 k-columns x 64 batch rows x a slice of N and walks it in steps of 64 n.
+//  * Per step every thread loads 8 packed bytes (16 k of one weight row; eight threads cover a row's 64 bytes) and its
 //    scale, decodes through the bank-private byte -> (code[hi], code[lo]) fp32 table (one v_perm_b32 + one ds_read_b64 per
-//    byte), multiplies, rounds to T and stores 64 bytes of the [64 n][128 k] tile; the 64 x 64 grad_out tile is staged
-//    through LDS as well (coalesced 32-byte pieces in, 16-byte MFMA A fragments out). The loads of step s + 1 are issued
-//    before step s is multiplied; tiles are double-buffered: one barrier per step.
-//  * Wavefront w multiplies its 32 columns (two MFMA column tiles) with the four 16-row batch tiles: 16 MFMAs per step.
+//    byte), multiplies, rounds to T and stores 32 bytes of the [64 n][128 k] tile; the 64 x 64 grad_out tile is staged
+//    through LDS as well (coalesced 16-byte pieces in, 16-byte MFMA A fragments out). The loads of steps s + 1 .. s + 3 are
+//    in flight while step s is multiplied (register ring); tiles are double-buffered: one barrier per step.
+//  * Wavefront w multiplies its 16 columns (one MFMA column tile) with the four 16-row batch tiles: 8 MFMAs per step.
 //  * N slices across workgroups fill the chip; fp32 slabs are added in slice order by gemm4_finalize: bit-reproducible.
 #include "bnb_common.h"
 
@@ -81,7 +82,7 @@ constexpr int kGiLds = kGiLut + 2 * kGiWTile + 2 * kGiGTile + 1024;
 #define BNB_GI_STAMP(i)                                                                            \
     {                                                                                              \
         if (p.dbg && lane == 0)                                                                    \
-            p.dbg[((((static_cast<long>(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4) + wave) * 16 + (i)] = \
+            p.dbg[((((static_cast<long>(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8) + wave) * 16 + (i)] = \
                 __builtin_amdgcn_s_memtime();                                                      \
     }
 #else
@@ -108,9 +109,11 @@ __device__ __forceinline__ float gi_code_literal(int i, bool fp4) {
     return v;
 }
 
-// grid = (K / 128, nslices, ceil(M / 64)); 256 threads
+constexpr int kGiThreads = 512;
+
+// grid = (K / 128, nslices, ceil(M / 64)); 512 threads
 template <typename T, bool NESTED>
-__global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
+__global__ __launch_bounds__(kGiThreads) void gemm4_grad_input_kernel(
     const void* hot_G, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, int hot_M, int hot_N,
     int hot_K, int hot_flags /* bs_shift | fp4 << 8 */, int hot_sps /* steps per N slice */, int hot_nslices, const GiArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -132,26 +135,26 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
     unsigned char* const gtiles = wtiles + 2 * kGiWTile;
     float* const code2 = reinterpret_cast<float*>(gtiles + 2 * kGiGTile);
 
-    // ---- per-thread roles of the loads: weight row (tid >> 2) of the step, 16-byte piece (tid & 3) = 32 k;
-    // grad_out row (tid >> 2) of the batch tile, 32-byte piece (tid & 3) = 16 n
-    const int wr = tid >> 2, wp = tid & 3;
-    const uint8_t* const wsrc = hot_B + static_cast<long>(wr) * (K >> 1) + ((k0 + 32 * wp) >> 1);
-    const long we0 = static_cast<long>(wr) * K + k0 + 32 * wp; // flat element index of the piece at n = 0
+    // ---- per-thread roles of the loads: weight row (tid >> 3) of the step, 8-byte piece (tid & 7) = 16 k = one MFMA
+    // column tile; grad_out row (tid >> 3) of the batch tile, 16-byte piece (tid & 7) = 8 n
+    const int wr = tid >> 3, wp = tid & 7;
+    const uint8_t* const wsrc = hot_B + static_cast<long>(wr) * (K >> 1) + ((k0 + 16 * wp) >> 1);
+    const long we0 = static_cast<long>(wr) * K + k0 + 16 * wp; // flat element index of the piece at n = 0
     int grow = m_base + wr;
     grow = grow < M ? grow : M - 1; // rows past the end of the batch re-read the last row: never stored
-    const T* const gsrc = static_cast<const T*>(hot_G) + static_cast<long>(grow) * N + 16 * wp;
+    const T* const gsrc = static_cast<const T*>(hot_G) + static_cast<long>(grow) * N + 8 * wp;
 
     struct Stage {
-        u32x4 w;
+        u32x2 w;
         uint32_t s, s2;
-        u32x4 g[2];
+        u32x4 g;
     };
     // (the step index is clamped to the slice: a harmless re-read at the tail instead of a branch around the loads, so the
     // compiler's counted waits stay exact)
     auto issue = [&](Stage& st, int step_unclamped) {
         const int step = step_unclamped < se ? step_unclamped : se - 1;
         const long n0 = static_cast<long>(step) * kGiStep;
-        st.w = *reinterpret_cast<const u32x4*>(wsrc + n0 * (K >> 1));
+        st.w = *reinterpret_cast<const u32x2*>(wsrc + n0 * (K >> 1));
         const long e = we0 + n0 * K;
         if constexpr (NESTED) {
             st.s = hot_absmax8[e >> bs_shift];
@@ -160,8 +163,7 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
             st.s = __builtin_bit_cast(uint32_t, hot_absmax[e >> bs_shift]);
             st.s2 = 0;
         }
-        st.g[0] = *reinterpret_cast<const u32x4*>(gsrc + n0);
-        st.g[1] = *reinterpret_cast<const u32x4*>(gsrc + n0 + 8);
+        st.g = *reinterpret_cast<const u32x4*>(gsrc + n0);
     };
 
     // a three-deep register ring: the loads of step s + 3 are issued while step s is multiplied (one step of compute is far
@@ -177,21 +179,24 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- decode table, built while the first loads fly: entry e (a packed byte) = 32 copies of (code[e >> 4], code[e & 15])
-    // in fp32, 256 B per entry; thread e writes its 16 chunks in an order rotated by e (eight lanes -> eight bank quads)
+    // in fp32, 256 B per entry; thread (half, e) writes 8 of its 16 chunks in an order rotated by e (eight lanes -> eight
+    // bank quads)
     {
         const float cv = gi_code_literal((lane & 15) + opaque_zero(), fp4);
         const int cvb = __builtin_bit_cast(int, cv);
-        const float hi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((tid >> 4) & 15) * 4, cvb));
-        const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((tid & 15) * 4, cvb));
+        const int e = tid & 255, half = tid >> 8;
+        const float hi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((e >> 4) & 15) * 4, cvb));
+        const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e & 15) * 4, cvb));
         const f32x4 v = {hi, lo, hi, lo};
-        f32x4* const dst = reinterpret_cast<f32x4*>(smem + tid * 256);
+        f32x4* const dst = reinterpret_cast<f32x4*>(smem + e * 256 + half * 128);
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            dst[(j + tid) & 15] = v;
+        for (int j = 0; j < 8; ++j)
+            dst[(j + e) & 7] = v;
     }
     float offset = 0.0f;
     if constexpr (NESTED) {
-        code2[tid] = p.absmax_code[tid];
+        if (tid < 256)
+            code2[tid] = p.absmax_code[tid];
         offset = p.absmax_offset[0];
     }
     __syncthreads();
@@ -215,12 +220,11 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
         }
         // (the 32-byte column blocks of rows 8..15 (mod 16) are stored 4 blocks away: the transpose read serves 32 lanes per
         // pass = rows j and 8 + j of one column block, which a plain row stride puts into the same banks)
-        unsigned char* const wrow = wtiles + buf * kGiWTile + wr * kGiWStride + ((wp ^ (2 * ((wr >> 3) & 1))) * 64);
-        // all 16 look-ups in flight before the first product (left alone, hipcc waits for each group of four: with one
-        // wavefront per SIMD that is four exposed LDS round trips per thread and step)
-        f32x2 pr[16];
+        unsigned char* const wrow = wtiles + buf * kGiWTile + wr * kGiWStride + ((wp ^ (4 * ((wr >> 3) & 1))) * 32);
+        // all 8 look-ups in flight before the first product
+        f32x2 pr[8];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
+        for (int d = 0; d < 2; ++d) {
             const uint32_t w = s.w[d];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
+        for (int d = 0; d < 2; ++d) {
             u32x4 o;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -250,23 +254,19 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
         }
         // grad_out tile: 16-byte chunk c of row m at position c ^ (m & 7) - conflict-free for the 8-contiguous-lane groups of
         // ds_write_b128 here and for the 16-lane groups {0-3, 12-15, 20-27}, ... of the ds_read_b128 fragment reads below
-        unsigned char* const grow_p = gtiles + buf * kGiGTile + wr * kGiGStride;
-        *reinterpret_cast<u32x4*>(grow_p + (((2 * wp) ^ (wr & 7)) << 4)) = s.g[0];
-        *reinterpret_cast<u32x4*>(grow_p + (((2 * wp + 1) ^ (wr & 7)) << 4)) = s.g[1];
+        *reinterpret_cast<u32x4*>(gtiles + buf * kGiGTile + wr * kGiGStride + ((wp ^ (wr & 7)) << 4)) = s.g;
     };
 
-    f32x4 acc[2][4];
+    f32x4 acc[4];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-            acc[ct][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < 4; ++mt)
+        acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // per-lane LDS addresses: transpose read - lane (i = ln, group lg) addresses row 8 lg + (i >> 2), 8-byte piece (i & 3) of a
     // 16-column block; A fragment - row ln of a batch tile, 16 bytes at n = 8 lg
-    // (column block = 2 wave + ct, stored at block ^ 4 for rows with bit 3 set, i.e. for odd lane groups)
-    const uint32_t tr_lane = static_cast<uint32_t>((8 * lg + (ln >> 2)) * kGiWStride + (ln & 3) * 8);
-    const uint32_t tr_sw = static_cast<uint32_t>((lg & 1) * 4);
+    // (column block = wave, stored at block ^ 4 for rows with bit 3 set, i.e. for odd lane groups)
+    const uint32_t tr_lane = static_cast<uint32_t>((8 * lg + (ln >> 2)) * kGiWStride + (ln & 3) * 8 +
+                                                   ((static_cast<uint32_t>(wave) ^ static_cast<uint32_t>((lg & 1) * 4)) << 5));
     const uint32_t a_row = static_cast<uint32_t>(ln * kGiGStride); // + ((4 ks + lg) ^ (row & 7)) << 4
 
     auto do_step = [&](Stage& stg, int step) {
@@ -280,31 +280,28 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
         issue(stg, step + D);
         const uint32_t wbase = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)(wtiles + buf * kGiWTile)));
         const unsigned char* const gb = gtiles + buf * kGiGTile;
+        // both k-steps' fragments are requested before the first MFMA (one exposed LDS round trip per step instead of two)
+        u32x4 bf[2], af[2][4];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            u32x4 bf[2];
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    u32x2 v;
-                    const uint32_t addr = wbase + tr_lane + static_cast<uint32_t>((32 * ks + 4 * h) * kGiWStride) +
-                                          ((static_cast<uint32_t>(2 * wave + ct) ^ tr_sw) << 5);
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-                    bf[ct][2 * h] = v[0];
-                    bf[ct][2 * h + 1] = v[1];
-                }
-            u32x4 af[4];
+            for (int h = 0; h < 2; ++h) {
+                u32x2 v;
+                const uint32_t addr = wbase + tr_lane + static_cast<uint32_t>((32 * ks + 4 * h) * kGiWStride);
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+                bf[ks][2 * h] = v[0];
+                bf[ks][2 * h + 1] = v[1];
+            }
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
-                af[mt] = *reinterpret_cast<const u32x4*>(gb + mt * 16 * kGiGStride + a_row + (((4 * ks + lg) ^ (ln & 7)) << 4));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the transpose reads are invisible to the compiler's counters
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[ct][mt] = GiMma<T>::run(af[mt], bf[ct], acc[ct][mt]);
+                af[ks][mt] = *reinterpret_cast<const u32x4*>(gb + mt * 16 * kGiGStride + a_row + (((4 * ks + lg) ^ (ln & 7)) << 4));
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the transpose reads are invisible to the compiler's counters
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                acc[mt] = GiMma<T>::run(af[ks][mt], bf[ks], acc[mt]);
         if (step - sb < 3)
             BNB_GI_STAMP(5 + 3 * (step - sb))
     };
@@ -323,31 +320,29 @@ __global__ __launch_bounds__(256) void gemm4_grad_input_kernel(
             do_step(st[j], base + j);
 
     BNB_GI_STAMP(12)
-    // ---- store. Lane (i = ln, lg) of tile (ct, mt) holds rows 16 mt + 4 lg + q of column 32 wave + 16 ct + i: stored as it
-    // sits, that is 32 four-byte stores per lane, 64 bytes contiguous each (measured: 4100 of the kernel's 24 k cycles). The
-    // wavefront's [64 rows][32 columns] fp32 tile goes through LDS instead (the step tiles are free now) and leaves as 16
-    // bytes per lane, 8 rows x 128 contiguous bytes per instruction.
+    // ---- store. Lane (i = ln, lg) of row tile mt holds rows 16 mt + 4 lg + q of column 16 wave + i: stored as it sits, that
+    // is 16 four-byte stores per lane, 64 bytes contiguous each (the first version spent 4100 of its 24 k cycles there). Each
+    // PAIR of wavefronts' [64 rows][32 columns] fp32 tile goes through LDS instead (the step tiles are free now) and leaves
+    // as 16 bytes per lane, 128 contiguous bytes per row.
     __syncthreads(); // every wavefront is done reading the step tiles
     {
-        constexpr int kOutStride = 144; // bytes per row of the staged tile: rows 4 apart land 16 banks apart
-        unsigned char* const ot = wtiles + wave * (kGiRows * kOutStride);
+        constexpr int kOutStride = 144; // bytes per row of a staged [64][32] tile: rows 4 apart land 16 banks apart
+        unsigned char* const ot = wtiles + (wave >> 1) * (kGiRows * kOutStride);
         static_assert(4 * kGiRows * kOutStride <= 2 * kGiWTile, "the staged output tiles fit over the step tiles");
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float*>(ot + (16 * mt + 4 * lg + q) * kOutStride + (16 * ct + ln) * 4) = acc[ct][mt][q];
-        // (same wavefront wrote and reads: in-order LDS, no barrier)
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float*>(ot + (16 * mt + 4 * lg + q) * kOutStride + (16 * (wave & 1) + ln) * 4) = acc[mt][q];
+        __syncthreads(); // (the pair's other wavefront wrote the other 16 columns)
         const int rr = lane >> 3, cq = lane & 7;
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-            const int row = 8 * ps + rr;
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = 32 * (wave & 1) + 8 * ps + rr; // each wavefront of the pair stores half of the rows
             const f32x4 v = *reinterpret_cast<const f32x4*>(ot + row * kOutStride + cq * 16);
             const int m = m_base + row;
             if (m < M) {
-                const long idx = static_cast<long>(m) * K + k0 + 32 * wave + 4 * cq;
+                const long idx = static_cast<long>(m) * K + k0 + 32 * (wave >> 1) + 4 * cq;
                 if (hot_nslices == 1) {
                     using T4 = __attribute__((ext_vector_type(4))) T;
                     T4 o;
@@ -390,12 +385,12 @@ template <typename T> void gi_launch(const void* G, const uint8_t* B, const floa
         auto kern = gemm4_grad_input_kernel<T, true>;
         static LdsLimit lim;
         ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), kGiLds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), kGiLds, stream, G, B, absmax, absmax8, M, N, K, flags, pl.sps, pl.ns, a);
+        hipLaunchKernelGGL(kern, grid, dim3(kGiThreads), kGiLds, stream, G, B, absmax, absmax8, M, N, K, flags, pl.sps, pl.ns, a);
     } else {
         auto kern = gemm4_grad_input_kernel<T, false>;
         static LdsLimit lim;
         ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), kGiLds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), kGiLds, stream, G, B, absmax, absmax8, M, N, K, flags, pl.sps, pl.ns, a);
+        hipLaunchKernelGGL(kern, grid, dim3(kGiThreads), kGiLds, stream, G, B, absmax, absmax8, M, N, K, flags, pl.sps, pl.ns, a);
     }
 }
 

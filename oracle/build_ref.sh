@@ -19,3 +19,24 @@ g++ -O3 -std=c++17 -shared -fPIC -fopenmp -DHAS_OPENMP -DBUILD_CUDA=0 -DBUILD_HI
     -I"$REF/csrc" "$REF/csrc/cpu_ops.cpp" "$REF/csrc/pythonInterface.cpp" \
     -o "$OUT/libbitsandbytes_cpu.so"
 echo "build_ref: built $OUT/libbitsandbytes_cpu.so"
+
+# The reference's Python package, BYTE-COMPILED (sourceless .pyc, nothing copied) into oracle/_ref/ref_py/: lets the
+# GPU box - where /root/reference does not exist - run the reference's unmodified host code (bitsandbytes/functional.py,
+# backends/cuda/ops.py, nn/modules.py ...) over OUR shared library: INTEGRATION.md mode A, tests/test_gpu_mode_a.py.
+python3 - "$REF/bitsandbytes" "$OUT/ref_py/bitsandbytes" <<'PY'
+import os, py_compile, shutil, sys
+src, dst = sys.argv[1], sys.argv[2]
+shutil.rmtree(os.path.dirname(dst), ignore_errors=True)
+n = 0
+for root, dirs, files in os.walk(src):
+    dirs[:] = [d for d in dirs if d != "__pycache__"]
+    rel = os.path.relpath(root, src)
+    out = dst if rel == "." else os.path.join(dst, rel)
+    os.makedirs(out, exist_ok=True)
+    for f in files:
+        if f.endswith(".py"):
+            py_compile.compile(os.path.join(root, f), cfile=os.path.join(out, f + "c"),
+                               dfile=os.path.join("bitsandbytes", "" if rel == "." else rel, f), doraise=True)
+            n += 1
+print(f"build_ref: byte-compiled {n} reference modules into {os.path.dirname(dst)}", file=sys.stderr)
+PY

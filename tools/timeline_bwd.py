@@ -27,7 +27,7 @@ for _ in range(L):
     del W
 g = torch.randn(a.m, N, device="cuda", generator=g_).bfloat16()
 WG = 1024
-buf = torch.zeros(WG * 4 * 16, dtype=torch.int64, device="cuda")
+buf = torch.zeros(WG * 8 * 16, dtype=torch.int64, device="cuda")
 
 
 def step(i):
@@ -43,7 +43,7 @@ for i in range(L):
     step(i)
 torch.cuda.synchronize()
 bnb.lib.bnb_mi355x_set_stamp_buffer(None)
-t = buf.view(WG, 4, 16).cpu().double()
+t = buf.view(WG, 8, 16).cpu().double()
 t = t[(t[:, :, 0] > 0).any(dim=1)]
 if t.shape[0] == 0:
     print("no stamps: not a profiling build?")
@@ -51,7 +51,7 @@ if t.shape[0] == 0:
 t0 = torch.where(t[:, :, 0] > 0, t[:, :, 0], torch.full_like(t[:, :, 0], 1e30)).min(dim=1, keepdim=True).values
 names = ["start", "loads issued", "table + barrier", "s0 tile stored", "s0 past barrier", "s0 mfma done", "s1 tile stored",
          "s1 past barrier", "s1 mfma done", "s2 tile stored", "s2 past barrier", "s2 mfma done", "step loop done", "end"]
-print(f"# backward kernel, M={a.m}, N={N}, K={K}: {t.shape[0]} workgroups x 4 wavefronts; s_memtime ticks relative to the first "
+print(f"# backward kernel, M={a.m}, N={N}, K={K}: {t.shape[0]} workgroups x 8 wavefronts; s_memtime ticks relative to the first "
       f"wavefront start of the SAME workgroup")
 print(f"{'stamp':20s} {'min':>7s} {'median':>7s} {'p90':>7s} {'max':>7s}   median delta to previous stamp")
 prev = None
