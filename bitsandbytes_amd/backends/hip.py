@@ -430,8 +430,7 @@ def _gemm_4bit_unfused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax
     return torch.nn.functional.linear(A, W, bias)
 
 
-@register_kernel("bitsandbytes::gemm_4bit", "cuda")
-def _(
+def _gemm_4bit_python_kernel(
     A: torch.Tensor,
     B: torch.Tensor,
     shapeB: Sequence[int],
@@ -452,4 +451,29 @@ def _(
     return _gemm_4bit_unfused(*args)
 
 
-__all__ = ["FUSED_MAX_M", "gemm_4bit_grouped", "prod"]
+def _load_native_dispatch() -> bool:
+    """bitsandbytes::gemm_4bit's device kernel registered from C++ (csrc/torch_dispatch.cpp -> libbitsandbytes_mi355x_torch.so):
+    the same glue as `_gemm_4bit_python_kernel` over the same C ABI without a Python frame and ctypes marshalling per call
+    (eager Linear4bit.forward: profiles/r2_host_overhead.txt). Not used when another kernel library was selected with
+    BNB_MI355X_LIBRARY (the dispatcher library is linked against the product library) or with BNB_MI355X_PYTHON_DISPATCH=1."""
+    import os
+
+    from ..cextension import LIB_NAME, LIB_PATH, PACKAGE_DIR
+
+    if os.environ.get("BNB_MI355X_PYTHON_DISPATCH") == "1" or LIB_PATH != PACKAGE_DIR / LIB_NAME:
+        return False
+    path = PACKAGE_DIR / "libbitsandbytes_mi355x_torch.so"
+    if not path.exists():
+        warn(f"{path.name} is not built (make -C bitsandbytes_amd/csrc): gemm_4bit is dispatched through the slower Python glue",
+             RuntimeWarning)
+        return False
+    torch.ops.load_library(str(path))
+    return True
+
+
+NATIVE_DISPATCH = _load_native_dispatch()
+if not NATIVE_DISPATCH:
+    register_kernel("bitsandbytes::gemm_4bit", "cuda")(_gemm_4bit_python_kernel)
+
+
+__all__ = ["FUSED_MAX_M", "NATIVE_DISPATCH", "gemm_4bit_grouped", "prod"]

@@ -1,0 +1,186 @@
+// bitsandbytes::gemm_4bit registered from C++ for the HIP ("CUDA" dispatch key) device: the host side of one
+// Linear4bit.forward without a Python frame between the dispatcher and the C ABI.
+//
+// The Python kernel of the same op (bitsandbytes_amd/backends/hip.py, the counterpart of the reference's
+// bitsandbytes/backends/cuda/ops.py:921-982) costs ~10 us per call in eager mode for a ~4 us kernel (profiles/r1_host_overhead.txt):
+// argument boxing, a Python frame, ctypes marshalling of 19 arguments. This translation unit does the same glue - validation,
+// contiguity, output allocation from torch's caching allocator, current raw stream, device guard, split-K scratch, routing
+// between the fused kernels and dequantize + hipBLASLt - in C++ and calls the UNCHANGED C ABI of libbitsandbytes_mi355x.so
+// (include/bnb_mi355x.h). PyTorch is plumbing here: no arithmetic of the path happens in this file except the reference's own
+// large-batch strategy (dequantize once, then at::linear; reference backends/cuda/ops.py:904-916).
+//
+// Built by the Makefile with g++ (no device code) into bitsandbytes_amd/libbitsandbytes_mi355x_torch.so and loaded with
+// torch.ops.load_library by backends/hip.py, which then leaves the op's "cuda" kernel to this library.
+#include <Python.h>
+
+#include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <torch/library.h>
+
+#include <limits>
+#include <optional>
+#include <string>
+
+#include "../../include/bnb_mi355x.h"
+
+namespace {
+
+// keep in step with bitsandbytes_amd/backends/hip.py (FUSED_MAX_M, _REFERENCE_CUSTOM_MAX_M, _gemm_4bit_route); the GPU test
+// tests/test_gpu_parity.py::test_native_dispatch_matches_python_kernel runs both over fused and unfused shapes
+constexpr int64_t kFusedMaxM = 128;
+constexpr int64_t kFusedMaxMFp32 = 4;
+constexpr int64_t kReferenceCustomMaxM = 256; // reference backends/cuda/ops.py:816
+
+int dtype_code(at::ScalarType t) {
+    switch (t) {
+    case at::kFloat:
+        return 0;
+    case at::kHalf:
+        return 1;
+    case at::kBFloat16:
+        return 2;
+    default:
+        TORCH_CHECK(false, "unsupported dtype ", t);
+    }
+}
+
+int quant_code(c10::string_view quant_type) {
+    if (quant_type == "fp4")
+        return 1;
+    if (quant_type == "nf4")
+        return 2;
+    TORCH_CHECK(false, "quant_type must be 'nf4' or 'fp4', got '", std::string(quant_type), "'");
+}
+
+const void* ptr(const std::optional<at::Tensor>& t) { return t.has_value() ? t->const_data_ptr() : nullptr; }
+
+void check_c_int(int64_t n, const char* what) {
+    // the reference ABI carries element counts as C int (csrc/pythonInterface.cpp:346-444)
+    TORCH_CHECK_VALUE(n <= std::numeric_limits<int>::max(), what, ": ", n, " elements exceed the C-ABI limit of 2**31 - 1");
+}
+
+// The reference raises this as a Python UserWarning from the op's kernel (backends/cuda/ops.py:956-962). TORCH_WARN from a
+// library loaded with torch.ops.load_library only reaches stderr (no Python warning handler is installed around the call, and
+// the GIL is released), so the warning is raised through the interpreter directly when there is one.
+void warn_user(const std::string& msg) {
+    if (!Py_IsInitialized()) {
+        TORCH_WARN(msg);
+        return;
+    }
+    const PyGILState_STATE gil = PyGILState_Ensure();
+    const int rc = PyErr_WarnEx(PyExc_UserWarning, msg.c_str(), 1);
+    if (rc < 0)
+        PyErr_Clear(); // warnings turned into errors by a filter: reported as the op's error below
+    PyGILState_Release(gil);
+    TORCH_CHECK(rc >= 0, msg);
+}
+
+void dequantize_4bit_into(const at::Tensor& B, const at::Tensor& absmax, int64_t blocksize, int qt, at::Tensor& W, hipStream_t stream) {
+    check_c_int(W.numel(), "dequantize_4bit");
+    const bool nf4 = qt == 2;
+    auto* packed = static_cast<unsigned char*>(B.data_ptr());
+    auto* am = static_cast<float*>(absmax.data_ptr());
+    const int bs = static_cast<int>(blocksize), n = static_cast<int>(W.numel());
+    switch (W.scalar_type()) {
+    case at::kFloat:
+        (nf4 ? cdequantize_blockwise_fp32_nf4 : cdequantize_blockwise_fp32_fp4)(nullptr, packed, am, static_cast<float*>(W.data_ptr()), bs, n, stream);
+        break;
+    case at::kHalf:
+        (nf4 ? cdequantize_blockwise_fp16_nf4 : cdequantize_blockwise_fp16_fp4)(nullptr, packed, am, W.data_ptr(), bs, n, stream);
+        break;
+    default:
+        (nf4 ? cdequantize_blockwise_bf16_nf4 : cdequantize_blockwise_bf16_fp4)(nullptr, packed, am, W.data_ptr(), bs, n, stream);
+        break;
+    }
+}
+
+at::Tensor gemm_4bit_hip(const at::Tensor& A_in, const at::Tensor& B_in, at::IntArrayRef shapeB, const at::Tensor& absmax_in, int64_t blocksize,
+                         c10::string_view quant_type, const std::optional<at::Tensor>& bias_in, const std::optional<at::Tensor>& absmax_8bit_in,
+                         const std::optional<at::Tensor>& absmax_code_in, const std::optional<at::Tensor>& absmax_offset_in) {
+    TORCH_CHECK(shapeB.size() == 2, "shapeB must be [N, K]");
+    const int64_t K = A_in.dim() > 0 ? A_in.size(-1) : 0;
+    const int64_t M = K ? A_in.numel() / K : 0;
+    const int64_t N = shapeB[0];
+    const int dt = dtype_code(A_in.scalar_type());
+    const int qt = quant_code(quant_type);
+    TORCH_CHECK(K == shapeB[1], "A inner dim (", K, ") does not match weight (", shapeB[1], ")");
+    TORCH_CHECK(absmax_in.scalar_type() == at::kFloat, "absmax must be float32, got ", absmax_in.scalar_type());
+    std::optional<at::Tensor> bias;
+    if (bias_in.has_value()) {
+        TORCH_CHECK(bias_in->dim() == 1, "bias must be 1D, got ", bias_in->dim(), "D");
+        TORCH_CHECK(bias_in->scalar_type() == A_in.scalar_type(), "bias dtype (", bias_in->scalar_type(), ") must match A dtype (",
+                    A_in.scalar_type(), ")");
+        bias = bias_in->contiguous();
+    }
+    // (PyTorch-ROCm presents HIP devices under the "cuda" device type: its guard / stream classes for that are these)
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(std::optional<c10::Device>(A_in.device()));
+    hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(A_in.get_device()).stream();
+    const at::Tensor A = A_in.contiguous();
+    const at::Tensor B = B_in.contiguous();
+    const at::Tensor absmax = absmax_in.contiguous();
+
+    // ---- MI355X routing (backends/hip.py:_gemm_4bit_route; replaces reference backends/cuda/ops.py:814-843,921-962)
+    bool fused;
+    if (blocksize <= 0 || K % blocksize != 0) {
+        if (M <= kReferenceCustomMaxM)
+            warn_user(c10::str("inner dimension (", K, ") is not aligned for fast kernel with blocksize=", blocksize,
+                               ", falling back to slower implementation."));
+        fused = false;
+    } else {
+        fused = M <= (dt == 0 ? kFusedMaxMFp32 : kFusedMaxM);
+    }
+
+    if (!fused) {
+        // dequantize once + library GEMM: the reference's own strategy for these batches (backends/cuda/ops.py:904-916)
+        at::Tensor am = absmax;
+        if (absmax_8bit_in.has_value()) {
+            TORCH_CHECK(absmax_code_in.has_value() && absmax_offset_in.has_value(), "nested absmax needs absmax_code and absmax_offset");
+            const at::Tensor a8 = absmax_8bit_in->contiguous();
+            const at::Tensor code = absmax_code_in->contiguous();
+            TORCH_CHECK(a8.scalar_type() == at::kByte, "A must be uint8, got ", a8.scalar_type());
+            check_c_int(a8.numel(), "dequantize_blockwise");
+            at::Tensor dq = at::empty(a8.sizes(), a8.options().dtype(at::kFloat));
+            cdequantize_blockwise_fp32(static_cast<float*>(code.data_ptr()), static_cast<unsigned char*>(a8.data_ptr()),
+                                       static_cast<float*>(absmax.data_ptr()), static_cast<float*>(dq.data_ptr()), 256,
+                                       static_cast<int>(a8.numel()), stream);
+            am = dq + *absmax_offset_in;
+        }
+        at::Tensor W = at::empty(shapeB, A.options());
+        dequantize_4bit_into(B, am, blocksize, qt, W, stream);
+        return at::linear(A, W, bias);
+    }
+
+    check_c_int(M, "gemm_4bit M");
+    check_c_int(N, "gemm_4bit N");
+    check_c_int(K, "gemm_4bit K");
+    auto out_sizes = A.sizes().vec();
+    out_sizes.back() = N;
+    at::Tensor out = at::empty(out_sizes, A.options());
+    std::optional<at::Tensor> a8, code, offset;
+    if (absmax_8bit_in.has_value())
+        a8 = absmax_8bit_in->contiguous();
+    if (absmax_code_in.has_value())
+        code = absmax_code_in->contiguous();
+    if (absmax_offset_in.has_value())
+        offset = absmax_offset_in->to(at::kFloat);
+    // split-K scratch for the MFMA kernels comes from torch's caching allocator: stream-ordered and legal under hipGraph
+    // capture (the library never has to allocate). M <= 2 always runs the streaming kernel, which needs none.
+    at::Tensor ws;
+    size_t ws_bytes = 0;
+    if (M > 2)
+        ws_bytes = bnb_mi355x_gemm_4bit_workspace_bytes(0, dt, static_cast<int>(M), static_cast<int>(N), static_cast<int>(K), static_cast<int>(blocksize));
+    if (ws_bytes)
+        ws = at::empty({static_cast<int64_t>(ws_bytes)}, A.options().dtype(at::kByte));
+    bnb_mi355x_gemm_4bit(0, dt, A.const_data_ptr(), static_cast<const uint8_t*>(B.const_data_ptr()), static_cast<const float*>(absmax.const_data_ptr()),
+                         static_cast<const uint8_t*>(ptr(a8)), static_cast<const float*>(ptr(code)), static_cast<const float*>(ptr(offset)), nullptr,
+                         out.data_ptr(), ptr(bias), static_cast<int>(M), static_cast<int>(N), static_cast<int>(K), static_cast<int>(blocksize), qt,
+                         ws_bytes ? ws.data_ptr() : nullptr, ws_bytes, stream);
+    return out;
+}
+
+} // namespace
+
+// The schema is defined by bitsandbytes_amd/_ops.py (string-identical to the reference's bitsandbytes/_ops.py:239-295), or by the
+// reference package itself when that is imported first; this only adds the device kernel.
+TORCH_LIBRARY_IMPL(bitsandbytes, CUDA, m) { m.impl("gemm_4bit", &gemm_4bit_hip); }

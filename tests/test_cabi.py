@@ -57,6 +57,27 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
         importlib.reload(ce)
 
 
+def test_native_dispatch_library_registers_gemm_4bit():
+    """csrc/torch_dispatch.cpp -> libbitsandbytes_mi355x_torch.so: loads (linked against the product library next to it),
+    provides the device kernel of bitsandbytes::gemm_4bit, and the Python glue steps aside; BNB_MI355X_PYTHON_DISPATCH=1 keeps
+    the Python kernel instead."""
+    import subprocess
+    import sys
+
+    code = (
+        "import torch, bitsandbytes_amd as b\n"
+        "from bitsandbytes_amd.backends import hip\n"
+        "assert torch._C._dispatch_has_kernel_for_dispatch_key('bitsandbytes::gemm_4bit', 'CUDA')\n"
+        "maps = open('/proc/self/maps').read()\n"
+        "print('NATIVE' if hip.NATIVE_DISPATCH else 'PYTHON', 'libbitsandbytes_mi355x_torch.so' in maps)\n"
+    )
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert "NATIVE True" in out.stdout, out.stderr[-2000:]
+    env = dict(os.environ, BNB_MI355X_PYTHON_DISPATCH="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env)
+    assert "PYTHON False" in out.stdout, out.stderr[-2000:]
+
+
 def test_no_cpu_kernels_registered_by_product():
     """Calling an op on CPU tensors must fail (no CPU kernel) unless a test registered the oracle."""
     import subprocess

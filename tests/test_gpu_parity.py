@@ -1071,6 +1071,65 @@ def test_opcheck_schema_and_fake_kernels():
         torch.library.opcheck(op, args, kwargs, test_utils=("test_schema", "test_faketensor"))
 
 
+def test_native_dispatch_matches_python_kernel():
+    """bitsandbytes::gemm_4bit is served by the C++-registered kernel (csrc/torch_dispatch.cpp); it must route, validate and
+    compute exactly like the Python kernel it replaces: fused stream / MFMA shapes, nested absmax, bias, batch dims, the
+    unfused large-batch route, the misaligned-K warning route, non-contiguous inputs, and the same errors."""
+    import warnings
+
+    from bitsandbytes_amd.backends import hip
+
+    assert hip.NATIVE_DISPATCH, "libbitsandbytes_mi355x_torch.so was not loaded"
+    F = _F()
+    op = torch.ops.bitsandbytes.gemm_4bit.default
+    torch.manual_seed(11)
+    for (lead, N, K, bs, qt, dq, dtype, with_bias) in [
+        ((1,), 512, 1024, 64, "nf4", False, torch.bfloat16, False),
+        ((2, 3), 384, 2048, 128, "fp4", True, torch.float16, True),
+        ((24,), 256, 1024, 64, "nf4", True, torch.bfloat16, True),
+        ((64,), 512, 2048, 64, "nf4", False, torch.bfloat16, False),
+        ((3,), 256, 1024, 64, "nf4", False, torch.float32, True),
+        ((8,), 256, 1024, 64, "fp4", False, torch.float32, False),       # fp32 above 4 rows: unfused
+        ((200,), 256, 1024, 64, "nf4", True, torch.bfloat16, True),      # above FUSED_MAX_M: unfused
+        ((5,), 64, 96, 64, "nf4", False, torch.bfloat16, True),          # K % blocksize != 0: warning + unfused
+    ]:
+        W = (torch.randn(N, K, device=DEV) / K**0.5).to(dtype)
+        q, st = F.quantize_4bit(W, blocksize=bs, quant_type=qt, compress_statistics=dq)
+        x = torch.randn(*lead, K, device=DEV, dtype=dtype)
+        bias = torch.randn(N, device=DEV, dtype=dtype) if with_bias else None
+        if dq:
+            args = (x, q, st.shape, st.state2.absmax, bs, qt, bias, st.absmax, st.state2.code, st.offset)
+        else:
+            args = (x, q, st.shape, st.absmax, bs, qt, bias)
+        with warnings.catch_warnings(record=True) as w_native:
+            warnings.simplefilter("always")
+            got = op(*args)
+        with warnings.catch_warnings(record=True) as w_py:
+            warnings.simplefilter("always")
+            want = hip._gemm_4bit_python_kernel(*args)
+        assert got.shape == (*lead, N) and got.dtype == dtype
+        assert torch.equal(got, want), (lead, N, K, bs, qt, dq, dtype)
+        misaligned = K % bs != 0
+        assert any("not aligned for fast kernel" in str(m.message) for m in w_native) == misaligned
+        assert any("not aligned for fast kernel" in str(m.message) for m in w_py) == misaligned
+    # non-contiguous activations are made contiguous by the glue
+    xt = torch.randn(K, 4, device=DEV, dtype=dtype).t()
+    assert torch.equal(op(xt, q, st.shape, st.absmax, bs, qt), hip._gemm_4bit_python_kernel(xt.contiguous(), q, st.shape, st.absmax, bs, qt))
+    # the same argument errors
+    W = torch.randn(64, 128, device=DEV).bfloat16()
+    q, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4")
+    x = torch.randn(2, 128, device=DEV).bfloat16()
+    for bad in (
+        lambda f: f(x[:, :64], q, st.shape, st.absmax, 64, "nf4"),                                   # inner dim mismatch
+        lambda f: f(x, q, st.shape, st.absmax.half(), 64, "nf4"),                                    # absmax dtype
+        lambda f: f(x, q, st.shape, st.absmax, 64, "nf4", torch.zeros(64, device=DEV)),              # bias dtype
+        lambda f: f(x, q, st.shape, st.absmax, 64, "nf4", torch.zeros(1, 64, device=DEV).bfloat16()),  # bias rank
+    ):
+        for f in (op, hip._gemm_4bit_python_kernel):
+            with pytest.raises(RuntimeError):
+                bad(f)
+
+
 def test_linear4bit_under_torch_compile_aot_eager():
     """Fake kernels are sufficient to trace Linear4bit without graph breaks (reference
     tests/test_linear4bit.py:359-420 compiles with inductor; aot_eager needs no host C++ toolchain)."""

@@ -39,8 +39,10 @@ with torch.no_grad():
         ("Linear4bit.forward", lambda: layer(x)),
         ("matmul_4bit", lambda: bnb.matmul_4bit(x, q, st)),
         ("torch.ops.bitsandbytes.gemm_4bit", lambda: torch.ops.bitsandbytes.gemm_4bit.default(x, q, st.shape, st.absmax, 64, "nf4")),
+        ("Python kernel of the op (replaced)", lambda: hip._gemm_4bit_python_kernel(x, q, st.shape, st.absmax, 64, "nf4")),
         ("backend _gemm_4bit_fused(out=)", lambda: hip._gemm_4bit_fused(x, q, st.shape, st.absmax, 64, "nf4", None, None, None, None, out=out)),
         ("torch.add (reference point)", lambda: torch.add(x, x)),
     ]
+    print(f"# native dispatch (csrc/torch_dispatch.cpp) loaded: {hip.NATIVE_DISPATCH}")
     for name, fn in rows:
         print(f"{name:36s} {timeit(fn):7.1f} us per call")
