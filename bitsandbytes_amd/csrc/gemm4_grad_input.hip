@@ -2,26 +2,32 @@
 //     grad_A[m, k] = sum_n grad_out[m, n] * T(code[B[n, k]] * scale[n, k / bs])          (bf16 / fp16)
 //
 // The reference computes this as dequantize_4bit(B) -> [N, K] in T, then a dense matmul (autograd/_functions.py:365-386):
-// (0.5 + 2 + 2) bytes per weight through HBM against 0.56 when the dequantized tile never leaves the CU. Here the weight
-// tile is dequantized into LDS - the same arithmetic as dequantize_4bit: fp32 product, ONE rounding to T - and multiplied
-// from there, so the result equals the unfused path up to the order of the fp32 sums.
+// (0.5 + 2 + 2) bytes per weight through HBM against 0.56 when the dequantized weights never leave the CU. Here they never
+// even leave the registers: every weight is decoded with the arithmetic of dequantize_4bit - fp32 product, ONE rounding to
+// T - straight into the MFMA operand, so the result equals the unfused path up to the order of the fp32 sums.
 //
-// Why this is not the forward kernel with the operands swapped: the contraction now runs over n, the weight ROW index, while
+// Why this is not the forward kernel with the operands swapped: the contraction runs over n, the weight ROW index, while
 // the packed format keeps k contiguous and the scale is indexed by (n, k / bs) - it varies along the contraction, so it
 // cannot be applied to a partial tile after the matrix instruction and has to be folded into the operand. The MFMA B
-// operand wants, per lane, 8 consecutive n at one k: a column of the row-major tile. gfx950's ds_read_b64_tr_b16 delivers
-// exactly that from a row-major LDS image (semantics probed on the device, tools/ubench/tr_probe.hip: inside a 16-lane
-// group lane 4 j + q addresses the 8-byte piece q of row j, and lane i receives column i of the resulting 4 x 16 block).
+// operand wants, per lane, 8 consecutive n at one k: a COLUMN of the row-major weights.
 //
-//  * A workgroup (8 wavefronts, two per SIMD: the decode phase of one overlaps the LDS / MFMA latencies of the other) owns
-//    128 k-columns x 64 batch rows x a slice of N and walks it in steps of 64 n.
-//  * Per step every thread loads 8 packed bytes (16 k of one weight row; eight threads cover a row's 64 bytes) and its
-//    scale, decodes through the bank-private byte -> (code[hi], code[lo]) fp32 table (one v_perm_b32 + one ds_read_b64 per
-//    byte), multiplies, rounds to T and stores 32 bytes of the [64 n][128 k] tile; the 64 x 64 grad_out tile is staged
-//    through LDS as well (coalesced 16-byte pieces in, 16-byte MFMA A fragments out). The loads of steps s + 1 .. s + 3 are
-//    in flight while step s is multiplied (register ring); tiles are double-buffered: one barrier per step.
-//  * Wavefront w multiplies its 16 columns (one MFMA column tile) with the four 16-row batch tiles: 8 MFMAs per step.
-//  * N slices across workgroups fill the chip; fp32 slabs are added in slice order by gemm4_finalize: bit-reproducible.
+// The first version of this kernel dequantized a [64 n][128 k] tile into LDS and read it back transposed
+// (ds_read_b64_tr_b16); its timeline (profiles/r2_timeline_bwd.txt) showed it bound by LDS bandwidth: 136 KB through LDS
+// per 4 KB of packed weights. This version needs no transposition at all:
+//
+//  * lane (c, g) of a wavefront (c = lane % 16, g = lane / 16) loads ONE DWORD (8 k: columns 8c .. 8c+7) from each of the 8
+//    weight rows n0 + 8g .. n0 + 8g + 7 - a quad of lanes reads 16 contiguous bytes, a wavefront-wide load 4 rows x 64 B.
+//    Nibble j of the lane's 8 dwords IS the B operand of an MFMA whose 16 columns are {8c + j}: 8 consecutive n at one k,
+//    already in the lane that needs them. The column tiles are strided (j, j + 8, ...), which costs nothing: lane c holds
+//    columns 8c .. 8c+7 of an output row in its 8 accumulators and stores them as one contiguous piece.
+//  * decode: one v_perm_b32 + one ds_read_b64 per byte through the bank-private byte -> (code[hi], code[lo]) fp32 table,
+//    a packed multiply by the row's scale, one convert per (row pair, column): 8 B of LDS traffic per packed byte, nothing else.
+//  * a wavefront owns a whole 32-n block x 128 k x 64 batch rows: 32 MFMAs per block with 128 accumulator registers; its
+//    grad_out block [64 m][32 n] (coalesced loads) and its 64 scales pass through a PRIVATE LDS patch on their way to the
+//    fragment layout - no barrier anywhere in the main loop, the 8 wavefronts of a workgroup run decoupled.
+//  * the wavefronts of a workgroup take different n blocks of the workgroup's N slice; their partial tiles are added through
+//    LDS in a fixed order at the end. N slices across workgroups fill the chip; fp32 slabs are added in slice order by
+//    gemm4_finalize: bit-reproducible.
 #include "bnb_common.h"
 
 namespace bnb {
@@ -68,15 +74,19 @@ template <> struct GiMma<f16> {
     }
 };
 
-constexpr int kGiCols = 128;      // k-columns per workgroup
-constexpr int kGiRows = 64;       // batch rows per workgroup (4 MFMA row tiles)
-constexpr int kGiStep = 64;       // n per step (two MFMA k-steps)
+constexpr int kGiCols = 128;      // k-columns per workgroup = per wavefront (16 lanes x 8)
+constexpr int kGiMaxRows = 64;    // batch rows per workgroup: 16 MT, MT = 1, 2 or 4 MFMA row tiles (template parameter)
+constexpr int kGiBlockN = 32;     // n per wavefront block (one MFMA reduction: 4 lane groups x 8)
+constexpr int kGiWaves = 8;       // wavefronts per workgroup (a 4-wavefront variant with a deeper ring measured the same within noise)
 constexpr int kGiLut = 65536;     // 256 entries x 32 copies x 8 B (fp32 pair), at LDS address 0
-constexpr int kGiWStride = 288;   // bytes per row of the dequantized tile: 256 + 32 (consecutive rows in different banks)
-constexpr int kGiGStride = 128;   // bytes per row of the grad_out tile (16-byte chunk c of row m stored at c ^ (m & 7))
-constexpr int kGiWTile = kGiStep * kGiWStride;
-constexpr int kGiGTile = kGiRows * kGiGStride;
-constexpr int kGiLds = kGiLut + 2 * kGiWTile + 2 * kGiGTile + 1024;
+constexpr int kGiGPatch = kGiMaxRows * kGiBlockN * 2; // one wavefront's grad_out block [<= 64 m][32 n] in T: 4 KiB
+constexpr int kGiSPatch = 256;    // ... and its scales [2 halves of the 128 columns][32 rows] fp32
+constexpr int gi_acc_bytes(int mt) { return 16 * mt * kGiCols * 4; } // one wavefront's fp32 partial tile: 8 KiB per row tile
+// LDS: table | nested code (1 KiB) | per-wavefront patches; the final reduction reuses everything from address 0
+constexpr int gi_lds_bytes(int mt) {
+    const int loop = kGiLut + 1024 + kGiWaves * (kGiGPatch + kGiSPatch);
+    return (4 * gi_acc_bytes(mt) > loop) ? 4 * gi_acc_bytes(mt) : loop;
+}
 
 #ifdef BNB_PROFILING
 #define BNB_GI_STAMP(i)                                                                            \
@@ -109,13 +119,11 @@ __device__ __forceinline__ float gi_code_literal(int i, bool fp4) {
     return v;
 }
 
-constexpr int kGiThreads = 512;
-
-// grid = (K / 128, nslices, ceil(M / 64)); 512 threads
-template <typename T, bool NESTED>
-__global__ __launch_bounds__(kGiThreads) void gemm4_grad_input_kernel(
+// grid = (K / 128, nslices, ceil(M / (16 MT))); 512 threads
+template <typename T, bool NESTED, int MT>
+__global__ __launch_bounds__(kGiWaves * 64) void gemm4_grad_input_kernel(
     const void* hot_G, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, int hot_M, int hot_N,
-    int hot_K, int hot_flags /* bs_shift | fp4 << 8 */, int hot_sps /* steps per N slice */, int hot_nslices, const GiArgs p) {
+    int hot_K, int hot_flags /* bs_shift | fp4 << 8 */, int hot_bps /* 32-n blocks per N slice */, int hot_nslices, const GiArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -125,56 +133,74 @@ __global__ __launch_bounds__(kGiThreads) void gemm4_grad_input_kernel(
     const bool fp4 = (hot_flags >> 8) & 1;
     BNB_GI_STAMP(0)
     const int k0 = blockIdx.x * kGiCols;
-    const int m_base = blockIdx.z * kGiRows;
-    const int steps_total = N / kGiStep;
-    const int sb = blockIdx.y * hot_sps;
-    int se = sb + hot_sps;
-    se = se < steps_total ? se : steps_total;
-
-    unsigned char* const wtiles = smem + kGiLut;
-    unsigned char* const gtiles = wtiles + 2 * kGiWTile;
-    float* const code2 = reinterpret_cast<float*>(gtiles + 2 * kGiGTile);
-
-    // ---- per-thread roles of the loads: weight row (tid >> 3) of the step, 8-byte piece (tid & 7) = 16 k = one MFMA
-    // column tile; grad_out row (tid >> 3) of the batch tile, 16-byte piece (tid & 7) = 8 n
-    const int wr = tid >> 3, wp = tid & 7;
-    const uint8_t* const wsrc = hot_B + static_cast<long>(wr) * (K >> 1) + ((k0 + 16 * wp) >> 1);
-    const long we0 = static_cast<long>(wr) * K + k0 + 16 * wp; // flat element index of the piece at n = 0
-    int grow = m_base + wr;
-    grow = grow < M ? grow : M - 1; // rows past the end of the batch re-read the last row: never stored
-    const T* const gsrc = static_cast<const T*>(hot_G) + static_cast<long>(grow) * N + 8 * wp;
-
-    struct Stage {
-        u32x2 w;
-        uint32_t s, s2;
-        u32x4 g;
+    constexpr int kGiAccBytes = gi_acc_bytes(MT);
+    const int m_base = blockIdx.z * (16 * MT);
+    const int blocks_total = N / kGiBlockN;
+    const int bb = blockIdx.y * hot_bps;
+    int be = bb + hot_bps;
+    be = be < blocks_total ? be : blocks_total;
+    // this wavefront's blocks: bb + wave, bb + wave + 8, ... < be
+    static_assert(kGiWaves == 8, "the final reduction is written for 8 partial tiles");
+    const int nb = (be - bb - wave + kGiWaves - 1) / kGiWaves > 0 ? (be - bb - wave + kGiWaves - 1) / kGiWaves : 0;
+    const int last_blk = be - 1;
+    auto block_of = [&](int it) -> int { // clamped: a prefetch past the end re-reads the slice's last block, never used
+        const int b = bb + wave + it * kGiWaves;
+        return b < last_blk ? b : last_blk;
     };
-    // (the step index is clamped to the slice: a harmless re-read at the tail instead of a branch around the loads, so the
-    // compiler's counted waits stay exact)
-    auto issue = [&](Stage& st, int step_unclamped) {
-        const int step = step_unclamped < se ? step_unclamped : se - 1;
-        const long n0 = static_cast<long>(step) * kGiStep;
-        st.w = *reinterpret_cast<const u32x2*>(wsrc + n0 * (K >> 1));
-        const long e = we0 + n0 * K;
+
+    float* const code2 = reinterpret_cast<float*>(smem + kGiLut);
+    unsigned char* const gpatch = smem + kGiLut + 1024 + wave * (kGiGPatch + kGiSPatch);
+    float* const spatch = reinterpret_cast<float*>(gpatch + kGiGPatch);
+
+    const int c = lane & 15, g = lane >> 4;
+    // ---- loads of a block. Weights: row n0 + 8 g + i, the dword of columns 8 c .. 8 c + 7. Scale: lane l fetches the scale of
+    // (row n0 + l / 2, 64-column half l & 1). grad_out: row 16 t + l / 4 of the batch tile, 16-byte piece l & 3 (8 n).
+    const uint8_t* const wsrc = hot_B + static_cast<long>(8 * g) * (K >> 1) + ((k0 + 8 * c) >> 1);
+    const long se0 = static_cast<long>(lane >> 1) * K + k0 + 64 * (lane & 1);
+    const T* gsrc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        int row = m_base + 16 * t + (lane >> 2);
+        row = row < M ? row : M - 1; // rows past the end of the batch re-read the last row: never stored
+        gsrc[t] = static_cast<const T*>(hot_G) + static_cast<long>(row) * N + 8 * (lane & 3);
+    }
+    struct WStage {
+        uint32_t w[8];
+        uint32_t s, s2;
+    };
+    auto issue_w = [&](WStage& st, int it) {
+        const long n0 = static_cast<long>(block_of(it)) * kGiBlockN;
+        const uint8_t* src = wsrc + n0 * (K >> 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            st.w[i] = *reinterpret_cast<const uint32_t*>(src + static_cast<long>(i) * (K >> 1));
+        const long e = (se0 + n0 * K) >> bs_shift;
         if constexpr (NESTED) {
-            st.s = hot_absmax8[e >> bs_shift];
-            st.s2 = __builtin_bit_cast(uint32_t, hot_absmax[(e >> bs_shift) >> 8]);
+            st.s = hot_absmax8[e];
+            st.s2 = __builtin_bit_cast(uint32_t, hot_absmax[e >> 8]);
         } else {
-            st.s = __builtin_bit_cast(uint32_t, hot_absmax[e >> bs_shift]);
+            st.s = __builtin_bit_cast(uint32_t, hot_absmax[e]);
             st.s2 = 0;
         }
-        st.g = *reinterpret_cast<const u32x4*>(gsrc + n0);
+    };
+    auto issue_g = [&](u32x4 (&gr)[MT], int it) {
+        const long n0 = static_cast<long>(block_of(it)) * kGiBlockN;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            gr[t] = *reinterpret_cast<const u32x4*>(gsrc[t] + n0);
     };
 
-    // a three-deep register ring: the loads of step s + 3 are issued while step s is multiplied (one step of compute is far
-    // shorter than an HBM round trip)
-    constexpr int D = 3;
-    if (sb >= se)
+    // weights: a D-deep register ring (block it + D is requested when block it has been decoded); grad_out: requested one
+    // block ahead, right after the previous block's registers went to LDS. Only the first block's loads go out before the
+    // decode table is built (every load instruction costs the CU's address pipeline, and the table build of the other
+    // wavefronts waits at the barrier for the slowest issuer); the rest of the ring follows after the barrier.
+    constexpr int D = (MT == 4) ? 2 : 3; // (three stages spill at MT = 4: 2 wavefronts per SIMD = 256 registers per lane, 128 of them accumulators)
+    WStage st[D];
+    u32x4 gr[MT];
+    if (be <= bb)
         return; // (never: the host makes every N slice non-empty)
-    Stage st[D];
-#pragma unroll
-    for (int j = 0; j < D; ++j)
-        issue(st[j], sb + j);
+    issue_w(st[0], 0);
+    issue_g(gr, 0);
     BNB_GI_STAMP(1)
     __builtin_amdgcn_sched_barrier(0);
 
@@ -184,176 +210,200 @@ __global__ __launch_bounds__(kGiThreads) void gemm4_grad_input_kernel(
     {
         const float cv = gi_code_literal((lane & 15) + opaque_zero(), fp4);
         const int cvb = __builtin_bit_cast(int, cv);
-        const int e = tid & 255, half = tid >> 8;
+        constexpr int PER = 16 * 256 / (kGiWaves * 64); // 16-byte chunks of an entry per thread
+        const int e = tid & 255, part = tid >> 8;
         const float hi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((e >> 4) & 15) * 4, cvb));
         const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e & 15) * 4, cvb));
         const f32x4 v = {hi, lo, hi, lo};
-        f32x4* const dst = reinterpret_cast<f32x4*>(smem + e * 256 + half * 128);
+        f32x4* const dst = reinterpret_cast<f32x4*>(smem + e * 256 + part * (PER * 16));
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            dst[(j + e) & 7] = v;
+        for (int j = 0; j < PER; ++j)
+            dst[(j + e) & (PER - 1)] = v;
     }
     float offset = 0.0f;
     if constexpr (NESTED) {
         if (tid < 256)
             code2[tid] = p.absmax_code[tid];
+        static_assert(kGiWaves * 64 >= 256, "one thread per entry of the nested code");
         offset = p.absmax_offset[0];
     }
     __syncthreads();
     BNB_GI_STAMP(2)
+#pragma unroll
+    for (int j = 1; j < D; ++j)
+        issue_w(st[j], j);
     if (reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem) != 0)
         __builtin_trap(); // the table is addressed with raw v_perm_b32 results: it must sit at LDS address 0
 
     const uint32_t perm_sel = 0x0C0C0400u + static_cast<uint32_t>(opaque_zero()); // {lane offset, weight byte, 0, 0}
     const uint32_t lane_off = static_cast<uint32_t>(lane & 31) * 8u;
-    const int ln = lane & 15, lg = lane >> 4;
 
-    // dequantize this thread's 32 weights and store them (and its grad_out pieces) into LDS buffer `buf`
-    auto stage_to_lds = [&](const Stage& s, int buf) {
-        float scale;
-        if constexpr (NESTED) {
-            const uint32_t q = s.s, a2 = s.s2;
-            scale = __fadd_rn(__fmul_rn(code2[q & 0xFFu], __builtin_bit_cast(float, a2)), offset);
-        } else {
-            const uint32_t sv = s.s;
-            scale = __builtin_bit_cast(float, sv);
+    // private grad_out patch: row r (64 B) holds its 16-byte piece q at q ^ f(r), f = {0, 3, 2, 1}[(r / 4) % 4] - conflict-free
+    // for the 8-contiguous-lane passes of ds_write_b128 (two rows x four pieces) and for the 16-lane groups {0-3, 12-15,
+    // 20-27}, {4-11, 16-19, 28-31}, + 32 of the ds_read_b128 fragment reads (lane (m, g): row 16 mt + m, piece g)
+    auto swz = [](int r) -> int { return (4 - ((r >> 2) & 3)) & 3; };
+    const int wrow = lane >> 2, wpiece = lane & 3;
+    const uint32_t g_wr = static_cast<uint32_t>(wrow * 64 + ((wpiece ^ swz(wrow)) << 4));  // + t * 1024
+    const uint32_t g_rd = static_cast<uint32_t>(c * 64 + ((g ^ swz(c)) << 4));             // + mt * 1024
+    const uint32_t s_wr = static_cast<uint32_t>(((lane & 1) * 32 + (lane >> 1)) * 4);
+    const uint32_t s_rd = static_cast<uint32_t>(((c >> 3) * 32 + 8 * g) * 4);
+
+    f32x4 acc[MT][8];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // one 32-n block: ISSUE = whether later blocks are prefetched (off in the peeled tail)
+    auto do_block = [&](WStage& ws, int it) {
+        // grad_out block and scales: registers -> private patch (LDS operations of one wavefront execute in order: the
+        // fragment reads of the previous block are done before these writes land)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            *reinterpret_cast<u32x4*>(gpatch + t * 1024 + g_wr) = gr[t];
+        {
+            float scale;
+            if constexpr (NESTED) {
+                const uint32_t q = ws.s, a2 = ws.s2;
+                scale = __fadd_rn(__fmul_rn(code2[q & 0xFFu], __builtin_bit_cast(float, a2)), offset);
+            } else {
+                const uint32_t sv = ws.s;
+                scale = __builtin_bit_cast(float, sv);
+            }
+            *reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(spatch) + s_wr) = scale;
         }
-        // (the 32-byte column blocks of rows 8..15 (mod 16) are stored 4 blocks away: the transpose read serves 32 lanes per
-        // pass = rows j and 8 + j of one column block, which a plain row stride puts into the same banks)
-        unsigned char* const wrow = wtiles + buf * kGiWTile + wr * kGiWStride + ((wp ^ (4 * ((wr >> 3) & 1))) * 32);
-        // all 8 look-ups in flight before the first product
-        f32x2 pr[8];
+        issue_g(gr, it + 1);
+        if (it < 3)
+            BNB_GI_STAMP(3 + 3 * it)
+        const f32x4 s_lo = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(spatch) + s_rd);
+        const f32x4 s_hi = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(spatch) + s_rd + 16);
+        const float sc[8] = {s_lo[0], s_lo[1], s_lo[2], s_lo[3], s_hi[0], s_hi[1], s_hi[2], s_hi[3]};
+        u32x4 af[MT];
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const uint32_t w = s.w[d];
+        for (int mt = 0; mt < MT; ++mt)
+            af[mt] = *reinterpret_cast<const u32x4*>(gpatch + mt * 1024 + g_rd);
+        if (it < 3)
+            BNB_GI_STAMP(4 + 3 * it)
+        // byte b of the lane's 8 dwords = columns 8 c + 2 b (high nibbles) and 8 c + 2 b + 1 (low nibbles) of rows 8 g .. 8 g + 7
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                pr[4 * d + q] = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>(
-                    __builtin_amdgcn_perm(w, lane_off, perm_sel + (q << 8)));
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int b = 0; b < 4; ++b) {
+            f32x2 pr[8];
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            u32x4 o;
+            for (int i = 0; i < 8; ++i)
+                pr[i] = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>(
+                    __builtin_amdgcn_perm(ws.w[i], lane_off, perm_sel + (b << 8)));
+            u32x4 bx, by;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int d = 0; d < 4; ++d) {
                 // the reference's dequantize rounds the fp32 product to T once (csrc/cpu_ops.cpp:419-431). bf16 has no fused
                 // multiply-convert on gfx950, so the plain expression already is "product in fp32, then one rounding"; for fp16
                 // hipcc would fuse it into v_fma_mix*_f16 (one rounding of the exact product): an opaque (non-volatile: it may
                 // be scheduled freely) register copy keeps the two steps apart
-                f32x2 pv = pr[4 * d + q] * f32x2{scale, scale};
+                f32x2 p0 = pr[2 * d] * f32x2{sc[2 * d], sc[2 * d]};
+                f32x2 p1 = pr[2 * d + 1] * f32x2{sc[2 * d + 1], sc[2 * d + 1]};
                 if constexpr (sizeof(T) == 2 && !__is_same(T, bf16)) {
-                    float p0 = pv[0], p1 = pv[1];
-                    asm("" : "+v"(p0));
-                    asm("" : "+v"(p1));
-                    pv = f32x2{p0, p1};
+                    float a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1];
+                    asm("" : "+v"(a0));
+                    asm("" : "+v"(a1));
+                    asm("" : "+v"(b0));
+                    asm("" : "+v"(b1));
+                    p0 = f32x2{a0, a1};
+                    p1 = f32x2{b0, b1};
                 }
-                o[q] = GiMma<T>::pack(pv[0], pv[1]);
-            }
-            *reinterpret_cast<u32x4*>(wrow + d * 16) = o;
-        }
-        // grad_out tile: 16-byte chunk c of row m at position c ^ (m & 7) - conflict-free for the 8-contiguous-lane groups of
-        // ds_write_b128 here and for the 16-lane groups {0-3, 12-15, 20-27}, ... of the ds_read_b128 fragment reads below
-        *reinterpret_cast<u32x4*>(gtiles + buf * kGiGTile + wr * kGiGStride + ((wp ^ (wr & 7)) << 4)) = s.g;
-    };
-
-    f32x4 acc[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-        acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // per-lane LDS addresses: transpose read - lane (i = ln, group lg) addresses row 8 lg + (i >> 2), 8-byte piece (i & 3) of a
-    // 16-column block; A fragment - row ln of a batch tile, 16 bytes at n = 8 lg
-    // (column block = wave, stored at block ^ 4 for rows with bit 3 set, i.e. for odd lane groups)
-    const uint32_t tr_lane = static_cast<uint32_t>((8 * lg + (ln >> 2)) * kGiWStride + (ln & 3) * 8 +
-                                                   ((static_cast<uint32_t>(wave) ^ static_cast<uint32_t>((lg & 1) * 4)) << 5));
-    const uint32_t a_row = static_cast<uint32_t>(ln * kGiGStride); // + ((4 ks + lg) ^ (row & 7)) << 4
-
-    auto do_step = [&](Stage& stg, int step) {
-        const int buf = (step - sb) & 1;
-        stage_to_lds(stg, buf);
-        if (step - sb < 3)
-            BNB_GI_STAMP(3 + 3 * (step - sb))
-        __syncthreads();
-        if (step - sb < 3)
-            BNB_GI_STAMP(4 + 3 * (step - sb))
-        issue(stg, step + D);
-        const uint32_t wbase = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)(wtiles + buf * kGiWTile)));
-        const unsigned char* const gb = gtiles + buf * kGiGTile;
-        // both k-steps' fragments are requested before the first MFMA (one exposed LDS round trip per step instead of two)
-        u32x4 bf[2], af[2][4];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                u32x2 v;
-                const uint32_t addr = wbase + tr_lane + static_cast<uint32_t>((32 * ks + 4 * h) * kGiWStride);
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-                bf[ks][2 * h] = v[0];
-                bf[ks][2 * h + 1] = v[1];
+                bx[d] = GiMma<T>::pack(p0[0], p1[0]);
+                by[d] = GiMma<T>::pack(p0[1], p1[1]);
             }
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                af[ks][mt] = *reinterpret_cast<const u32x4*>(gb + mt * 16 * kGiGStride + a_row + (((4 * ks + lg) ^ (ln & 7)) << 4));
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[mt][2 * b] = GiMma<T>::run(af[mt], bx, acc[mt][2 * b]);
+                acc[mt][2 * b + 1] = GiMma<T>::run(af[mt], by, acc[mt][2 * b + 1]);
+            }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the transpose reads are invisible to the compiler's counters
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                acc[mt] = GiMma<T>::run(af[ks][mt], bf[ks], acc[mt]);
-        if (step - sb < 3)
-            BNB_GI_STAMP(5 + 3 * (step - sb))
+        if (it < 3)
+            BNB_GI_STAMP(5 + 3 * it)
+        issue_w(ws, it + D);
     };
-    // whole rounds of D steps with nothing conditional around the loads (a branch around a load makes the compiler merge
-    // the pending-load state of both paths at the join and wait with vmcnt(0): that drained the prefetch ring every step),
-    // then the tail
-    int base = sb;
-    for (; base + D <= se; base += D) {
+    // whole rounds of the ring with nothing conditional around the loads (a branch around a load makes the compiler merge
+    // the pending-load state of both paths at the join and wait with vmcnt(0)), then the tail
+    int it = 0;
+    for (; it + D <= nb; it += D) {
 #pragma unroll
         for (int j = 0; j < D; ++j)
-            do_step(st[j], base + j);
+            do_block(st[j], it + j);
     }
 #pragma unroll
-    for (int j = 0; j < D; ++j)
-        if (base + j < se)
-            do_step(st[j], base + j);
+    for (int j = 0; j < D - 1; ++j)
+        if (it + j < nb)
+            do_block(st[j], it + j);
 
     BNB_GI_STAMP(12)
-    // ---- store. Lane (i = ln, lg) of row tile mt holds rows 16 mt + 4 lg + q of column 16 wave + i: stored as it sits, that
-    // is 16 four-byte stores per lane, 64 bytes contiguous each (the first version spent 4100 of its 24 k cycles there). Each
-    // PAIR of wavefronts' [64 rows][32 columns] fp32 tile goes through LDS instead (the step tiles are free now) and leaves
-    // as 16 bytes per lane, 128 contiguous bytes per row.
-    __syncthreads(); // every wavefront is done reading the step tiles
+    // ---- the partial tiles of the workgroup, added in a fixed order: 8 wavefronts: p_w = tile_w + tile_{w+4} (w = 0..3) first;
+    // then (p_0 + p_1) + (p_2 + p_3). A tile in LDS: accumulator register group r = 8 mt + j of lane l at r * 1024 + l * 16.
+    __syncthreads(); // every wavefront is done with the table and its patches
     {
-        constexpr int kOutStride = 144; // bytes per row of a staged [64][32] tile: rows 4 apart land 16 banks apart
-        unsigned char* const ot = wtiles + (wave >> 1) * (kGiRows * kOutStride);
-        static_assert(4 * kGiRows * kOutStride <= 2 * kGiWTile, "the staged output tiles fit over the step tiles");
+        const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
+        if (wave >= 4) {
+            unsigned char* const dst = smem + (wave - 4) * kGiAccBytes + lane16;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float*>(ot + (16 * mt + 4 * lg + q) * kOutStride + (16 * (wave & 1) + ln) * 4) = acc[mt][q];
-        __syncthreads(); // (the pair's other wavefront wrote the other 16 columns)
-        const int rr = lane >> 3, cq = lane & 7;
+                for (int j = 0; j < 8; ++j)
+                    *reinterpret_cast<f32x4*>(dst + (8 * mt + j) * 1024) = acc[mt][j];
+        }
+        __syncthreads();
+        if (wave < 4) {
+            unsigned char* const buf = smem + wave * kGiAccBytes + lane16;
+            // (eight reads in flight before the first add: written element by element the compiler waits for every read)
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int row = 32 * (wave & 1) + 8 * ps + rr; // each wavefront of the pair stores half of the rows
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ot + row * kOutStride + cq * 16);
-            const int m = m_base + row;
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    o[j] = *reinterpret_cast<const f32x4*>(buf + (8 * mt + j) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    *reinterpret_cast<f32x4*>(buf + (8 * mt + j) * 1024) = acc[mt][j] + o[j];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        // the 2 MT units (row tile mt, column half jh: columns 8 c + 4 jh .. + 3 of every lane) are dealt to the wavefronts;
+        // lane (c, g) holds rows 16 mt + 4 g + q of those columns
+#pragma unroll
+        for (int u0 = 0; u0 < 2 * MT; u0 += kGiWaves) {
+        const int u = u0 + wave;
+        if (u >= 2 * MT)
+            break;
+        const int mt = u >> 1, jh = u & 1;
+        f32x4 v[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const uint32_t o = static_cast<uint32_t>((8 * mt + 4 * jh + jj) * 1024) + lane16;
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(smem + 0 * kGiAccBytes + o);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(smem + 1 * kGiAccBytes + o);
+            const f32x4 t2 = *reinterpret_cast<const f32x4*>(smem + 2 * kGiAccBytes + o);
+            const f32x4 t3 = *reinterpret_cast<const f32x4*>(smem + 3 * kGiAccBytes + o);
+            v[jj] = (t0 + t1) + (t2 + t3);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = m_base + 16 * mt + 4 * g + q;
             if (m < M) {
-                const long idx = static_cast<long>(m) * K + k0 + 32 * (wave >> 1) + 4 * cq;
+                const long idx = static_cast<long>(m) * K + k0 + 8 * c + 4 * jh;
                 if (hot_nslices == 1) {
                     using T4 = __attribute__((ext_vector_type(4))) T;
                     T4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        o[e] = static_cast<T>(v[e]);
+                    for (int jj = 0; jj < 4; ++jj)
+                        o[jj] = static_cast<T>(v[jj][q]);
                     *reinterpret_cast<T4*>(static_cast<T*>(p.out) + idx) = o;
                 } else {
-                    *reinterpret_cast<f32x4*>(p.ws + static_cast<long>(blockIdx.y) * M * K + idx) = v;
+                    *reinterpret_cast<f32x4*>(p.ws + static_cast<long>(blockIdx.y) * M * K + idx) = f32x4{v[0][q], v[1][q], v[2][q], v[3][q]};
                 }
             }
+        }
         }
     }
     BNB_GI_STAMP(13)
@@ -362,48 +412,68 @@ __global__ __launch_bounds__(kGiThreads) void gemm4_grad_input_kernel(
 int gi_cu_count() { return device_cu_count_or_default(); }
 
 struct GiPlan {
-    int ns, sps;
+    int ns, bps; // N slices, 32-n blocks per slice
+    int mt;      // MFMA row tiles per workgroup (16 batch rows each)
 };
-// N slices to fill the chip (one workgroup per CU), at least two steps each
-GiPlan gi_plan(int M, int N, int K) {
+int gi_row_tiles(int M) { return M <= 16 ? 1 : M <= 32 ? 2 : 4; }
+GiPlan gi_slices(int blocks, int ns, int mt) {
     GiPlan pl;
-    const int steps = N / kGiStep;
-    const int wgs = (K / kGiCols) * ((M + kGiRows - 1) / kGiRows);
-    int ns = gi_cu_count() / wgs;
-    const int max_ns = steps / 2 > 0 ? steps / 2 : 1;
-    ns = ns > max_ns ? max_ns : ns;
+    pl.mt = mt;
     ns = ns < 1 ? 1 : ns;
-    pl.sps = (steps + ns - 1) / ns;
-    pl.ns = (steps + pl.sps - 1) / pl.sps;
+    pl.bps = (blocks + ns - 1) / ns;
+    pl.ns = (blocks + pl.bps - 1) / pl.bps;
     return pl;
 }
+// N slices to fill the chip (one workgroup per CU), at least two blocks per wavefront each
+GiPlan gi_plan(int M, int N, int K) {
+    const int blocks = N / kGiBlockN;
+    const int mt = gi_row_tiles(M);
+    const int wgs = (K / kGiCols) * ((M + 16 * mt - 1) / (16 * mt));
+    int ns = gi_cu_count() / wgs;
+    const int max_ns = blocks / (2 * kGiWaves) > 0 ? blocks / (2 * kGiWaves) : 1;
+    ns = ns > max_ns ? max_ns : ns;
+    return gi_slices(blocks, ns, mt);
+}
 
+template <typename T, bool NESTED, int MT>
+void gi_launch_mt(const void* G, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
+                  const GiPlan& pl, const GiArgs& a, hipStream_t stream) {
+    dim3 grid(K / kGiCols, pl.ns, (M + 16 * MT - 1) / (16 * MT));
+    auto kern = gemm4_grad_input_kernel<T, NESTED, MT>;
+    static LdsLimit lim;
+    ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), gi_lds_bytes(MT));
+    hipLaunchKernelGGL(kern, grid, dim3(kGiWaves * 64), gi_lds_bytes(MT), stream, G, B, absmax, absmax8, M, N, K, flags, pl.bps, pl.ns, a);
+}
+template <typename T, bool NESTED>
+void gi_launch_one(const void* G, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
+                   const GiPlan& pl, const GiArgs& a, hipStream_t stream) {
+    if (pl.mt == 1)
+        gi_launch_mt<T, NESTED, 1>(G, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+    else if (pl.mt == 2)
+        gi_launch_mt<T, NESTED, 2>(G, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+    else
+        gi_launch_mt<T, NESTED, 4>(G, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+}
 template <typename T> void gi_launch(const void* G, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K,
                                      int flags, const GiPlan& pl, const GiArgs& a, hipStream_t stream) {
-    dim3 grid(K / kGiCols, pl.ns, (M + kGiRows - 1) / kGiRows);
-    if (absmax8 != nullptr) {
-        auto kern = gemm4_grad_input_kernel<T, true>;
-        static LdsLimit lim;
-        ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), kGiLds);
-        hipLaunchKernelGGL(kern, grid, dim3(kGiThreads), kGiLds, stream, G, B, absmax, absmax8, M, N, K, flags, pl.sps, pl.ns, a);
-    } else {
-        auto kern = gemm4_grad_input_kernel<T, false>;
-        static LdsLimit lim;
-        ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), kGiLds);
-        hipLaunchKernelGGL(kern, grid, dim3(kGiThreads), kGiLds, stream, G, B, absmax, absmax8, M, N, K, flags, pl.sps, pl.ns, a);
-    }
+    if (absmax8 != nullptr)
+        gi_launch_one<T, true>(G, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+    else
+        gi_launch_one<T, false>(G, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
 }
 
 } // namespace
 
-// Preconditions of the fused backward: 16-bit gradients, whole 128-column tiles and 64-row steps, blocksize >= 64.
+constexpr int kGiNAlign = 64; // N % 64 == 0 (whole 32-n blocks, 16-byte aligned grad_out rows with room to spare)
+
+// Preconditions of the fused backward: 16-bit gradients, whole 128-column tiles and 32-n blocks, blocksize >= 64.
 bool gemm_4bit_grad_input_supported(int dtype, const void* G, const uint8_t* B, int M, int N, int K, int blocksize) {
-    return (dtype == 1 || dtype == 2) && M >= 1 && N >= kGiStep && (N % kGiStep) == 0 && K >= kGiCols && (K % kGiCols) == 0 &&
+    return (dtype == 1 || dtype == 2) && M >= 1 && N >= kGiNAlign && (N % kGiNAlign) == 0 && K >= kGiCols && (K % kGiCols) == 0 &&
            blocksize >= 64 && is_pow2(blocksize) && aligned_to(G, 16) && aligned_to(B, 16);
 }
 
 size_t gemm_4bit_grad_input_workspace_bytes(int M, int N, int K) {
-    if (M < 1 || N < kGiStep || K < kGiCols)
+    if (M < 1 || N < kGiNAlign || K < kGiCols)
         return 0;
     const GiPlan pl = gi_plan(M, N, K);
     return pl.ns > 1 ? static_cast<size_t>(pl.ns) * M * K * sizeof(float) : 0;
@@ -426,10 +496,7 @@ void gemm_4bit_grad_input(int dtype, const void* G, const uint8_t* B, const floa
     const size_t slab = static_cast<size_t>(M) * K * sizeof(float);
     if (pl.ns > 1 && (workspace == nullptr || workspace_bytes < slab * pl.ns)) {
         const int fit = workspace ? static_cast<int>(workspace_bytes / slab) : 0;
-        const int steps = N / kGiStep;
-        const int ns = fit >= 2 ? fit : 1;
-        pl.sps = (steps + ns - 1) / ns;
-        pl.ns = (steps + pl.sps - 1) / pl.sps;
+        pl = gi_slices(N / kGiBlockN, fit >= 2 ? fit : 1, pl.mt);
     }
     GiArgs a;
 #ifdef BNB_PROFILING

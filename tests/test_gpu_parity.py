@@ -807,6 +807,25 @@ def test_gemm_4bit_grad_input_fused_vs_oracle(M, N, K, variant):
     assert torch.equal(y1, y2)
 
 
+@pytest.mark.parametrize("M,N,K", [(16, 4096, 256), (17, 2240, 384), (32, 11008, 128), (33, 704, 512), (64, 64, 128), (128, 1088, 256)])
+def test_gemm_4bit_grad_input_geometries(M, N, K):
+    """The fused backward over 1 / 2 / 4 row tiles, N slices of unequal length, wavefronts with unequal block counts (N / 32
+    not a multiple of the wavefront count), a slice shorter than a workgroup, two 64-row passes; plain and nested absmax."""
+    F = _F()
+    W = (torch.randn(N, K) / K**0.5).bfloat16()
+    g = torch.randn(M, N).bfloat16()
+    for nested in (False, True):
+        q, st = F.quantize_4bit(W.to(DEV), blocksize=64, quant_type="nf4", compress_statistics=nested)
+        ref = _oracle_grad_input(g, q, st)
+        if nested:
+            args = (g.to(DEV), q, st.shape, st.state2.absmax, 64, "nf4", st.absmax, st.state2.code, st.offset)
+        else:
+            args = (g.to(DEV), q, st.shape, st.absmax, 64, "nf4")
+        y = torch.ops.bitsandbytes_amd.gemm_4bit_grad_input.default(*args)
+        assert rel_err(y.cpu(), ref) < 4e-3, (nested, rel_err(y.cpu(), ref))
+        assert torch.equal(y, torch.ops.bitsandbytes_amd.gemm_4bit_grad_input.default(*args))
+
+
 def test_gemm_4bit_grad_input_exact_on_representable_inputs():
     """Gradients that are small integers and weights whose codes / scales are exactly representable: every product and sum
     is exact, so the fused kernel must equal the oracle bit for bit - an n paired with the wrong weight row, or a scale taken

@@ -15,6 +15,11 @@ from stream_ab import graph_time, make_layers  # noqa: E402
 
 
 def main():
+    import argparse
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fused-only", action="store_true")
+    args = ap.parse_args()
     print(torch.cuda.get_device_name(0), bnb.lib.bnb_mi355x_version().decode())
     print(f"{'N x K':>14s} {'dq':>2s} {'M':>4s} {'fused us':>9s} {'unfused us':>10s} {'(dequantize':>11s} {'+ matmul)':>9s} {'speed-up':>8s}")
     for (N, K, dq) in ((4096, 4096, False), (4096, 4096, True), (11008, 4096, False), (4096, 11008, False), (8192, 8192, False)):
@@ -44,6 +49,10 @@ def main():
                 tf = graph_time(fused, len(layers))
             else:
                 tf = float("nan")
+            if args.fused_only:
+                print(f"{N:>7d}x{K:<6d} {int(dq):>2d} {M:>4d} {tf:9.2f}", flush=True)
+                del Ws
+                continue
             td, tm = graph_time(deq, len(layers)), graph_time(mm, len(layers))
             print(f"{N:>7d}x{K:<6d} {int(dq):>2d} {M:>4d} {tf:9.2f} {td + tm:10.2f} {td:11.2f} {tm:9.2f} {(td + tm) / tf:8.2f}", flush=True)
             del Ws

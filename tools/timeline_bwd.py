@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-wavefront timeline of the fused backward kernel (gemm4_grad_input_kernel) from in-kernel s_memtime stamps (profiling
-build only): 0 start, 1 loads issued, 2 table built + barrier, then for the first three steps: tile stored (3, 6, 9), past
-the step barrier (4, 7, 10), MFMA phase done (5, 8, 11); 12 step loop done, 13 end.  python tools/timeline_bwd.py [--m 64]"""
+build only): 0 start, 1 first loads issued, 2 table built + barrier, then for the wavefront's first three 32-n blocks: grad_out /
+scales staged in the private LDS patch (3, 6, 9), fragments read back (4, 7, 10), decode + MFMAs done (5, 8, 11); 12 block loop
+done, 13 end.  python tools/timeline_bwd.py [--m 64]"""
 import argparse
 import os
 import sys
@@ -49,8 +50,8 @@ if t.shape[0] == 0:
     print("no stamps: not a profiling build?")
     sys.exit(0)
 t0 = torch.where(t[:, :, 0] > 0, t[:, :, 0], torch.full_like(t[:, :, 0], 1e30)).min(dim=1, keepdim=True).values
-names = ["start", "loads issued", "table + barrier", "s0 tile stored", "s0 past barrier", "s0 mfma done", "s1 tile stored",
-         "s1 past barrier", "s1 mfma done", "s2 tile stored", "s2 past barrier", "s2 mfma done", "step loop done", "end"]
+names = ["start", "loads issued", "table + barrier", "b0 staged", "b0 fragments", "b0 mfma done", "b1 staged",
+         "b1 fragments", "b1 mfma done", "b2 staged", "b2 fragments", "b2 mfma done", "block loop done", "end"]
 print(f"# backward kernel, M={a.m}, N={N}, K={K}: {t.shape[0]} workgroups x 8 wavefronts; s_memtime ticks relative to the first "
       f"wavefront start of the SAME workgroup")
 print(f"{'stamp':20s} {'min':>7s} {'median':>7s} {'p90':>7s} {'max':>7s}   median delta to previous stamp")
