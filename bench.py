@@ -17,8 +17,8 @@ a long one. Bracketed by barrier + synchronize; MAX over ranks.
 
 --gpus N > 1 (weak scaling, bitsandbytes_amd.parallel semantics: rows sharded, x replicated, no reduction): every
 rank owns a full-size 4096-row shard of an (N*4096)-row layer, held in parallel.ShardedLinear4bit modules. The y
-shards of one step are re-assembled by ONE RCCL all-gather per step on a side stream (bucketed: a step's 128 shard
-outputs travel together and overlap the next step's weight streaming). The per-layer form (kernel, then all-gather
+shards of one step are re-assembled by ONE RCCL all-gather per step, in stream order (bucketed: a step's 128 shard
+outputs travel together). The per-layer form (kernel, then all-gather
 of that layer's 8 KB, as a tensor-parallel decode needs it) is timed as well and reported beside it.
 
 Extra objects on the JSON line:
@@ -269,6 +269,9 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--no-rocprof", action="store_true", help="skip the rocprofv3 kernel-trace pass (roofline then falls back to HIP events)")
     ap.add_argument("--profile-out", default=None, help="copy the rocprofv3 kernel_stats.csv of the roofline pass here (e.g. profiles/r2_bench_kernel_stats.csv)")
+    ap.add_argument("--sharded-path", action="store_true",
+                    help="run the multi-GPU code path (ShardedLinear4bit shards, bucketed RCCL all-gather, per-layer "
+                         "gather) even at world size 1: how that path is exercised on a 1-GPU box")
     ap.add_argument("--prof-child", action="store_true", help=argparse.SUPPRESS)  # workload run under rocprofv3
     ap.add_argument("--prof-eager", action="store_true", help=argparse.SUPPRESS)  # ... enqueued eagerly (PMC passes serialise dispatches)
     args = ap.parse_args()
@@ -283,8 +286,12 @@ def main():
 
     import torch.distributed as dist
 
-    if world > 1:
+    multi = world > 1 or args.sharded_path
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     import bitsandbytes_amd as bnb
@@ -299,7 +306,7 @@ def main():
     flops_step = LAYERS * 2 * M * N * K
 
     # ---- one step = the 128 layers, each its own launch through the public op
-    if world == 1:
+    if not multi:
         def step_fn():
             for q, st in layers:
                 bnb.matmul_4bit(x, q, st)
@@ -312,8 +319,9 @@ def main():
 
         def make_step(b):
             def fn():
-                for j, sh in enumerate(shards):
-                    sh.local_forward(x, out=buckets[b][j])
+                # (one stack kernel per step moves the 128 shard outputs into the gather bucket: the public op allocates its own
+                # output, and an out= copy per layer would add 128 launches)
+                torch.stack([sh.local_forward(x) for sh in shards], out=buckets[b])
             return fn
 
     if args.prof_child:
@@ -328,34 +336,24 @@ def main():
         torch.cuda.synchronize()
         return
 
-    if world == 1:
+    if not multi:
         graphs = [capture(step_fn)]
     else:
         graphs = [capture(make_step(b)) for b in range(2)]
-        comm_stream = torch.cuda.Stream()
-        pending = [None, None]
 
     def run_steps(nsteps):
-        """Enqueue exactly nsteps steps (+ one all-gather per step when world > 1)."""
+        """Enqueue exactly nsteps steps (+ one all-gather per step on the multi-GPU path)."""
         for c in range(nsteps):
             b = c & 1
-            if world > 1 and pending[b] is not None:
-                torch.cuda.current_stream().wait_event(pending[b])  # bucket b's previous gather finished
-            graphs[b if world > 1 else 0].replay()
-            if world > 1:
-                ready = torch.cuda.Event()
-                ready.record()
-                with torch.cuda.stream(comm_stream):
-                    comm_stream.wait_event(ready)
-                    dist.all_gather_into_tensor(gathered[b].view(world * LAYERS * M, N), buckets[b].view(LAYERS * M, N))
-                    ev = torch.cuda.Event()
-                    ev.record()
-                pending[b] = ev
-        if world > 1:
-            torch.cuda.current_stream().wait_stream(comm_stream)
+            graphs[b if multi else 0].replay()
+            if multi:
+                # On the SAME stream: a cross-stream event wait behind a graph launch stalls the queue for ~190 us per step on
+                # this stack (measured on MI355X at world size 1: 5.7 us per layer against 4.2 with the gather in-stream,
+                # profiles/r2_sharded_path_probe.txt) - more than the 1 MB-per-rank gather it would hide.
+                dist.all_gather_into_tensor(gathered[b].view(world * LAYERS * M, N), buckets[b].view(LAYERS * M, N))
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
 
     # ---- warm-up
@@ -370,7 +368,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -397,7 +395,7 @@ def main():
     kernel_us_events = per_launch_us(M)
 
     per_layer_gather = None
-    if world > 1:
+    if multi:
         # the tensor-parallel form: every layer's y is gathered before the next layer may start (no bucketing);
         # ShardedLinear4bit.forward = kernel + all_gather_into_tensor, enqueued eagerly on one stream
         n_pl = 2 * LAYERS
@@ -419,7 +417,7 @@ def main():
                                     "outputs, eager, one stream (no bucketing, no overlap)"}
 
     sweep = grouped = None
-    if (args.sweep or (world == 1 and not args.no_sweep)) and rank == 0:
+    if (args.sweep or (not multi and not args.no_sweep)) and rank == 0:
         sweep = []
         for m_rows in (1, 2, 4, 8, 16, 32, 64):
             t_us = per_launch_us(m_rows, reps=5)
@@ -443,7 +441,7 @@ def main():
         value = nbytes_step * total_steps / elapsed / 1e9
         extra = ["--m", str(M), "--n", str(N), "--k", str(K), "--blocksize", str(bs), "--quant-type", qt]
         avg_ns, kt_detail = (None, {"skipped": "--no-rocprof or multi-GPU run"})
-        if world == 1 and not args.no_rocprof:
+        if not multi and not args.no_rocprof:
             avg_ns, kt_detail = rocprof_kernel_stats(extra, args.profile_out)
         if avg_ns is not None:
             kernel_us = avg_ns / 1e3
@@ -478,7 +476,7 @@ def main():
                 "launch": f"hipGraph replay per step ({LAYERS} dependent launches of bitsandbytes_amd.matmul_4bit), every step of warm-up and timed region",
                 "timed_region_s": round(elapsed, 6),
                 "parallelism": (f"rows sharded x{world} (parallel.ShardedLinear4bit), one all-gather per step ({LAYERS} layers bucketed) "
-                                "on a side stream") if world > 1 else "single GPU",
+                                "in stream order") if multi else "single GPU",
             },
             "roofline": {
                 "bound": "hbm",
@@ -494,7 +492,7 @@ def main():
                 "kernel_trace": kt_detail,
             },
         }
-        if world == 1 and not args.no_pmc:
+        if not multi and not args.no_pmc:
             traffic, detail = pmc_traffic(extra)
             line["roofline"]["traffic"] = None if traffic is None else round(traffic)
             line["roofline"]["traffic_detail"] = detail
@@ -504,15 +502,20 @@ def main():
             line["headline_sweep_N4096_K4096"] = sweep
         if grouped is not None:
             line["grouped"] = grouped
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(M, N, K, bs, qt)
             except Exception as exc:  # baseline is informational; never lose the GPU line over it
                 line["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {exc}"}
-        print(json.dumps(line), flush=True)
-
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST line of stdout: RCCL prints its version banner through C stdio, which is block-buffered
+        # when stdout is a pipe and would otherwise be flushed after this line, at exit
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

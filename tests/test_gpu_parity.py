@@ -5,6 +5,7 @@ the public Python API and straight through the C ABI. Bars (BASELINE.json north_
   * fused dequant+matmul: relative Frobenius error <= 1e-2 vs fp32-dequantize + fp32-linear
     (REL_TOL below; observed values are ~1e-3 for bf16, ~2e-4 for fp16)
 """
+import os
 import ctypes as ct
 import warnings
 
@@ -1392,3 +1393,25 @@ def test_sharded_linear4bit_over_rccl_world_size_one():
             assert torch.equal(y, layer(x))
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_multi_gpu_code_path_at_world_size_one():
+    """bench.py's --gpus N > 1 branch (ShardedLinear4bit shards, step graphs writing the gather bucket, RCCL all-gather per
+    step, the per-layer gather timing) cannot run with N > 1 on a 1-GPU box; `--sharded-path` runs the same code with an RCCL
+    group of one rank. The JSON line must be the LAST line of stdout (RCCL prints a banner through C stdio) and carry the
+    contract's keys."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--sharded-path", "--steps", "6", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 6 and line["value"] > 0
+    assert "ShardedLinear4bit" in line["config"]["parallelism"] and line["per_layer_gather"]["us_per_layer"] > 0
