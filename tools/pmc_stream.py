@@ -17,6 +17,7 @@ ap.add_argument("--k", type=int, default=8192)
 ap.add_argument("--m", type=int, default=1)
 ap.add_argument("--layers", type=int, default=4)
 ap.add_argument("--rounds", type=int, default=4)
+ap.add_argument("--backward", action="store_true", help="launch the fused backward (gemm_4bit_grad_input) with M gradient rows instead")
 a = ap.parse_args()
 g = torch.Generator(device="cuda").manual_seed(0)
 layers = []
@@ -25,7 +26,11 @@ for _ in range(a.layers):
     layers.append(F.quantize_4bit(W, quant_type="nf4"))
     del W
 x = torch.randn(a.m, a.k, device="cuda", generator=g).bfloat16()
+go = torch.randn(a.m, a.n, device="cuda", generator=g).bfloat16()
 for _ in range(a.rounds):
     for q, st in layers:
-        bnb.matmul_4bit(x, q, st)
+        if a.backward:
+            torch.ops.bitsandbytes_amd.gemm_4bit_grad_input.default(go, q, st.shape, st.absmax, 64, "nf4")
+        else:
+            bnb.matmul_4bit(x, q, st)
 torch.cuda.synchronize()
