@@ -398,3 +398,20 @@ def test_rt_mfma_lane_algebra_emulation():
         assert mod.emulate(M=M, K=512, seed=M) < 1e-12
     assert mod.final_sum_mapping_ok()
 
+
+
+def test_grad_input_lane_algebra_emulation():
+    """The index algebra of csrc/gemm4_grad_input.hip (one dword per weight row and lane, nibble j = B operand of the strided
+    column tile {8 c + j}, the swizzled private grad_out patch, the scale patch, the output mapping, the dealing of the final
+    sum) replayed lane by lane against the hardware semantics of the MFMA - see tests/checks/emulate_grad_input.py."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location(
+        "emulate_grad_input", os.path.join(os.path.dirname(__file__), "checks", "emulate_grad_input.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for (M, N, MT) in ((37, 96, 4), (20, 64, 2), (9, 32, 1)):
+        assert mod.emulate(M=M, N=N, MT=MT, seed=M) < 1e-12
+    assert mod.patch_swizzle_conflict_free()
+    assert all(mod.final_sum_units_cover_the_tile(mt) for mt in (1, 2, 4))
