@@ -11,13 +11,14 @@
 //     u   = uint16( (clamp(x * (1/absmax), -1, 1) + 1) * 0.5 * 65535 + 0.5 )
 //     val(u) = -1 + (2*u) / 65535                    (fp32, IEEE division)
 //     q   = #{ i < 255 : 0.5*(code[i] + code[i+1]) < val(u) }
-// The 64 K-entry table is never materialised and no element pays the division: val(u) is monotone in u,
-// so every midpoint i has a threshold bin T_i = min{u : val(u) > mid_i} (found once per workgroup by a
-// 16-step search that evaluates val() with exactly the expression above) and q = #{i : T_i <= u} - an
-// integer count. A 1024-cell table over u (64 bins per cell) gives the count below the cell and, when the cell
-// holds exactly one threshold, its offset inside the cell: an element then costs ONE LDS read and one compare;
-// the few cells with several thresholds (the dynamic map is dense only around zero) count them in a short
-// loop. Same function of u, bit for bit.
+// No element pays the division: val(u) is monotone in u, so every midpoint i has a threshold bin
+// T_i = min{u : val(u) > mid_i} (found once per workgroup: the algebraic inverse, corrected by comparisons that evaluate val()
+// with exactly the expression above) and q = #{i : T_i <= u} - an integer count. Two encoders evaluate it:
+//  * quantize8_kernel (small inputs): a 1024-cell table over u (64 bins per cell) gives the count below the cell and, when the
+//    cell holds exactly one threshold, its offset inside the cell: an element then costs ONE LDS read and one compare; the few
+//    cells with several thresholds (the dynamic map is dense only around zero) count them in a short loop;
+//  * quantize8_lut_kernel (>= 2^20 elements): the 64 K-entry byte table itself, in LDS, built by a prefix sum over the marked
+//    thresholds. Same function of u, bit for bit, in both.
 //
 // dequantize: out[i] = T(code[A[i]] * absmax[i / blocksize])   (reference csrc/cpu_ops.cpp:436-486).
 //
@@ -26,14 +27,34 @@
 // blocksize/4 lanes, or an accumulation over blocksize/256 steps of one wavefront for the larger blocks.
 #include "bnb_common.h"
 
+#include <atomic>
+
 namespace bnb {
 
 namespace {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float bin_value(unsigned u) {
     return -1.0f + (2.0f * static_cast<float>(u)) / 65535.0f; // the reference's expression, IEEE division
+}
+
+// T(m) = min{u in [0, 65536] : bin_value(u) > m}  (65536 if none). bin_value is non-decreasing in u, so instead of 17 bisection
+// steps (17 correctly rounded divisions on the critical path of every launch) start from the algebraic inverse and walk the
+// few steps the roundings can be off; every comparison is made with bin_value itself, so T is the same number.
+__device__ __forceinline__ unsigned first_bin_above(float m) {
+    if (m < -1.0f)
+        return 0u; // bin_value(0) = -1 > m
+    if (!(m < 1.0f))
+        return 65536u; // bin_value(65535) = 1 is not > m; NaN compares false everywhere (what the bisection returned as well)
+    int c = static_cast<int>((m + 1.0f) * 32767.5f);
+    c = c < 0 ? 0 : (c > 65535 ? 65535 : c);
+    while (c > 0 && bin_value(static_cast<unsigned>(c - 1)) > m)
+        --c;
+    while (c < 65536 && !(bin_value(static_cast<unsigned>(c)) > m))
+        ++c;
+    return static_cast<unsigned>(c);
 }
 
 __device__ __forceinline__ unsigned bin_of(float x, float inv) {
@@ -77,20 +98,7 @@ __global__ __launch_bounds__(256) void quantize8_kernel(const float* __restrict_
     const int tid = threadIdx.x;
     mid[tid] = (tid < 255) ? 0.5f * (code[tid] + code[tid + 1]) : __builtin_inff();
     __syncthreads();
-    {
-        // T = min{u in [0, 65536] : bin_value(u) > mid[tid]}  (65536 if none)
-        const float m = mid[tid];
-        unsigned lo = 0, hi = 65536; // invariant: bin_value(u) <= m for u < lo; bin_value(u) > m for u >= hi
-#pragma unroll 1
-        for (int step = 0; step < 17 && lo < hi; ++step) {
-            const unsigned c = (lo + hi) >> 1;
-            if (bin_value(c) > m)
-                hi = c;
-            else
-                lo = c + 1;
-        }
-        thr[tid] = hi;
-    }
+    thr[tid] = first_bin_above(mid[tid]);
     __syncthreads();
     __shared__ uint8_t below_s[1025];
     for (int c = tid; c < 1025; c += 256) {
@@ -169,6 +177,172 @@ __global__ __launch_bounds__(256) void quantize8_kernel(const float* __restrict_
     }
 }
 
+// Large inputs: the reference's own formulation - a 65536-entry byte table (csrc/cpu_ops.cpp:501-520 builds exactly this) -
+// held in LDS: one ds_read_u8 per element whatever the data (the cell table above falls into an 8-step search inside the
+// cells around zero, which is where block-normalised data lives: 2.1 TB/s on randn input). 64 KiB of table per workgroup is
+// only worth building when a workgroup has megabytes to encode, so small inputs (the absmax vectors of double quantisation)
+// keep the cell kernel. Same function of u, bit for bit: lut[u] = #{i : T_i <= u}.
+std::atomic<int> g_q8_variant{0}; // tuning / tests (bnb_mi355x_set_tuning reserved0): 1 = cell-table kernel, 2 = byte-table kernel, else by size
+constexpr long kQ8LutMinElements = 1L << 20; // below this the 64 KiB table per workgroup costs more than it saves
+constexpr int kQ8LutThreads = 512;
+constexpr int kQ8LutLds = 65536 + 1024 + 1024;
+
+template <typename T, int BS>
+__global__ __launch_bounds__(kQ8LutThreads) void quantize8_lut_kernel(const float* __restrict__ code, const T* __restrict__ A,
+                                                                      float* __restrict__ absmax, uint8_t* __restrict__ out, long n,
+                                                                      int vec_ok) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char q8_smem[];
+    uint8_t* const lut = q8_smem;
+    uint32_t* const thr = reinterpret_cast<uint32_t*>(q8_smem + 65536); // T_i, ascending; thr[255] = 65536
+    float* const mid = reinterpret_cast<float*>(q8_smem + 65536 + 1024);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    constexpr int WAVES = kQ8LutThreads / 64;
+    const long wave_global = static_cast<long>(blockIdx.x) * WAVES + (tid >> 6);
+    const long wave_count = static_cast<long>(gridDim.x) * WAVES;
+    constexpr int SPB = BS > 256 ? BS / 256 : 1;   // wavefront steps per block
+    constexpr int GROUP = BS >= 256 ? 64 : BS / 4; // lanes sharing one block within a step
+    constexpr bool PREFETCH = SPB <= 4;            // the next unit's loads in flight while this one is encoded
+    const long units = (n + 256L * SPB - 1) / (256L * SPB);
+
+    // U units (1 KiB of input per wavefront each, for fp32) are loaded together and the next U are requested before these are
+    // encoded: 8 KiB per wavefront in flight - one unit at a time left the kernel latency-bound at 2 TB/s
+    constexpr int U = SPB >= 4 ? 1 : 4 / SPB;
+    const long groups = (units + U - 1) / U;
+    auto load_group = [&](float (&dst)[U][SPB][4], long grp) {
+#pragma unroll
+        for (int uu = 0; uu < U; ++uu)
+#pragma unroll
+            for (int sp = 0; sp < SPB; ++sp)
+                load4<T>(A, (grp * U + uu) * 256L * SPB + lane * 4 + sp * 256L, n, vec_ok != 0, dst[uu][sp]);
+    };
+    // the first group's loads go out before the tables are built: the table build hides their latency
+    float xn[U][SPB][4];
+    if (PREFETCH && wave_global < groups)
+        load_group(xn, wave_global);
+    if (tid < 256)
+        mid[tid] = (tid < 255) ? 0.5f * (code[tid] + code[tid + 1]) : __builtin_inff();
+    __syncthreads();
+    if (tid < 256)
+        thr[tid] = first_bin_above(mid[tid]);
+    __syncthreads();
+    // lut[u] = #{i : T_i <= u} as a prefix sum: mark every threshold in a zeroed byte array (a 32-bit LDS atomic on the containing
+    // dword: thresholds may coincide), then thread t owns bytes [128 t, 128 t + 128): their sum, a workgroup-wide exclusive scan
+    // of the 512 sums, and a SWAR running sum over its 32 dwords. No byte can overflow: there are 255 thresholds in all.
+    // (A per-u walk over the sorted thresholds cost ~5 us per launch: ~10 instructions for each of the 65536 entries.)
+    {
+        u32x4_t* const z = reinterpret_cast<u32x4_t*>(lut);
+#pragma unroll
+        for (int i = 0; i < 65536 / 16 / kQ8LutThreads; ++i)
+            z[i * kQ8LutThreads + tid] = u32x4_t{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+    if (tid < 255) {
+        const unsigned t = thr[tid];
+        if (t < 65536u)
+            atomicAdd(reinterpret_cast<unsigned*>(lut) + (t >> 2), 1u << (8u * (t & 3u)));
+    }
+    __syncthreads();
+    {
+        uint32_t d[32];
+        const u32x4_t* const src = reinterpret_cast<const u32x4_t*>(lut + tid * 128);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const u32x4_t v = src[i];
+            d[4 * i] = v[0];
+            d[4 * i + 1] = v[1];
+            d[4 * i + 2] = v[2];
+            d[4 * i + 3] = v[3];
+        }
+        unsigned sum = 0;
+#pragma unroll
+        for (int w = 0; w < 32; ++w)
+            sum = __builtin_amdgcn_sad_u8(d[w], 0u, sum); // sum of the four bytes
+        // exclusive scan over the workgroup: inclusive wavefront scan by shuffles, wavefront totals through LDS
+        unsigned incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(incl, off, 64);
+            incl += ((tid & 63) >= off) ? o : 0u;
+        }
+        uint32_t* const wave_tot = reinterpret_cast<uint32_t*>(mid); // (mid is dead: the thresholds are in thr)
+        __syncthreads();
+        if ((tid & 63) == 63)
+            wave_tot[tid >> 6] = incl;
+        __syncthreads();
+        unsigned run = incl - sum;
+#pragma unroll
+        for (int w = 0; w < kQ8LutThreads / 64; ++w)
+            run += (w < (tid >> 6)) ? wave_tot[w] : 0u;
+        u32x4_t* const dst = reinterpret_cast<u32x4_t*>(lut + tid * 128);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            u32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t x = d[4 * i + e];
+                x += x << 8;
+                x += x << 16; // inclusive running sum inside the dword
+                x += run * 0x01010101u;
+                run = x >> 24;
+                o[e] = x;
+            }
+            dst[i] = o;
+        }
+    }
+    __syncthreads();
+
+    for (long grp = wave_global; grp < groups; grp += wave_count) {
+        float xg[U][SPB][4];
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu)
+#pragma unroll
+                for (int sp = 0; sp < SPB; ++sp)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        xg[uu][sp][j] = xn[uu][sp][j];
+            if (grp + wave_count < groups)
+                load_group(xn, grp + wave_count);
+        } else {
+            load_group(xg, grp);
+        }
+#pragma unroll
+        for (int uu = 0; uu < U; ++uu) {
+            const long base = (grp * U + uu) * 256L * SPB + lane * 4;
+            float m = 0.0f;
+#pragma unroll
+            for (int sp = 0; sp < SPB; ++sp)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    m = fmaxf(m, fabsf(xg[uu][sp][j]));
+            m = group_max<GROUP>(m);
+            if ((lane % GROUP) == 0 && base < n)
+                absmax[base / BS] = m;
+            const float inv = 1.0f / m; // m == 0: inf; the codes are forced to 0 below (reference: all-zero block)
+#pragma unroll
+            for (int sp = 0; sp < SPB; ++sp) {
+                uint32_t q4 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned q = lut[bin_of(xg[uu][sp][j], inv)];
+                    q = (m == 0.0f) ? 0u : q;
+                    q4 |= q << (8 * j);
+                }
+                const long i = base + sp * 256L;
+                if (vec_ok && i + 4 <= n) {
+                    *reinterpret_cast<uint32_t*>(out + i) = q4;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (i + j < n)
+                            out[i + j] = static_cast<uint8_t>(q4 >> (8 * j));
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void dequantize8_kernel(const float* __restrict__ code,
                                                           const uint8_t* __restrict__ A,
@@ -213,6 +387,37 @@ void launch_quantize8(const float* code, const T* A, float* absmax, uint8_t* out
     // per-workgroup threshold / cell tables
     const long unit_elems = blocksize > 256 ? blocksize : 256;
     const long units = (n + unit_elems - 1) / unit_elems;
+    const int variant = g_q8_variant.load(std::memory_order_relaxed);
+    if (variant == 2 || (variant != 1 && n >= kQ8LutMinElements)) {
+        // byte-table kernel: two 512-thread workgroups per CU (64 KiB of table each), persistent
+        long grid = (units + 31) / 32; // (a wavefront takes up to 4 units per round)
+        const long max_grid = 2L * device_cu_count_or_default();
+        if (grid > max_grid)
+            grid = max_grid;
+#define BNB_Q8L_CASE(BS)                                                                           \
+    case BS: {                                                                                     \
+        auto kern = quantize8_lut_kernel<T, BS>;                                                   \
+        static LdsLimit lim;                                                                       \
+        ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), kQ8LutLds);                   \
+        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(kQ8LutThreads), kQ8LutLds, stream, code, A, absmax, out, n, vec_ok); \
+        break;                                                                                     \
+    }
+        switch (blocksize) {
+            BNB_Q8L_CASE(64)
+            BNB_Q8L_CASE(128)
+            BNB_Q8L_CASE(256)
+            BNB_Q8L_CASE(512)
+            BNB_Q8L_CASE(1024)
+            BNB_Q8L_CASE(2048)
+            BNB_Q8L_CASE(4096)
+        default:
+            fprintf(stderr, "bitsandbytes_amd: quantize_blockwise: unsupported blocksize %d\n", blocksize);
+            exit(1);
+        }
+#undef BNB_Q8L_CASE
+        BNB_CHECK_LAUNCH();
+        return;
+    }
     long grid = (units + 3) / 4;
     if (grid > 2048)
         grid = 2048; // 8 workgroups per CU: fewer (1024) measured slower, the loads need the wavefronts
@@ -256,6 +461,8 @@ void launch_dequantize8(const float* code, const uint8_t* A, const float* absmax
 }
 
 } // namespace
+
+void quantize_8bit_set_variant(int variant) { g_q8_variant.store(variant, std::memory_order_relaxed); }
 
 void quantize_8bit_f32(const float* code, const float* A, float* absmax, uint8_t* out, int bs, long n, hipStream_t s) {
     launch_quantize8<float>(code, A, absmax, out, bs, n, s);

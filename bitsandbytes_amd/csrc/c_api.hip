@@ -46,6 +46,7 @@ extern std::atomic<int> g_mfma_knob0, g_mfma_knob1;
 // gemm4_grad_input.hip
 bool gemm_4bit_grad_input_supported(int dtype, const void* G, const uint8_t* B, int M, int N, int K, int blocksize);
 size_t gemm_4bit_grad_input_workspace_bytes(int M, int N, int K);
+void quantize_8bit_set_variant(int variant);
 void gemm_4bit_grad_input(int dtype, const void* G, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                           const float* absmax_code, const float* absmax_offset, void* out, int M, int N, int K, int blocksize,
                           int quant_type, void* workspace, size_t workspace_bytes, hipStream_t stream);
@@ -293,7 +294,7 @@ int bnb_mi355x_gemm_4bit_grad_input_supported(int dtype, int M, int N, int K, in
     return gemm_4bit_grad_input_supported(dtype, dummy_aligned, reinterpret_cast<const uint8_t*>(dummy_aligned), M, N, K, blocksize) ? 1 : 0;
 }
 void bnb_mi355x_set_tuning(int reserved0, int reserved1, int mfma_knob0, int mfma_knob1) {
-    (void)reserved0;
+    quantize_8bit_set_variant(reserved0); // 1 / 2: force the cell-table / byte-table 8-bit encoder, anything else: by size
     (void)reserved1;
     g_mfma_knob0.store(mfma_knob0, std::memory_order_relaxed);
     g_mfma_knob1.store(mfma_knob1, std::memory_order_relaxed);

@@ -349,6 +349,67 @@ def test_blockwise_8bit_other_code_maps_golden(i):
     assert same_values_ftz(d.cpu(), from_bits(M8[f"m8/{i}/deq_fp32"], 0)), name
 
 
+@pytest.mark.parametrize("variant", [1, 2], ids=["cell-table", "byte-table"])
+def test_blockwise_8bit_both_encoders(variant):
+    """The 8-bit quantize has two encoders chosen by input size (cell table below 2**20 elements, the reference's own
+    65536-entry byte table - held in LDS - above). Forced one at a time: every discretisation bin +- just under half a bin,
+    every blocksize and dtype with ragged sizes and all-zero blocks, and the code maps whose thresholds crowd one cell."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    try:
+        bnb.lib.bnb_mi355x_set_tuning(variant, 0, 0, 0)
+        code = F.create_dynamic_map()
+        u = torch.arange(65536, dtype=torch.float64)
+        centres = -1.0 + 2.0 * u / 65535.0
+        vals = torch.cat([centres, centres + 0.499 / 65535.0, centres - 0.499 / 65535.0, centres + 0.501 / 65535.0]).clamp(-1, 1).float()
+        vals = torch.cat([vals, torch.zeros((-vals.numel()) % 255)])
+        A = torch.cat([torch.ones(vals.numel() // 255, 1), vals.view(-1, 255)], dim=1).reshape(-1).contiguous()
+        q_o, am_o = O.quantize_blockwise(A, code, 256)
+        q, am = torch.ops.bitsandbytes.quantize_blockwise.default(A.to(DEV), code.to(DEV), 256)
+        assert torch.equal(q.cpu(), q_o) and torch.equal(am.cpu(), am_o)
+        for blocksize in (64, 256, 1024, 2048, 4096):
+            for dtype in (torch.float32, torch.float16, torch.bfloat16):
+                for n in (blocksize * 37 + 5, 3, 70001):
+                    X = (torch.randn(n) * 0.1).to(dtype)
+                    X[::7] = 0
+                    if n > 3 * blocksize:
+                        X[blocksize: 2 * blocksize] = 0
+                    q_o, am_o = O.quantize_blockwise(X, code, blocksize)
+                    q, am = torch.ops.bitsandbytes.quantize_blockwise.default(X.to(DEV), code.to(DEV), blocksize)
+                    assert torch.equal(q.cpu(), q_o) and torch.equal(am.cpu(), am_o), (blocksize, dtype, n)
+        R = torch.randn(256 * 61 + 17) * 0.2
+        for mk in (lambda: F.create_linear_map(True, 2), lambda: F.create_fp8_map(True, 2, 1, 4), lambda: F.create_normal_map(),
+                   lambda: F.create_dynamic_map(signed=False)):
+            c2 = mk()
+            for data, bs in ((A, 256), (R, 64)):
+                q_o, am_o = O.quantize_blockwise(data, c2, bs)
+                q, am = torch.ops.bitsandbytes.quantize_blockwise.default(data.to(DEV), c2.to(DEV), bs)
+                assert torch.equal(q.cpu(), q_o) and torch.equal(am.cpu(), am_o)
+        # unaligned view: scalar loads / byte stores
+        base = (torch.randn(256 * 9 + 1) * 0.3).to(DEV)
+        q_o, am_o = O.quantize_blockwise(base[1:].cpu().contiguous(), code, 256)
+        q, am = torch.ops.bitsandbytes.quantize_blockwise.default(base[1:], code.to(DEV), 256)
+        assert torch.equal(q.cpu(), q_o) and torch.equal(am.cpu(), am_o)
+    finally:
+        bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+
+
+def test_blockwise_8bit_large_input_takes_the_byte_table_kernel():
+    """3 M elements through the default dispatch (byte-table kernel, persistent workgroups with a prefetched unit), ragged
+    tail, bit-exact against the oracle; dequantize round trip within the map's resolution."""
+    F = _F()
+    code = F.create_dynamic_map()
+    n = 3 * 1024 * 1024 + 333
+    A = torch.randn(n) * 0.05
+    A[5000:5256] = 0
+    q_o, am_o = O.quantize_blockwise(A, code, 256)
+    q, am = torch.ops.bitsandbytes.quantize_blockwise.default(A.to(DEV), code.to(DEV), 256)
+    assert torch.equal(q.cpu(), q_o) and torch.equal(am.cpu(), am_o)
+    d = torch.ops.bitsandbytes.dequantize_blockwise.default(q, am, code.to(DEV), 256, torch.float32)
+    assert same_values_ftz(d.cpu(), O.dequantize_blockwise(q_o, am_o, code, 256, torch.float32))
+
+
 def test_blockwise_8bit_every_bin():
     """All 65536 discretisation bins (and their neighbourhood) with absmax pinned to 1: the threshold /
     cell-table encoder must reproduce the reference's 64K-entry table exactly."""
