@@ -229,8 +229,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
         const float cv = rt_code_literal((lane & 15) + opaque_zero(), fp4);
         const int cvb = __builtin_bit_cast(int, cv);
         u32x4* const lut = reinterpret_cast<u32x4*>(smem);
+        // (the wavefronts of a 16-wavefront workgroup start ~90 cycles apart and every one of them first pushes its loads
+        // through the CU's address pipeline: the early half builds the table, the late half only issues loads - the barrier
+        // then waits for the last issuer, not for the last issuer's share of the table)
+        constexpr int BUILD_THREADS = (WAVES >= 16) ? THREADS / 2 : THREADS;
 #pragma unroll
-        for (int idx = tid; idx < 1024; idx += THREADS) {
+        for (int idx = tid; idx < 1024 && tid < BUILD_THREADS; idx += BUILD_THREADS) {
             const int e = idx >> 2, sub = idx & 3;
             const float hi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e >> 4) * 4, cvb));
             const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e & 15) * 4, cvb));
@@ -409,8 +413,9 @@ RtPlan rt_plan(int M, int N, int K, int force_ks) {
     // 11008 x 4096 11.2 vs 16.0; 4096 x 11008 11.5 vs 10.8)
     pl.waves = (pl.mt == 1 && wgs * pl.ks <= cus && pl.cps > 16) ? 16 : 8;
     // with directly loaded activation fragments (M <= 4) sixteen wavefronts x one chunk win from 16 chunks on
-    // (4096^2 M = 3: 6.33 vs 6.59 us)
-    if (M <= kRtDirectMaxM && wgs * pl.ks <= cus && pl.cps >= 16)
+    // (4096^2 M = 3: 6.07 vs 6.59 us), and - since the early half of the wavefronts builds the table alone - up to M = 8
+    // (4096^2 M = 5 / 8: 6.40 / 6.47 vs 6.51 / 6.58 us; M = 16: 6.90 vs 6.78)
+    if (M <= 8 && wgs * pl.ks <= cus && pl.cps >= 16)
         pl.waves = 16;
     return pl;
 }
