@@ -275,10 +275,18 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
     if constexpr (NESTED)
         offset = p.absmax_offset[0]; // scalar load
 
+    // Only chunk 0 goes out now. A wavefront pushes its loads into the memory pipeline back to back, so with the whole ring
+    // requested at once the chunk-0 data of the last wavefronts queues behind chunks 1 .. D-1 of the first ones (the first
+    // chunk landed ~9100 cycles into the kernel, r1_timeline_mfma_pc_smemtime.txt); the rest of the ring follows after
+    // barrier #0, still a chunk of compute ahead of its use.
+    constexpr bool STAGGER = (NTW == 1); // (the two-tile instances have no registers to spare for the second issue site)
+    issue_w(c_begin, 0);
+    if constexpr (!STAGGER) {
 #pragma unroll
-    for (int j = 0; j < D; ++j)
-        if (j < n)
-            issue_w(c_begin + j, j);
+        for (int j = 1; j < D; ++j)
+            if (j < n)
+                issue_w(c_begin + j, j);
+    }
 
     f32x4 acc[MT][NTW];
 #pragma unroll
@@ -305,7 +313,8 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
             if (k >= n)
                 break;
             // chunk k of this wavefront has landed; the min(D-1, n-1-k) younger ones stay in flight
-            const int younger = (n - 1 - k < D - 1) ? n - 1 - k : D - 1;
+            const bool first = STAGGER && (j == 0) && (k0 == 0); // (j is a constant of the unrolled copy: the extra code exists once)
+            const int younger = first ? 0 : ((n - 1 - k < D - 1) ? n - 1 - k : D - 1); // (chunk 0: nothing else is in flight yet)
             if (younger <= 0)
                 wait_vmcnt<0>();
             else if (younger == 1)
@@ -322,6 +331,12 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
             __builtin_amdgcn_s_barrier(); // #k: A(k) is in LDS (and, the first time, the tables)
             if (k < 4)
                 BNB_PC_STAMP(3 + 3 * k)
+            if (first) {
+#pragma unroll
+                for (int jj = 1; jj < D; ++jj)
+                    if (jj < n)
+                        issue_w(c_begin + jj, jj);
+            }
             const int zsh = opaque_zero();
 
             const unsigned char* xb = xring + (k & 1) * XB;
