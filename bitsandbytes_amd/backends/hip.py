@@ -308,9 +308,9 @@ def _gemm_4bit_fused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8
 
 
 # ------------------------------------------------------------------------------------------ gemm_4bit backward
-# Largest batch the fused backward is used for: the kernel dequantizes the weight tile once per 64-row pass, so above two
-# passes one dequantize_4bit + hipBLASLt GEMM is cheaper (measured on MI355X, profiles/r2_backward_bench.txt: 4096^2 M = 64
-# 19 vs 32 us, 11008 x 4096 37 vs 100 us, but M = 256 48 vs 33 us).
+# Largest batch the fused backward is used for: the kernel decodes the weights once per 64-row pass, so above two passes
+# one dequantize_4bit + hipBLASLt GEMM is cheaper (measured on MI355X, profiles/r2_backward_bench.txt: 4096^2 M = 64 15.9 vs
+# 31.6 us, M = 128 17.4 vs 40.6; 11008 x 4096 M = 64 22.8 vs 99 us; but 4096^2 M = 256 35 vs 32 us).
 FUSED_BACKWARD_MAX_M = 128
 
 
