@@ -30,6 +30,8 @@
 //    gemm4_finalize: bit-reproducible.
 #include "bnb_common.h"
 
+#include <atomic>
+
 namespace bnb {
 
 #ifdef BNB_PROFILING
@@ -425,6 +427,7 @@ GiPlan gi_slices(int blocks, int ns, int mt) {
     return pl;
 }
 // N slices to fill the chip (one workgroup per CU), at least two blocks per wavefront each
+std::atomic<int> g_gi_force_ns{0}; // sweeps (bnb_mi355x_set_tuning reserved1): N slices, 0 = built-in choice
 GiPlan gi_plan(int M, int N, int K) {
     const int blocks = N / kGiBlockN;
     const int mt = gi_row_tiles(M);
@@ -432,6 +435,9 @@ GiPlan gi_plan(int M, int N, int K) {
     int ns = gi_cu_count() / wgs;
     const int max_ns = blocks / (2 * kGiWaves) > 0 ? blocks / (2 * kGiWaves) : 1;
     ns = ns > max_ns ? max_ns : ns;
+    const int force = g_gi_force_ns.load(std::memory_order_relaxed);
+    if (force > 0)
+        ns = force < blocks ? force : blocks;
     return gi_slices(blocks, ns, mt);
 }
 
@@ -463,6 +469,8 @@ template <typename T> void gi_launch(const void* G, const uint8_t* B, const floa
 }
 
 } // namespace
+
+void gemm_4bit_grad_input_set_slices(int ns) { g_gi_force_ns.store(ns, std::memory_order_relaxed); }
 
 constexpr int kGiNAlign = 64; // N % 64 == 0 (whole 32-n blocks, 16-byte aligned grad_out rows with room to spare)
 

@@ -140,7 +140,8 @@ size_t bnb_mi355x_gemm_4bit_grad_input_workspace_bytes(int M, int N, int K);
 int bnb_mi355x_gemm_4bit_grad_input_supported(int dtype, int M, int N, int K, int blocksize);
 
 /* Tuning overrides for sweeps and tests (0 = built-in heuristic). reserved0: encoder of the 8-bit blockwise quantize - 1 =
- * cell-table kernel, 2 = byte-table kernel, anything else = by input size; reserved1: unused. MFMA kernels: knob0 reserved,
+ * cell-table kernel, 2 = byte-table kernel, anything else = by input size; reserved1: N slices of the fused backward (> 0; the
+ * workspace-size query follows it). MFMA kernels: knob0 reserved,
  * knob1 = 100 * cfg + K-slice count (cfg 11-14 producer/consumer geometries, 20/21/22
  * register-transposed kernel with built-in / 8 / 16 wavefronts). Every setting
  * computes correct results - the knobs only choose a launch geometry (atomics; a call takes one snapshot). */
