@@ -1160,6 +1160,8 @@ def test_native_dispatch_matches_python_kernel():
 
     from bitsandbytes_amd.backends import hip
 
+    if os.environ.get("BNB_MI355X_PYTHON_DISPATCH") == "1":
+        pytest.skip("the Python kernel was requested instead of the C++-registered one")
     assert hip.NATIVE_DISPATCH, "libbitsandbytes_mi355x_torch.so was not loaded"
     F = _F()
     op = torch.ops.bitsandbytes.gemm_4bit.default
