@@ -415,3 +415,25 @@ def test_grad_input_lane_algebra_emulation():
         assert mod.emulate(M=M, N=N, MT=MT, seed=M) < 1e-12
     assert mod.patch_swizzle_conflict_free()
     assert all(mod.final_sum_units_cover_the_tile(mt) for mt in (1, 2, 4))
+
+
+def test_blockwise8_threshold_finders_and_byte_table_emulation():
+    """csrc/blockwise8.hip restated in numpy fp32: the inverse-and-walk threshold finder equals the 17-step bisection it
+    replaced, and the scatter + prefix-sum byte table equals both the direct count and the reference's own table rule
+    (csrc/cpu_ops.cpp:501-520) - for every code map constructor of the package and the edge values of the comparison."""
+    import importlib.util
+    import os
+
+    import numpy as np
+
+    import bitsandbytes_amd.functional as F
+
+    spec = importlib.util.spec_from_file_location(
+        "emulate_q8_thresholds", os.path.join(os.path.dirname(__file__), "checks", "emulate_q8_thresholds.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for code in (F.create_dynamic_map(), F.create_dynamic_map(signed=False), F.create_linear_map(True, 8), F.create_linear_map(True, 2),
+                 F.create_fp8_map(True, 4, 3, 8), F.create_fp8_map(True, 2, 1, 4), F.create_normal_map(), F.create_dynamic_map(True, 3, 3)):
+        assert mod.check_code(code.numpy())
+    for m in (-2.0, -1.0, 0.0, 1.0, 2.0, float("inf"), float("nan")):
+        assert mod.first_bin_above(m) == mod.bisect_threshold(np.float32(m))
