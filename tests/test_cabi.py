@@ -217,3 +217,26 @@ def test_bench_contract_flags_and_algorithmic_bytes():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
+
+
+def test_native_dispatch_routing_constants_match_python():
+    """csrc/torch_dispatch.cpp repeats the routing thresholds of backends/hip.py (the two kernels of bitsandbytes::gemm_4bit must
+    route identically; the GPU test compares their results, this one pins the constants on a host without a GPU)."""
+    from bitsandbytes_amd.backends import hip
+
+    src = open(os.path.join(ROOT, "bitsandbytes_amd", "csrc", "torch_dispatch.cpp")).read()
+
+    def const(name):
+        m = re.search(rf"constexpr\s+int64_t\s+{name}\s*=\s*(\d+)\s*;", src)
+        assert m, name
+        return int(m.group(1))
+
+    assert const("kFusedMaxM") == hip.FUSED_MAX_M
+    assert const("kReferenceCustomMaxM") == hip._REFERENCE_CUSTOM_MAX_M
+    # fp32 activations: fused up to 4 rows in both
+    assert const("kFusedMaxMFp32") == 4
+    import torch
+
+    assert hip._gemm_4bit_route(torch.float32, 4, 64, 64, 64) == "fused" and hip._gemm_4bit_route(torch.float32, 5, 64, 64, 64) == "unfused"
+    assert hip._gemm_4bit_route(torch.bfloat16, hip.FUSED_MAX_M, 64, 64, 64) == "fused"
+    assert hip._gemm_4bit_route(torch.bfloat16, hip.FUSED_MAX_M + 1, 64, 64, 64) == "unfused"
