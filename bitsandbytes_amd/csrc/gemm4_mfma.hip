@@ -475,7 +475,7 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
 }
 
 // out = T(sum_s ws[s] + bias), slabs added in slice order (deterministic)
-template <typename T>
+template <typename T, int BATCH>
 __global__ __launch_bounds__(256) void gemm4_finalize_kernel(const float* __restrict__ ws, const T* __restrict__ bias,
                                                              T* __restrict__ out, long total, int N, int kslices) {
     const long i = (static_cast<long>(blockIdx.x) * 256 + threadIdx.x) * 4;
@@ -486,15 +486,16 @@ __global__ __launch_bounds__(256) void gemm4_finalize_kernel(const float* __rest
         // waits for every load before issuing the next one and the launch costs kslices memory round trips
         // (4.6 us measured for 8 slabs). The adds still run in slice order.
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s0 = 0; s0 < kslices; s0 += 8) {
-            f32x4 w[8];
+        // (BATCH = 2 / 4 / 8 by slice count: with a fixed batch of 8, four slices meant four wasted re-reads per thread)
+        for (int s0 = 0; s0 < kslices; s0 += BATCH) {
+            f32x4 w[BATCH];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < BATCH; ++j) {
                 const int sl = (s0 + j < kslices) ? s0 + j : kslices - 1; // clamp: a re-read, never out of range
                 w[j] = *reinterpret_cast<const f32x4*>(ws + static_cast<long>(sl) * total + i);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < BATCH; ++j) {
                 const bool live = s0 + j < kslices; // wave-uniform
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -516,6 +517,18 @@ __global__ __launch_bounds__(256) void gemm4_finalize_kernel(const float* __rest
             out[e] = static_cast<T>(v + b);
         }
     }
+}
+
+template <typename T>
+void launch_finalize(const float* ws, const T* bias, T* out, long total, int N, int kslices, hipStream_t stream) {
+    const long threads = (total + 3) / 4;
+    const dim3 grid(static_cast<unsigned>((threads + 255) / 256));
+    if (kslices <= 2)
+        hipLaunchKernelGGL((gemm4_finalize_kernel<T, 2>), grid, dim3(256), 0, stream, ws, bias, out, total, N, kslices);
+    else if (kslices <= 4)
+        hipLaunchKernelGGL((gemm4_finalize_kernel<T, 4>), grid, dim3(256), 0, stream, ws, bias, out, total, N, kslices);
+    else
+        hipLaunchKernelGGL((gemm4_finalize_kernel<T, 8>), grid, dim3(256), 0, stream, ws, bias, out, total, N, kslices);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -702,10 +715,7 @@ template <typename T> void dispatch_mfma(GemmArgs& p, float* ws, size_t ws_bytes
     BNB_CHECK_LAUNCH();
 
     if (pl.ks > 1) {
-        const long total = static_cast<long>(p.M) * p.N;
-        const long threads = (total + 3) / 4;
-        hipLaunchKernelGGL((gemm4_finalize_kernel<T>), dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0,
-                           stream, p.ws, static_cast<const T*>(p.bias), static_cast<T*>(p.out), total, p.N, pl.ks);
+        launch_finalize<T>(p.ws, static_cast<const T*>(p.bias), static_cast<T*>(p.out), static_cast<long>(p.M) * p.N, p.N, pl.ks, stream);
         BNB_CHECK_LAUNCH();
     }
 }
@@ -723,14 +733,10 @@ void gemm_4bit_rt(int dtype, const void* A, const uint8_t* B, const float* absma
 // shared with gemm4_mfma_rt.hip: the slab finalize launch and the library-owned workspace
 void gemm_4bit_finalize(int dtype, const float* ws, const void* bias, void* out, int M, int N, int kslices, hipStream_t stream) {
     const long total = static_cast<long>(M) * N;
-    const long threads = (total + 3) / 4;
-    const dim3 grid(static_cast<unsigned>((threads + 255) / 256));
     if (dtype == 2)
-        hipLaunchKernelGGL((gemm4_finalize_kernel<bf16>), grid, dim3(256), 0, stream, ws, static_cast<const bf16*>(bias),
-                           static_cast<bf16*>(out), total, N, kslices);
+        launch_finalize<bf16>(ws, static_cast<const bf16*>(bias), static_cast<bf16*>(out), total, N, kslices, stream);
     else
-        hipLaunchKernelGGL((gemm4_finalize_kernel<f16>), grid, dim3(256), 0, stream, ws, static_cast<const f16*>(bias),
-                           static_cast<f16*>(out), total, N, kslices);
+        launch_finalize<f16>(ws, static_cast<const f16*>(bias), static_cast<f16*>(out), total, N, kslices, stream);
     BNB_CHECK_LAUNCH();
 }
 float* gemm_4bit_internal_workspace(size_t bytes, hipStream_t stream) { return get_internal_workspace(bytes, stream); }
