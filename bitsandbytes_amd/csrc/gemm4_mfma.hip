@@ -730,7 +730,15 @@ void gemm_4bit_rt(int dtype, const void* A, const uint8_t* B, const float* absma
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int force_waves,
                   hipStream_t stream);
 
-// shared with gemm4_mfma_rt.hip: the slab finalize launch and the library-owned workspace
+// gemm4_mfma_ps.hip (the pre-scaled-operand kernel: 32x32x16 MFMA, register ring, one barrier per 256 k)
+bool gemm_4bit_ps_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize);
+size_t gemm_4bit_ps_workspace_bytes(int M, int N, int K, int force_ks);
+void gemm_4bit_ps(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
+                  const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
+                  int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int variant,
+                  hipStream_t stream);
+
+// shared with gemm4_mfma_rt.hip / gemm4_mfma_ps.hip: the slab finalize launch and the library-owned workspace
 void gemm_4bit_finalize(int dtype, const float* ws, const void* bias, void* out, int M, int N, int kslices, hipStream_t stream) {
     const long total = static_cast<long>(M) * N;
     if (dtype == 2)
@@ -768,6 +776,19 @@ bool rt_selected(int M, int N, int K, int knob1, int* force_ks, int* force_waves
         return weights <= (20L << 20);
     return false;
 }
+// Which problems go to the pre-scaled-operand kernel (tuning knob cfg 30 / 31 forces it: pinned software pipeline /
+// compiler-scheduled steps; knob % 100 = K slices).
+bool ps_selected(int M, int N, int K, int knob1, int* force_ks, int* variant) {
+    const int cfg = knob1 / 100;
+    *force_ks = 0;
+    *variant = 0;
+    if (cfg == 30 || cfg == 31) {
+        *force_ks = knob1 % 100;
+        *variant = cfg - 30;
+        return true;
+    }
+    return false;
+}
 } // namespace
 
 // Preconditions of the MFMA kernel: 16-bit activations, K a multiple of 256, blocksize >= 64
@@ -783,6 +804,9 @@ size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K) {
         return 0;
     int fks, fw;
     const int knob1 = g_mfma_knob1.load(std::memory_order_relaxed);
+    int pks, pvar;
+    if (ps_selected(M, N, K, knob1, &pks, &pvar))
+        return gemm_4bit_ps_workspace_bytes(M, N, K, pks);
     if (rt_selected(M, N, K, knob1, &fks, &fw))
         return gemm_4bit_rt_workspace_bytes(M, N, K, fks);
     const Plan pl = make_plan(M, N, K, knob1);
@@ -795,6 +819,10 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
                     size_t workspace_bytes, hipStream_t stream) {
     int fks, fw;
     const int knob0 = g_mfma_knob0.load(std::memory_order_relaxed), knob1 = g_mfma_knob1.load(std::memory_order_relaxed);
+    int pks, pvar;
+    if (ps_selected(M, N, K, knob1, &pks, &pvar) && gemm_4bit_ps_supported(dtype, A, B, code16, M, N, K, blocksize))
+        return gemm_4bit_ps(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type,
+                            workspace, workspace_bytes, pks, pvar, stream);
     if (rt_selected(M, N, K, knob1, &fks, &fw) && gemm_4bit_rt_supported(dtype, A, B, code16, M, N, K, blocksize))
         return gemm_4bit_rt(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize,
                             quant_type, workspace, workspace_bytes, fks, fw, stream);

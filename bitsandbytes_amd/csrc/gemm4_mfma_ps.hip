@@ -1,0 +1,548 @@
+// gemm4_mfma_ps.hip — "pre-scaled operand" MFMA kernel for batched 4-bit linear layers on gfx950 (round 3):
+//     out[m, n] = sum_k A[m, k] * T(code[B[n, k]] * scale[n, k / bs])  (+ bias[n])          T in {bf16, fp16}
+//
+// Fills, on MI355X, the tensor-core capability the reference has on CUDA only (csrc/gemm_4bit_sm80.cu:127-457,493-689) and
+// uses that kernel's arithmetic: every weight is decoded to T(code * scale) - fp32 product, ONE rounding to T, exactly
+// csrc/gemm_4bit_sm80.cu:300-307 and exactly what dequantize_4bit produces (csrc/cpu_ops.cpp:419-431) - straight into the MFMA
+// B operand, so the result equals dequantize_4bit + a T matmul with fp32 accumulation up to the order of the fp32 sums.
+// The round-1/2 kernels (gemm4_mfma.hip, gemm4_mfma_rt.hip) multiplied bf16-rounded codes and applied the fp32 scale to
+// the partial tile of every 64-k block with VALU FMAs: that pins the accumulators to architectural VGPRs, costs 4 v_fma
+// per (tile, block) and batch tile, and spends one address instruction + one ds_read_b32 per weight byte and batch tile
+// pair. Here the accumulators are touched by MFMA instructions only and the decode of a chunk is shared by all batch rows.
+//
+// Shape of the kernel (what the PMC passes of round 2 asked for - fewer LDS operand bytes per FLOP, no VALU on the
+// accumulators, a deep weight stream that no barrier drains):
+//
+//  * v_mfma_f32_32x32x16_{bf16,f16}: A operand = activations (row m = lane % 32), B operand = weights (column n = lane % 32),
+//    lane half h = lane / 32 holds k = 8 h + 0..7 of the 16-k step. Half the LDS operand traffic per FLOP of the 16x16x32 form.
+//  * one workgroup = 128 output columns x (32 MT batch rows, MT = 1 | 2) x one K slice; 8 wavefronts = 4 column groups of 32
+//    x 2 K halves. A "stage" is 256 k: K half q works on its own 128-k chunk of it, so every wavefront decodes ONE chunk
+//    (32 columns x 128 k = 2 KiB of packed weights) per stage and multiplies it with all 32 MT rows.
+//  * EVERY global load of a wavefront - its two weight loads, its share of the activation stage (2 MT loads of 4 rows x
+//    256 B) and its scale - is an ordinary coalesced load into a D-deep REGISTER ring, all at the same prefetch distance:
+//    vmcnt retires in order, so streams with different distances in one wavefront collapse to the shortest (round 1); with
+//    one distance the compiler's counted waits are exact and D - 1 stages per wavefront stay in flight across the barrier.
+//    No LDS-DMA, no producer wavefronts, no inline-asm waits.
+//  * weights: lane 4 r + p loads 16 bytes of row r (four neighbouring lanes = 64 contiguous bytes: 16 L1 tag look-ups per
+//    instruction); the MFMA wants the row in the low lane bits, so the chunk goes through a 2-KiB tile private to the
+//    wavefront (ds_write_b128 / ds_read_b128, same wavefront, in-order LDS, no barrier; XOR swizzle conflict-free under the
+//    hardware's lane groups). After it lane (n, h) holds the 64 consecutive k [64 h, 64 h + 64) of column n = ONE
+//    quantization block (bs >= 64): one scale per lane and chunk; MFMA step s consumes dword s (k = 64 h + 8 s + 0..7) and
+//    the activation fragment of the same k - K order inside an MFMA is free as long as both operands agree.
+//  * decode per packed byte: v_perm_b32 (LDS address) + ds_read_b64 (bank-private byte -> (code[hi], code[lo]) fp32 table
+//    built from literals) + v_pk_mul_f32 by the lane's scale + one convert-and-pack.
+//  * activations: the wavefronts write their pieces of stage t into LDS buffer t & 1 (rows of 512 B = both chunks, 16-byte
+//    pieces XOR-swizzled by the row: conflict-free ds_write_b128 and ds_read_b128), ONE s_barrier per stage.
+//  * the two K halves of a column group are added through LDS (fixed order), K slices across workgroups write fp32 slabs
+//    that gemm4_finalize adds in slice order: bit-reproducible.
+#include "bnb_common.h"
+
+namespace bnb {
+
+#ifdef BNB_PROFILING
+extern unsigned long long* g_dbg_buf;
+#endif
+
+// gemm4_mfma.hip
+void gemm_4bit_finalize(int dtype, const float* ws, const void* bias, void* out, int M, int N, int kslices, hipStream_t stream);
+float* gemm_4bit_internal_workspace(size_t bytes, hipStream_t stream);
+
+namespace {
+
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+template <typename T> struct PsMma;
+template <> struct PsMma<bf16> {
+    using frag = __attribute__((ext_vector_type(8))) bf16;
+    static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(frag, a), __builtin_bit_cast(frag, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t pack(float first, float second) {
+        using V = __attribute__((ext_vector_type(2))) bf16;
+        V v;
+        v[0] = static_cast<bf16>(first);
+        v[1] = static_cast<bf16>(second);
+        return __builtin_bit_cast(uint32_t, v);
+    }
+};
+template <> struct PsMma<f16> {
+    using frag = __attribute__((ext_vector_type(8))) f16;
+    static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(frag, a), __builtin_bit_cast(frag, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t pack(float first, float second) {
+        // (the fp32 products are opaque register values here - see the decode loop - so hipcc cannot fuse the multiply into
+        // v_fma_mix*_f16, which would round the exact product once instead of fp32 first, T second)
+        using V = __attribute__((ext_vector_type(2))) f16;
+        V v;
+        v[0] = static_cast<f16>(first);
+        v[1] = static_cast<f16>(second);
+        return __builtin_bit_cast(uint32_t, v);
+    }
+};
+
+constexpr int kPsCols = 128;        // output columns per workgroup: 4 column groups of 32
+constexpr int kPsStageK = 256;      // k per stage: one 128-k chunk per K half
+constexpr int kPsWaves = 8;         // 4 column groups x 2 K halves
+constexpr int kPsLut = 65536;       // 256 entries x 32 copies x 8 B (fp32 pair), at LDS address 0
+constexpr int kPsABuf = 32768;      // one activation stage buffer: up to 64 rows x 512 B
+constexpr int kPsABase = kPsLut;    // two stage buffers
+constexpr int kPsTileBase = kPsABase + 2 * kPsABuf; // per-wavefront transposition tiles, 2 KiB each
+constexpr int kPsCode2 = kPsTileBase + kPsWaves * 2048;
+constexpr int kPsLdsBytes = kPsCode2 + 1024;
+
+struct PsArgs {
+#ifdef BNB_PROFILING
+    unsigned long long* dbg;
+#endif
+    const float* absmax_code;
+    const float* absmax_offset;
+    void* out;
+    const void* bias;
+    float* ws; // fp32 [kslices][M][N] partial slabs when kslices > 1
+};
+
+#ifdef BNB_PROFILING
+#define BNB_PS_STAMP(i)                                                                            \
+    {                                                                                              \
+        if (p.dbg && lane == 0)                                                                    \
+            p.dbg[((static_cast<long>(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * kPsWaves * 16 + wave * 16 + (i)] = \
+                __builtin_amdgcn_s_memtime();                                                      \
+    }
+#else
+#define BNB_PS_STAMP(i) {}
+#endif
+
+__device__ __forceinline__ float ps_code_literal(int i, bool fp4) {
+    // compare/select over literals: no memory access in front of the table
+    constexpr float nf4[16] = {BNB_NF4_VALUES};
+    constexpr float fp4v[16] = {BNB_FP4_VALUES};
+    float v = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        v = (i == j) ? (fp4 ? fp4v[j] : nf4[j]) : v;
+    return v;
+}
+
+// grid = (ceil(N / 128), kslices, ceil(M / (32 MT))); 512 threads. D = depth of the register ring in stages.
+template <typename T, int MT, bool NESTED, int D, bool PIPE>
+__global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
+    // hot arguments as separate scalars: preloaded into SGPRs by the command processor (14 dwords)
+    const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, int hot_M, int hot_N,
+    int hot_K, int hot_flags /* bs_shift | fp4 << 8 */, int hot_sps /* stages per K slice */, int hot_kslices,
+    const PsArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    BNB_PS_STAMP(0)
+    const int g = wave & 3, q = wave >> 2;        // column group, K half
+    const int r = lane >> 2, pp = lane & 3;       // weight-load roles: row r of a 16-row half tile, 16-byte piece pp of its 64 bytes
+    const int n = lane & 31, h = lane >> 5;       // MFMA roles: column / row n, k half h
+    const int arow = lane >> 4, apiece = lane & 15; // activation-load roles: row arow of a 4-row group, 16-byte piece of its 256 bytes
+    const int M = hot_M, N = hot_N, K = hot_K;
+    const int bs_shift = hot_flags & 31;
+    const bool fp4 = (hot_flags >> 8) & 1;
+    const int col0 = blockIdx.x * kPsCols + 32 * g;
+    const int m_base = blockIdx.z * (32 * MT);
+    const int stages_total = K >> 8;
+    const int sb = blockIdx.y * hot_sps;
+    int se = sb + hot_sps;
+    se = se < stages_total ? se : stages_total;
+    const int ns = se - sb; // stages of this slice (>= 1: the host makes every slice non-empty)
+    // K half q owns the chunks [kq, kq + 128 ns) of the slice [256 sb, 256 se): chunk j of the wavefront = k kq + 128 j
+    const long kq = (static_cast<long>(sb) << 8) + static_cast<long>(q) * 128 * ns;
+
+    // ---- sources. Rows past the end (ragged N or M) re-read the last row: MFMA rows / columns are independent and those
+    // results are never stored, so no masking instructions are needed.
+    const uint8_t* wsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int row = col0 + 16 * i + r;
+        row = row < N ? row : N - 1;
+        wsrc[i] = hot_B + static_cast<long>(row) * (K >> 1) + (kq >> 1) + pp * 16;
+    }
+    constexpr int AI = 2 * MT; // activation loads per wavefront and stage: 4 rows x 256 B each
+    const T* asrc[AI];
+    uint32_t a_wr[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int row_local = 8 * MT * g + 4 * i + arow;
+        int m = m_base + row_local;
+        m = m < M ? m : M - 1;
+        asrc[i] = static_cast<const T*>(hot_A) + static_cast<long>(m) * K + kq + 8 * apiece;
+        a_wr[i] = static_cast<uint32_t>(kPsABase + row_local * 512 + (((16 * q + apiece) ^ (row_local & 15)) << 4));
+    }
+    // scale of lane (n, h) for chunk j: block of flat element (row n) * K + kq + 128 j + 64 h
+    int srow = col0 + n;
+    srow = srow < N ? srow : N - 1;
+    const long se0 = static_cast<long>(srow) * K + kq + 64 * h;
+
+    struct Stage {
+        u32x4 w[2];  // lane (r, pp) holds bytes [16 pp, 16 pp + 16) of the chunk's 64 bytes of rows r, 16 + r
+        u32x4 a[AI]; // this wavefront's share of the activation stage
+        uint32_t s, s2;
+    };
+    auto issue = [&](Stage& x, int j) {
+        j = j < ns ? j : ns - 1; // a prefetch past the end re-reads the last chunk: never used, keeps every wait counted
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            x.w[i] = *reinterpret_cast<const u32x4*>(wsrc[i] + static_cast<long>(j) * 64);
+        const long blk = (se0 + static_cast<long>(j) * 128) >> bs_shift;
+        if constexpr (NESTED) {
+            x.s = hot_absmax8[blk];
+            x.s2 = __builtin_bit_cast(uint32_t, hot_absmax[blk >> 8]);
+        } else {
+            x.s = __builtin_bit_cast(uint32_t, hot_absmax[blk]);
+            x.s2 = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+            x.a[i] = *reinterpret_cast<const u32x4*>(asrc[i] + static_cast<long>(j) * 128);
+    };
+
+    Stage st[D];
+    // (nested: the second-level code entry of this thread is requested FIRST, so that the wait in front of its LDS copy is a
+    // counted one that leaves the stage-0 loads in flight)
+    float code2_v = 0.0f, offset = 0.0f;
+    if constexpr (NESTED) {
+        code2_v = p.absmax_code[tid & 255];
+        offset = p.absmax_offset[0];
+    }
+    issue(st[0], 0);
+    BNB_PS_STAMP(1)
+    __builtin_amdgcn_sched_barrier(0); // nothing that is not needed for the loads runs before them
+
+    // ---- decode table, built while the first loads fly: entry e (a packed byte) = 32 copies of (code[e >> 4], code[e & 15])
+    // in fp32, 256 B per entry; thread (part, e) writes 8 of its 16 chunks in an order rotated by e (eight lanes -> eight
+    // bank quads)
+    {
+        const float cv = ps_code_literal((lane & 15) + opaque_zero(), fp4);
+        const int cvb = __builtin_bit_cast(int, cv);
+        constexpr int PER = 16 * 256 / (kPsWaves * 64); // 16-byte chunks of an entry per thread
+        const int e = tid & 255, part = tid >> 8;
+        const float hi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((e >> 4) & 15) * 4, cvb));
+        const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e & 15) * 4, cvb));
+        const f32x4 v = {hi, lo, hi, lo};
+        f32x4* const dst = reinterpret_cast<f32x4*>(smem + e * 256 + part * (PER * 16));
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            dst[(j + e) & (PER - 1)] = v;
+    }
+    float* const code2 = reinterpret_cast<float*>(smem + kPsCode2);
+    if constexpr (NESTED) {
+        if (tid < 256)
+            code2[tid] = code2_v;
+    }
+    __syncthreads();
+    BNB_PS_STAMP(2)
+#pragma unroll
+    for (int j = 1; j < D; ++j)
+        issue(st[j], j);
+    if (reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem) != 0)
+        __builtin_trap(); // the table is addressed with raw v_perm_b32 results: it must sit at LDS address 0
+
+    const uint32_t perm_sel = 0x0C0C0400u + static_cast<uint32_t>(opaque_zero()); // {lane offset, weight byte, 0, 0}
+    const uint32_t lane_off = static_cast<uint32_t>(lane & 31) * 8u;
+
+    // transposition tile: row R (64 B) keeps its 16-byte piece P at position P ^ ((R >> 2) & 3): the 8 contiguous lanes one
+    // ds_write_b128 pass serves (rows 2 i, 2 i + 1 x pieces 0..3) land in 8 different 16-byte positions mod 128 B, the 16-lane
+    // groups of ds_read_b128 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32: sixteen rows distinct mod 16, one piece) in 16
+    // different positions mod 256 B
+    unsigned char* const tile = smem + kPsTileBase + wave * 2048;
+    uint32_t t_wr[2], t_rd[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 16 * i + r;
+        t_wr[i] = static_cast<uint32_t>((row * 4 + (pp ^ ((row >> 2) & 3))) * 16);
+        t_rd[i] = static_cast<uint32_t>((n * 4 + ((2 * h + i) ^ ((n >> 2) & 3))) * 16);
+    }
+    // activation fragment of step s, row tile mt, stage buffer par: (a_rd ^ (s << 4)) + par * 32768 + mt * 16384
+    const uint32_t a_rd = static_cast<uint32_t>(kPsABase + n * 512 + (((16 * q + 8 * h) ^ (n & 15)) << 4));
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            acc[mt][i] = 0.0f;
+
+    auto do_stage = [&](Stage& x, int j) {
+        const uint32_t par = static_cast<uint32_t>(j & 1) * kPsABuf;
+        // (1) this wavefront's share of activation stage j -> LDS buffer j & 1 (its last readers passed barrier j - 1)
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+            *reinterpret_cast<u32x4*>(smem + a_wr[i] + par) = x.a[i];
+        // (2) packed weights: coalesced shape -> MFMA shape through the private tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<u32x4*>(tile + t_wr[i]) = x.w[i];
+        u32x4 wt[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            wt[i] = *reinterpret_cast<const u32x4*>(tile + t_rd[i]);
+        float scale;
+        {
+            // The scale leaves its ring register HERE, through an instruction the compiler cannot move: left to itself hipcc
+            // parks the copy in the loop latch, where its wait for this one load becomes s_waitcnt vmcnt(0) - a drain of the
+            // whole ring once per round (seen in the ISA of the first build). At this point every load of stage j is needed
+            // anyway, so the wait in front of the copy is the counted one.
+            uint32_t sv, s2v;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(sv) : "v"(x.s));
+            if constexpr (NESTED)
+                asm volatile("v_mov_b32 %0, %1" : "=v"(s2v) : "v"(x.s2));
+            else
+                s2v = 0;
+            if constexpr (NESTED)
+                scale = __fadd_rn(__fmul_rn(code2[sv & 0xFFu], __builtin_bit_cast(float, s2v)), offset);
+            else
+                scale = __builtin_bit_cast(float, sv);
+        }
+        const f32x2 sc2 = {scale, scale};
+        auto dword_of = [&](int s) -> uint32_t { return (s < 4) ? wt[0][s & 3] : wt[1][s & 3]; };
+        auto lut_reads = [&](int s, f32x2 (&pr)[4]) {
+            const uint32_t w = dword_of(s);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                pr[b] = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>(
+                    __builtin_amdgcn_perm(w, lane_off, perm_sel + (b << 8)));
+        };
+        auto convert = [&](const f32x2 (&pr)[4]) -> u32x4 {
+            u32x4 bf;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const f32x2 pv = pr[b] * sc2;
+                float p0 = pv[0], p1 = pv[1];
+                if constexpr (!__is_same(T, bf16)) {
+                    asm("" : "+v"(p0));
+                    asm("" : "+v"(p1));
+                }
+                bf[b] = PsMma<T>::pack(p0, p1);
+            }
+            return bf;
+        };
+        f32x2 pr[2][4];
+        u32x4 af[2][MT];
+        if constexpr (PIPE)
+            lut_reads(0, pr[0]); // (the table look-ups of step 0 need nothing from the other wavefronts: ahead of the barrier)
+        // (3) the ring slot is free: request stage j + D
+        issue(x, j + D);
+        if (j < 3)
+            BNB_PS_STAMP(3 + 3 * j)
+        // (4) activation stage j complete in LDS for every wavefront
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j < 3)
+            BNB_PS_STAMP(4 + 3 * j)
+        // (5) eight 16-k MFMA steps: dword s of the lane = k [64 h + 8 s, + 8) of column n
+        const uint32_t a_base = a_rd + par;
+        auto a_reads = [&](int s, u32x4 (&f)[MT]) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                f[mt] = *reinterpret_cast<const u32x4*>(smem + (a_base ^ static_cast<uint32_t>(s << 4)) + mt * 16384);
+        };
+        if constexpr (PIPE) {
+            // two-deep software pipeline, pinned: the LDS reads of step s + 1 (table look-ups, activation fragments) go out
+            // before the converts and MFMAs of step s, so no MFMA sits behind an LDS round trip issued just in front of it
+            a_reads(0, af[0]);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int cur = s & 1, nxt = cur ^ 1;
+                if (s + 1 < 8) {
+                    lut_reads(s + 1, pr[nxt]);
+                    a_reads(s + 1, af[nxt]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x4 bf = convert(pr[cur]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = PsMma<T>::run(af[cur][mt], bf, acc[mt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                lut_reads(s, pr[0]);
+                const u32x4 bf = convert(pr[0]);
+                a_reads(s, af[0]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = PsMma<T>::run(af[0][mt], bf, acc[mt]);
+            }
+        }
+        if (j < 3)
+            BNB_PS_STAMP(5 + 3 * j)
+    };
+    // whole rounds of the ring with nothing conditional around the loads, then the tail
+    int j = 0;
+    for (; j + D <= ns; j += D) {
+#pragma unroll
+        for (int jj = 0; jj < D; ++jj)
+            do_stage(st[jj], j + jj);
+    }
+#pragma unroll
+    for (int jj = 0; jj < D - 1; ++jj)
+        if (j + jj < ns)
+            do_stage(st[jj], j + jj);
+    BNB_PS_STAMP(12)
+
+    // ---- the two K halves of a column group, added in a fixed order (half 0 + half 1); the parking area reuses the
+    // activation buffers: [g][mt][4 register quads][64 lanes x 16 B]
+    __syncthreads();
+    unsigned char* const red = smem + kPsABase + (g * MT) * 4096 + lane * 16;
+    if (q == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                *reinterpret_cast<f32x4*>(red + (mt * 4 + r4) * 1024) =
+                    f32x4{acc[mt][4 * r4], acc[mt][4 * r4 + 1], acc[mt][4 * r4 + 2], acc[mt][4 * r4 + 3]};
+    }
+    __syncthreads();
+    if (q == 0) {
+        const int ncol = col0 + n;
+        const T* const bias = static_cast<const T*>(p.bias);
+        const float bv = (bias && hot_kslices == 1 && ncol < N) ? static_cast<float>(bias[ncol]) : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 o[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                o[r4] = *reinterpret_cast<const f32x4*>(red + (mt * 4 + r4) * 1024);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = acc[mt][i] + o[i >> 2][i & 3];
+                // 32x32 accumulator layout: register i of lane (n, h) = row (i & 3) + 8 (i >> 2) + 4 h, column n
+                const int m = m_base + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (m < M && ncol < N) {
+                    const long o2 = static_cast<long>(m) * N + ncol;
+                    if (hot_kslices == 1)
+                        static_cast<T*>(p.out)[o2] = static_cast<T>(v + bv);
+                    else
+                        p.ws[static_cast<long>(blockIdx.y) * M * N + o2] = v;
+                }
+            }
+        }
+    }
+    BNB_PS_STAMP(13)
+}
+
+struct PsPlan {
+    int mt, ks, sps;
+};
+
+// Row tiles, K slices and stages per slice: a pure function of (M, N, K) and the forced slice count, shared by the launch
+// and the workspace-size query. One workgroup per CU (145 KiB of LDS): K slices fill the chip without spilling into a second
+// round of workgroups; every slice keeps at least two stages so the ring has something to overlap.
+PsPlan ps_plan(int M, int N, int K, int force_ks) {
+    PsPlan pl;
+    pl.mt = M > 32 ? 2 : 1;
+    const int stages = K / kPsStageK;
+    const int gx = (N + kPsCols - 1) / kPsCols;
+    const int gz = (M + 32 * pl.mt - 1) / (32 * pl.mt);
+    const int cus = device_cu_count_or_default();
+    int ks = force_ks > 0 ? force_ks : cus / (gx * gz);
+    const int max_ks = stages / 2 > 0 ? stages / 2 : 1;
+    ks = ks > max_ks ? max_ks : ks;
+    ks = ks < 1 ? 1 : ks;
+    pl.sps = (stages + ks - 1) / ks;
+    pl.ks = (stages + pl.sps - 1) / pl.sps; // every slice non-empty
+    return pl;
+}
+
+template <typename T, int MT, bool NESTED, bool PIPE>
+void ps_launch_one(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
+                   const PsPlan& pl, const PsArgs& a, hipStream_t stream) {
+    constexpr int D = 3;
+    dim3 grid((N + kPsCols - 1) / kPsCols, pl.ks, (M + 32 * MT - 1) / (32 * MT));
+    auto kern = gemm4_mfma_ps_kernel<T, MT, NESTED, D, PIPE>;
+    static LdsLimit lim;
+    ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), kPsLdsBytes);
+    hipLaunchKernelGGL(kern, grid, dim3(kPsWaves * 64), kPsLdsBytes, stream, A, B, absmax, absmax8, M, N, K, flags, pl.sps, pl.ks, a);
+}
+
+template <typename T, bool PIPE>
+void ps_launch(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
+               const PsPlan& pl, const PsArgs& a, hipStream_t stream) {
+    if (absmax8 != nullptr) {
+        if (pl.mt == 1)
+            ps_launch_one<T, 1, true, PIPE>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+        else
+            ps_launch_one<T, 2, true, PIPE>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+    } else {
+        if (pl.mt == 1)
+            ps_launch_one<T, 1, false, PIPE>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+        else
+            ps_launch_one<T, 2, false, PIPE>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+    }
+}
+
+} // namespace
+
+// Preconditions: 16-bit activations, literal code tables, K a multiple of 256, blocksize >= 64 (a lane's 64 k of a chunk
+// stay inside one quantization block), 16-byte aligned A and B.
+bool gemm_4bit_ps_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize) {
+    return (dtype == 1 || dtype == 2) && code16 == nullptr && M >= 1 && N >= 1 && K >= kPsStageK && (K % kPsStageK) == 0 &&
+           blocksize >= 64 && is_pow2(blocksize) && aligned_to(A, 16) && aligned_to(B, 16);
+}
+
+size_t gemm_4bit_ps_workspace_bytes(int M, int N, int K, int force_ks) {
+    if (M < 1 || N < 1 || K < kPsStageK)
+        return 0;
+    const PsPlan pl = ps_plan(M, N, K, force_ks);
+    return pl.ks > 1 ? static_cast<size_t>(pl.ks) * M * N * sizeof(float) : 0;
+}
+
+// dtype: 1 = f16, 2 = bf16. force_ks (0 = built-in choice), variant (0 = pinned software pipeline, 1 = compiler-scheduled
+// steps): sweeps and tests.
+void gemm_4bit_ps(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
+                  const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
+                  int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int variant,
+                  hipStream_t stream) {
+    PsPlan pl = ps_plan(M, N, K, force_ks);
+    float* ws = static_cast<float*>(workspace);
+    const size_t slab = static_cast<size_t>(M) * N * sizeof(float);
+    if (pl.ks > 1) {
+        if (ws == nullptr) {
+            ws = gemm_4bit_internal_workspace(slab * pl.ks, stream);
+            workspace_bytes = ws ? slab * pl.ks : 0;
+        }
+        if (workspace_bytes < slab * pl.ks) {
+            const int fit = static_cast<int>(workspace_bytes / slab);
+            const int stages = K / kPsStageK;
+            const int ks = fit >= 2 ? fit : 1;
+            pl.sps = (stages + ks - 1) / ks;
+            pl.ks = (stages + pl.sps - 1) / pl.sps;
+        }
+    }
+    PsArgs a;
+#ifdef BNB_PROFILING
+    a.dbg = g_dbg_buf;
+#endif
+    a.absmax_code = absmax_code;
+    a.absmax_offset = absmax_offset;
+    a.out = out;
+    a.bias = bias;
+    a.ws = ws;
+    const int flags = ilog2(blocksize) | ((quant_type == kFP4) ? 256 : 0);
+    if (dtype == 2) {
+        if (variant == 1)
+            ps_launch<bf16, false>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+        else
+            ps_launch<bf16, true>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+    } else {
+        if (variant == 1)
+            ps_launch<f16, false>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+        else
+            ps_launch<f16, true>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+    }
+    BNB_CHECK_LAUNCH();
+    if (pl.ks > 1)
+        gemm_4bit_finalize(dtype, ws, bias, out, M, N, pl.ks, stream);
+}
+
+} // namespace bnb

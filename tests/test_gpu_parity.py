@@ -1005,6 +1005,65 @@ def test_mfma_rt_kernel_geometries(cfg, ks, M, N, K):
         assert rel_err(y3.cpu(), _oracle_y(x, q, st, None)) < REL_TOL
 
 
+@pytest.mark.parametrize("cfg,ks", [(30, 0), (31, 0), (30, 1), (30, 2), (30, 3)])
+@pytest.mark.parametrize("M,N,K", [(5, 256, 1024), (16, 200, 2048), (32, 4096, 4096), (33, 384, 1024), (64, 512, 4096),
+                                   (64, 1000, 2816), (100, 130, 512), (128, 1376, 4096), (200, 256, 256), (17, 512, 11008 - 11008 % 256)])
+def test_mfma_ps_kernel_geometries(cfg, ks, M, N, K):
+    """The pre-scaled-operand MFMA kernel (csrc/gemm4_mfma_ps.hip) - pinned software pipeline / compiler-scheduled steps, built-in
+    and forced K slices (incl. slices of unequal length and single-stage slices), ragged N and M, one and two 32-row tiles,
+    several row passes - against the oracle, for fp32 and nested absmax, NF4 and FP4, blocksize 64 / 128 / 256, bf16 and fp16;
+    bit-reproducible run to run."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    for dtype, qt, bs, dq in ((torch.bfloat16, "nf4", 64, False), (torch.bfloat16, "nf4", 64, True),
+                              (torch.float16, "fp4", 128, True), (torch.float16, "nf4", 256, False)):
+        W = (torch.randn(N, K) / K**0.5).to(dtype)
+        x = torch.randn(M, K).to(dtype)
+        bias = torch.randn(N).to(dtype)
+        q, st = F.quantize_4bit(W.to(DEV), blocksize=bs, quant_type=qt, compress_statistics=dq)
+        y_ref = _oracle_y(x, q, st, bias)
+        try:
+            bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, cfg * 100 + ks)
+            y1 = _run_kernel(2, x.to(DEV), q, st, bias.to(DEV))
+            y2 = _run_kernel(2, x.to(DEV), q, st, bias.to(DEV))
+            y3 = _run_kernel(2, x.to(DEV), q, st, None)
+        finally:
+            bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+        assert rel_err(y1.cpu(), y_ref) < REL_TOL, (dtype, qt, bs, dq)
+        assert torch.equal(y1, y2)
+        assert rel_err(y3.cpu(), _oracle_y(x, q, st, None)) < REL_TOL
+
+
+def test_mfma_ps_kernel_equals_dequantize_then_matmul_in_fp64():
+    """The kernel's operand is T(code * scale) - dequantize_4bit's own arithmetic (fp32 product, one rounding). So on ANY
+    data its result must equal the oracle's dequantize_4bit (in T) followed by an exact (fp64) product of the T values up to
+    fp32 summation error only: ~1e-6 relative, two orders of magnitude below what a bf16-rounded code or a post-scaled
+    accumulator would give. A wrong rounding point, a k paired with the wrong weight or a neighbour's scale fails this."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    M, N, K = 48, 384, 2048
+    for dtype, qt, bs, dq in ((torch.bfloat16, "nf4", 64, False), (torch.float16, "fp4", 128, True)):
+        W = (torch.randn(N, K) / K**0.5).to(dtype)
+        x = torch.randn(M, K).to(dtype)
+        q, st = F.quantize_4bit(W.to(DEV), blocksize=bs, quant_type=qt, compress_statistics=dq)
+        Wd = F.dequantize_4bit(q, st).cpu().double()        # the HIP dequantize is bit-exact vs the oracle (tested above)
+        y_ref = x.double() @ Wd.T
+        for knob in (3000, 3002, 3100):
+            try:
+                bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, knob)
+                y = _run_kernel(2, x.to(DEV), q, st, None)
+            finally:
+                bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+            # the only differences left: fp32 accumulation order and the final rounding of y to T
+            yt = y_ref.to(dtype).double()
+            ulp_rel = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
+            bad = (y.cpu().double() - y_ref).abs() > (ulp_rel * y_ref.abs() + 1e-5 * y_ref.abs().max())
+            assert not bad.any(), (dtype, knob, int(bad.sum()))
+            assert (y.cpu().double() != yt).double().mean() < 0.02, (dtype, knob)  # almost every output rounds identically
+
+
 def test_mfma_rt_kernel_exact_on_representable_inputs():
     """Activations that are small integers and weights whose codes / scales are exactly representable make every product
     and every partial sum exact in fp32: the kernel must then equal the oracle bit for bit - a k that is paired with the
@@ -1024,7 +1083,8 @@ def test_mfma_rt_kernel_exact_on_representable_inputs():
     q, st = F.quantize_4bit(W.to(DEV), blocksize=64, quant_type="fp4")
     y_ref = _oracle_y(x, q, st, None)
     import bitsandbytes_amd as bnb
-    for knob in (2000, 2002, 1100):  # register-transposed kernel (one / two K slices), producer/consumer kernel
+    # register-transposed kernel (one / two K slices), producer/consumer kernel, pre-scaled-operand kernel (both variants)
+    for knob in (2000, 2002, 1100, 3000, 3002, 3100):
         try:
             bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, knob)
             y = _run_kernel(2, x.to(DEV), q, st, None)

@@ -400,6 +400,22 @@ def test_rt_mfma_lane_algebra_emulation():
 
 
 
+def test_ps_mfma_lane_algebra_emulation():
+    """The index algebra of csrc/gemm4_mfma_ps.hip (coalesced "4r + p" weight loads, the XOR-swizzled private transposition
+    tile, the activation stage shared by 4 column groups x 2 K halves, the k order of the 32x32x16 MFMA steps, the accumulator
+    layout of the epilogue, K slices) replayed lane by lane against the hardware semantics - see tests/checks/emulate_ps_mfma.py.
+    Every LDS access is also checked against the lane groups one ds_write_b128 / ds_read_b128 pass serves (no bank conflicts)."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location(
+        "emulate_ps_mfma", os.path.join(os.path.dirname(__file__), "checks", "emulate_ps_mfma.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for (M, K, MT, sps) in ((40, 768, 2, None), (64, 1024, 2, 2), (17, 512, 1, None)):
+        assert mod.emulate(M=M, K=K, MT=MT, seed=M, sps=sps) < 1e-12
+
+
 def test_grad_input_lane_algebra_emulation():
     """The index algebra of csrc/gemm4_grad_input.hip (one dword per weight row and lane, nibble j = B operand of the strided
     column tile {8 c + j}, the swizzled private grad_out patch, the scale patch, the output mapping, the dealing of the final
