@@ -776,8 +776,8 @@ bool rt_selected(int M, int N, int K, int knob1, int* force_ks, int* force_waves
         return weights <= (20L << 20);
     return false;
 }
-// Which problems go to the pre-scaled-operand kernel (tuning knob cfg 30 / 31 forces it: pinned software pipeline /
-// compiler-scheduled steps; knob % 100 = K slices).
+// Which problems go to the pre-scaled-operand kernel (tuning knob cfg 30 / 31 forces it: three / two ring stages;
+// knob % 100 = K slices).
 bool ps_selected(int M, int N, int K, int knob1, int* force_ks, int* variant) {
     const int cfg = knob1 / 100;
     *force_ks = 0;

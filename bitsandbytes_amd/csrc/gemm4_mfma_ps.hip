@@ -128,7 +128,7 @@ __device__ __forceinline__ float ps_code_literal(int i, bool fp4) {
 }
 
 // grid = (ceil(N / 128), kslices, ceil(M / (32 MT))); 512 threads. D = depth of the register ring in stages.
-template <typename T, int MT, bool NESTED, int D, bool PIPE>
+template <typename T, int MT, bool NESTED, int D>
 __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
     // hot arguments as separate scalars: preloaded into SGPRs by the command processor (14 dwords)
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, int hot_M, int hot_N,
@@ -154,69 +154,89 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
     se = se < stages_total ? se : stages_total;
     const int ns = se - sb; // stages of this slice (>= 1: the host makes every slice non-empty)
     // K half q owns the chunks [kq, kq + 128 ns) of the slice [256 sb, 256 se): chunk j of the wavefront = k kq + 128 j
-    const long kq = (static_cast<long>(sb) << 8) + static_cast<long>(q) * 128 * ns;
+    const uint32_t kq = (static_cast<uint32_t>(sb) << 8) + static_cast<uint32_t>(q) * 128u * static_cast<uint32_t>(ns);
 
-    // ---- sources. Rows past the end (ragged N or M) re-read the last row: MFMA rows / columns are independent and those
-    // results are never stored, so no masking instructions are needed.
-    const uint8_t* wsrc[2];
+    // ---- sources: buffer loads (base in SGPRs, a 32-bit per-lane byte offset computed ONCE, the chunk as a scalar offset):
+    // no per-load address arithmetic on the VALU. All byte offsets are < 2^31 (gemm_4bit_ps_supported). Rows past the end
+    // (ragged N or M) re-read the last row: MFMA rows / columns are independent and those results are never stored, so no
+    // masking instructions are needed.
+    constexpr int kRsrcFlags = 0x00020000;
+    constexpr int kRecords = 0x7FFFFFFF;
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hot_B), 0, kRecords, kRsrcFlags);
+    const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(hot_A), 0, kRecords, kRsrcFlags);
+    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hot_absmax), 0, kRecords, kRsrcFlags);
+    // (nested codes are fetched as ALIGNED dwords - see prep_t: the descriptor starts at the aligned address at or below the
+    // array, q_mis = the array's offset in it; a shard's absmax view may start at any byte)
+    const uint32_t q_mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(hot_absmax8) & 3u);
+    const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hot_absmax8) - q_mis, 0, kRecords, kRsrcFlags);
+    uint32_t wo[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         int row = col0 + 16 * i + r;
         row = row < N ? row : N - 1;
-        wsrc[i] = hot_B + static_cast<long>(row) * (K >> 1) + (kq >> 1) + pp * 16;
+        wo[i] = static_cast<uint32_t>(row) * static_cast<uint32_t>(K >> 1) + (kq >> 1) + static_cast<uint32_t>(pp * 16);
     }
     constexpr int AI = 2 * MT; // activation loads per wavefront and stage: 4 rows x 256 B each
-    const T* asrc[AI];
-    uint32_t a_wr[AI];
+    uint32_t ao[AI], a_wr[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
         const int row_local = 8 * MT * g + 4 * i + arow;
         int m = m_base + row_local;
         m = m < M ? m : M - 1;
-        asrc[i] = static_cast<const T*>(hot_A) + static_cast<long>(m) * K + kq + 8 * apiece;
+        ao[i] = (static_cast<uint32_t>(m) * static_cast<uint32_t>(K) + kq + static_cast<uint32_t>(8 * apiece)) * 2u;
         a_wr[i] = static_cast<uint32_t>(kPsABase + row_local * 512 + (((16 * q + apiece) ^ (row_local & 15)) << 4));
     }
     // scale of lane (n, h) for chunk j: block of flat element (row n) * K + kq + 128 j + 64 h
     int srow = col0 + n;
     srow = srow < N ? srow : N - 1;
-    const long se0 = static_cast<long>(srow) * K + kq + 64 * h;
+    const uint32_t se0 = static_cast<uint32_t>(srow) * static_cast<uint32_t>(K) + kq + static_cast<uint32_t>(64 * h);
 
     struct Stage {
         u32x4 w[2];  // lane (r, pp) holds bytes [16 pp, 16 pp + 16) of the chunk's 64 bytes of rows r, 16 + r
         u32x4 a[AI]; // this wavefront's share of the activation stage
-        uint32_t s, s2;
+        uint32_t s;       // fp32 absmax bits of the lane's block (nested: of its second-level block)
+        uint32_t s8;      // nested: the aligned dword of 8-bit absmax codes that holds the block's (see prep_t)
     };
-    auto issue = [&](Stage& x, int j) {
+    auto issue_w = [&](Stage& x, int j) {
         j = j < ns ? j : ns - 1; // a prefetch past the end re-reads the last chunk: never used, keeps every wait counted
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            x.w[i] = *reinterpret_cast<const u32x4*>(wsrc[i] + static_cast<long>(j) * 64);
-        const long blk = (se0 + static_cast<long>(j) * 128) >> bs_shift;
+            x.w[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wo[i], j * 64, 0));
+        const uint32_t blk = (se0 + static_cast<uint32_t>(j) * 128u) >> bs_shift;
         if constexpr (NESTED) {
-            x.s = hot_absmax8[blk];
-            x.s2 = __builtin_bit_cast(uint32_t, hot_absmax[blk >> 8]);
+            x.s8 = __builtin_amdgcn_raw_buffer_load_b32(rs_q, (blk + q_mis) & ~3u, 0, 0);
+            x.s = __builtin_amdgcn_raw_buffer_load_b32(rs_s, (blk >> 8) * 4u, 0, 0);
         } else {
-            x.s = __builtin_bit_cast(uint32_t, hot_absmax[blk]);
-            x.s2 = 0;
+            x.s = __builtin_amdgcn_raw_buffer_load_b32(rs_s, blk * 4u, 0, 0);
+            x.s8 = 0;
         }
+    };
+    auto issue_a = [&](Stage& x, int j, int i0, int i1) {
+        j = j < ns ? j : ns - 1;
 #pragma unroll
-        for (int i = 0; i < AI; ++i)
-            x.a[i] = *reinterpret_cast<const u32x4*>(asrc[i] + static_cast<long>(j) * 128);
+        for (int i = i0; i < i1; ++i)
+            x.a[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, ao[i], j * 256, 0));
     };
 
     Stage st[D];
     // (nested: the second-level code entry of this thread is requested FIRST, so that the wait in front of its LDS copy is a
-    // counted one that leaves the stage-0 loads in flight)
+    // counted one that leaves the ring in flight)
     float code2_v = 0.0f, offset = 0.0f;
     if constexpr (NESTED) {
         code2_v = p.absmax_code[tid & 255];
         offset = p.absmax_offset[0];
     }
-    issue(st[0], 0);
+    // the whole ring goes out before anything else: the first bytes need ~2 us to arrive, the table ~1
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        issue_w(st[j], j);
+        issue_a(st[j], j, 0, AI);
+        __builtin_amdgcn_sched_barrier(0); // (program order = queue order: the loop's counted waits assume stage by stage)
+    }
     BNB_PS_STAMP(1)
     __builtin_amdgcn_sched_barrier(0); // nothing that is not needed for the loads runs before them
 
-    // ---- decode table, built while the first loads fly: entry e (a packed byte) = 32 copies of (code[e >> 4], code[e & 15])
+    // ---- decode table, built while the loads fly: entry e (a packed byte) = 32 copies of (code[e >> 4], code[e & 15])
     // in fp32, 256 B per entry; thread (part, e) writes 8 of its 16 chunks in an order rotated by e (eight lanes -> eight
     // bank quads)
     {
@@ -239,9 +259,6 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
     }
     __syncthreads();
     BNB_PS_STAMP(2)
-#pragma unroll
-    for (int j = 1; j < D; ++j)
-        issue(st[j], j);
     if (reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem) != 0)
         __builtin_trap(); // the table is addressed with raw v_perm_b32 results: it must sit at LDS address 0
 
@@ -270,129 +287,162 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
         for (int i = 0; i < 16; ++i)
             acc[mt][i] = 0.0f;
 
-    auto do_stage = [&](Stage& x, int j) {
-        const uint32_t par = static_cast<uint32_t>(j & 1) * kPsABuf;
-        // (1) this wavefront's share of activation stage j -> LDS buffer j & 1 (its last readers passed barrier j - 1)
+    // ---- the pieces of "prepare stage jn" (executed between the MFMA steps of stage jn - 1, see below)
+    // activation pieces [i0, i1) of ring slot x -> LDS buffer jn & 1. Its last readers (stage jn - 2) are past barrier jn - 1.
+    auto prep_a = [&](Stage& x, int jn, int i0, int i1) {
+        const uint32_t par = static_cast<uint32_t>(jn & 1) * kPsABuf;
 #pragma unroll
-        for (int i = 0; i < AI; ++i)
+        for (int i = i0; i < i1; ++i)
             *reinterpret_cast<u32x4*>(smem + a_wr[i] + par) = x.a[i];
-        // (2) packed weights: coalesced shape -> MFMA shape through the private tile
+    };
+    // packed weights: coalesced shape -> private tile
+    auto prep_w = [&](Stage& x) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             *reinterpret_cast<u32x4*>(tile + t_wr[i]) = x.w[i];
-        u32x4 wt[2];
+    };
+    // private tile -> MFMA shape; the scale leaves its ring register
+    auto prep_t = [&](Stage& x, int jn, u32x4 (&wt)[2], float& scale) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             wt[i] = *reinterpret_cast<const u32x4*>(tile + t_rd[i]);
-        float scale;
-        {
-            // The scale leaves its ring register HERE, through an instruction the compiler cannot move: left to itself hipcc
-            // parks the copy in the loop latch, where its wait for this one load becomes s_waitcnt vmcnt(0) - a drain of the
-            // whole ring once per round (seen in the ISA of the first build). At this point every load of stage j is needed
-            // anyway, so the wait in front of the copy is the counted one.
-            uint32_t sv, s2v;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(sv) : "v"(x.s));
-            if constexpr (NESTED)
-                asm volatile("v_mov_b32 %0, %1" : "=v"(s2v) : "v"(x.s2));
-            else
-                s2v = 0;
-            if constexpr (NESTED)
-                scale = __fadd_rn(__fmul_rn(code2[sv & 0xFFu], __builtin_bit_cast(float, s2v)), offset);
-            else
-                scale = __builtin_bit_cast(float, sv);
+        // The scale leaves its ring register through an instruction the compiler cannot move: left to itself hipcc parks the
+        // copy in the loop latch, where its wait for this one load becomes s_waitcnt vmcnt(0) - a drain of the whole ring once
+        // per round (seen in the ISA of the first build). For the same reason the nested code is fetched as the aligned
+        // DWORD that holds it and the byte is cut out here: a byte load's zero extension is an instruction of its own, and
+        // hipcc hoisted that one to the loop top behind a vmcnt(5).
+        uint32_t sv;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(sv) : "v"(x.s));
+        if constexpr (NESTED) {
+            uint32_t qw;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(qw) : "v"(x.s8));
+            jn = jn < ns ? jn : ns - 1;
+            const uint32_t blk = (se0 + static_cast<uint32_t>(jn) * 128u) >> bs_shift;
+            const uint32_t qv = __builtin_amdgcn_ubfe(qw, 8u * ((blk + q_mis) & 3u), 8u);
+            scale = __fadd_rn(__fmul_rn(code2[qv], __builtin_bit_cast(float, sv)), offset);
+        } else {
+            scale = __builtin_bit_cast(float, sv);
         }
+    };
+    auto lut_reads = [&](const u32x4 (&wt)[2], int s, f32x2 (&pr)[4]) {
+        const uint32_t w = (s < 4) ? wt[0][s & 3] : wt[1][s & 3];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            pr[b] = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>(
+                __builtin_amdgcn_perm(w, lane_off, perm_sel + (b << 8)));
+    };
+    auto convert = [&](const f32x2 (&pr)[4], float scale) -> u32x4 {
         const f32x2 sc2 = {scale, scale};
-        auto dword_of = [&](int s) -> uint32_t { return (s < 4) ? wt[0][s & 3] : wt[1][s & 3]; };
-        auto lut_reads = [&](int s, f32x2 (&pr)[4]) {
-            const uint32_t w = dword_of(s);
+        u32x4 bf;
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                pr[b] = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>(
-                    __builtin_amdgcn_perm(w, lane_off, perm_sel + (b << 8)));
-        };
-        auto convert = [&](const f32x2 (&pr)[4]) -> u32x4 {
-            u32x4 bf;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const f32x2 pv = pr[b] * sc2;
-                float p0 = pv[0], p1 = pv[1];
-                if constexpr (!__is_same(T, bf16)) {
-                    asm("" : "+v"(p0));
-                    asm("" : "+v"(p1));
-                }
-                bf[b] = PsMma<T>::pack(p0, p1);
+        for (int b = 0; b < 4; ++b) {
+            const f32x2 pv = pr[b] * sc2;
+            float p0 = pv[0], p1 = pv[1];
+            if constexpr (!__is_same(T, bf16)) {
+                asm("" : "+v"(p0));
+                asm("" : "+v"(p1));
             }
-            return bf;
-        };
-        f32x2 pr[2][4];
-        u32x4 af[2][MT];
-        if constexpr (PIPE)
-            lut_reads(0, pr[0]); // (the table look-ups of step 0 need nothing from the other wavefronts: ahead of the barrier)
-        // (3) the ring slot is free: request stage j + D
-        issue(x, j + D);
-        if (j < 3)
-            BNB_PS_STAMP(3 + 3 * j)
-        // (4) activation stage j complete in LDS for every wavefront
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (j < 3)
-            BNB_PS_STAMP(4 + 3 * j)
-        // (5) eight 16-k MFMA steps: dword s of the lane = k [64 h + 8 s, + 8) of column n
-        const uint32_t a_base = a_rd + par;
+            bf[b] = PsMma<T>::pack(p0, p1);
+        }
+        return bf;
+    };
+
+    // ---- stage 0 is prepared in one go; every later stage between the MFMA steps of its predecessor
+    u32x4 wt[2], wt_n[2];
+    float scale, scale_n;
+    f32x2 pr[2][4];
+    u32x4 af[2][MT];
+    prep_a(st[0], 0, 0, AI);
+    prep_w(st[0]);
+    prep_t(st[0], 0, wt, scale);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_w(st[0], D);
+    issue_a(st[0], D, 0, AI);
+    __builtin_amdgcn_sched_barrier(0);
+    lut_reads(wt, 0, pr[0]);
+    BNB_PS_STAMP(3)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    BNB_PS_STAMP(4)
+
+    // Stage j: eight 16-k MFMA steps (dword s of the lane = k [64 h + 8 s, + 8) of column n) as a pinned two-deep software
+    // pipeline - the LDS reads of step s + 1 go out before the converts and MFMAs of step s - with the preparation of stage
+    // j + 1 dealt over the steps: its activation pieces go to the OTHER stage buffer (free since barrier j), its weights
+    // through the private tile, and its ring slot x is re-requested for stage j + 1 + D. So the LDS stores, the loads and the
+    // MFMA steps of a wavefront overlap instead of taking turns between two barriers (the first build: 3400 cycles per
+    // stage, of which 2100 in the steps, 1300 in stores + load issue + barrier).
+    auto do_stage = [&](Stage& x, int j) {
+        const uint32_t a_base = a_rd + static_cast<uint32_t>(j & 1) * kPsABuf;
         auto a_reads = [&](int s, u32x4 (&f)[MT]) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
                 f[mt] = *reinterpret_cast<const u32x4*>(smem + (a_base ^ static_cast<uint32_t>(s << 4)) + mt * 16384);
         };
-        if constexpr (PIPE) {
-            // two-deep software pipeline, pinned: the LDS reads of step s + 1 (table look-ups, activation fragments) go out
-            // before the converts and MFMAs of step s, so no MFMA sits behind an LDS round trip issued just in front of it
-            a_reads(0, af[0]);
+        a_reads(0, af[0]);
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int cur = s & 1, nxt = cur ^ 1;
-                if (s + 1 < 8) {
-                    lut_reads(s + 1, pr[nxt]);
-                    a_reads(s + 1, af[nxt]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const u32x4 bf = convert(pr[cur]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = PsMma<T>::run(af[cur][mt], bf, acc[mt]);
-                __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < 8; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s < 7) {
+                lut_reads(wt, s + 1, pr[nxt]);
+                a_reads(s + 1, af[nxt]);
             }
-        } else {
+            if (s == 0)
+                prep_a(x, j + 1, 0, AI / 2);
+            else if (s == 1)
+                prep_a(x, j + 1, AI / 2, AI);
+            else if (s == 2)
+                prep_w(x);
+            else if (s == 3)
+                prep_t(x, j + 1, wt_n, scale_n);
+            else if (s == 4)
+                issue_w(x, j + 1 + D);
+            else if (s == 5)
+                issue_a(x, j + 1 + D, 0, AI / 2);
+            else if (s == 6)
+                issue_a(x, j + 1 + D, AI / 2, AI);
+            else
+                lut_reads(wt_n, 0, pr[nxt]); // (s = 7: the table look-ups of the next stage's step 0 need no barrier)
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 bf = convert(pr[cur], scale);
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                lut_reads(s, pr[0]);
-                const u32x4 bf = convert(pr[0]);
-                a_reads(s, af[0]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = PsMma<T>::run(af[0][mt], bf, acc[mt]);
-            }
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = PsMma<T>::run(af[cur][mt], bf, acc[mt]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (j < 3)
+        if (j < 2)
             BNB_PS_STAMP(5 + 3 * j)
+        // activation stage j + 1 complete in LDS for every wavefront; everybody done with buffer j & 1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j < 2)
+            BNB_PS_STAMP(7 + 3 * j)
+        wt[0] = wt_n[0];
+        wt[1] = wt_n[1];
+        scale = scale_n;
     };
-    // whole rounds of the ring with nothing conditional around the loads, then the tail
-    int j = 0;
-    for (; j + D <= ns; j += D) {
+    // stage j + 1 lives in ring slot (j + 1) % D: the loop is unrolled by D so that every slot index is a constant. Whole
+    // rounds first, with nothing conditional around the loads (at the join of a branch around a load the compiler merges the
+    // pending-load state of both paths and waits conservatively - a first version with one conditional per stage drained the
+    // ring to vmcnt(0) in every second stage), then the tail.
+    {
+        int j = 0;
+        for (; j + D <= ns; j += D) {
 #pragma unroll
-        for (int jj = 0; jj < D; ++jj)
-            do_stage(st[jj], j + jj);
+            for (int jj = 0; jj < D; ++jj)
+                do_stage(st[(jj + 1) % D], j + jj);
+        }
+#pragma unroll
+        for (int jj = 0; jj < D - 1; ++jj)
+            if (j + jj < ns)
+                do_stage(st[(jj + 1) % D], j + jj);
     }
-#pragma unroll
-    for (int jj = 0; jj < D - 1; ++jj)
-        if (j + jj < ns)
-            do_stage(st[jj], j + jj);
     BNB_PS_STAMP(12)
 
     // ---- the two K halves of a column group, added in a fixed order (half 0 + half 1); the parking area reuses the
-    // activation buffers: [g][mt][4 register quads][64 lanes x 16 B]
-    __syncthreads();
+    // activation buffers (the last barrier of the loop has passed: nobody reads them any more):
+    // [g][mt][4 register quads][64 lanes x 16 B]
     unsigned char* const red = smem + kPsABase + (g * MT) * 4096 + lane * 16;
     if (q == 1) {
 #pragma unroll
@@ -454,30 +504,29 @@ PsPlan ps_plan(int M, int N, int K, int force_ks) {
     return pl;
 }
 
-template <typename T, int MT, bool NESTED, bool PIPE>
+template <typename T, int MT, bool NESTED, int D>
 void ps_launch_one(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
                    const PsPlan& pl, const PsArgs& a, hipStream_t stream) {
-    constexpr int D = 3;
     dim3 grid((N + kPsCols - 1) / kPsCols, pl.ks, (M + 32 * MT - 1) / (32 * MT));
-    auto kern = gemm4_mfma_ps_kernel<T, MT, NESTED, D, PIPE>;
+    auto kern = gemm4_mfma_ps_kernel<T, MT, NESTED, D>;
     static LdsLimit lim;
     ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), kPsLdsBytes);
     hipLaunchKernelGGL(kern, grid, dim3(kPsWaves * 64), kPsLdsBytes, stream, A, B, absmax, absmax8, M, N, K, flags, pl.sps, pl.ks, a);
 }
 
-template <typename T, bool PIPE>
+template <typename T, int D>
 void ps_launch(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
                const PsPlan& pl, const PsArgs& a, hipStream_t stream) {
     if (absmax8 != nullptr) {
         if (pl.mt == 1)
-            ps_launch_one<T, 1, true, PIPE>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+            ps_launch_one<T, 1, true, D>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
         else
-            ps_launch_one<T, 2, true, PIPE>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+            ps_launch_one<T, 2, true, D>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
     } else {
         if (pl.mt == 1)
-            ps_launch_one<T, 1, false, PIPE>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+            ps_launch_one<T, 1, false, D>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
         else
-            ps_launch_one<T, 2, false, PIPE>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+            ps_launch_one<T, 2, false, D>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
     }
 }
 
@@ -486,8 +535,10 @@ void ps_launch(const void* A, const uint8_t* B, const float* absmax, const uint8
 // Preconditions: 16-bit activations, literal code tables, K a multiple of 256, blocksize >= 64 (a lane's 64 k of a chunk
 // stay inside one quantization block), 16-byte aligned A and B.
 bool gemm_4bit_ps_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize) {
+    // (byte offsets of the buffer loads are 32-bit and must stay below 2^31)
+    const long long nk = static_cast<long long>(N) * K, mk = static_cast<long long>(M) * K;
     return (dtype == 1 || dtype == 2) && code16 == nullptr && M >= 1 && N >= 1 && K >= kPsStageK && (K % kPsStageK) == 0 &&
-           blocksize >= 64 && is_pow2(blocksize) && aligned_to(A, 16) && aligned_to(B, 16);
+           blocksize >= 64 && is_pow2(blocksize) && aligned_to(A, 16) && aligned_to(B, 16) && nk < (1LL << 31) && mk < (1LL << 30);
 }
 
 size_t gemm_4bit_ps_workspace_bytes(int M, int N, int K, int force_ks) {
@@ -497,8 +548,7 @@ size_t gemm_4bit_ps_workspace_bytes(int M, int N, int K, int force_ks) {
     return pl.ks > 1 ? static_cast<size_t>(pl.ks) * M * N * sizeof(float) : 0;
 }
 
-// dtype: 1 = f16, 2 = bf16. force_ks (0 = built-in choice), variant (0 = pinned software pipeline, 1 = compiler-scheduled
-// steps): sweeps and tests.
+// dtype: 1 = f16, 2 = bf16. force_ks (0 = built-in choice), variant (0 = three ring stages, 1 = two): sweeps and tests.
 void gemm_4bit_ps(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int variant,
@@ -531,14 +581,14 @@ void gemm_4bit_ps(int dtype, const void* A, const uint8_t* B, const float* absma
     const int flags = ilog2(blocksize) | ((quant_type == kFP4) ? 256 : 0);
     if (dtype == 2) {
         if (variant == 1)
-            ps_launch<bf16, false>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+            ps_launch<bf16, 2>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
         else
-            ps_launch<bf16, true>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+            ps_launch<bf16, 3>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
     } else {
         if (variant == 1)
-            ps_launch<f16, false>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+            ps_launch<f16, 2>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
         else
-            ps_launch<f16, true>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+            ps_launch<f16, 3>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
     }
     BNB_CHECK_LAUNCH();
     if (pl.ks > 1)

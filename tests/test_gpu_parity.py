@@ -1009,10 +1009,10 @@ def test_mfma_rt_kernel_geometries(cfg, ks, M, N, K):
 @pytest.mark.parametrize("M,N,K", [(5, 256, 1024), (16, 200, 2048), (32, 4096, 4096), (33, 384, 1024), (64, 512, 4096),
                                    (64, 1000, 2816), (100, 130, 512), (128, 1376, 4096), (200, 256, 256), (17, 512, 11008 - 11008 % 256)])
 def test_mfma_ps_kernel_geometries(cfg, ks, M, N, K):
-    """The pre-scaled-operand MFMA kernel (csrc/gemm4_mfma_ps.hip) - pinned software pipeline / compiler-scheduled steps, built-in
-    and forced K slices (incl. slices of unequal length and single-stage slices), ragged N and M, one and two 32-row tiles,
-    several row passes - against the oracle, for fp32 and nested absmax, NF4 and FP4, blocksize 64 / 128 / 256, bf16 and fp16;
-    bit-reproducible run to run."""
+    """The pre-scaled-operand MFMA kernel (csrc/gemm4_mfma_ps.hip) - three / two ring stages, built-in and forced K slices
+    (incl. slices of unequal length and single-stage slices), ragged N and M, one and two 32-row tiles, several row passes -
+    against the oracle, for fp32 and nested absmax, NF4 and FP4, blocksize 64 / 128 / 256, bf16 and fp16; bit-reproducible
+    run to run."""
     import bitsandbytes_amd as bnb
 
     F = _F()
@@ -1033,6 +1033,32 @@ def test_mfma_ps_kernel_geometries(cfg, ks, M, N, K):
         assert rel_err(y1.cpu(), y_ref) < REL_TOL, (dtype, qt, bs, dq)
         assert torch.equal(y1, y2)
         assert rel_err(y3.cpu(), _oracle_y(x, q, st, None)) < REL_TOL
+
+
+@pytest.mark.parametrize("mis", [1, 2, 3])
+def test_mfma_ps_kernel_nested_codes_at_any_byte_offset(mis):
+    """The nested 8-bit absmax codes are fetched as aligned dwords; a row shard's view of them starts at any byte."""
+    import bitsandbytes_amd as bnb
+    from bitsandbytes_amd.backends import hip
+
+    F = _F()
+    M, N, K = 40, 260, 1024
+    W = (torch.randn(N, K) / K**0.5).bfloat16()
+    x = torch.randn(M, K).bfloat16().to(DEV)
+    q, st = F.quantize_4bit(W.to(DEV), blocksize=64, quant_type="nf4", compress_statistics=True)
+    buf = torch.zeros(st.absmax.numel() + 8, dtype=torch.uint8, device=DEV)
+    a8 = buf[mis:mis + st.absmax.numel()]
+    a8.copy_(st.absmax)
+    assert a8.data_ptr() % 4 == mis
+    try:
+        bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 3000)
+        y = hip._gemm_4bit_fused(x, q, st.shape, st.state2.absmax, st.blocksize, st.quant_type, None, a8, st.state2.code,
+                                 st.offset, kernel=2)
+        y0 = _run_kernel(2, x, q, st, None)
+    finally:
+        bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+    assert torch.equal(y, y0)
+    assert rel_err(y.cpu(), _oracle_y(x.cpu(), q, st, None)) < REL_TOL
 
 
 def test_mfma_ps_kernel_equals_dequantize_then_matmul_in_fp64():

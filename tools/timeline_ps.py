@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Per-wavefront timeline of the pre-scaled-operand MFMA kernel (gemm4_mfma_ps_kernel) from in-kernel s_memtime stamps
 (profiling build only: make -C bitsandbytes_amd/csrc profiling; BNB_MI355X_LIBRARY=.../libbitsandbytes_mi355x_prof.so):
-0 start, 1 stage-0 loads issued, 2 past the table barrier, then per stage j < 3: 3+3j its loads landed, pieces written to LDS and
-the ring slot re-requested, 4+3j past the stage barrier, 5+3j its eight MFMA steps done; 12 stage loop done, 13 end.
+0 start, 1 ring requested, 2 past the table barrier, 3 stage 0 landed + prepared, 4 past its barrier, then per stage j < 2: 5+3j
+its eight MFMA steps (with the preparation of stage j + 1 between them) done, 7+3j past the barrier; 12 stage loop done, 13 end.
     python tools/timeline_ps.py [--m 64] [--n 8192] [--k 8192] [--cfg 3000]"""
 import argparse
 import os
@@ -58,11 +58,9 @@ if WG == 0:
     print("no stamps: not a profiling build?")
     sys.exit(0)
 t0k = t[:, :, 0][t[:, :, 0] > 0].min()                   # first wavefront start of the whole launch
-names = {0: "start", 1: "stage-0 loads issued", 2: "past table barrier", 12: "stage loop done", 13: "end"}
-for j in range(3):
-    names[3 + 3 * j] = f"stage {j} landed, written, refilled"
-    names[4 + 3 * j] = f"stage {j} past barrier"
-    names[5 + 3 * j] = f"stage {j} MFMA steps done"
+names = {0: "start", 1: "ring requested", 2: "past table barrier", 3: "stage 0 landed + prepared", 4: "past barrier (stage 0 ready)",
+         5: "stage 0 steps + prep 1 done", 7: "past barrier (stage 1 ready)", 8: "stage 1 steps + prep 2 done",
+         10: "past barrier (stage 2 ready)", 12: "stage loop done", 13: "end"}
 print(f"# ps kernel cfg={a.cfg}, M={a.m}, N={N}, K={K}: {WG} workgroups x {waves} wavefronts; s_memtime ticks "
       f"relative to the first wavefront start of the LAUNCH")
 print(f"{'stamp':34s} {'min':>7s} {'median':>7s} {'p90':>7s} {'max':>7s}   median delta to previous stamp")
