@@ -16,6 +16,7 @@ ap.add_argument("--n", type=int, default=8192)
 ap.add_argument("--k", type=int, default=8192)
 ap.add_argument("--m", type=int, default=64)
 ap.add_argument("--layers", type=int, default=8)
+ap.add_argument("--knob", type=int, default=0, help="bnb_mi355x_set_tuning mfma_knob1 (e.g. 3000 = ps kernel)")
 a = ap.parse_args()
 g = torch.Generator(device="cuda").manual_seed(0)
 layers = []
@@ -24,6 +25,7 @@ for _ in range(a.layers):
     layers.append(F.quantize_4bit(W, quant_type="nf4"))
     del W
 x = torch.randn(a.m, a.k, device="cuda", generator=g).bfloat16()
+bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, a.knob)
 for _ in range(3):
     for q, st in layers:
         bnb.matmul_4bit(x, q, st)
