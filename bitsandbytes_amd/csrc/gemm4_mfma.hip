@@ -776,7 +776,7 @@ bool rt_selected(int M, int N, int K, int knob1, int* force_ks, int* force_waves
         return weights <= (20L << 20);
     return false;
 }
-// Which problems go to the pre-scaled-operand kernel (tuning knob cfg 30 / 31 forces it: three / two ring stages;
+// Which problems go to the pre-scaled-operand kernel (tuning knob cfg 30 / 31 forces it: two / three ring slots;
 // knob % 100 = K slices).
 bool ps_selected(int M, int N, int K, int knob1, int* force_ks, int* variant) {
     const int cfg = knob1 / 100;

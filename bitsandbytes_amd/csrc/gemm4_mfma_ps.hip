@@ -10,18 +10,25 @@
 // per (tile, block) and batch tile, and spends one address instruction + one ds_read_b32 per weight byte and batch tile
 // pair. Here the accumulators are touched by MFMA instructions only and the decode of a chunk is shared by all batch rows.
 //
-// Shape of the kernel (what the PMC passes of round 2 asked for - fewer LDS operand bytes per FLOP, no VALU on the
-// accumulators, a deep weight stream that no barrier drains):
+// Shape of the kernel:
 //
 //  * v_mfma_f32_32x32x16_{bf16,f16}: A operand = activations (row m = lane % 32), B operand = weights (column n = lane % 32),
 //    lane half h = lane / 32 holds k = 8 h + 0..7 of the 16-k step. Half the LDS operand traffic per FLOP of the 16x16x32 form.
 //  * one workgroup = 128 output columns x (32 MT batch rows, MT = 1 | 2) x one K slice; 8 wavefronts = 4 column groups of 32
 //    x 2 K halves. A "stage" is 256 k: K half q works on its own 128-k chunk of it, so every wavefront decodes ONE chunk
 //    (32 columns x 128 k = 2 KiB of packed weights) per stage and multiplies it with all 32 MT rows.
-//  * EVERY global load of a wavefront - its two weight loads, its share of the activation stage (2 MT loads of 4 rows x
-//    256 B) and its scale - is an ordinary coalesced load into a D-deep REGISTER ring, all at the same prefetch distance:
-//    vmcnt retires in order, so streams with different distances in one wavefront collapse to the shortest (round 1); with
-//    one distance the compiler's counted waits are exact and D - 1 stages per wavefront stay in flight across the barrier.
+//  * PING-PONG. The first two builds of this kernel interleaved decode and MFMA step by step in every wavefront; their PMC
+//    passes (profiles/r3_pmc_ps_v2_c3.txt) showed per stage and SIMD 1024 cycles of matrix pipe, ~1340 of VALU and ~1640 of
+//    LDS adding up to the ~3900 cycles a stage took: with all wavefronts in the same phase of the same dependent chain
+//    nothing overlaps. Now a wavefront alternates between a DECODE phase (the chunk's 32 table look-ups per lane, scale
+//    multiplies, converts: VALU + LDS, no matrix instruction; result = the chunk's 8 B fragments in 32 registers) and an MFMA
+//    phase (16 back-to-back MFMAs fed by activation fragments from LDS: ~512 cycles of matrix pipe, almost no VALU), and
+//    the two K halves run in OPPOSITE phases - wavefronts g and g + 4 share a SIMD - with one s_barrier per phase: while one
+//    wavefront of a SIMD owns the matrix pipe, its partner owns the VALU.
+//  * EVERY global load of a wavefront - its two weight loads, its share of the activation chunk (MT loads of 8 rows x
+//    256 B... see below) and its scale - is an ordinary coalesced BUFFER load (base in SGPRs, one 32-bit lane offset
+//    computed once, the chunk as scalar offset: no address arithmetic per load) into a D-deep REGISTER ring; vmcnt retires in
+//    order, so the ring is refilled in consumption order and every wait the compiler emits is a counted one.
 //    No LDS-DMA, no producer wavefronts, no inline-asm waits.
 //  * weights: lane 4 r + p loads 16 bytes of row r (four neighbouring lanes = 64 contiguous bytes: 16 L1 tag look-ups per
 //    instruction); the MFMA wants the row in the low lane bits, so the chunk goes through a 2-KiB tile private to the
@@ -31,8 +38,9 @@
 //    the activation fragment of the same k - K order inside an MFMA is free as long as both operands agree.
 //  * decode per packed byte: v_perm_b32 (LDS address) + ds_read_b64 (bank-private byte -> (code[hi], code[lo]) fp32 table
 //    built from literals) + v_pk_mul_f32 by the lane's scale + one convert-and-pack.
-//  * activations: the wavefronts write their pieces of stage t into LDS buffer t & 1 (rows of 512 B = both chunks, 16-byte
-//    pieces XOR-swizzled by the row: conflict-free ds_write_b128 and ds_read_b128), ONE s_barrier per stage.
+//  * activations: the four wavefronts of a K half write their pieces of the half's chunk into the half's LDS buffer (rows of
+//    256 B, 16-byte pieces XOR-swizzled by the row: conflict-free ds_write_b128 and ds_read_b128) in their decode phase and
+//    read fragments from it in the MFMA phase that follows: one buffer per K half is enough.
 //  * the two K halves of a column group are added through LDS (fixed order), K slices across workgroups write fp32 slabs
 //    that gemm4_finalize adds in slice order: bit-reproducible.
 #include "bnb_common.h"
@@ -88,8 +96,8 @@ constexpr int kPsCols = 128;        // output columns per workgroup: 4 column gr
 constexpr int kPsStageK = 256;      // k per stage: one 128-k chunk per K half
 constexpr int kPsWaves = 8;         // 4 column groups x 2 K halves
 constexpr int kPsLut = 65536;       // 256 entries x 32 copies x 8 B (fp32 pair), at LDS address 0
-constexpr int kPsABuf = 32768;      // one activation stage buffer: up to 64 rows x 512 B
-constexpr int kPsABase = kPsLut;    // two stage buffers
+constexpr int kPsABuf = 16384;      // the activation chunk of one K half: up to 64 rows x 256 B
+constexpr int kPsABase = kPsLut;    // one buffer per K half
 constexpr int kPsTileBase = kPsABase + 2 * kPsABuf; // per-wavefront transposition tiles, 2 KiB each
 constexpr int kPsCode2 = kPsTileBase + kPsWaves * 2048;
 constexpr int kPsLdsBytes = kPsCode2 + 1024;
@@ -127,7 +135,7 @@ __device__ __forceinline__ float ps_code_literal(int i, bool fp4) {
     return v;
 }
 
-// grid = (ceil(N / 128), kslices, ceil(M / (32 MT))); 512 threads. D = depth of the register ring in stages.
+// grid = (ceil(N / 128), kslices, ceil(M / (32 MT))); 512 threads. D = depth of the register rings in chunks.
 template <typename T, int MT, bool NESTED, int D>
 __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
     // hot arguments as separate scalars: preloaded into SGPRs by the command processor (14 dwords)
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     BNB_PS_STAMP(0)
-    const int g = wave & 3, q = wave >> 2;        // column group, K half
+    const int g = wave & 3, q = wave >> 2;        // column group, K half (wavefronts g and g + 4 share a SIMD)
     const int r = lane >> 2, pp = lane & 3;       // weight-load roles: row r of a 16-row half tile, 16-byte piece pp of its 64 bytes
     const int n = lane & 31, h = lane >> 5;       // MFMA roles: column / row n, k half h
     const int arow = lane >> 4, apiece = lane & 15; // activation-load roles: row arow of a 4-row group, 16-byte piece of its 256 bytes
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
     const int sb = blockIdx.y * hot_sps;
     int se = sb + hot_sps;
     se = se < stages_total ? se : stages_total;
-    const int ns = se - sb; // stages of this slice (>= 1: the host makes every slice non-empty)
+    const int ns = se - sb; // stages of this slice = chunks of this wavefront (>= 1: the host makes every slice non-empty)
     // K half q owns the chunks [kq, kq + 128 ns) of the slice [256 sb, 256 se): chunk j of the wavefront = k kq + 128 j
     const uint32_t kq = (static_cast<uint32_t>(sb) << 8) + static_cast<uint32_t>(q) * 128u * static_cast<uint32_t>(ns);
 
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
         row = row < N ? row : N - 1;
         wo[i] = static_cast<uint32_t>(row) * static_cast<uint32_t>(K >> 1) + (kq >> 1) + static_cast<uint32_t>(pp * 16);
     }
-    constexpr int AI = 2 * MT; // activation loads per wavefront and stage: 4 rows x 256 B each
+    constexpr int AI = 2 * MT; // activation loads per wavefront and chunk: 4 rows x 256 B each
     uint32_t ao[AI], a_wr[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
@@ -184,20 +192,22 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
         int m = m_base + row_local;
         m = m < M ? m : M - 1;
         ao[i] = (static_cast<uint32_t>(m) * static_cast<uint32_t>(K) + kq + static_cast<uint32_t>(8 * apiece)) * 2u;
-        a_wr[i] = static_cast<uint32_t>(kPsABase + row_local * 512 + (((16 * q + apiece) ^ (row_local & 15)) << 4));
+        a_wr[i] = static_cast<uint32_t>(kPsABase + q * kPsABuf + row_local * 256 + ((apiece ^ (row_local & 15)) << 4));
     }
     // scale of lane (n, h) for chunk j: block of flat element (row n) * K + kq + 128 j + 64 h
     int srow = col0 + n;
     srow = srow < N ? srow : N - 1;
     const uint32_t se0 = static_cast<uint32_t>(srow) * static_cast<uint32_t>(K) + kq + static_cast<uint32_t>(64 * h);
 
-    struct Stage {
+    struct WSlot {
         u32x4 w[2];  // lane (r, pp) holds bytes [16 pp, 16 pp + 16) of the chunk's 64 bytes of rows r, 16 + r
-        u32x4 a[AI]; // this wavefront's share of the activation stage
-        uint32_t s;       // fp32 absmax bits of the lane's block (nested: of its second-level block)
-        uint32_t s8;      // nested: the aligned dword of 8-bit absmax codes that holds the block's (see prep_t)
+        uint32_t s;  // fp32 absmax bits of the lane's block (nested: of its second-level block)
+        uint32_t s8; // nested: the aligned dword of 8-bit absmax codes that holds the block's (see prep_t)
     };
-    auto issue_w = [&](Stage& x, int j) {
+    struct ASlot {
+        u32x4 a[AI]; // this wavefront's share of the K half's activation chunk
+    };
+    auto issue_w = [&](WSlot& x, int j) {
         j = j < ns ? j : ns - 1; // a prefetch past the end re-reads the last chunk: never used, keeps every wait counted
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -211,14 +221,15 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
             x.s8 = 0;
         }
     };
-    auto issue_a = [&](Stage& x, int j, int i0, int i1) {
+    auto issue_a = [&](ASlot& x, int j) {
         j = j < ns ? j : ns - 1;
 #pragma unroll
-        for (int i = i0; i < i1; ++i)
+        for (int i = 0; i < AI; ++i)
             x.a[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, ao[i], j * 256, 0));
     };
 
-    Stage st[D];
+    WSlot ws[D];
+    ASlot as[D];
     // (nested: the second-level code entry of this thread is requested FIRST, so that the wait in front of its LDS copy is a
     // counted one that leaves the ring in flight)
     float code2_v = 0.0f, offset = 0.0f;
@@ -226,13 +237,11 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
         code2_v = p.absmax_code[tid & 255];
         offset = p.absmax_offset[0];
     }
-    // the whole ring goes out before anything else: the first bytes need ~2 us to arrive, the table ~1
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-        issue_w(st[j], j);
-        issue_a(st[j], j, 0, AI);
-        __builtin_amdgcn_sched_barrier(0); // (program order = queue order: the loop's counted waits assume stage by stage)
-    }
+    // Chunk 0 goes out before anything else, the rest of the ring after the table: a CU keeps only a few tens of KiB of loads
+    // in flight, every further load instruction BLOCKS its wavefront until an older one returns - with the whole ring
+    // requested up front the table build started ~9000 cycles into the kernel (profiles/r3_timeline_ps_v2.txt).
+    issue_w(ws[0], 0);
+    issue_a(as[0], 0);
     BNB_PS_STAMP(1)
     __builtin_amdgcn_sched_barrier(0); // nothing that is not needed for the loads runs before them
 
@@ -257,6 +266,13 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
         if (tid < 256)
             code2[tid] = code2_v;
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 1; j < D; ++j) {
+        issue_w(ws[j], j);
+        issue_a(as[j], j);
+        __builtin_amdgcn_sched_barrier(0); // (program order = queue order: the loop's counted waits assume chunk by chunk)
+    }
     __syncthreads();
     BNB_PS_STAMP(2)
     if (reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem) != 0)
@@ -277,8 +293,8 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
         t_wr[i] = static_cast<uint32_t>((row * 4 + (pp ^ ((row >> 2) & 3))) * 16);
         t_rd[i] = static_cast<uint32_t>((n * 4 + ((2 * h + i) ^ ((n >> 2) & 3))) * 16);
     }
-    // activation fragment of step s, row tile mt, stage buffer par: (a_rd ^ (s << 4)) + par * 32768 + mt * 16384
-    const uint32_t a_rd = static_cast<uint32_t>(kPsABase + n * 512 + (((16 * q + 8 * h) ^ (n & 15)) << 4));
+    // activation fragment of step s, row tile mt: (a_rd ^ (s << 4)) + mt * 8192 (row n of the tile, piece (8 h + s) ^ (n & 15))
+    const uint32_t a_rd = static_cast<uint32_t>(kPsABase + q * kPsABuf + n * 256 + (((8 * h) ^ (n & 15)) << 4));
 
     f32x16 acc[MT];
 #pragma unroll
@@ -287,22 +303,13 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
         for (int i = 0; i < 16; ++i)
             acc[mt][i] = 0.0f;
 
-    // ---- the pieces of "prepare stage jn" (executed between the MFMA steps of stage jn - 1, see below)
-    // activation pieces [i0, i1) of ring slot x -> LDS buffer jn & 1. Its last readers (stage jn - 2) are past barrier jn - 1.
-    auto prep_a = [&](Stage& x, int jn, int i0, int i1) {
-        const uint32_t par = static_cast<uint32_t>(jn & 1) * kPsABuf;
-#pragma unroll
-        for (int i = i0; i < i1; ++i)
-            *reinterpret_cast<u32x4*>(smem + a_wr[i] + par) = x.a[i];
-    };
-    // packed weights: coalesced shape -> private tile
-    auto prep_w = [&](Stage& x) {
+    // packed weights of a ring slot: coalesced shape -> private tile -> MFMA shape; the scale leaves its ring register
+    auto prep_w = [&](WSlot& x) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             *reinterpret_cast<u32x4*>(tile + t_wr[i]) = x.w[i];
     };
-    // private tile -> MFMA shape; the scale leaves its ring register
-    auto prep_t = [&](Stage& x, int jn, u32x4 (&wt)[2], float& scale) {
+    auto prep_t = [&](WSlot& x, int jn, u32x4 (&wt)[2], float& scale) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             wt[i] = *reinterpret_cast<const u32x4*>(tile + t_rd[i]);
@@ -324,125 +331,136 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
             scale = __builtin_bit_cast(float, sv);
         }
     };
-    auto lut_reads = [&](const u32x4 (&wt)[2], int s, f32x2 (&pr)[4]) {
-        const uint32_t w = (s < 4) ? wt[0][s & 3] : wt[1][s & 3];
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-            pr[b] = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>(
-                __builtin_amdgcn_perm(w, lane_off, perm_sel + (b << 8)));
-    };
-    auto convert = [&](const f32x2 (&pr)[4], float scale) -> u32x4 {
-        const f32x2 sc2 = {scale, scale};
-        u32x4 bf;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const f32x2 pv = pr[b] * sc2;
-            float p0 = pv[0], p1 = pv[1];
-            if constexpr (!__is_same(T, bf16)) {
-                asm("" : "+v"(p0));
-                asm("" : "+v"(p1));
-            }
-            bf[b] = PsMma<T>::pack(p0, p1);
-        }
-        return bf;
-    };
 
-    // ---- stage 0 is prepared in one go; every later stage between the MFMA steps of its predecessor
-    u32x4 wt[2], wt_n[2];
-    float scale, scale_n;
-    f32x2 pr[2][4];
-    u32x4 af[2][MT];
-    prep_a(st[0], 0, 0, AI);
-    prep_w(st[0]);
-    prep_t(st[0], 0, wt, scale);
+    u32x4 wt[2];  // the current chunk's packed weights in MFMA shape: dword s of lane (n, h) = k [64 h + 8 s, + 8) of column n
+    float scale;
+    u32x4 bfr[8]; // ... decoded: the B fragments of its eight 16-k steps
+    prep_w(ws[0]);
+    prep_t(ws[0], 0, wt, scale);
     __builtin_amdgcn_sched_barrier(0);
-    issue_w(st[0], D);
-    issue_a(st[0], D, 0, AI);
+    issue_w(ws[0], D);
     __builtin_amdgcn_sched_barrier(0);
-    lut_reads(wt, 0, pr[0]);
     BNB_PS_STAMP(3)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    BNB_PS_STAMP(4)
-
-    // Stage j: eight 16-k MFMA steps (dword s of the lane = k [64 h + 8 s, + 8) of column n) as a pinned two-deep software
-    // pipeline - the LDS reads of step s + 1 go out before the converts and MFMAs of step s - with the preparation of stage
-    // j + 1 dealt over the steps: its activation pieces go to the OTHER stage buffer (free since barrier j), its weights
-    // through the private tile, and its ring slot x is re-requested for stage j + 1 + D. So the LDS stores, the loads and the
-    // MFMA steps of a wavefront overlap instead of taking turns between two barriers (the first build: 3400 cycles per
-    // stage, of which 2100 in the steps, 1300 in stores + load issue + barrier).
-    auto do_stage = [&](Stage& x, int j) {
-        const uint32_t a_base = a_rd + static_cast<uint32_t>(j & 1) * kPsABuf;
-        auto a_reads = [&](int s, u32x4 (&f)[MT]) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                f[mt] = *reinterpret_cast<const u32x4*>(smem + (a_base ^ static_cast<uint32_t>(s << 4)) + mt * 16384);
-        };
-        a_reads(0, af[0]);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int cur = s & 1, nxt = cur ^ 1;
-            if (s < 7) {
-                lut_reads(wt, s + 1, pr[nxt]);
-                a_reads(s + 1, af[nxt]);
-            }
-            if (s == 0)
-                prep_a(x, j + 1, 0, AI / 2);
-            else if (s == 1)
-                prep_a(x, j + 1, AI / 2, AI);
-            else if (s == 2)
-                prep_w(x);
-            else if (s == 3)
-                prep_t(x, j + 1, wt_n, scale_n);
-            else if (s == 4)
-                issue_w(x, j + 1 + D);
-            else if (s == 5)
-                issue_a(x, j + 1 + D, 0, AI / 2);
-            else if (s == 6)
-                issue_a(x, j + 1 + D, AI / 2, AI);
-            else
-                lut_reads(wt_n, 0, pr[nxt]); // (s = 7: the table look-ups of the next stage's step 0 need no barrier)
-            __builtin_amdgcn_sched_barrier(0);
-            const u32x4 bf = convert(pr[cur], scale);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = PsMma<T>::run(af[cur][mt], bf, acc[mt]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (j < 2)
-            BNB_PS_STAMP(5 + 3 * j)
-        // activation stage j + 1 complete in LDS for every wavefront; everybody done with buffer j & 1
+    // K half 1 runs one phase behind K half 0
+    if (q == 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (j < 2)
-            BNB_PS_STAMP(7 + 3 * j)
-        wt[0] = wt_n[0];
-        wt[1] = wt_n[1];
-        scale = scale_n;
+    }
+    BNB_PS_STAMP(4)
+
+    // ---- DECODE phase of chunk j (ring slot x): its activation pieces -> the K half's LDS buffer (whose readers, the MFMA
+    // phase of chunk j - 1, are behind the last barrier), the slot is re-requested for chunk j + D, then 32 table look-ups per
+    // lane in four batches of eight (batch b + 1 in flight while batch b is multiplied and converted).
+    auto decode_phase = [&](ASlot& x, int j) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+            *reinterpret_cast<u32x4*>(smem + a_wr[i]) = x.a[i];
+        __builtin_amdgcn_sched_barrier(0);
+        issue_a(x, j + D);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x2 sc2 = {scale, scale};
+        f32x2 pr[2][8];
+        auto lut_reads = [&](int b, f32x2 (&o)[8]) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int s = 2 * b + t;
+                const uint32_t w = (s < 4) ? wt[0][s & 3] : wt[1][s & 3];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    o[4 * t + c] = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>(
+                        __builtin_amdgcn_perm(w, lane_off, perm_sel + (c << 8)));
+            }
+        };
+        lut_reads(0, pr[0]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b + 1 < 4)
+                lut_reads(b + 1, pr[(b + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x2 pv = pr[b & 1][4 * t + c] * sc2;
+                    float p0 = pv[0], p1 = pv[1];
+                    if constexpr (!__is_same(T, bf16)) {
+                        asm("" : "+v"(p0));
+                        asm("" : "+v"(p1));
+                    }
+                    bfr[2 * b + t][c] = PsMma<T>::pack(p0, p1);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
-    // stage j + 1 lives in ring slot (j + 1) % D: the loop is unrolled by D so that every slot index is a constant. Whole
-    // rounds first, with nothing conditional around the loads (at the join of a branch around a load the compiler merges the
-    // pending-load state of both paths and waits conservatively - a first version with one conditional per stage drained the
-    // ring to vmcnt(0) in every second stage), then the tail.
+    // ---- MFMA phase of chunk j: eight 16-k steps, activation fragments two steps ahead; between the steps the NEXT chunk's
+    // packed weights (ring slot x) go through the private tile and the slot is re-requested for chunk j + 1 + D.
+    auto mfma_phase = [&](WSlot& x, int j) {
+        u32x4 af[3][MT];
+        auto a_reads = [&](int s, u32x4 (&f)[MT]) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                f[mt] = *reinterpret_cast<const u32x4*>(smem + (a_rd ^ static_cast<uint32_t>(s << 4)) + mt * 8192);
+        };
+        a_reads(0, af[0]);
+        a_reads(1, af[1]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s + 2 < 8)
+                a_reads(s + 2, af[(s + 2) % 3]);
+            if (s == 1)
+                prep_w(x);
+            else if (s == 4)
+                prep_t(x, j + 1, wt, scale);
+            else if (s == 5)
+                issue_w(x, j + 1 + D);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = PsMma<T>::run(af[s % 3][mt], bfr[s], acc[mt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto phase_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto do_chunk = [&](ASlot& xa, WSlot& xw_next, int j) {
+        decode_phase(xa, j);
+        if (j < 2)
+            BNB_PS_STAMP(5 + 4 * j)
+        phase_barrier(); // the chunk's activations are complete in LDS; the partner half is done with the matrix pipe
+        if (j < 2)
+            BNB_PS_STAMP(6 + 4 * j)
+        mfma_phase(xw_next, j);
+        if (j < 2)
+            BNB_PS_STAMP(7 + 4 * j)
+        phase_barrier(); // everybody is done with this half's activation buffer
+        if (j < 2)
+            BNB_PS_STAMP(8 + 4 * j)
+    };
+    // chunk j lives in ring slot j % D: the loop is unrolled by D so that every slot index is a constant. Whole rounds first,
+    // with nothing conditional around the loads (at the join of a branch around a load the compiler merges the pending-load
+    // state of both paths and waits conservatively), then the tail.
     {
         int j = 0;
         for (; j + D <= ns; j += D) {
 #pragma unroll
             for (int jj = 0; jj < D; ++jj)
-                do_stage(st[(jj + 1) % D], j + jj);
+                do_chunk(as[jj], ws[(jj + 1) % D], j + jj);
         }
 #pragma unroll
         for (int jj = 0; jj < D - 1; ++jj)
             if (j + jj < ns)
-                do_stage(st[(jj + 1) % D], j + jj);
+                do_chunk(as[jj], ws[(jj + 1) % D], j + jj);
     }
-    BNB_PS_STAMP(12)
+    if (q == 0)
+        phase_barrier(); // (K half 1's last MFMA phase)
+    BNB_PS_STAMP(13)
 
     // ---- the two K halves of a column group, added in a fixed order (half 0 + half 1); the parking area reuses the
-    // activation buffers (the last barrier of the loop has passed: nobody reads them any more):
-    // [g][mt][4 register quads][64 lanes x 16 B]
+    // activation buffers (every MFMA phase is behind the last barrier): [g][mt][4 register quads][64 lanes x 16 B]
     unsigned char* const red = smem + kPsABase + (g * MT) * 4096 + lane * 16;
     if (q == 1) {
 #pragma unroll
@@ -478,7 +496,7 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
             }
         }
     }
-    BNB_PS_STAMP(13)
+    BNB_PS_STAMP(14)
 }
 
 struct PsPlan {
@@ -514,6 +532,8 @@ void ps_launch_one(const void* A, const uint8_t* B, const float* absmax, const u
     hipLaunchKernelGGL(kern, grid, dim3(kPsWaves * 64), kPsLdsBytes, stream, A, B, absmax, absmax8, M, N, K, flags, pl.sps, pl.ks, a);
 }
 
+// D = 3 leaves the two-row-tile instances 8-12 registers short (a spill's reload waits with vmcnt(0) and drains the ring):
+// they always run with two ring slots.
 template <typename T, int D>
 void ps_launch(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
                const PsPlan& pl, const PsArgs& a, hipStream_t stream) {
@@ -521,12 +541,12 @@ void ps_launch(const void* A, const uint8_t* B, const float* absmax, const uint8
         if (pl.mt == 1)
             ps_launch_one<T, 1, true, D>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
         else
-            ps_launch_one<T, 2, true, D>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+            ps_launch_one<T, 2, true, 2>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
     } else {
         if (pl.mt == 1)
             ps_launch_one<T, 1, false, D>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
         else
-            ps_launch_one<T, 2, false, D>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+            ps_launch_one<T, 2, false, 2>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
     }
 }
 
@@ -548,7 +568,8 @@ size_t gemm_4bit_ps_workspace_bytes(int M, int N, int K, int force_ks) {
     return pl.ks > 1 ? static_cast<size_t>(pl.ks) * M * N * sizeof(float) : 0;
 }
 
-// dtype: 1 = f16, 2 = bf16. force_ks (0 = built-in choice), variant (0 = three ring stages, 1 = two): sweeps and tests.
+// dtype: 1 = f16, 2 = bf16. force_ks (0 = built-in choice), variant (0 = two ring slots, 1 = three where they fit): sweeps
+// and tests.
 void gemm_4bit_ps(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int variant,
@@ -581,14 +602,14 @@ void gemm_4bit_ps(int dtype, const void* A, const uint8_t* B, const float* absma
     const int flags = ilog2(blocksize) | ((quant_type == kFP4) ? 256 : 0);
     if (dtype == 2) {
         if (variant == 1)
-            ps_launch<bf16, 2>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
-        else
             ps_launch<bf16, 3>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+        else
+            ps_launch<bf16, 2>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
     } else {
         if (variant == 1)
-            ps_launch<f16, 2>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
-        else
             ps_launch<f16, 3>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+        else
+            ps_launch<f16, 2>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
     }
     BNB_CHECK_LAUNCH();
     if (pl.ks > 1)

@@ -1,8 +1,8 @@
 """Lane-level emulation (numpy, CPU) of the data movement of gemm4_mfma_ps_kernel (bitsandbytes_amd/csrc/gemm4_mfma_ps.hip).
 
 The kernel's correctness rests on index algebra that cannot run in a GPU-less container: coalesced weight loads in the
-"lane 4r + p" shape, the transposition through the wavefront-private LDS tile, the XOR-swizzled activation stage shared by the
-8 wavefronts of a workgroup (4 column groups x 2 K halves), the k order of the 32x32x16 MFMA steps and the accumulator layout
+"lane 4r + p" shape, the transposition through the wavefront-private LDS tile, the XOR-swizzled activation chunk buffers (one per K
+half, written and read by the half's 4 column-group wavefronts), the k order of the 32x32x16 MFMA steps and the accumulator layout
 of the epilogue. This script replays exactly those formulas per lane against the HARDWARE semantics (what a 32x32x16 MFMA sums,
 which lanes one ds_write_b128 / ds_read_b128 pass serves, little-endian byte order of a dword) and compares the result with a
 plain matrix product.
@@ -12,7 +12,7 @@ plain matrix product.
 import numpy as np
 
 A_BASE = 65536
-A_BUF = 32768
+A_BUF = 16384
 READ_GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
                list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
 READ_GROUPS = READ_GROUPS + [[l + 32 for l in g_] for g_ in READ_GROUPS]
@@ -52,22 +52,21 @@ def emulate(M=40, K=768, MT=2, seed=0, sps=None):
         ns = min(sps, stages_total - sb)
         acc = np.zeros((8, MT, 64, 16))                           # [wave][mt][lane][register]
         for j in range(ns):
-            par = (j & 1) * A_BUF
-            lds = {}                                              # the activation stage buffer, 16-byte granules by byte address
-            # ---- (1) every wavefront writes its share of the stage
+            lds = {}                                              # the two activation buffers, 16-byte granules by byte address
+            # ---- decode phase: every wavefront writes its share of its K half's chunk
             for wave in range(8):
                 g, q = wave & 3, wave >> 2
                 kq = 256 * sb + q * 128 * ns
                 for i in range(AI):
                     row_local = 8 * MT * g + 4 * i + arow
-                    addr = A_BASE + row_local * 512 + (((16 * q + apiece) ^ (row_local & 15)) << 4) + par
+                    addr = A_BASE + q * A_BUF + row_local * 256 + ((apiece ^ (row_local & 15)) << 4)
                     _check_write_b128(addr)
                     for l in lanes:
                         m = min(int(row_local[l]), M - 1)
                         k0 = kq + 128 * j + 8 * apiece[l]
                         assert addr[l] not in lds
                         lds[int(addr[l])] = (m, k0)
-            assert len(lds) == 32 * MT * 32
+            assert len(lds) == 2 * 32 * MT * 16
             # ---- (2..5) per wavefront: transposition, decode, MFMA steps
             for wave in range(8):
                 g, q = wave & 3, wave >> 2
@@ -88,7 +87,7 @@ def emulate(M=40, K=768, MT=2, seed=0, sps=None):
                     _check_read_b128(t_rd)
                     for dw in range(4):
                         d.append([(tile[int(t_rd[l])][0], tile[int(t_rd[l])][1] + 4 * dw) for l in lanes])
-                a_rd = A_BASE + n * 512 + (((16 * q + 8 * h) ^ (n & 15)) << 4)
+                a_rd = A_BASE + q * A_BUF + n * 256 + (((8 * h) ^ (n & 15)) << 4)
                 for s in range(8):
                     # provenance: lane (n, h), step s must hold k [64 h + 8 s, + 8) of column col0 + n
                     for l in lanes:
@@ -105,7 +104,7 @@ def emulate(M=40, K=768, MT=2, seed=0, sps=None):
                         assert k0 // 64 == (kq + 128 * j + 64 * h[l]) // 64, "MFMA step leaves the lane's quantization block"
                         Bop[l] = [sc * (code[b >> 4] if e == 0 else code[b & 15]) for b in byts for e in (0, 1)]
                     for mt in range(MT):
-                        addr = (a_rd ^ (s << 4)) + par + mt * 16384
+                        addr = (a_rd ^ (s << 4)) + mt * 8192
                         _check_read_b128(addr)
                         Aop = np.zeros((64, 8))
                         for l in lanes:

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Per-wavefront timeline of the pre-scaled-operand MFMA kernel (gemm4_mfma_ps_kernel) from in-kernel s_memtime stamps
 (profiling build only: make -C bitsandbytes_amd/csrc profiling; BNB_MI355X_LIBRARY=.../libbitsandbytes_mi355x_prof.so):
-0 start, 1 ring requested, 2 past the table barrier, 3 stage 0 landed + prepared, 4 past its barrier, then per stage j < 2: 5+3j
-its eight MFMA steps (with the preparation of stage j + 1 between them) done, 7+3j past the barrier; 12 stage loop done, 13 end.
+0 start, 1 chunk 0 requested, 2 past the table barrier, 3 chunk 0's weights transposed, 4 K half 1's extra barrier, then per chunk
+j < 2: 5+4j decode phase done, 6+4j past the barrier, 7+4j MFMA phase done, 8+4j past the barrier; 13 chunk loop done, 14 end.
     python tools/timeline_ps.py [--m 64] [--n 8192] [--k 8192] [--cfg 3000]"""
 import argparse
 import os
@@ -58,9 +58,9 @@ if WG == 0:
     print("no stamps: not a profiling build?")
     sys.exit(0)
 t0k = t[:, :, 0][t[:, :, 0] > 0].min()                   # first wavefront start of the whole launch
-names = {0: "start", 1: "ring requested", 2: "past table barrier", 3: "stage 0 landed + prepared", 4: "past barrier (stage 0 ready)",
-         5: "stage 0 steps + prep 1 done", 7: "past barrier (stage 1 ready)", 8: "stage 1 steps + prep 2 done",
-         10: "past barrier (stage 2 ready)", 12: "stage loop done", 13: "end"}
+names = {0: "start", 1: "chunk 0 requested", 2: "past table barrier", 3: "chunk 0 transposed", 4: "phase offset barrier",
+         5: "decode 0 done", 6: "past barrier", 7: "mfma 0 done", 8: "past barrier", 9: "decode 1 done", 10: "past barrier",
+         11: "mfma 1 done", 12: "past barrier", 13: "chunk loop done", 14: "end"}
 print(f"# ps kernel cfg={a.cfg}, M={a.m}, N={N}, K={K}: {WG} workgroups x {waves} wavefronts; s_memtime ticks "
       f"relative to the first wavefront start of the LAUNCH")
 print(f"{'stamp':34s} {'min':>7s} {'median':>7s} {'p90':>7s} {'max':>7s}   median delta to previous stamp")
