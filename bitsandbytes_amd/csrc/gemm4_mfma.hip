@@ -736,7 +736,7 @@ size_t gemm_4bit_ps_workspace_bytes(int M, int N, int K, int force_ks);
 void gemm_4bit_ps(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int variant,
-                  hipStream_t stream);
+                  int ablate, hipStream_t stream);
 
 // shared with gemm4_mfma_rt.hip / gemm4_mfma_ps.hip: the slab finalize launch and the library-owned workspace
 void gemm_4bit_finalize(int dtype, const float* ws, const void* bias, void* out, int M, int N, int kslices, hipStream_t stream) {
@@ -822,7 +822,7 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
     int pks, pvar;
     if (ps_selected(M, N, K, knob1, &pks, &pvar) && gemm_4bit_ps_supported(dtype, A, B, code16, M, N, K, blocksize))
         return gemm_4bit_ps(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type,
-                            workspace, workspace_bytes, pks, pvar, stream);
+                            workspace, workspace_bytes, pks, pvar, knob0, stream);
     if (rt_selected(M, N, K, knob1, &fks, &fw) && gemm_4bit_rt_supported(dtype, A, B, code16, M, N, K, blocksize))
         return gemm_4bit_rt(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize,
                             quant_type, workspace, workspace_bytes, fks, fw, stream);

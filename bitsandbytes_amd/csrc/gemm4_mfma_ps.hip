@@ -207,12 +207,21 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
     struct ASlot {
         u32x4 a[AI]; // this wavefront's share of the K half's activation chunk
     };
+#ifdef BNB_PROFILING
+    // ablations (profiling build only, bnb_mi355x_set_tuning knob0 bits 0 / 1 / 2): every lane fetches the FIRST lane's scale /
+    // activation piece / weight piece - one request per load instruction instead of 64 / 16 / 16; results are wrong, the
+    // timing tells what that operand's traffic costs
+    const int ablate = hot_flags >> 16;
+#define BNB_PS_ABL(bit, v) ((ablate & (bit)) ? static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))) : (v))
+#else
+#define BNB_PS_ABL(bit, v) (v)
+#endif
     auto issue_w = [&](WSlot& x, int j) {
         j = j < ns ? j : ns - 1; // a prefetch past the end re-reads the last chunk: never used, keeps every wait counted
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            x.w[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wo[i], j * 64, 0));
-        const uint32_t blk = (se0 + static_cast<uint32_t>(j) * 128u) >> bs_shift;
+            x.w[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, BNB_PS_ABL(4, wo[i]), j * 64, 0));
+        const uint32_t blk = BNB_PS_ABL(1, (se0 + static_cast<uint32_t>(j) * 128u) >> bs_shift);
         if constexpr (NESTED) {
             x.s8 = __builtin_amdgcn_raw_buffer_load_b32(rs_q, (blk + q_mis) & ~3u, 0, 0);
             x.s = __builtin_amdgcn_raw_buffer_load_b32(rs_s, (blk >> 8) * 4u, 0, 0);
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
         j = j < ns ? j : ns - 1;
 #pragma unroll
         for (int i = 0; i < AI; ++i)
-            x.a[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, ao[i], j * 256, 0));
+            x.a[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, BNB_PS_ABL(2, ao[i]), j * 256, 0));
     };
 
     WSlot ws[D];
@@ -573,7 +582,7 @@ size_t gemm_4bit_ps_workspace_bytes(int M, int N, int K, int force_ks) {
 void gemm_4bit_ps(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int variant,
-                  hipStream_t stream) {
+                  int ablate, hipStream_t stream) {
     PsPlan pl = ps_plan(M, N, K, force_ks);
     float* ws = static_cast<float*>(workspace);
     const size_t slab = static_cast<size_t>(M) * N * sizeof(float);
@@ -599,7 +608,12 @@ void gemm_4bit_ps(int dtype, const void* A, const uint8_t* B, const float* absma
     a.out = out;
     a.bias = bias;
     a.ws = ws;
-    const int flags = ilog2(blocksize) | ((quant_type == kFP4) ? 256 : 0);
+    int flags = ilog2(blocksize) | ((quant_type == kFP4) ? 256 : 0);
+#ifdef BNB_PROFILING
+    flags |= (ablate & 7) << 16;
+#else
+    (void)ablate;
+#endif
     if (dtype == 2) {
         if (variant == 1)
             ps_launch<bf16, 3>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
