@@ -239,48 +239,48 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
 
     WSlot ws[D];
     ASlot as[D];
-    // (nested: the second-level code entry of this thread is requested FIRST, so that the wait in front of its LDS copy is a
-    // counted one that leaves the ring in flight)
-    float code2_v = 0.0f, offset = 0.0f;
-    if constexpr (NESTED) {
-        code2_v = p.absmax_code[tid & 255];
+    // ---- start-up, split by K half. Half 0 (whose first decode phase opens the pipeline) requests its ring before anything
+    // else and then only waits; half 1 - which runs one phase behind anyway - builds the decode table first (256 threads, one
+    // entry each) and requests its ring afterwards. A CU keeps only a few tens of KiB of loads in flight and every further
+    // load instruction BLOCKS its wavefront until an older one returns, so whoever issues loads cannot build tables in
+    // time: with all eight wavefronts doing both, the table barrier fell ~8800 cycles into the kernel
+    // (profiles/r3_timeline_ps_v3.txt).
+    float offset = 0.0f;
+    if constexpr (NESTED)
         offset = p.absmax_offset[0];
-    }
-    // Chunk 0 goes out before anything else, the rest of the ring after the table: a CU keeps only a few tens of KiB of loads
-    // in flight, every further load instruction BLOCKS its wavefront until an older one returns - with the whole ring
-    // requested up front the table build started ~9000 cycles into the kernel (profiles/r3_timeline_ps_v2.txt).
-    issue_w(ws[0], 0);
-    issue_a(as[0], 0);
-    BNB_PS_STAMP(1)
-    __builtin_amdgcn_sched_barrier(0); // nothing that is not needed for the loads runs before them
-
-    // ---- decode table, built while the loads fly: entry e (a packed byte) = 32 copies of (code[e >> 4], code[e & 15])
-    // in fp32, 256 B per entry; thread (part, e) writes 8 of its 16 chunks in an order rotated by e (eight lanes -> eight
-    // bank quads)
-    {
+    float* const code2 = reinterpret_cast<float*>(smem + kPsCode2);
+    auto issue_ring = [&]() {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            issue_w(ws[j], j);
+            issue_a(as[j], j);
+            __builtin_amdgcn_sched_barrier(0); // (program order = queue order: the loop's counted waits assume chunk by chunk)
+        }
+    };
+    if (q == 0) {
+        issue_ring();
+        BNB_PS_STAMP(1)
+    } else {
+        // decode table: entry e (a packed byte) = 32 copies of (code[e >> 4], code[e & 15]) in fp32, 256 B per entry, its 16
+        // chunks written in an order rotated by e (eight lanes -> eight bank quads). Literals only: no load in front of it.
+        float code2_v = 0.0f;
+        if constexpr (NESTED)
+            code2_v = p.absmax_code[tid & 255];
         const float cv = ps_code_literal((lane & 15) + opaque_zero(), fp4);
         const int cvb = __builtin_bit_cast(int, cv);
-        constexpr int PER = 16 * 256 / (kPsWaves * 64); // 16-byte chunks of an entry per thread
-        const int e = tid & 255, part = tid >> 8;
+        const int e = tid & 255;
         const float hi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((e >> 4) & 15) * 4, cvb));
         const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e & 15) * 4, cvb));
         const f32x4 v = {hi, lo, hi, lo};
-        f32x4* const dst = reinterpret_cast<f32x4*>(smem + e * 256 + part * (PER * 16));
+        f32x4* const dst = reinterpret_cast<f32x4*>(smem + e * 256);
 #pragma unroll
-        for (int j = 0; j < PER; ++j)
-            dst[(j + e) & (PER - 1)] = v;
-    }
-    float* const code2 = reinterpret_cast<float*>(smem + kPsCode2);
-    if constexpr (NESTED) {
-        if (tid < 256)
-            code2[tid] = code2_v;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 1; j < D; ++j) {
-        issue_w(ws[j], j);
-        issue_a(as[j], j);
-        __builtin_amdgcn_sched_barrier(0); // (program order = queue order: the loop's counted waits assume chunk by chunk)
+        for (int j = 0; j < 16; ++j)
+            dst[(j + e) & 15] = v;
+        if constexpr (NESTED)
+            code2[e] = code2_v;
+        BNB_PS_STAMP(1)
+        __builtin_amdgcn_sched_barrier(0);
+        issue_ring();
     }
     __syncthreads();
     BNB_PS_STAMP(2)
@@ -359,8 +359,10 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
     BNB_PS_STAMP(4)
 
     // ---- DECODE phase of chunk j (ring slot x): its activation pieces -> the K half's LDS buffer (whose readers, the MFMA
-    // phase of chunk j - 1, are behind the last barrier), the slot is re-requested for chunk j + D, then 32 table look-ups per
-    // lane in four batches of eight (batch b + 1 in flight while batch b is multiplied and converted).
+    // phase of chunk j - 1, are behind the last barrier), the slot is re-requested for chunk j + D, then the chunk's 32 table
+    // look-ups per lane: ALL of them are issued before the first result is used (64 registers that the MFMA phase reuses for
+    // its activation fragments) - in batches of eight with one batch in flight the phase paid an LDS round trip per batch
+    // (~1400 cycles per phase for ~130 instructions, profiles/r3_timeline_ps_v3.txt).
     auto decode_phase = [&](ASlot& x, int j) {
 #pragma unroll
         for (int i = 0; i < AI; ++i)
@@ -369,66 +371,58 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
         issue_a(x, j + D);
         __builtin_amdgcn_sched_barrier(0);
         const f32x2 sc2 = {scale, scale};
-        f32x2 pr[2][8];
-        auto lut_reads = [&](int b, f32x2 (&o)[8]) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int s = 2 * b + t;
-                const uint32_t w = (s < 4) ? wt[0][s & 3] : wt[1][s & 3];
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    o[4 * t + c] = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>(
-                        __builtin_amdgcn_perm(w, lane_off, perm_sel + (c << 8)));
-            }
-        };
-        lut_reads(0, pr[0]);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (b + 1 < 4)
-                lut_reads(b + 1, pr[(b + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const f32x2 pv = pr[b & 1][4 * t + c] * sc2;
-                    float p0 = pv[0], p1 = pv[1];
-                    if constexpr (!__is_same(T, bf16)) {
-                        asm("" : "+v"(p0));
-                        asm("" : "+v"(p1));
-                    }
-                    bfr[2 * b + t][c] = PsMma<T>::pack(p0, p1);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // ---- MFMA phase of chunk j: eight 16-k steps, activation fragments two steps ahead; between the steps the NEXT chunk's
-    // packed weights (ring slot x) go through the private tile and the slot is re-requested for chunk j + 1 + D.
-    auto mfma_phase = [&](WSlot& x, int j) {
-        u32x4 af[3][MT];
-        auto a_reads = [&](int s, u32x4 (&f)[MT]) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                f[mt] = *reinterpret_cast<const u32x4*>(smem + (a_rd ^ static_cast<uint32_t>(s << 4)) + mt * 8192);
-        };
-        a_reads(0, af[0]);
-        a_reads(1, af[1]);
+        f32x2 pr[8][4];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            if (s + 2 < 8)
-                a_reads(s + 2, af[(s + 2) % 3]);
-            if (s == 1)
+            const uint32_t w = (s < 4) ? wt[0][s & 3] : wt[1][s & 3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                pr[s][c] = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>(
+                    __builtin_amdgcn_perm(w, lane_off, perm_sel + (c << 8)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x2 pv = pr[s][c] * sc2;
+                float p0 = pv[0], p1 = pv[1];
+                if constexpr (!__is_same(T, bf16)) {
+                    asm("" : "+v"(p0));
+                    asm("" : "+v"(p1));
+                }
+                bfr[s][c] = PsMma<T>::pack(p0, p1);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // ---- MFMA phase of chunk j: eight 16-k steps; ALL activation fragments are requested up front (the registers of the
+    // decode phase's look-ups), the wavefront runs at raised priority so that its MFMAs issue the moment their operands are
+    // there - its SIMD partner is in its decode phase and competes for the same issue port. Between the steps the NEXT
+    // chunk's packed weights (ring slot x) go through the private tile and the slot is re-requested for chunk j + 1 + D.
+    auto mfma_phase = [&](WSlot& x, int j) {
+        u32x4 af[8][MT];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                af[s][mt] = *reinterpret_cast<const u32x4*>(smem + (a_rd ^ static_cast<uint32_t>(s << 4)) + mt * 8192);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s == 2)
                 prep_w(x);
-            else if (s == 4)
-                prep_t(x, j + 1, wt, scale);
             else if (s == 5)
+                prep_t(x, j + 1, wt, scale);
+            else if (s == 6)
                 issue_w(x, j + 1 + D);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = PsMma<T>::run(af[s % 3][mt], bfr[s], acc[mt]);
+                acc[mt] = PsMma<T>::run(af[s][mt], bfr[s], acc[mt]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_s_setprio(0);
     };
     auto phase_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
