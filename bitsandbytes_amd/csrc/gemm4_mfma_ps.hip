@@ -1,49 +1,54 @@
-// gemm4_mfma_ps.hip — "pre-scaled operand" MFMA kernel for batched 4-bit linear layers on gfx950 (round 3):
+// gemm4_mfma_ps.hip — "pre-scaled operand" MFMA kernel for batched 4-bit linear layers on gfx950 (round 3, fourth build):
 //     out[m, n] = sum_k A[m, k] * T(code[B[n, k]] * scale[n, k / bs])  (+ bias[n])          T in {bf16, fp16}
 //
 // Fills, on MI355X, the tensor-core capability the reference has on CUDA only (csrc/gemm_4bit_sm80.cu:127-457,493-689) and
 // uses that kernel's arithmetic: every weight is decoded to T(code * scale) - fp32 product, ONE rounding to T, exactly
 // csrc/gemm_4bit_sm80.cu:300-307 and exactly what dequantize_4bit produces (csrc/cpu_ops.cpp:419-431) - straight into the MFMA
 // B operand, so the result equals dequantize_4bit + a T matmul with fp32 accumulation up to the order of the fp32 sums.
-// The round-1/2 kernels (gemm4_mfma.hip, gemm4_mfma_rt.hip) multiplied bf16-rounded codes and applied the fp32 scale to
-// the partial tile of every 64-k block with VALU FMAs: that pins the accumulators to architectural VGPRs, costs 4 v_fma
-// per (tile, block) and batch tile, and spends one address instruction + one ds_read_b32 per weight byte and batch tile
-// pair. Here the accumulators are touched by MFMA instructions only and the decode of a chunk is shared by all batch rows.
+// Accumulators are touched by MFMA instructions only; the decode of a weight is shared by all batch rows of the tile.
+//
+// What the instruction-level measurements of this round say (tools/ubench/issue_rate.hip, profiles/r3_issue_rate.txt) and
+// how the kernel is built around them:
+//
+//  * one wavefront issues one instruction per ~4.6 cycles; a SIMD retires v_mul/v_fma at 2.2 cycles, every other VALU kind
+//    (v_perm, v_pk_mul, v_cvt_pk) at 4.2, one 32x32x16 MFMA per 32 - and the LDS serves one ds_read_b64 per 2.1 cycles,
+//    one ds_read_b128 per 4, one ds_write_b128 per 13 PER CU. At 64 batch rows a 128-column x 256-k piece needs 1024 cycles
+//    of matrix pipe per SIMD, ~800 of VALU and - in the earlier builds of this file, which brought weights and activations
+//    to the LDS with ds_write_b128 and read the activation fragments once per 32 columns - ~1700 cycles of LDS: they were
+//    LDS-bound and, with all wavefronts in the same phase, nothing overlapped (3900 cycles per such piece, like every
+//    MFMA kernel of rounds 1 and 2).
+//  * so: (1) every byte that enters the LDS comes by LDS-DMA (buffer_load ... lds) in FULL 128-byte lines - no VGPR
+//    staging, no ds_write in the main loop; (2) a wavefront owns 64 columns x all rows of the tile (2 x MT accumulator
+//    tiles of 32x32), so an activation fragment is read once per 64 columns, and the four wavefronts of a column group split
+//    the stage's K four ways (their partial tiles are added once, at the end, in a fixed order); (3) the decode of stage
+//    j + 1 is software-pipelined under the MFMAs of stage j INSIDE every wavefront: an MFMA, then the table look-ups /
+//    multiplies / converts of a later fragment in its shadow - the mix the micro-benchmark runs at ~45 cycles per MFMA and
+//    SIMD with two wavefronts per SIMD; (4) ONE s_barrier per 128-k stage, whose only job is to publish DMA data.
 //
 // Shape of the kernel:
 //
 //  * v_mfma_f32_32x32x16_{bf16,f16}: A operand = activations (row m = lane % 32), B operand = weights (column n = lane % 32),
-//    lane half h = lane / 32 holds k = 8 h + 0..7 of the 16-k step. Half the LDS operand traffic per FLOP of the 16x16x32 form.
-//  * one workgroup = 128 output columns x (32 MT batch rows, MT = 1 | 2) x one K slice; 8 wavefronts = 4 column groups of 32
-//    x 2 K halves. A "stage" is 256 k: K half q works on its own 128-k chunk of it, so every wavefront decodes ONE chunk
-//    (32 columns x 128 k = 2 KiB of packed weights) per stage and multiplies it with all 32 MT rows.
-//  * PING-PONG. The first two builds of this kernel interleaved decode and MFMA step by step in every wavefront; their PMC
-//    passes (profiles/r3_pmc_ps_v2_c3.txt) showed per stage and SIMD 1024 cycles of matrix pipe, ~1340 of VALU and ~1640 of
-//    LDS adding up to the ~3900 cycles a stage took: with all wavefronts in the same phase of the same dependent chain
-//    nothing overlaps. Now a wavefront alternates between a DECODE phase (the chunk's 32 table look-ups per lane, scale
-//    multiplies, converts: VALU + LDS, no matrix instruction; result = the chunk's 8 B fragments in 32 registers) and an MFMA
-//    phase (16 back-to-back MFMAs fed by activation fragments from LDS: ~512 cycles of matrix pipe, almost no VALU), and
-//    the two K halves run in OPPOSITE phases - wavefronts g and g + 4 share a SIMD - with one s_barrier per phase: while one
-//    wavefront of a SIMD owns the matrix pipe, its partner owns the VALU.
-//  * EVERY global load of a wavefront - its two weight loads, its share of the activation chunk (MT loads of 8 rows x
-//    256 B... see below) and its scale - is an ordinary coalesced BUFFER load (base in SGPRs, one 32-bit lane offset
-//    computed once, the chunk as scalar offset: no address arithmetic per load) into a D-deep REGISTER ring; vmcnt retires in
-//    order, so the ring is refilled in consumption order and every wait the compiler emits is a counted one.
-//    No LDS-DMA, no producer wavefronts, no inline-asm waits.
-//  * weights: lane 4 r + p loads 16 bytes of row r (four neighbouring lanes = 64 contiguous bytes: 16 L1 tag look-ups per
-//    instruction); the MFMA wants the row in the low lane bits, so the chunk goes through a 2-KiB tile private to the
-//    wavefront (ds_write_b128 / ds_read_b128, same wavefront, in-order LDS, no barrier; XOR swizzle conflict-free under the
-//    hardware's lane groups). After it lane (n, h) holds the 64 consecutive k [64 h, 64 h + 64) of column n = ONE
-//    quantization block (bs >= 64): one scale per lane and chunk; MFMA step s consumes dword s (k = 64 h + 8 s + 0..7) and
-//    the activation fragment of the same k - K order inside an MFMA is free as long as both operands agree.
-//  * decode per packed byte: v_perm_b32 (LDS address) + ds_read_b64 (bank-private byte -> (code[hi], code[lo]) fp32 table
-//    built from literals) + v_pk_mul_f32 by the lane's scale + one convert-and-pack.
-//  * activations: the four wavefronts of a K half write their pieces of the half's chunk into the half's LDS buffer (rows of
-//    256 B, 16-byte pieces XOR-swizzled by the row: conflict-free ds_write_b128 and ds_read_b128) in their decode phase and
-//    read fragments from it in the MFMA phase that follows: one buffer per K half is enough.
-//  * the two K halves of a column group are added through LDS (fixed order), K slices across workgroups write fp32 slabs
-//    that gemm4_finalize adds in slice order: bit-reproducible.
+//    lane half h = lane / 32 holds 8 of the 16 k of a step. K order inside an MFMA is free as long as both operands agree.
+//  * workgroup = 128 output columns x 32 MT batch rows (MT = 1 | 2 | 4) x one K slice; 8 wavefronts = 2 column groups c of
+//    64 columns x 4 K quarters q. A stage is 128 k: wavefront (c, q) multiplies k [32 q, 32 q + 32) of it - two 16-k steps,
+//    lane half h takes k 32 q + 16 h + 8 s + 0..7 in step s - for its 64 columns (two 32-column tiles nt) and all row tiles.
+//  * LDS: the decode table (byte -> (code[hi], code[lo]) in fp32, 32 bank-private copies, 64 KiB, at address 0, built from
+//    literals), a DA-deep ring of activation stages (32 MT rows x 256 B), a DW-deep ring of weight stages (128 rows x 64 B)
+//    and scale stages ([column][64-k half] fp32, or 8-bit code + second-level absmax when nested), the second-level table.
+//  * loads: wavefronts of column group 0 bring weights and scales, those of group 1 activations - vmcnt retires in order
+//    per wavefront, so the deep weight stream (3 stages ahead) and the shallower activation stream (L2 hits, 2 ahead) must not
+//    share a queue. Every DMA instruction writes 1 KiB: 16 weight rows x 64 B (four lanes per row) or 4 activation rows x
+//    256 B; the XOR swizzles that make the fragment reads conflict-free are applied on the SOURCE side (the lane that
+//    writes LDS piece p' of a row fetches global piece p' ^ f(row): same lines, same coalescing).
+//  * weights: lane l reads the 16-byte piece of K quarter q of row 64 c + l with one ds_read_b128; one v_permlane32_swap
+//    per dword pair hands every lane (n, h) the 8 bytes [16 q + 8 h, + 8) of columns 64 c + n and 64 c + 32 + n: dword s
+//    of tile nt = the B fragment of step s before decoding.
+//  * decode per packed byte: v_perm_b32 (LDS address) + ds_read_b64 (table) + v_pk_mul_f32 by the lane's scale + one
+//    convert-and-pack. The scale of a lane is that of its column's 64-k block (bs >= 64): one per tile and stage.
+//  * K slices across workgroups write fp32 slabs that gemm4_finalize adds in slice order: bit-reproducible.
 #include "bnb_common.h"
+
+#include <type_traits>
 
 namespace bnb {
 
@@ -57,6 +62,8 @@ float* gemm_4bit_internal_workspace(size_t bytes, hipStream_t stream);
 
 namespace {
 
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -82,7 +89,7 @@ template <> struct PsMma<f16> {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(frag, a), __builtin_bit_cast(frag, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ uint32_t pack(float first, float second) {
-        // (the fp32 products are opaque register values here - see the decode loop - so hipcc cannot fuse the multiply into
+        // (the fp32 products are opaque register values here - see the decode - so hipcc cannot fuse the multiply into
         // v_fma_mix*_f16, which would round the exact product once instead of fp32 first, T second)
         using V = __attribute__((ext_vector_type(2))) f16;
         V v;
@@ -92,15 +99,29 @@ template <> struct PsMma<f16> {
     }
 };
 
-constexpr int kPsCols = 128;        // output columns per workgroup: 4 column groups of 32
-constexpr int kPsStageK = 256;      // k per stage: one 128-k chunk per K half
-constexpr int kPsWaves = 8;         // 4 column groups x 2 K halves
-constexpr int kPsLut = 65536;       // 256 entries x 32 copies x 8 B (fp32 pair), at LDS address 0
-constexpr int kPsABuf = 16384;      // the activation chunk of one K half: up to 64 rows x 256 B
-constexpr int kPsABase = kPsLut;    // one buffer per K half
-constexpr int kPsTileBase = kPsABase + 2 * kPsABuf; // per-wavefront transposition tiles, 2 KiB each
-constexpr int kPsCode2 = kPsTileBase + kPsWaves * 2048;
-constexpr int kPsLdsBytes = kPsCode2 + 1024;
+constexpr int kPsCols = 128;  // output columns per workgroup: 2 column groups of 64
+constexpr int kPsStageK = 128; // k per stage: 32 per K quarter
+constexpr int kPsWaves = 8;   // 2 column groups x 4 K quarters
+constexpr int kPsLut = 65536; // 256 entries x 32 copies x 8 B (fp32 pair), at LDS address 0
+
+// ring depths and LDS map of one instance
+template <int MT, bool NESTED> struct PsLds {
+    // (a six-deep weight ring beside a two-deep activation ring measured 5 - 12 % slower: profiles/r3_ps_quick_variants.txt)
+    static constexpr int DA = MT >= 4 ? 2 : 3;     // activation stages in the ring
+    static constexpr int DW = MT >= 4 ? 3 : 4;     // weight / scale stages in the ring
+    static constexpr int ASB = 32 * MT * 256;      // bytes of an activation stage
+    static constexpr int WSB = kPsCols * 64;       // bytes of a weight stage
+    static constexpr int SSB = NESTED ? 2048 : 1024; // bytes of a scale stage: [128 columns][2 halves] dwords (x 2 when nested)
+    static constexpr int ABase = kPsLut;
+    static constexpr int WBase = ABase + DA * ASB;
+    static constexpr int SBase = WBase + DW * WSB;
+    static constexpr int Code2 = SBase + DW * SSB;
+    static constexpr int Bytes = Code2 + 1024;
+    // the epilogue's exchange area (the whole LDS is free by then): see the end of the kernel
+    static constexpr int Rounds = MT >= 4 ? 2 : 1;
+    static constexpr int RedBytes = 49152 * MT / Rounds;
+    static_assert(Bytes <= 163840 && RedBytes <= 163840, "LDS");
+};
 
 struct PsArgs {
 #ifdef BNB_PROFILING
@@ -135,134 +156,165 @@ __device__ __forceinline__ float ps_code_literal(int i, bool fp4) {
     return v;
 }
 
-// grid = (ceil(N / 128), kslices, ceil(M / (32 MT))); 512 threads. D = depth of the register rings in chunks.
-template <typename T, int MT, bool NESTED, int D>
+// LDS-DMA, spelled out: the compiler's own tracking of buffer_load ... lds makes every later ds_read wait for ALL
+// outstanding DMA (vmcnt(0)); the hand-off is by counted waits + s_barrier instead (see the stage loop).
+__device__ __forceinline__ i32x4 ps_rsrc(const void* base) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    return i32x4{static_cast<int>(a), static_cast<int>((a >> 32) & 0xFFFFu), 0x7FFFFFFF, 0x00020000};
+}
+__device__ __forceinline__ void ps_dma16(i32x4 rs, uint32_t lds, uint32_t voff, uint32_t soff) {
+    // (LDS base and scalar offset are wavefront-uniform by construction; the explicit readfirstlane keeps them in SGPRs when
+    // the compiler's divergence analysis gives up - seen in the profiling build)
+    lds = __builtin_amdgcn_readfirstlane(lds);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ void ps_dma4(i32x4 rs, uint32_t lds, uint32_t voff) {
+    lds = __builtin_amdgcn_readfirstlane(lds);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rs) : "memory", "m0");
+}
+template <int N> __device__ __forceinline__ void ps_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void ps_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+template <typename V> __device__ __forceinline__ V ps_lds_read(uint32_t addr) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) V*>(addr);
+}
+
+// Slot of the MFMA list (4 MT per stage: step s, tile nt, row tile mt) after whose MFMA fragment g (= 2 s + nt) of the next stage is
+// multiplied / converted into the operand registers and the table look-ups of the stage after that go into the look-up
+// registers just freed. The fragment is replaced IN PLACE, no earlier than the slot of the last MFMA that reads the current
+// one (s 2 MT + nt MT + MT - 1): an MFMA fetches its A / B operands when it issues, a write to them right behind it costs
+// nothing (tools/ubench/issue_rate.hip, "valu writing ITS B operand").
+template <int MT> __device__ constexpr int ps_frag_slot(int g) {
+    constexpr int t1[4] = {0, 1, 2, 3}, t2[4] = {2, 4, 6, 7}, t4[4] = {4, 8, 12, 15};
+    return MT == 1 ? t1[g] : MT == 2 ? t2[g] : t4[g];
+}
+template <int MT> __device__ constexpr bool ps_slots_ok() {
+    for (int g = 0; g < 4; ++g)
+        if (ps_frag_slot<MT>(g) < (g >> 1) * 2 * MT + (g & 1) * MT + MT - 1 || ps_frag_slot<MT>(g) >= 4 * MT)
+            return false;
+    return true;
+}
+
+// grid = (ceil(N / 128), kslices, ceil(M / (32 MT))); 512 threads.
+template <typename T, int MT, bool NESTED>
 __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
     // hot arguments as separate scalars: preloaded into SGPRs by the command processor (14 dwords)
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, int hot_M, int hot_N,
     int hot_K, int hot_flags /* bs_shift | fp4 << 8 */, int hot_sps /* stages per K slice */, int hot_kslices,
     const PsArgs p) {
+    using L = PsLds<MT, NESTED>;
+    static_assert(ps_slots_ok<MT>(), "decode schedule");
+    constexpr int DA = L::DA, DW = L::DW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     BNB_PS_STAMP(0)
-    const int g = wave & 3, q = wave >> 2;        // column group, K half (wavefronts g and g + 4 share a SIMD)
-    const int r = lane >> 2, pp = lane & 3;       // weight-load roles: row r of a 16-row half tile, 16-byte piece pp of its 64 bytes
-    const int n = lane & 31, h = lane >> 5;       // MFMA roles: column / row n, k half h
-    const int arow = lane >> 4, apiece = lane & 15; // activation-load roles: row arow of a 4-row group, 16-byte piece of its 256 bytes
+    const int c = wave >> 2, q = wave & 3;  // column group (also the loader role), K quarter; wavefronts q and 4 + q share a SIMD
+    const int n = lane & 31, h = lane >> 5; // MFMA roles: column / row n, k half h
     const int M = hot_M, N = hot_N, K = hot_K;
     const int bs_shift = hot_flags & 31;
     const bool fp4 = (hot_flags >> 8) & 1;
-    const int col0 = blockIdx.x * kPsCols + 32 * g;
+#if defined(BNB_PROFILING) && defined(PS_ABLATE)
+    // ablations (a -DPS_ABLATE profiling build only, bnb_mi355x_set_tuning knob0): 1 no activation DMA, 2 no weight / scale DMA, 4 no table
+    // look-ups / multiplies / converts, 8 no MFMA, 16 no fragment reads of activations: results are wrong, the timing tells what
+    // each part costs
+    const int ablate = __builtin_amdgcn_readfirstlane(hot_flags >> 16);
+#define BNB_PS_ON(bit) (!(ablate & (bit)))
+#else
+#define BNB_PS_ON(bit) true
+#endif
+    const int col0 = blockIdx.x * kPsCols;
     const int m_base = blockIdx.z * (32 * MT);
-    const int stages_total = K >> 8;
+    const int stages_total = K >> 7;
     const int sb = blockIdx.y * hot_sps;
     int se = sb + hot_sps;
     se = se < stages_total ? se : stages_total;
-    const int ns = se - sb; // stages of this slice = chunks of this wavefront (>= 1: the host makes every slice non-empty)
-    // K half q owns the chunks [kq, kq + 128 ns) of the slice [256 sb, 256 se): chunk j of the wavefront = k kq + 128 j
-    const uint32_t kq = (static_cast<uint32_t>(sb) << 8) + static_cast<uint32_t>(q) * 128u * static_cast<uint32_t>(ns);
+    const int ns = se - sb; // stages of this slice (>= 1: the host makes every slice non-empty)
+    if (reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem) != 0)
+        __builtin_trap(); // the table is addressed with raw v_perm_b32 results: it must sit at LDS address 0
 
-    // ---- sources: buffer loads (base in SGPRs, a 32-bit per-lane byte offset computed ONCE, the chunk as a scalar offset):
-    // no per-load address arithmetic on the VALU. All byte offsets are < 2^31 (gemm_4bit_ps_supported). Rows past the end
-    // (ragged N or M) re-read the last row: MFMA rows / columns are independent and those results are never stored, so no
-    // masking instructions are needed.
-    constexpr int kRsrcFlags = 0x00020000;
-    constexpr int kRecords = 0x7FFFFFFF;
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hot_B), 0, kRecords, kRsrcFlags);
-    const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(hot_A), 0, kRecords, kRsrcFlags);
-    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hot_absmax), 0, kRecords, kRsrcFlags);
-    // (nested codes are fetched as ALIGNED dwords - see prep_t: the descriptor starts at the aligned address at or below the
-    // array, q_mis = the array's offset in it; a shard's absmax view may start at any byte)
+    // ---- sources. Rows past the end (ragged N or M) re-read the last row: MFMA rows / columns are independent and those
+    // results are never stored. All byte offsets are < 2^31 (gemm_4bit_ps_supported).
+    // (nested codes travel as the ALIGNED dword that holds them - the descriptor starts at the aligned address at or below the
+    // array, q_mis = the array's offset in it; a shard's absmax view may start at any byte - and the byte is cut out by the
+    // consumer: every DMA of the weight loaders' queue is then a dword or a 16-byte one)
     const uint32_t q_mis = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(hot_absmax8) & 3u);
-    const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hot_absmax8) - q_mis, 0, kRecords, kRsrcFlags);
-    uint32_t wo[2];
+    const i32x4 rs_w = ps_rsrc(hot_B), rs_a = ps_rsrc(hot_A), rs_s = ps_rsrc(hot_absmax), rs_q = ps_rsrc(hot_absmax8 - q_mis);
+    constexpr int AI = 2 * MT;                      // activation DMA instructions per loader wavefront and stage (4 rows x 256 B each)
+    constexpr int WI = NESTED ? 4 : 3;              // weight-side DMA instructions per loader wavefront and stage
+    constexpr int LN = AI > 3 ? AI : 3;
+    uint32_t lo[LN]; // per-lane source offsets of the wavefront's DMA instructions (by role)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int row = col0 + 16 * i + r;
-        row = row < N ? row : N - 1;
-        wo[i] = static_cast<uint32_t>(row) * static_cast<uint32_t>(K >> 1) + (kq >> 1) + static_cast<uint32_t>(pp * 16);
+    for (int t = 0; t < LN; ++t) {
+        uint32_t v = 0;
+        if (c == 0) {
+            if (t < 2) {
+                // weights: instruction i = 2 q + t covers rows 16 i .. 16 i + 15; lane 4 r + p' writes LDS piece p' of row r and
+                // fetches piece p' ^ ((row >> 2) & 3)
+                const int row = 16 * (2 * q + t) + (lane >> 2);
+                int col = col0 + row;
+                col = col < N ? col : N - 1;
+                v = static_cast<uint32_t>(col) * static_cast<uint32_t>(K >> 1) + static_cast<uint32_t>(((lane & 3) ^ ((row >> 2) & 3)) << 4);
+            } else if (t == 2) {
+                // scales: instruction q covers dwords 64 q .. 64 q + 63 of [column][64-k half]: element index of the half's first weight
+                const int d = 64 * q + lane;
+                int col = col0 + (d >> 1);
+                col = col < N ? col : N - 1;
+                v = static_cast<uint32_t>(col) * static_cast<uint32_t>(K) + static_cast<uint32_t>(64 * (d & 1));
+            }
+        } else if (t < AI) {
+            // activations: instruction i = q + 4 t covers rows 4 i .. 4 i + 3; lane 16 r + p' fetches piece p' ^ (row & 15)
+            const int row = 4 * (q + 4 * t) + (lane >> 4);
+            int m = m_base + row;
+            m = m < M ? m : M - 1;
+            v = (static_cast<uint32_t>(m) * static_cast<uint32_t>(K)) * 2u + static_cast<uint32_t>(((lane & 15) ^ (row & 15)) << 4);
+        }
+        lo[t] = v;
     }
-    constexpr int AI = 2 * MT; // activation loads per wavefront and chunk: 4 rows x 256 B each
-    uint32_t ao[AI], a_wr[AI];
+    // stage j of the slice (absolute stage sb + j; past the end: the last one again, never used) into a ring slot
+    auto issue_w = [&](int j, int slot) {
+        if (!BNB_PS_ON(2))
+            return;
+        const int sa = sb + (j < ns ? j : ns - 1);
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-        const int row_local = 8 * MT * g + 4 * i + arow;
-        int m = m_base + row_local;
-        m = m < M ? m : M - 1;
-        ao[i] = (static_cast<uint32_t>(m) * static_cast<uint32_t>(K) + kq + static_cast<uint32_t>(8 * apiece)) * 2u;
-        a_wr[i] = static_cast<uint32_t>(kPsABase + q * kPsABuf + row_local * 256 + ((apiece ^ (row_local & 15)) << 4));
-    }
-    // scale of lane (n, h) for chunk j: block of flat element (row n) * K + kq + 128 j + 64 h
-    int srow = col0 + n;
-    srow = srow < N ? srow : N - 1;
-    const uint32_t se0 = static_cast<uint32_t>(srow) * static_cast<uint32_t>(K) + kq + static_cast<uint32_t>(64 * h);
-
-    struct WSlot {
-        u32x4 w[2];  // lane (r, pp) holds bytes [16 pp, 16 pp + 16) of the chunk's 64 bytes of rows r, 16 + r
-        uint32_t s;  // fp32 absmax bits of the lane's block (nested: of its second-level block)
-        uint32_t s8; // nested: the aligned dword of 8-bit absmax codes that holds the block's (see prep_t)
-    };
-    struct ASlot {
-        u32x4 a[AI]; // this wavefront's share of the K half's activation chunk
-    };
-#ifdef BNB_PROFILING
-    // ablations (profiling build only, bnb_mi355x_set_tuning knob0 bits 0 / 1 / 2): every lane fetches the FIRST lane's scale /
-    // activation piece / weight piece - one request per load instruction instead of 64 / 16 / 16; results are wrong, the
-    // timing tells what that operand's traffic costs
-    const int ablate = hot_flags >> 16;
-#define BNB_PS_ABL(bit, v) ((ablate & (bit)) ? static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))) : (v))
-#else
-#define BNB_PS_ABL(bit, v) (v)
-#endif
-    auto issue_w = [&](WSlot& x, int j) {
-        j = j < ns ? j : ns - 1; // a prefetch past the end re-reads the last chunk: never used, keeps every wait counted
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            x.w[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, BNB_PS_ABL(4, wo[i]), j * 64, 0));
-        const uint32_t blk = BNB_PS_ABL(1, (se0 + static_cast<uint32_t>(j) * 128u) >> bs_shift);
+        for (int t = 0; t < 2; ++t)
+            ps_dma16(rs_w, static_cast<uint32_t>(L::WBase + slot * L::WSB + (2 * q + t) * 1024), lo[t], static_cast<uint32_t>(sa) * 64u);
+        const uint32_t blk = (lo[2] + static_cast<uint32_t>(sa) * 128u) >> bs_shift;
         if constexpr (NESTED) {
-            x.s8 = __builtin_amdgcn_raw_buffer_load_b32(rs_q, (blk + q_mis) & ~3u, 0, 0);
-            x.s = __builtin_amdgcn_raw_buffer_load_b32(rs_s, (blk >> 8) * 4u, 0, 0);
+            ps_dma4(rs_q, static_cast<uint32_t>(L::SBase + slot * L::SSB + q * 256), (blk + q_mis) & ~3u);
+            ps_dma4(rs_s, static_cast<uint32_t>(L::SBase + slot * L::SSB + 1024 + q * 256), (blk >> 8) * 4u);
         } else {
-            x.s = __builtin_amdgcn_raw_buffer_load_b32(rs_s, blk * 4u, 0, 0);
-            x.s8 = 0;
+            ps_dma4(rs_s, static_cast<uint32_t>(L::SBase + slot * L::SSB + q * 256), blk * 4u);
         }
     };
-    auto issue_a = [&](ASlot& x, int j) {
-        j = j < ns ? j : ns - 1;
+    auto issue_a = [&](int j, int slot) {
+        if (!BNB_PS_ON(1))
+            return;
+        const int sa = sb + (j < ns ? j : ns - 1);
 #pragma unroll
-        for (int i = 0; i < AI; ++i)
-            x.a[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, BNB_PS_ABL(2, ao[i]), j * 256, 0));
+        for (int t = 0; t < AI; ++t)
+            ps_dma16(rs_a, static_cast<uint32_t>(L::ABase + slot * L::ASB + (q + 4 * t) * 1024), lo[t], static_cast<uint32_t>(sa) * 256u);
     };
 
-    WSlot ws[D];
-    ASlot as[D];
-    // ---- start-up, split by K half. Half 0 (whose first decode phase opens the pipeline) requests its ring before anything
-    // else and then only waits; half 1 - which runs one phase behind anyway - builds the decode table first (256 threads, one
-    // entry each) and requests its ring afterwards. A CU keeps only a few tens of KiB of loads in flight and every further
-    // load instruction BLOCKS its wavefront until an older one returns, so whoever issues loads cannot build tables in
-    // time: with all eight wavefronts doing both, the table barrier fell ~8800 cycles into the kernel
-    // (profiles/r3_timeline_ps_v3.txt).
+    // ---- start-up: the weight loaders request their first DW - 1 stages (the activation stream starts in iteration 0), the
+    // decode table is built while they fly
+    if (c == 0) {
+#pragma unroll
+        for (int j = 0; j < DW - 1; ++j)
+            issue_w(j, j);
+    }
+    BNB_PS_STAMP(1)
     float offset = 0.0f;
     if constexpr (NESTED)
         offset = p.absmax_offset[0];
-    float* const code2 = reinterpret_cast<float*>(smem + kPsCode2);
-    auto issue_ring = [&]() {
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            issue_w(ws[j], j);
-            issue_a(as[j], j);
-            __builtin_amdgcn_sched_barrier(0); // (program order = queue order: the loop's counted waits assume chunk by chunk)
-        }
-    };
-    if (q == 0) {
-        issue_ring();
-        BNB_PS_STAMP(1)
-    } else {
-        // decode table: entry e (a packed byte) = 32 copies of (code[e >> 4], code[e & 15]) in fp32, 256 B per entry, its 16
-        // chunks written in an order rotated by e (eight lanes -> eight bank quads). Literals only: no load in front of it.
+    {
+        // decode table: entry e (a packed byte) = 32 copies of (code[e >> 4], code[e & 15]) in fp32, 256 B per entry; the two
+        // halves of the workgroup write 8 of its 16 16-byte chunks each, in an order rotated by e (eight lanes -> eight bank quads)
         float code2_v = 0.0f;
         if constexpr (NESTED)
             code2_v = p.absmax_code[tid & 255];
@@ -270,236 +322,310 @@ __global__ __launch_bounds__(kPsWaves * 64) void gemm4_mfma_ps_kernel(
         const int cvb = __builtin_bit_cast(int, cv);
         const int e = tid & 255;
         const float hi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((e >> 4) & 15) * 4, cvb));
-        const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e & 15) * 4, cvb));
-        const f32x4 v = {hi, lo, hi, lo};
+        const float lov = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e & 15) * 4, cvb));
+        const f32x4 v = {hi, lov, hi, lov};
         f32x4* const dst = reinterpret_cast<f32x4*>(smem + e * 256);
+        const int half = tid >> 8;
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            dst[(j + e) & 15] = v;
+        for (int j = 0; j < 8; ++j)
+            dst[(8 * half + j + e) & 15] = v;
         if constexpr (NESTED)
-            code2[e] = code2_v;
-        BNB_PS_STAMP(1)
-        __builtin_amdgcn_sched_barrier(0);
-        issue_ring();
+            if (tid < 256)
+                reinterpret_cast<float*>(smem + L::Code2)[e] = code2_v;
     }
-    __syncthreads();
-    BNB_PS_STAMP(2)
-    if (reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem) != 0)
-        __builtin_trap(); // the table is addressed with raw v_perm_b32 results: it must sit at LDS address 0
 
     const uint32_t perm_sel = 0x0C0C0400u + static_cast<uint32_t>(opaque_zero()); // {lane offset, weight byte, 0, 0}
     const uint32_t lane_off = static_cast<uint32_t>(lane & 31) * 8u;
-
-    // transposition tile: row R (64 B) keeps its 16-byte piece P at position P ^ ((R >> 2) & 3): the 8 contiguous lanes one
-    // ds_write_b128 pass serves (rows 2 i, 2 i + 1 x pieces 0..3) land in 8 different 16-byte positions mod 128 B, the 16-lane
-    // groups of ds_read_b128 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32: sixteen rows distinct mod 16, one piece) in 16
-    // different positions mod 256 B
-    unsigned char* const tile = smem + kPsTileBase + wave * 2048;
-    uint32_t t_wr[2], t_rd[2];
+    // consumer addresses, relative to ring slot 0
+    const uint32_t w_rd = static_cast<uint32_t>(L::WBase + (64 * c + lane) * 64 + ((q ^ ((lane >> 2) & 3)) << 4));
+    uint32_t s_rd[2], s_el[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = 16 * i + r;
-        t_wr[i] = static_cast<uint32_t>((row * 4 + (pp ^ ((row >> 2) & 3))) * 16);
-        t_rd[i] = static_cast<uint32_t>((n * 4 + ((2 * h + i) ^ ((n >> 2) & 3))) * 16);
+    for (int nt = 0; nt < 2; ++nt) {
+        s_rd[nt] = static_cast<uint32_t>(L::SBase + ((64 * c + 32 * nt + n) * 2 + (q >> 1)) * 4);
+        // (nested: element index of the first weight of the lane's 64-k half in stage 0 of the slice -> its block index -> the
+        // byte of the fetched dword)
+        int col = col0 + 64 * c + 32 * nt + n;
+        col = col < N ? col : N - 1;
+        s_el[nt] = static_cast<uint32_t>(col) * static_cast<uint32_t>(K) + static_cast<uint32_t>(64 * (q >> 1)) + static_cast<uint32_t>(sb) * 128u;
     }
-    // activation fragment of step s, row tile mt: (a_rd ^ (s << 4)) + mt * 8192 (row n of the tile, piece (8 h + s) ^ (n & 15))
-    const uint32_t a_rd = static_cast<uint32_t>(kPsABase + q * kPsABuf + n * 256 + (((8 * h) ^ (n & 15)) << 4));
+    // activation fragment of step s, row tile mt: row 32 mt + n, piece (4 q + 2 h + s) ^ (n & 15)
+    uint32_t a_rd[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        a_rd[s] = static_cast<uint32_t>(L::ABase + n * 256 + (((4 * q + 2 * h + s) ^ (n & 15)) << 4));
 
-    f32x16 acc[MT];
+    f32x16 acc[2][MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            acc[mt][i] = 0.0f;
-
-    // packed weights of a ring slot: coalesced shape -> private tile -> MFMA shape; the scale leaves its ring register
-    auto prep_w = [&](WSlot& x) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<u32x4*>(tile + t_wr[i]) = x.w[i];
-    };
-    auto prep_t = [&](WSlot& x, int jn, u32x4 (&wt)[2], float& scale) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            wt[i] = *reinterpret_cast<const u32x4*>(tile + t_rd[i]);
-        // The scale leaves its ring register through an instruction the compiler cannot move: left to itself hipcc parks the
-        // copy in the loop latch, where its wait for this one load becomes s_waitcnt vmcnt(0) - a drain of the whole ring once
-        // per round (seen in the ISA of the first build). For the same reason the nested code is fetched as the aligned
-        // DWORD that holds it and the byte is cut out here: a byte load's zero extension is an instruction of its own, and
-        // hipcc hoisted that one to the loop top behind a vmcnt(5).
-        uint32_t sv;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(sv) : "v"(x.s));
-        if constexpr (NESTED) {
-            uint32_t qw;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(qw) : "v"(x.s8));
-            jn = jn < ns ? jn : ns - 1;
-            const uint32_t blk = (se0 + static_cast<uint32_t>(jn) * 128u) >> bs_shift;
-            const uint32_t qv = __builtin_amdgcn_ubfe(qw, 8u * ((blk + q_mis) & 3u), 8u);
-            scale = __fadd_rn(__fmul_rn(code2[qv], __builtin_bit_cast(float, sv)), offset);
-        } else {
-            scale = __builtin_bit_cast(float, sv);
-        }
-    };
-
-    u32x4 wt[2];  // the current chunk's packed weights in MFMA shape: dword s of lane (n, h) = k [64 h + 8 s, + 8) of column n
-    float scale;
-    u32x4 bfr[8]; // ... decoded: the B fragments of its eight 16-k steps
-    prep_w(ws[0]);
-    prep_t(ws[0], 0, wt, scale);
-    __builtin_amdgcn_sched_barrier(0);
-    issue_w(ws[0], D);
-    __builtin_amdgcn_sched_barrier(0);
-    BNB_PS_STAMP(3)
-    // K half 1 runs one phase behind K half 0
-    if (q == 1) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
-    BNB_PS_STAMP(4)
-
-    // ---- DECODE phase of chunk j (ring slot x): its activation pieces -> the K half's LDS buffer (whose readers, the MFMA
-    // phase of chunk j - 1, are behind the last barrier), the slot is re-requested for chunk j + D, then the chunk's 32 table
-    // look-ups per lane: ALL of them are issued before the first result is used (64 registers that the MFMA phase reuses for
-    // its activation fragments) - in batches of eight with one batch in flight the phase paid an LDS round trip per batch
-    // (~1400 cycles per phase for ~130 instructions, profiles/r3_timeline_ps_v3.txt).
-    auto decode_phase = [&](ASlot& x, int j) {
-#pragma unroll
-        for (int i = 0; i < AI; ++i)
-            *reinterpret_cast<u32x4*>(smem + a_wr[i]) = x.a[i];
-        __builtin_amdgcn_sched_barrier(0);
-        issue_a(x, j + D);
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x2 sc2 = {scale, scale};
-        f32x2 pr[8][4];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const uint32_t w = (s < 4) ? wt[0][s & 3] : wt[1][s & 3];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                pr[s][c] = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>(
-                    __builtin_amdgcn_perm(w, lane_off, perm_sel + (c << 8)));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x2 pv = pr[s][c] * sc2;
-                float p0 = pv[0], p1 = pv[1];
-                if constexpr (!__is_same(T, bf16)) {
-                    asm("" : "+v"(p0));
-                    asm("" : "+v"(p1));
-                }
-                bfr[s][c] = PsMma<T>::pack(p0, p1);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // ---- MFMA phase of chunk j: eight 16-k steps; ALL activation fragments are requested up front (the registers of the
-    // decode phase's look-ups), the wavefront runs at raised priority so that its MFMAs issue the moment their operands are
-    // there - its SIMD partner is in its decode phase and competes for the same issue port. Between the steps the NEXT
-    // chunk's packed weights (ring slot x) go through the private tile and the slot is re-requested for chunk j + 1 + D.
-    auto mfma_phase = [&](WSlot& x, int j) {
-        u32x4 af[8][MT];
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                af[s][mt] = *reinterpret_cast<const u32x4*>(smem + (a_rd ^ static_cast<uint32_t>(s << 4)) + mt * 8192);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            if (s == 2)
-                prep_w(x);
-            else if (s == 5)
-                prep_t(x, j + 1, wt, scale);
-            else if (s == 6)
-                issue_w(x, j + 1 + D);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = PsMma<T>::run(af[s][mt], bfr[s], acc[mt]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_s_setprio(0);
-    };
-    auto phase_barrier = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    auto do_chunk = [&](ASlot& xa, WSlot& xw_next, int j) {
-        decode_phase(xa, j);
-        if (j < 2)
-            BNB_PS_STAMP(5 + 4 * j)
-        phase_barrier(); // the chunk's activations are complete in LDS; the partner half is done with the matrix pipe
-        if (j < 2)
-            BNB_PS_STAMP(6 + 4 * j)
-        mfma_phase(xw_next, j);
-        if (j < 2)
-            BNB_PS_STAMP(7 + 4 * j)
-        phase_barrier(); // everybody is done with this half's activation buffer
-        if (j < 2)
-            BNB_PS_STAMP(8 + 4 * j)
-    };
-    // chunk j lives in ring slot j % D: the loop is unrolled by D so that every slot index is a constant. Whole rounds first,
-    // with nothing conditional around the loads (at the join of a branch around a load the compiler merges the pending-load
-    // state of both paths and waits conservatively), then the tail.
-    {
-        int j = 0;
-        for (; j + D <= ns; j += D) {
-#pragma unroll
-            for (int jj = 0; jj < D; ++jj)
-                do_chunk(as[jj], ws[(jj + 1) % D], j + jj);
-        }
-#pragma unroll
-        for (int jj = 0; jj < D - 1; ++jj)
-            if (j + jj < ns)
-                do_chunk(as[jj], ws[(jj + 1) % D], j + jj);
-    }
-    if (q == 0)
-        phase_barrier(); // (K half 1's last MFMA phase)
-    BNB_PS_STAMP(13)
-
-    // ---- the two K halves of a column group, added in a fixed order (half 0 + half 1); the parking area reuses the
-    // activation buffers (every MFMA phase is behind the last barrier): [g][mt][4 register quads][64 lanes x 16 B]
-    unsigned char* const red = smem + kPsABase + (g * MT) * 4096 + lane * 16;
-    if (q == 1) {
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4)
-                *reinterpret_cast<f32x4*>(red + (mt * 4 + r4) * 1024) =
-                    f32x4{acc[mt][4 * r4], acc[mt][4 * r4 + 1], acc[mt][4 * r4 + 2], acc[mt][4 * r4 + 3]};
+            for (int i = 0; i < 16; ++i)
+                acc[nt][mt][i] = 0.0f;
+
+    // ---- the stage pipeline, FOUR deep inside every wavefront, so that no LDS round trip is ever waited for inside an
+    // iteration (a 128-k stage is only 4 MT MFMAs = 128 MT cycles of matrix pipe per wavefront, less than the chain packed
+    // weights -> table address -> look-up -> operand; the first build of this loop decoded stage j + 1 under the MFMAs of stage j
+    // and spent two thirds of every iteration in s_waitcnt lgkmcnt, both wavefronts of a SIMD at the same time):
+    //   iteration i:  the packed weights + scales of stage i leave the LDS (dealt to the lanes at the END of the iteration),
+    //                 the table look-ups of stage i - 1 are issued,
+    //                 the look-ups of stage i - 2 (issued one iteration ago) are multiplied / converted into the B operand,
+    //                 the activation fragments of stage i - 2 are read,
+    //                 the MFMAs of stage i - 3 run.
+    // Operand and look-up registers are replaced IN PLACE as soon as their last reader has been issued.
+    // operands: B fragments [step][tile], A fragments [step][row tile] - one set, replaced in place (a second set was tried:
+    // +60 registers with the two copies of the iteration it needs, spills at MT >= 2, and nothing to gain - see above)
+    constexpr bool DB = false;
+    constexpr int NB = DB ? 2 : 1;
+    u32x4 opb[NB][2][2], opa[NB][2][MT];
+    f32x2 pr[4][4];              // table look-ups in flight, by fragment g = 2 s + nt
+    u32x4 wraw;                  // packed weights of stage i as read
+    u32x2 wt[2];                 // ... of stage i - 1, dealt: dword s of tile nt = step s
+    float sc_new[2], sc_mid[2], sc_fin[2]; // scales of stages i, i - 1, i - 2
+    uint32_t q8[2];
+    float a2[2], c2[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        wt[nt] = u32x2{0u, 0u};
+        sc_new[nt] = sc_mid[nt] = sc_fin[nt] = 0.0f;
+        q8[nt] = 0u;
+        a2[nt] = c2[nt] = 0.0f;
     }
-    __syncthreads();
-    if (q == 0) {
-        const int ncol = col0 + n;
+    wraw = u32x4{0u, 0u, 0u, 0u};
+    auto read_a = [&](int wb, int s, int mt, uint32_t aso) { opa[wb][s][mt] = ps_lds_read<u32x4>(a_rd[s] + aso + mt * 8192); };
+    auto read_w = [&](uint32_t wso, uint32_t sso) {
+        wraw = ps_lds_read<u32x4>(w_rd + wso);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            if constexpr (NESTED) {
+                q8[nt] = ps_lds_read<uint32_t>(s_rd[nt] + sso);
+                a2[nt] = ps_lds_read<float>(s_rd[nt] + sso + 1024);
+            } else {
+                sc_new[nt] = ps_lds_read<float>(s_rd[nt] + sso);
+            }
+        }
+    };
+    auto lut_read = [&](int g) {
+        const uint32_t w = wt[g & 1][g >> 1];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            pr[g][b] = ps_lds_read<f32x2>(__builtin_amdgcn_perm(w, lane_off, perm_sel + (b << 8)));
+    };
+    auto finish = [&](int wb, int g) {
+        const float sc = sc_fin[g & 1];
+        const f32x2 sc2 = {sc, sc};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const f32x2 pv = pr[g][b] * sc2;
+            float p0 = pv[0], p1 = pv[1];
+            if constexpr (!__is_same(T, bf16)) {
+                asm("" : "+v"(p0));
+                asm("" : "+v"(p1));
+            }
+            uint32_t pk = PsMma<T>::pack(p0, p1);
+            // (pinned here: the fragment is consumed one loop iteration later, and left alone the compiler sinks all sixteen
+            // converts of a stage to the loop latch, out of every MFMA's shadow - seen in the ISA of the first build)
+            asm volatile("" : "+v"(pk));
+            opb[wb][g >> 1][g & 1][b] = pk;
+        }
+    };
+
+    // ring slots (scalars): of weight stage i, of activation stage i - 2
+    int wslot = 0, aslot = DA - 2;
+    // FULL = every part of the pipeline is live (3 <= i < ns): no branch inside the iteration, every LDS wait the compiler
+    // emits is a counted one. The first three and the last three iterations run the same code with the parts that have no
+    // stage to work on switched off.
+    auto iteration = [&](auto full, auto parity, int i) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full)::value;
+        constexpr int RB = DB ? decltype(parity)::value : 0, WB = DB ? 1 - decltype(parity)::value : 0; // operand sets read / written
+        if (i == 8 || i == 9)
+            BNB_PS_STAMP(3 + 6 * (i - 8))
+        const bool do_w = FULL || i < ns, do_lut = FULL || (i >= 1 && i <= ns), do_fin = FULL || (i >= 2 && i <= ns + 1),
+                   do_mma = FULL || i >= 3;
+        // own queue: all but the newest D - 2 requested stages have landed (past the end nothing is requested: everything)
+        if (c == 0) {
+            if (i + DW - 2 < ns)
+                ps_wait_vm<(DW - 2) * WI>();
+            else
+                ps_wait_vm<0>();
+        } else {
+            if (i + DA - 4 < ns)
+                ps_wait_vm<(DA - 2) * AI>();
+            else
+                ps_wait_vm<0>();
+        }
+        if (i == 8 || i == 9)
+            BNB_PS_STAMP(4 + 6 * (i - 8))
+        ps_barrier();
+        if (i == 8 || i == 9)
+            BNB_PS_STAMP(5 + 6 * (i - 8))
+        // weight stage i - 1 and activation stage i - 3 have left the LDS (every wavefront, before the barrier): their slots are
+        // requested for stages i - 1 + DW and i - 3 + DA
+        if (c == 0) {
+            if (i - 1 + DW < ns)
+                issue_w(i - 1 + DW, wslot == 0 ? DW - 1 : wslot - 1);
+        } else {
+            const int ja = i - 3 + DA;
+            if (ja >= 0 && ja < ns)
+                issue_a(ja, aslot == 0 ? DA - 1 : aslot - 1);
+        }
+        if (i == 8 || i == 9)
+            BNB_PS_STAMP(6 + 6 * (i - 8))
+        const uint32_t wso = static_cast<uint32_t>(wslot * L::WSB), sso = static_cast<uint32_t>(wslot * L::SSB), aso = static_cast<uint32_t>(aslot * L::ASB);
+        constexpr int NM = 4 * MT;
+#pragma unroll
+        for (int k = 0; k < NM; ++k) {
+            // MFMA list: step s, tile nt, row tile mt: every accumulator is touched once per step
+            const int s = k / (2 * MT), nt = (k / MT) & 1, mt = k % MT;
+            if (do_mma && BNB_PS_ON(8))
+                acc[nt][mt] = PsMma<T>::run(opa[RB][s][mt], opb[RB][s][nt], acc[nt][mt]);
+            if (k == 0 && do_w)
+                read_w(wso, sso);
+            if constexpr (NESTED)
+                if (k == (MT == 1 ? 1 : 2) && do_w) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const uint32_t blk = (s_el[t] + static_cast<uint32_t>(i < ns ? i : ns - 1) * 128u) >> bs_shift;
+                        const uint32_t code8 = __builtin_amdgcn_ubfe(q8[t], 8u * ((blk + q_mis) & 3u), 8u);
+                        c2[t] = ps_lds_read<float>(static_cast<uint32_t>(L::Code2) + code8 * 4u);
+                    }
+                }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (k == ps_frag_slot<MT>(g)) {
+                    if (do_fin && BNB_PS_ON(4))
+                        finish(WB, g);
+                    if (do_lut && BNB_PS_ON(4))
+                        lut_read(g);
+                }
+            if (nt == 1 && do_fin && BNB_PS_ON(16))
+                read_a(WB, s, mt, aso); // (its last MFMA of this stage has just been issued)
+            __builtin_amdgcn_sched_barrier(0);
+            if (k == NM / 2 - 1 && (i == 8 || i == 9))
+                BNB_PS_STAMP(7 + 6 * (i - 8))
+        }
+        // end of the iteration: the packed weights of stage i are dealt to the lanes - lane l < 32 holds bytes 0-15 of column
+        // 64 c + l, lane 32 + l those of column 64 c + 32 + l: the high dwords of the lower half are swapped with the low dwords
+        // of the upper half - and the scales move up
+        {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(wraw[0], wraw[2], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(wraw[1], wraw[3], false, false);
+            wt[0] = u32x2{s0[0], s1[0]};
+            wt[1] = u32x2{s0[1], s1[1]};
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                sc_fin[nt] = sc_mid[nt];
+                if constexpr (NESTED)
+                    sc_mid[nt] = __fadd_rn(__fmul_rn(c2[nt], a2[nt]), offset);
+                else
+                    sc_mid[nt] = sc_new[nt];
+            }
+        }
+        wslot = wslot + 1 == DW ? 0 : wslot + 1;
+        aslot = aslot + 1 == DA ? 0 : aslot + 1;
+        if (i == 8 || i == 9)
+            BNB_PS_STAMP(8 + 6 * (i - 8))
+    };
+    {
+        // (the operand set alternates with i: two copies of the iteration, selected by a uniform branch)
+        auto step = [&](auto full, int i) __attribute__((always_inline)) {
+            if (DB && (i & 1))
+                iteration(full, std::integral_constant<int, 1>{}, i);
+            else
+                iteration(full, std::integral_constant<int, 0>{}, i);
+        };
+        int i = 0;
+        for (; i < 3; ++i)
+            step(std::false_type{}, i);
+        for (; i < ns; ++i)
+            step(std::true_type{}, i);
+        for (; i < ns + 3; ++i)
+            step(std::false_type{}, i);
+    }
+    BNB_PS_STAMP(15)
+
+    // ---- the four K quarters of a column group, added in a fixed order (q = 0, 1, 2, 3). The wavefront's 32 MT accumulator
+    // registers are cut into four sets of 8 MT; wavefront (c, o) owns set o: it receives that set from the other three
+    // quarters through the LDS (everything the loop used is dead: outstanding DMA of past-the-end stages is drained first),
+    // adds in the order q = 0..3 and stores. Area: [round owner][c][3 sources][2 MT chunks of 16 B][64 lanes].
+    ps_wait_vm<0>();
+    ps_barrier();
+    constexpr int RS = 8 * MT;     // registers of a set
+    constexpr int CH = RS / 4;     // 16-byte chunks of a set per lane
+    constexpr int OPR = 4 / L::Rounds; // owners served per round
+    // (the lane's two output columns and their bias: once, not per element)
+    bool col_ok[2];
+    float bv[2];
+    {
         const T* const bias = static_cast<const T*>(p.bias);
-        const float bv = (bias && hot_kslices == 1 && ncol < N) ? static_cast<float>(bias[ncol]) : 0.0f;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            f32x4 o[4];
+        for (int nt = 0; nt < 2; ++nt) {
+            const int ncol = col0 + 64 * c + 32 * nt + n;
+            col_ok[nt] = ncol < N;
+            bv[nt] = (bias && hot_kslices == 1 && col_ok[nt]) ? static_cast<float>(bias[ncol]) : 0.0f;
+        }
+    }
+    const long out_lane = static_cast<long>(m_base + 4 * h) * N + col0 + 64 * c + n;
+    float* const ws_slab = p.ws + static_cast<long>(blockIdx.y) * M * N;
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4)
-                o[r4] = *reinterpret_cast<const f32x4*>(red + (mt * 4 + r4) * 1024);
+    for (int round = 0; round < L::Rounds; ++round) {
+        // write the sets of this round's owners
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float v = acc[mt][i] + o[i >> 2][i & 3];
-                // 32x32 accumulator layout: register i of lane (n, h) = row (i & 3) + 8 (i >> 2) + 4 h, column n
-                const int m = m_base + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (m < M && ncol < N) {
-                    const long o2 = static_cast<long>(m) * N + ncol;
-                    if (hot_kslices == 1)
-                        static_cast<T*>(p.out)[o2] = static_cast<T>(v + bv);
-                    else
-                        p.ws[static_cast<long>(blockIdx.y) * M * N + o2] = v;
+        for (int oi = 0; oi < OPR; ++oi) {
+            const int o = round * OPR + oi;
+            if (q != o) {
+                const int src = q < o ? q : q - 1;
+                unsigned char* const dst = smem + ((((oi * 2 + c) * 3 + src) * CH) * 64 + lane) * 16;
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) {
+                    f32x4 v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int f = o * RS + ch * 4 + k; // flat register: tile (f / 16) = nt * MT + mt, register f % 16
+                        v[k] = acc[(f / 16) / MT][(f / 16) % MT][f % 16];
+                    }
+                    *reinterpret_cast<f32x4*>(dst + ch * 1024) = v;
                 }
             }
         }
+        __syncthreads();
+#pragma unroll
+        for (int oi = 0; oi < OPR; ++oi) {
+            const int o = round * OPR + oi;
+            if (q == o) {
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) {
+                    f32x4 x[3];
+#pragma unroll
+                    for (int src = 0; src < 3; ++src)
+                        x[src] = *reinterpret_cast<const f32x4*>(smem + ((((oi * 2 + c) * 3 + src) * CH + ch) * 64 + lane) * 16);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int f = o * RS + ch * 4 + k;
+                        const int nt = (f / 16) / MT, mt = (f / 16) % MT, i = f % 16;
+                        const float own = acc[nt][mt][i];
+                        // canonical order q = 0, 1, 2, 3 with the owner's value at position o
+                        float v = o == 0 ? own : x[0][k];
+#pragma unroll
+                        for (int qq = 1; qq < 4; ++qq)
+                            v += qq == o ? own : x[qq < o ? qq : qq - 1][k];
+                        // 32x32 accumulator layout: register i of lane (n, h) = row (i & 3) + 8 (i >> 2) + 4 h, column n
+                        const int mrel = 32 * mt + (i & 3) + 8 * (i >> 2);
+                        if (m_base + 4 * h + mrel < M && col_ok[nt]) {
+                            const long o2 = out_lane + static_cast<long>(mrel) * N + 32 * nt;
+                            if (hot_kslices == 1)
+                                static_cast<T*>(p.out)[o2] = static_cast<T>(v + bv[nt]);
+                            else
+                                ws_slab[o2] = v;
+                        }
+                    }
+                }
+            }
+        }
+        if (round + 1 < L::Rounds)
+            __syncthreads();
     }
-    BNB_PS_STAMP(14)
+    BNB_PS_STAMP(2)
 }
 
 struct PsPlan {
@@ -507,17 +633,20 @@ struct PsPlan {
 };
 
 // Row tiles, K slices and stages per slice: a pure function of (M, N, K) and the forced slice count, shared by the launch
-// and the workspace-size query. One workgroup per CU (145 KiB of LDS): K slices fill the chip without spilling into a second
-// round of workgroups; every slice keeps at least two stages so the ring has something to overlap.
+// and the workspace-size query. One workgroup per CU (~150 KiB of LDS): K slices fill the chip without spilling into a second
+// round of workgroups; every slice keeps at least four stages so the rings have something to overlap.
 PsPlan ps_plan(int M, int N, int K, int force_ks) {
     PsPlan pl;
-    pl.mt = M > 32 ? 2 : 1;
+    // (a one-row-tile instance existed and was dropped: it was never faster than the register-transposed kernel, which serves
+    // those batches, and its nested-absmax variant gave run-to-run different results on idle chips for a reason that was not
+    // found - DESIGN.md 6b)
+    pl.mt = M > 64 ? 4 : 2;
     const int stages = K / kPsStageK;
     const int gx = (N + kPsCols - 1) / kPsCols;
     const int gz = (M + 32 * pl.mt - 1) / (32 * pl.mt);
     const int cus = device_cu_count_or_default();
     int ks = force_ks > 0 ? force_ks : cus / (gx * gz);
-    const int max_ks = stages / 2 > 0 ? stages / 2 : 1;
+    const int max_ks = stages / 4 > 0 ? stages / 4 : 1;
     ks = ks > max_ks ? max_ks : ks;
     ks = ks < 1 ? 1 : ks;
     pl.sps = (stages + ks - 1) / ks;
@@ -525,40 +654,39 @@ PsPlan ps_plan(int M, int N, int K, int force_ks) {
     return pl;
 }
 
-template <typename T, int MT, bool NESTED, int D>
+template <typename T, int MT, bool NESTED>
 void ps_launch_one(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
                    const PsPlan& pl, const PsArgs& a, hipStream_t stream) {
     dim3 grid((N + kPsCols - 1) / kPsCols, pl.ks, (M + 32 * MT - 1) / (32 * MT));
-    auto kern = gemm4_mfma_ps_kernel<T, MT, NESTED, D>;
+    auto kern = gemm4_mfma_ps_kernel<T, MT, NESTED>;
     static LdsLimit lim;
-    ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), kPsLdsBytes);
-    hipLaunchKernelGGL(kern, grid, dim3(kPsWaves * 64), kPsLdsBytes, stream, A, B, absmax, absmax8, M, N, K, flags, pl.sps, pl.ks, a);
+    constexpr int lds = PsLds<MT, NESTED>::Bytes > PsLds<MT, NESTED>::RedBytes ? PsLds<MT, NESTED>::Bytes : PsLds<MT, NESTED>::RedBytes;
+    ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
+    hipLaunchKernelGGL(kern, grid, dim3(kPsWaves * 64), lds, stream, A, B, absmax, absmax8, M, N, K, flags, pl.sps, pl.ks, a);
 }
 
-// D = 3 leaves the two-row-tile instances 8-12 registers short (a spill's reload waits with vmcnt(0) and drains the ring):
-// they always run with two ring slots.
-template <typename T, int D>
+template <typename T>
 void ps_launch(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
                const PsPlan& pl, const PsArgs& a, hipStream_t stream) {
     if (absmax8 != nullptr) {
-        if (pl.mt == 1)
-            ps_launch_one<T, 1, true, D>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+        if (pl.mt == 2)
+            ps_launch_one<T, 2, true>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
         else
-            ps_launch_one<T, 2, true, 2>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+            ps_launch_one<T, 4, true>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
     } else {
-        if (pl.mt == 1)
-            ps_launch_one<T, 1, false, D>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+        if (pl.mt == 2)
+            ps_launch_one<T, 2, false>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
         else
-            ps_launch_one<T, 2, false, 2>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+            ps_launch_one<T, 4, false>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
     }
 }
 
 } // namespace
 
-// Preconditions: 16-bit activations, literal code tables, K a multiple of 256, blocksize >= 64 (a lane's 64 k of a chunk
+// Preconditions: 16-bit activations, literal code tables, K a multiple of 128, blocksize >= 64 (the 32 k of a K quarter
 // stay inside one quantization block), 16-byte aligned A and B.
 bool gemm_4bit_ps_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize) {
-    // (byte offsets of the buffer loads are 32-bit and must stay below 2^31)
+    // (element indices and byte offsets of the buffer loads are 32-bit)
     const long long nk = static_cast<long long>(N) * K, mk = static_cast<long long>(M) * K;
     return (dtype == 1 || dtype == 2) && code16 == nullptr && M >= 1 && N >= 1 && K >= kPsStageK && (K % kPsStageK) == 0 &&
            blocksize >= 64 && is_pow2(blocksize) && aligned_to(A, 16) && aligned_to(B, 16) && nk < (1LL << 31) && mk < (1LL << 30);
@@ -571,12 +699,12 @@ size_t gemm_4bit_ps_workspace_bytes(int M, int N, int K, int force_ks) {
     return pl.ks > 1 ? static_cast<size_t>(pl.ks) * M * N * sizeof(float) : 0;
 }
 
-// dtype: 1 = f16, 2 = bf16. force_ks (0 = built-in choice), variant (0 = two ring slots, 1 = three where they fit): sweeps
-// and tests.
+// dtype: 1 = f16, 2 = bf16. force_ks (0 = built-in choice): sweeps and tests.
 void gemm_4bit_ps(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int variant,
                   int ablate, hipStream_t stream) {
+    (void)variant;
     PsPlan pl = ps_plan(M, N, K, force_ks);
     float* ws = static_cast<float*>(workspace);
     const size_t slab = static_cast<size_t>(M) * N * sizeof(float);
@@ -604,21 +732,14 @@ void gemm_4bit_ps(int dtype, const void* A, const uint8_t* B, const float* absma
     a.ws = ws;
     int flags = ilog2(blocksize) | ((quant_type == kFP4) ? 256 : 0);
 #ifdef BNB_PROFILING
-    flags |= (ablate & 7) << 16;
+    flags |= (ablate & 0xFF) << 16;
 #else
     (void)ablate;
 #endif
-    if (dtype == 2) {
-        if (variant == 1)
-            ps_launch<bf16, 3>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
-        else
-            ps_launch<bf16, 2>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
-    } else {
-        if (variant == 1)
-            ps_launch<f16, 3>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
-        else
-            ps_launch<f16, 2>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
-    }
+    if (dtype == 2)
+        ps_launch<bf16>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+    else
+        ps_launch<f16>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
     BNB_CHECK_LAUNCH();
     if (pl.ks > 1)
         gemm_4bit_finalize(dtype, ws, bias, out, M, N, pl.ks, stream);
