@@ -208,6 +208,76 @@ def rocprof_kernel_stats(extra_args, profile_out=None, timeout_s=180):
         shutil.rmtree(out_dir, ignore_errors=True)
 
 
+PROF_LIB = os.path.join(ROOT, "bitsandbytes_amd", "libbitsandbytes_mi355x_prof.so")
+
+
+def kernel_span_child(M, N, K, bs, qt, layers_n=LAYERS, replays=20):
+    """(child process, measurement build of the library) The dominant kernel's own span per launch: every wavefront records
+    s_memrealtime (100 MHz constant clock) at its first instruction and after its last store; span of a launch = last end -
+    first start over all wavefronts. Same workload as the timed region: hipGraph replays of the dependent one-launch-per-layer
+    step; every launch of the graph writes its own stamp region (the buffer address is baked into the node at capture)."""
+    import torch
+
+    import bitsandbytes_amd as bnb
+    from bitsandbytes_amd.cextension import LIB_PATH
+
+    assert os.path.samefile(str(LIB_PATH), PROF_LIB), LIB_PATH
+    device = torch.device("cuda:0")
+    layers = build_layers(device, layers_n, N, K, M, bs, qt, seed=0)
+    x = torch.randn(M, K, device=device).to(torch.bfloat16)
+    region = 256 * 16 * 16                       # u64 words per launch: workgroups x wavefronts x 16 stamps
+    buf = torch.zeros(layers_n * region, dtype=torch.int64, device=device)
+
+    def step_fn():
+        for i, (q, st) in enumerate(layers):
+            bnb.lib.bnb_mi355x_set_stamp_buffer((buf.data_ptr() + 8 * i * region) | 1)   # bit 0: the two span stamps only
+            bnb.matmul_4bit(x, q, st)
+        bnb.lib.bnb_mi355x_set_stamp_buffer(None)
+
+    for _ in range(2):
+        step_fn()
+    torch.cuda.synchronize()
+    g = capture(step_fn)
+    spans = []
+    for _ in range(replays):
+        buf.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        t = buf.view(layers_n, 256 * 16, 16)
+        start, end = t[:, :, 13], t[:, :, 14]
+        used = start > 0
+        big = torch.full_like(start, 2**62)
+        first = torch.where(used, start, big).min(dim=1).values
+        last = torch.where(used, end, torch.zeros_like(end)).max(dim=1).values
+        spans.append((last - first).double().cpu() * 0.01)                             # 100 MHz ticks -> us
+    sp = torch.stack(spans)[2:]                                                          # drop two warm-up replays
+    out = {"kernel_span_us": round(float(sp.mean()), 4), "p50": round(float(sp.median()), 3), "min": round(float(sp.min()), 2),
+           "max": round(float(sp.max()), 2), "launches": int(sp.numel()), "wavefronts_per_launch": int(used[0].sum()),
+           "clock": "s_memrealtime, 100 MHz (10 ns per tick; the mean over thousands of launches resolves finer)"}
+    print("SPAN_JSON " + json.dumps(out), flush=True)
+
+
+def kernel_span(extra_args, span_out=None, timeout_s=240):
+    """Run the span child under the measurement build; None when that library is not there."""
+    if not os.path.exists(PROF_LIB):
+        return None, {"error": "libbitsandbytes_mi355x_prof.so not built (make -C bitsandbytes_amd/csrc profiling)"}
+    env = _child_env()
+    env["BNB_MI355X_LIBRARY"] = PROF_LIB
+    cmd = [sys.executable, os.path.abspath(__file__), "--span-child", "--no-cpu-baseline", "--no-pmc", "--no-rocprof", "--no-sweep"] + list(extra_args)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return None, {"error": "span child timed out"}
+    for ln in r.stdout.splitlines():
+        if ln.startswith("SPAN_JSON "):
+            d = json.loads(ln[len("SPAN_JSON "):])
+            if span_out:
+                with open(span_out, "w") as fh:
+                    json.dump({"command": " ".join(cmd[1:]), **d}, fh, indent=1)
+            return d["kernel_span_us"], d
+    return None, {"error": "no span line", "stderr": r.stderr[-400:]}
+
+
 def pmc_traffic(extra_args, timeout_s=180):
     """HBM bytes per launch of the dominant kernel from rocprofv3 PMC counters, collected the way
     /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE
@@ -272,9 +342,15 @@ def main():
     ap.add_argument("--sharded-path", action="store_true",
                     help="run the multi-GPU code path (ShardedLinear4bit shards, bucketed RCCL all-gather, per-layer "
                          "gather) even at world size 1: how that path is exercised on a 1-GPU box")
+    ap.add_argument("--no-span", action="store_true", help="skip the kernel-span leg (roofline then falls back to the rocprofv3 average)")
+    ap.add_argument("--span-out", default=None, help="write the kernel-span measurement here (e.g. profiles/r3_bench_kernel_span.json)")
+    ap.add_argument("--span-child", action="store_true", help=argparse.SUPPRESS)  # span measurement under the measurement build
     ap.add_argument("--prof-child", action="store_true", help=argparse.SUPPRESS)  # workload run under rocprofv3
     ap.add_argument("--prof-eager", action="store_true", help=argparse.SUPPRESS)  # ... enqueued eagerly (PMC passes serialise dispatches)
     args = ap.parse_args()
+    if args.span_child:
+        kernel_span_child(args.m, args.n, args.k, args.blocksize, args.quant_type)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -448,7 +524,19 @@ def main():
         avg_ns, kt_detail = (None, {"skipped": "--no-rocprof or multi-GPU run"})
         if not multi and not args.no_rocprof:
             avg_ns, kt_detail = rocprof_kernel_stats(extra, args.profile_out)
-        if avg_ns is not None:
+        span_us, span_detail = (None, {"skipped": "--no-span or multi-GPU run"})
+        if not multi and not args.no_span:
+            span_us, span_detail = kernel_span(extra, args.span_out)
+        if span_us is not None:
+            # the kernel's own span: first wavefront in -> last wavefront out, in-kernel clock, NON-serialised replay of the same
+            # graph: 128 x kernel_us fits inside the driver-timed step (the rest of the step is the launch boundary between
+            # dependent kernels); the rocprofv3 average - which carries the profiler's per-dispatch serialisation - is kept
+            # beside it as a cross-check
+            kernel_us = span_us
+            method = ("mean span of the dominant kernel, first wavefront's first instruction to last wavefront's end, from in-kernel "
+                      f"s_memrealtime stamps (measurement build of the library, child process) over hipGraph replays of the {LAYERS}-layer "
+                      "step; kernel_us_rocprof_stats = average duration from `rocprofv3 --kernel-trace --stats` over the same workload")
+        elif avg_ns is not None:
             kernel_us = avg_ns / 1e3
             method = ("average kernel duration of the dominant kernel from `rocprofv3 --kernel-trace --stats` over the same workload "
                       f"(hipGraph replays of the {LAYERS}-layer step; child process)")
@@ -493,6 +581,9 @@ def main():
                 "traffic": None,
                 "kernel_us": round(kernel_us, 3),
                 "kernel_us_launch_to_launch_events": round(kernel_us_events, 3),
+                "kernel_us_rocprof_stats": None if avg_ns is None else round(avg_ns / 1e3, 3),
+                "kernel_span": span_detail,
+                "fits_in_step": bool(kernel_us * LAYERS <= elapsed / args.steps * 1e6),
                 "method": method,
                 "kernel_trace": kt_detail,
             },

@@ -28,8 +28,13 @@ _DT_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 _QT_CODE = {"fp4": 1, "nf4": 2}
 
 # Largest M routed to the fused kernels; above it one dequantize + hipBLASLt GEMM moves fewer bytes
-# per FLOP than re-streaming the packed weight per 64-row slab. Calibrated on MI355X.
-FUSED_MAX_M = 128
+# per FLOP than re-streaming the packed weight per 64-row slab. Calibrated on MI355X (profiles/r3_tall_batch_ab.txt,
+# us per launch, fused vs dequantize + hipBLASLt): 4096^2 M = 256 / 512 23 / 29 vs 30 / 37; 8192^2 M = 256 53 vs 92 but
+# M = 512 104 vs 94; 11008 x 4096 M = 256 52 vs 61, M = 512 80 vs 69. So: 256 rows everywhere, 512 on matrices of up to
+# FUSED_SMALL_WEIGHTS weights (one dequantize pass over a small matrix is cheap, but so is re-streaming it).
+FUSED_MAX_M = 256
+FUSED_MAX_M_SMALL = 512
+FUSED_SMALL_WEIGHTS = 20 << 20
 _REFERENCE_CUSTOM_MAX_M = 256  # reference backends/cuda/ops.py:816 (_gemm_4bit_custom_max_m on ROCm)
 
 
@@ -263,7 +268,12 @@ def _gemm_4bit_route(dtype: torch.dtype, M: int, N: int, K: int, blocksize: int)
         # fp32 activations: the streaming kernel (fp32 FMA decode, same code path as bf16/fp16) for decode-sized batches;
         # no fp32 MFMA path worth having above that (1/16 of the bf16 matrix rate)
         return "fused" if M <= 4 else "unfused"
-    return "fused" if M <= FUSED_MAX_M else "unfused"
+    return "fused" if M <= fused_max_m(N, K) else "unfused"
+
+
+def fused_max_m(N: int, K: int) -> int:
+    """Largest batch (rows of A) the fused 16-bit kernels serve for an N x K weight."""
+    return FUSED_MAX_M_SMALL if N * K <= FUSED_SMALL_WEIGHTS else FUSED_MAX_M
 
 
 def _gemm_4bit_fused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8bit, absmax_code, absmax_offset,
@@ -467,7 +477,12 @@ def _load_native_dispatch() -> bool:
         warn(f"{path.name} is not built (make -C bitsandbytes_amd/csrc): gemm_4bit is dispatched through the slower Python glue",
              RuntimeWarning)
         return False
-    torch.ops.load_library(str(path))
+    try:
+        torch.ops.load_library(str(path))
+    except (OSError, RuntimeError) as exc:
+        # built against another torch / C++ ABI, missing libpython symbols ...: the Python glue does the same work
+        warn(f"{path.name} could not be loaded ({exc}): gemm_4bit is dispatched through the slower Python glue", RuntimeWarning)
+        return False
     return True
 
 
@@ -476,4 +491,4 @@ if not NATIVE_DISPATCH:
     register_kernel("bitsandbytes::gemm_4bit", "cuda")(_gemm_4bit_python_kernel)
 
 
-__all__ = ["FUSED_MAX_M", "NATIVE_DISPATCH", "gemm_4bit_grouped", "prod"]
+__all__ = ["FUSED_MAX_M", "NATIVE_DISPATCH", "fused_max_m", "gemm_4bit_grouped", "prod"]

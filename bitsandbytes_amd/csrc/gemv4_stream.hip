@@ -73,13 +73,17 @@ struct StreamMat {
     int row_start;    // first row of this matrix in the concatenated row space
 };
 
-// Profiling builds (-DBNB_PROFILING, libbitsandbytes_mi355x_prof.so, tools/ only): per-wavefront s_memtime stamps.
+// Profiling builds (-DBNB_PROFILING, libbitsandbytes_mi355x_prof.so, tools/ and bench.py's span leg only): per-wavefront
+// s_memtime stamps. A stamp buffer address with bit 0 set asks for the two s_memrealtime stamps (slots 13 / 14: first
+// instruction and end of every wavefront, 100 MHz constant clock) ONLY: the kernel's own span, first wavefront in to last
+// wavefront out, without the cost of the sixteen phase stamps.
 #ifdef BNB_PROFILING
 #define BNB_ST_STAMP(i)                                                                            \
     {                                                                                              \
-        if (p.dbg && lane == 0)                                                                    \
+        if (p.dbg && !(reinterpret_cast<uintptr_t>(p.dbg) & 1) && lane == 0)                       \
             p.dbg[(static_cast<long>(blockIdx.x) * WAVES + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
     }
+#define BNB_ST_DBG_BASE (reinterpret_cast<unsigned long long*>(reinterpret_cast<uintptr_t>(p.dbg) & ~static_cast<uintptr_t>(7)))
 #else
 #define BNB_ST_STAMP(i) {}
 #endif
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     const int sw = wave - g * SW;
 #ifdef BNB_PROFILING
     if (p.dbg && lane == 0)
-        p.dbg[(static_cast<long>(blockIdx.x) * WAVES + wave) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+        BNB_ST_DBG_BASE[(static_cast<long>(blockIdx.x) * WAVES + wave) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
 #endif
     BNB_ST_STAMP(0)
 
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         if (ph == 0)
             BNB_ST_STAMP(4)
 #ifdef BNB_PROFILING
-        if (ph == 0 && p.dbg) {
+        if (ph == 0 && p.dbg && !(reinterpret_cast<uintptr_t>(p.dbg) & 1)) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS * LPS - 1) : "memory");
             BNB_ST_STAMP(15)
         }
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     BNB_ST_STAMP(8)
 #ifdef BNB_PROFILING
     if (p.dbg && lane == 0)
-        p.dbg[(static_cast<long>(blockIdx.x) * WAVES + wave) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+        BNB_ST_DBG_BASE[(static_cast<long>(blockIdx.x) * WAVES + wave) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 

@@ -40,3 +40,16 @@ for root, dirs, files in os.walk(src):
             n += 1
 print(f"build_ref: byte-compiled {n} reference modules into {os.path.dirname(dst)}", file=sys.stderr)
 PY
+
+# The reference's own TEST files, byte-compiled the same way (sourceless .pyc, nothing copied) into oracle/_ref/ref_tests/:
+# tests/test_gpu_reference_suite.py runs them on the GPU box against this repository's HIP kernels.
+python3 - "$REF/tests" "$OUT/ref_tests" <<'PY'
+import os, py_compile, shutil, sys
+src, dst = sys.argv[1], sys.argv[2]
+shutil.rmtree(dst, ignore_errors=True)
+os.makedirs(dst)
+names = ["__init__", "conftest", "helpers", "test_ops", "test_functional", "test_autograd", "test_linear4bit", "test_parametrize", "test_modules"]
+for n in names:
+    py_compile.compile(os.path.join(src, n + ".py"), cfile=os.path.join(dst, n + ".pyc"), dfile=os.path.join("tests", n + ".py"), doraise=True)
+print(f"build_ref: byte-compiled {len(names)} reference test modules into {dst}", file=sys.stderr)
+PY

@@ -232,11 +232,15 @@ def test_native_dispatch_routing_constants_match_python():
         return int(m.group(1))
 
     assert const("kFusedMaxM") == hip.FUSED_MAX_M
+    assert const("kFusedMaxMSmall") == hip.FUSED_MAX_M_SMALL
+    assert const("kFusedSmallWeights") == hip.FUSED_SMALL_WEIGHTS
     assert const("kReferenceCustomMaxM") == hip._REFERENCE_CUSTOM_MAX_M
     # fp32 activations: fused up to 4 rows in both
     assert const("kFusedMaxMFp32") == 4
     import torch
 
     assert hip._gemm_4bit_route(torch.float32, 4, 64, 64, 64) == "fused" and hip._gemm_4bit_route(torch.float32, 5, 64, 64, 64) == "unfused"
-    assert hip._gemm_4bit_route(torch.bfloat16, hip.FUSED_MAX_M, 64, 64, 64) == "fused"
-    assert hip._gemm_4bit_route(torch.bfloat16, hip.FUSED_MAX_M + 1, 64, 64, 64) == "unfused"
+    assert hip._gemm_4bit_route(torch.bfloat16, hip.FUSED_MAX_M_SMALL, 64, 64, 64) == "fused"
+    assert hip._gemm_4bit_route(torch.bfloat16, hip.FUSED_MAX_M_SMALL + 1, 64, 64, 64) == "unfused"
+    assert hip._gemm_4bit_route(torch.bfloat16, hip.FUSED_MAX_M, 8192, 8192, 64) == "fused"
+    assert hip._gemm_4bit_route(torch.bfloat16, hip.FUSED_MAX_M + 1, 8192, 8192, 64) == "unfused"

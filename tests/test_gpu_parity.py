@@ -543,6 +543,7 @@ SHAPES = [  # (M, N, K)
     (1, 1000, 2048), (1, 31, 96), (1, 512, 11008 // 4), (2, 256, 4096), (3, 130, 1024), (4, 4096, 1024),
     (5, 256, 1024), (8, 4096, 4096), (16, 512, 2048), (17, 96, 512), (33, 200, 768), (64, 1024, 4096),
     (65, 128, 512), (130, 64, 256),
+    (200, 384, 1024), (256, 1024, 2048), (300, 130, 768), (512, 512, 1024),   # tall batches: several row passes of the MFMA kernels
 ]
 
 
@@ -558,6 +559,8 @@ def test_gemm_4bit_shapes_both_kernels(M, N, K, dtype):
     for kernel in (1, 2, 0):
         if kernel == 2 and K % 256:
             continue
+        if kernel == 1 and M > 130:
+            continue  # (the streaming kernel is exact at any M, and slow there: covered up to 130 rows)
         y = _run_kernel(kernel, x.to(DEV), q, st, bias.to(DEV))
         e = rel_err(y.cpu(), y_ref)
         assert e < REL_TOL, f"kernel={kernel} rel err {e}"
@@ -1259,7 +1262,8 @@ def test_native_dispatch_matches_python_kernel():
         ((64,), 512, 2048, 64, "nf4", False, torch.bfloat16, False),
         ((3,), 256, 1024, 64, "nf4", False, torch.float32, True),
         ((8,), 256, 1024, 64, "fp4", False, torch.float32, False),       # fp32 above 4 rows: unfused
-        ((200,), 256, 1024, 64, "nf4", True, torch.bfloat16, True),      # above FUSED_MAX_M: unfused
+        ((200,), 256, 1024, 64, "nf4", True, torch.bfloat16, True),      # tall batch on the fused kernels (several row passes)
+        ((600,), 256, 1024, 64, "nf4", True, torch.bfloat16, True),      # above FUSED_MAX_M_SMALL: unfused
         ((5,), 64, 96, 64, "nf4", False, torch.bfloat16, True),          # K % blocksize != 0: warning + unfused
     ]:
         W = (torch.randn(N, K, device=DEV) / K**0.5).to(dtype)

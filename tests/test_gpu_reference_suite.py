@@ -1,0 +1,65 @@
+"""GPU: the REFERENCE's own test files - tests/test_ops.py, test_functional.py, test_autograd.py, test_linear4bit.py,
+test_parametrize.py, test_modules.py, byte-compiled unmodified by oracle/build_ref.sh into oracle/_ref/ref_tests - executed with
+BNB_TEST_DEVICE=cuda against this package: ``import bitsandbytes`` resolves to ``bitsandbytes_amd`` (tests/_reference_suite_shim.py)
+and every device tensor goes through the HIP kernels of libbitsandbytes_mi355x.so. This is the reference maintainers' own
+statement of what the 4-bit path must do on an accelerator: op schemas and opcheck (test_ops.py:137-375), the quantize /
+dequantize error envelopes and the gemv accuracy envelope (test_functional.py:575-1034), matmul_4bit forward / backward
+(test_autograd.py:143-232), Linear4bit incl. serialization and torch.compile with the default (inductor) backend
+(test_linear4bit.py:359-449).
+
+Pass / fail / skip counts per selection are written to gpurun_out/reference_suite_gpu.txt (copied to profiles/ by hand)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT, gpu_ready
+
+COMPILED = os.path.join(ROOT, "oracle", "_ref", "ref_tests")
+
+# (file, -k expression, minimum number of tests that must pass)
+SELECTIONS = [
+    ("tests/test_ops.py", "4bit", 200),
+    ("tests/test_functional.py", "4bit and not bench", 300),
+    ("tests/test_functional.py", "Test8BitBlockwiseQuantizeFunctional and not bench", 8),
+    ("tests/test_autograd.py", "matmul_4bit", 40),
+    ("tests/test_linear4bit.py", "not fsdp", 200),
+    ("tests/test_parametrize.py", "", 80),
+    ("tests/test_modules.py", "(embedding or 4bit or NF4 or FP4) and not 8bit and not Int8 and not int8", 20),
+]
+
+
+@pytest.fixture(scope="module")
+def shim_root():
+    import _reference_suite_shim
+
+    return _reference_suite_shim.build_from_compiled(COMPILED)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(COMPILED), reason="oracle/_ref/ref_tests (the byte-compiled reference tests, built by "
+                    "oracle/build_ref.sh where /root/reference exists) is not in this tree")
+@pytest.mark.parametrize("path,expr,min_passed", SELECTIONS, ids=[f"{s[0].split('/')[-1]}[{s[1] or 'all'}]" for s in SELECTIONS])
+def test_reference_test_file_passes_on_the_hip_device(shim_root, path, expr, min_passed):
+    if not gpu_ready():
+        pytest.skip("no GPU")
+    env = dict(os.environ, BNB_TEST_DEVICE="cuda", PYTHONPATH=shim_root, PYTHONDONTWRITEBYTECODE="1")
+    cmd = [sys.executable, "-m", "pytest", path, "-q", "-p", "no:cacheprovider", "--maxfail=25", "-x" if os.environ.get("BNB_REF_X") else "-rf"]
+    if expr:
+        cmd += ["-k", expr]
+    proc = subprocess.run(cmd, cwd=shim_root, env=env, capture_output=True, text=True, timeout=3000)
+    lines = proc.stdout.strip().splitlines()
+    summary = lines[-1] if lines else "(no output)"
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "reference_suite_gpu.txt"), "a") as fh:
+        fh.write(f"{path} -k '{expr}' (BNB_TEST_DEVICE=cuda, bitsandbytes -> bitsandbytes_amd): {summary}\n")
+        for ln in lines:
+            if ln.startswith("FAILED"):
+                fh.write("    " + ln + "\n")
+    tail = "\n".join(lines[-40:])
+    assert proc.returncode == 0, f"{path} -k '{expr}' failed:\n{tail}\n{proc.stderr[-1500:]}"
+    m = re.search(r"(\d+) passed", summary)
+    assert m and int(m.group(1)) >= min_passed, summary

@@ -50,7 +50,7 @@ def main():
     if args.tall:
         variants = [("auto", 0, 0), ("ps", 2, 3000), ("pc11", 2, 1100), ("unfused", -1, 0)]
         Ms = (128, 256, 512, 1024, 2048)
-        shapes = [(4096, 4096, False), (8192, 8192, False), (11008, 4096, False)]
+        shapes = [(4096, 4096, False), (8192, 8192, False), (11008, 4096, False), (4096, 11008, False), (28672, 8192, False)]
     elif args.slices:
         variants = [("ps", 2, 3000)] + [(f"ps ks{k}", 2, 3000 + k) for k in (1, 2, 3, 4, 6, 8, 16)]
         Ms = (16, 32, 64, 128)
@@ -70,7 +70,7 @@ def main():
                 if kernel < 0:
                     row.append(unfused(layers, x))
                     continue
-                if name == "auto" and M > hip.FUSED_MAX_M:
+                if name == "auto" and M > hip.fused_max_m(N, K):
                     row.append(float("nan"))
                     continue
                 row.append(timed(layers, x, kernel, knob1))
