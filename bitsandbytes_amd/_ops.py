@@ -19,8 +19,32 @@ _VALID_BLOCKSIZES_4BIT = (32, 64, 128, 256, 512, 1024, 2048, 4096)
 _FLOAT_DTYPES = (torch.float16, torch.bfloat16, torch.float32)
 _STORAGE_DTYPES = (torch.uint8, torch.bfloat16, torch.float16, torch.float32)
 
-register_kernel = torch.library.register_kernel
 register_fake = torch.library.register_fake
+_OVERRIDE_LIB = None
+
+
+def register_kernel(op: str, device_types: str, func=None):
+    """torch.library.register_kernel, except that a kernel somebody else (the reference package's own backends/cuda/ops.py,
+    when this package is loaded through the reference's plug-in point on a box where the reference brought a ROCm build)
+    registered first for the same dispatch key is REPLACED instead of raising."""
+
+    def deco(fn):
+        global _OVERRIDE_LIB
+        try:
+            torch.library.register_kernel(op, device_types, fn)
+        except RuntimeError as exc:
+            if "already" not in str(exc):
+                raise
+            ns, name = op.split("::")
+            if _OVERRIDE_LIB is None:
+                _OVERRIDE_LIB = {}
+            if ns not in _OVERRIDE_LIB:
+                _OVERRIDE_LIB[ns] = torch.library.Library(ns, "IMPL")
+            key = {"cuda": "CUDA", "cpu": "CPU"}[device_types]
+            _OVERRIDE_LIB[ns].impl(name, fn, key, allow_override=True)
+        return fn
+
+    return deco(func) if func is not None else deco
 
 
 def _op_exists(name: str) -> bool:

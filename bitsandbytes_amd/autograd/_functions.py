@@ -2,7 +2,8 @@
 
 Forward is one ``bitsandbytes::gemm_4bit`` op call for every M (the op's MI355X kernel picks the
 streaming dot kernel or an MFMA kernel); backward is ``grad_A = grad_out @ dequantize_4bit(B)`` - fused into one
-launch on the HIP device for batches up to 256 rows (``bitsandbytes_amd::gemm_4bit_grad_input``).
+launch on the HIP device for batches up to 128 rows (``bitsandbytes_amd::gemm_4bit_grad_input``,
+``backends/hip.py: FUSED_BACKWARD_MAX_M``).
 Double-quantised states pass their pieces straight into the op so the absmax reconstruction is
 fused into the GEMM kernel.
 """
@@ -49,6 +50,9 @@ def _grad_input_from_state(grad_output: torch.Tensor, B: torch.Tensor, state: F.
         and len(state.shape) == 2
         and grad_output.shape[-1] == state.shape[0]
         and (not state.nested or state.state2.blocksize == 256)
+        # double backward (create_graph=True: gradient penalties, Hessian-vector products): the fused op has no autograd formula
+        # of its own; dequantize + matmul - the reference's formulation - is differentiable in grad_output
+        and not (torch.is_grad_enabled() and grad_output.requires_grad)
     )
     if not fused:
         return torch.matmul(grad_output, F.dequantize_4bit(B, state).to(grad_output.dtype))

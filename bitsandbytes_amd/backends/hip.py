@@ -303,11 +303,12 @@ def _gemm_4bit_fused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8
     # split-K scratch for the MFMA kernel comes from torch's caching allocator: stream-ordered and
     # legal under hipGraph capture (the library never has to allocate)
     ws = None
-    # (M <= 2 always runs the streaming kernel, which needs no scratch: the decode hot path skips the size query)
-    ws_bytes = lib.bnb_mi355x_gemm_4bit_workspace_bytes(kernel, _DT_CODE[A.dtype], M, N, K, blocksize) if M > 2 else 0
-    if ws_bytes:
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device)
     with _device_of(A):
+        # (M <= 2 always runs the streaming kernel, which needs no scratch: the decode hot path skips the size query; the
+        # query sits inside the guard because the launch plan depends on the current device's CU count)
+        ws_bytes = lib.bnb_mi355x_gemm_4bit_workspace_bytes(kernel, _DT_CODE[A.dtype], M, N, K, blocksize) if M > 2 else 0
+        if ws_bytes:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device)
         lib.bnb_mi355x_gemm_4bit(
             kernel, _DT_CODE[A.dtype], A.data_ptr(), B.data_ptr(), absmax.contiguous().data_ptr(),
             _ptr(absmax_8bit if absmax_8bit is None else absmax_8bit.contiguous()),
@@ -355,10 +356,11 @@ def _(grad_out, B, shapeB: Sequence[int], absmax, blocksize: int, quant_type: st
     B = B.contiguous()
     offset32 = absmax_offset.to(dtype=torch.float32) if absmax_offset is not None else None
     ws = None
-    ws_bytes = lib.bnb_mi355x_gemm_4bit_grad_input_workspace_bytes(M, N, K)
-    if ws_bytes:
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=G.device)  # stream-ordered, legal under graph capture
     with _device_of(G):
+        # (inside the guard: the launch plan depends on the current device's CU count)
+        ws_bytes = lib.bnb_mi355x_gemm_4bit_grad_input_workspace_bytes(M, N, K)
+        if ws_bytes:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=G.device)  # stream-ordered, legal under graph capture
         lib.bnb_mi355x_gemm_4bit_grad_input(
             _DT_CODE[G.dtype], G.data_ptr(), B.data_ptr(), absmax.contiguous().data_ptr(),
             _ptr(absmax_8bit if absmax_8bit is None else absmax_8bit.contiguous()),
@@ -386,8 +388,11 @@ def gemm_4bit_grouped(A: torch.Tensor, mats, blocksize: int, quant_type: str):
     if count == 0:
         return []
     nested = mats[0][4] is not None
-    if K % blocksize != 0 or M > 4 or count > 8:
-        # outside the grouped kernel's range: the single-matrix op (its own routing, its own split-K workspace)
+    to_mfma = M >= 3 and any(lib.bnb_mi355x_gemm_4bit_route(0, _DT_CODE[A.dtype], M, int(m[1][0]), K, blocksize) for m in mats)
+    if K % blocksize != 0 or M > 4 or count > 8 or to_mfma:
+        # outside the grouped kernel's range - or a member that the single-matrix op hands to the MFMA kernels (three or four
+        # rows on a big matrix: other arithmetic, and faster there): the single-matrix op (its own routing, its own split-K
+        # workspace from torch's allocator)
         return [torch.ops.bitsandbytes.gemm_4bit.default(A, B, shapeB, absmax, blocksize, quant_type, bias, a8, ac, ao)
                 for (B, shapeB, absmax, bias, a8, ac, ao) in mats]
     A = A.contiguous()

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void quantize8_kernel(const float* __restrict_
 // cells around zero, which is where block-normalised data lives: 2.1 TB/s on randn input). 64 KiB of table per workgroup is
 // only worth building when a workgroup has megabytes to encode, so small inputs (the absmax vectors of double quantisation)
 // keep the cell kernel. Same function of u, bit for bit: lut[u] = #{i : T_i <= u}.
-std::atomic<int> g_q8_variant{0}; // tuning / tests (bnb_mi355x_set_tuning reserved0): 1 = cell-table kernel, 2 = byte-table kernel, else by size
+thread_local TlsKnob g_q8_variant{0}; // tuning / tests (bnb_mi355x_set_tuning reserved0): 1 = cell-table kernel, 2 = byte-table kernel, else by size
 constexpr long kQ8LutMinElements = 1L << 20; // below this the 64 KiB table per workgroup costs more than it saves
 constexpr int kQ8LutThreads = 512;
 constexpr int kQ8LutLds = 65536 + 1024 + 1024;

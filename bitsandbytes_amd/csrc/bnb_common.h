@@ -61,6 +61,18 @@ inline void ensure_dynamic_lds(LdsLimit& state, const void* kernel, size_t dynam
 }
 
 // ---------------------------------------------------------------------------------------------
+// Tuning knobs (bnb_mi355x_set_tuning / bnb_mi355x_set_stream_tuning: sweeps, tests, tools - every setting computes correct
+// results) are THREAD-LOCAL: a tool or test that changes one and forgets to reset it changes the launches of its own thread
+// only, never the routing of another thread's calls in the same process. (load / store keep the std::atomic spelling of
+// the globals they replace.)
+// ---------------------------------------------------------------------------------------------
+struct TlsKnob {
+    int v;
+    int load(std::memory_order = std::memory_order_relaxed) const { return v; }
+    void store(int x, std::memory_order = std::memory_order_relaxed) { v = x; }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Element types. fp16/bf16 travel as their native clang types so that conversions lower to the
 // gfx950 hardware converts (v_cvt_f16_f32 / v_cvt_pk_bf16_f32, both round-to-nearest-even).
 // ---------------------------------------------------------------------------------------------

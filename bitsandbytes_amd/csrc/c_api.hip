@@ -42,7 +42,7 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
                     const void* bias, int M, int N, int K, int blocksize, int quant_type, void* workspace,
                     size_t workspace_bytes, hipStream_t stream);
 size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K);
-extern std::atomic<int> g_mfma_knob0, g_mfma_knob1;
+extern thread_local TlsKnob g_mfma_knob0, g_mfma_knob1;
 // gemm4_grad_input.hip
 bool gemm_4bit_grad_input_supported(int dtype, const void* G, const uint8_t* B, int M, int N, int K, int blocksize);
 size_t gemm_4bit_grad_input_workspace_bytes(int M, int N, int K);
@@ -261,8 +261,13 @@ void bnb_mi355x_gemm_4bit_grouped(int dtype, const void* A, int count, const uin
         fprintf(stderr, "bitsandbytes_amd: gemm_4bit_grouped: quant_type must be 1 (FP4) or 2 (NF4), got %d\n", quant_type);
         exit(1);
     }
-    if (gemv_4bit_grouped(dtype, A, count, B, absmax, absmax_8bit, absmax_code, absmax_offset, out, bias, N, M, K, blocksize,
-                          quant_type, S(s)))
+    // "bit-identical to separate calls": a matrix that the single-matrix entry point would hand to the MFMA kernels (three or
+    // four rows on a big matrix) must not run the streaming kernel's arithmetic here - then the whole group goes matrix by matrix
+    bool any_mfma = false;
+    for (int i = 0; i < count; ++i)
+        any_mfma = any_mfma || route_to_mfma(0, dtype, A, B[i], M, N[i], K, blocksize);
+    if (!any_mfma && gemv_4bit_grouped(dtype, A, count, B, absmax, absmax_8bit, absmax_code, absmax_offset, out, bias, N, M, K,
+                                       blocksize, quant_type, S(s)))
         return;
     // not a streaming-kernel shape (M > 4, more than 8 matrices, odd K ...): one launch per matrix, same results
     for (int i = 0; i < count; ++i)
@@ -277,6 +282,11 @@ size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N,
     if (!route_to_mfma(kernel, dtype, a, reinterpret_cast<const uint8_t*>(a), M, N, K, blocksize))
         return 0;
     return gemm_4bit_mfma_workspace_bytes(M, N, K);
+}
+int bnb_mi355x_gemm_4bit_route(int kernel, int dtype, int M, int N, int K, int blocksize) {
+    // (alignment of A / B is unknown here; the aligned - fast - case is assumed, as in the workspace query)
+    static const int dummy_aligned[4] __attribute__((aligned(16))) = {0, 0, 0, 0};
+    return route_to_mfma(kernel, dtype, dummy_aligned, reinterpret_cast<const uint8_t*>(dummy_aligned), M, N, K, blocksize) ? 1 : 0;
 }
 void bnb_mi355x_gemm_4bit_grad_input(int dtype, const void* grad_out, const uint8_t* B, const float* absmax,
                                      const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, void* grad_A,

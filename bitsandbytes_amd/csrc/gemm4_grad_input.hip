@@ -427,7 +427,7 @@ GiPlan gi_slices(int blocks, int ns, int mt) {
     return pl;
 }
 // N slices to fill the chip (one workgroup per CU), at least two blocks per wavefront each
-std::atomic<int> g_gi_force_ns{0}; // sweeps (bnb_mi355x_set_tuning reserved1): N slices, 0 = built-in choice
+thread_local TlsKnob g_gi_force_ns{0}; // sweeps (bnb_mi355x_set_tuning reserved1): N slices, 0 = built-in choice
 GiPlan gi_plan(int M, int N, int K) {
     const int blocks = N / kGiBlockN;
     const int mt = gi_row_tiles(M);

@@ -37,8 +37,8 @@ extern unsigned long long* g_dbg_buf; // c_api.hip (profiling builds only)
 #endif
 // Sweep / test overrides (bnb_mi355x_set_tuning). Atomics, and every call takes ONE snapshot of them: a sweep thread can
 // never corrupt a concurrent launch, it can only change which (always correct) geometry that launch uses.
-std::atomic<int> g_mfma_knob0{0}; // reserved (was: A-image variants of the retired LDS-DMA kernel)
-std::atomic<int> g_mfma_knob1{0}; // 100 * cfg + K-slice count (0 = heuristic)
+thread_local TlsKnob g_mfma_knob0{0}; // reserved (was: A-image variants of the retired LDS-DMA kernel)
+thread_local TlsKnob g_mfma_knob1{0}; // 100 * cfg + K-slice count (0 = heuristic)
 
 namespace {
 

@@ -657,9 +657,9 @@ Geometry make_geometry(int rows_total, int K, int mb, int waves, int tbytes, boo
 }
 
 struct StreamTuning {
-    std::atomic<int> ns{0}, sw{0}, rows{0}, nt{-1}, waves{0};
+    TlsKnob ns{0}, sw{0}, rows{0}, nt{-1}, waves{0};
 };
-StreamTuning g_tune;
+thread_local StreamTuning g_tune;
 
 // Production ring depth: 2 stages with 16 wavefronts per CU (2 KiB x 16 in flight already cover bandwidth x latency;
 // deeper rings only add refill work at the end of a row list), 4 stages - decoded two at a time - with 8.

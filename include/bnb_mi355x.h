@@ -72,9 +72,11 @@ void cdequantize_blockwise_bf16(float* code, unsigned char* A, float* absmax, vo
  *   scale of block b = absmax[b]                                            (absmax_8bit == NULL)
  *                    = absmax_code[absmax_8bit[b]] * absmax[b >> 8] + *absmax_offset   (nested)
  * K % blocksize == 0 is guaranteed by the caller (reference backends/cuda/ops.py:956-962);
- * absmax_offset is fp32; bias has A's dtype. M is any positive value: M <= 2 runs the
- * wave64 dot kernel, larger M the MFMA kernels (bf16/fp16, K % 256 == 0, blocksize >= 64; otherwise
- * the dot kernel loops over M). */
+ * absmax_offset is fp32; bias has A's dtype. M is any positive value: M <= 2 (and M = 3, 4 on matrices below 12 M weights)
+ * runs the streaming kernel (gemv4_stream.hip: persistent workgroups, weights through a register ring, any M in row
+ * passes of up to four), larger M the MFMA kernels (gemm4_mfma_rt.hip / gemm4_mfma.hip: bf16 / fp16, K % 256 == 0,
+ * blocksize >= 64, aligned pointers; any M in row tiles); shapes the MFMA kernels do not take (fp32, odd K, small blocks) run
+ * the streaming kernel at any M. */
 void cgemm_4bit_bf16(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K, int blocksize, int quant_type, bnb_stream_t stream);
 void cgemm_4bit_fp16(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K, int blocksize, int quant_type, bnb_stream_t stream);
 void cgemm_4bit_fp32(const float* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, float* out, const float* bias, int M, int N, int K, int blocksize, int quant_type, bnb_stream_t stream);
@@ -117,6 +119,9 @@ void bnb_mi355x_dequantize_4bit_rows(int dtype, const unsigned char* A, const fl
  * stream is not being captured). Its contents are scratch; no initialisation is required. */
 void bnb_mi355x_gemm_4bit(int kernel, int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, const float* code16, void* out, const void* bias, int M, int N, int K, int blocksize, int quant_type, void* workspace, size_t workspace_bytes, bnb_stream_t stream);
 size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N, int K, int blocksize);
+/* Which kernel family bnb_mi355x_gemm_4bit(kernel, ...) runs for this problem (aligned pointers assumed): 0 = streaming
+ * kernel, 1 = MFMA kernels. The grouped entry point below goes matrix by matrix when any member answers 1. */
+int bnb_mi355x_gemm_4bit_route(int kernel, int dtype, int M, int N, int K, int blocksize);
 
 /* Grouped gemm_4bit: `count` weight matrices applied to the SAME activations A[M, K] in one launch -
  *   out[i][M, N[i]] = A * dequant(B[i])^T (+ bias[i])        i = 0 .. count-1
@@ -143,13 +148,15 @@ int bnb_mi355x_gemm_4bit_grad_input_supported(int dtype, int M, int N, int K, in
  * cell-table kernel, 2 = byte-table kernel, anything else = by input size; reserved1: N slices of the fused backward (> 0; the
  * workspace-size query follows it). MFMA kernels: knob0 reserved,
  * knob1 = 100 * cfg + K-slice count (cfg 11-14 producer/consumer geometries, 20/21/22
- * register-transposed kernel with built-in / 8 / 16 wavefronts). Every setting
- * computes correct results - the knobs only choose a launch geometry (atomics; a call takes one snapshot). */
+ * register-transposed kernel with built-in / 8 / 16 wavefronts, 30 pre-scaled-operand kernel). Every setting
+ * computes correct results - the knobs only choose a launch geometry. THREAD-LOCAL: a setting applies to the calls the
+ * SAME host thread makes afterwards and to nothing else in the process. */
 void bnb_mi355x_set_tuning(int reserved0, int reserved1, int mfma_knob0, int mfma_knob1);
 
 /* Sweep-only overrides of the streaming kernel (0 / -1 = built-in choice): ring depth (2, 3, 6; bf16 M = 1 fp32-absmax
  * NF4 only), 2048-k segments side by side, rows per workgroup, non-temporal weight loads (0 / 1, -1 = default on),
- * wavefronts per workgroup (8; same restriction as ring depth). Every setting computes the same results. Atomics. */
+ * wavefronts per workgroup (8; same restriction as ring depth). Every setting computes the same results. Thread-local
+ * like bnb_mi355x_set_tuning. */
 void bnb_mi355x_set_stream_tuning(int ring_depth, int segments, int rows_per_workgroup, int nontemporal, int waves);
 
 /* Profiling builds only (libbitsandbytes_mi355x_prof.so, -DBNB_PROFILING): when non-NULL the kernels write s_memtime

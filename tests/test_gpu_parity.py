@@ -1421,6 +1421,42 @@ def test_matmul_4bit_grouped_equals_separate_calls(dtype, dq, M):
             assert y.shape == y1.shape and torch.equal(y, y1)
 
 
+@pytest.mark.parametrize("M", [3, 4])
+def test_matmul_4bit_grouped_big_members_equal_separate_calls(M):
+    """Three or four rows on a matrix of >= 12 M weights go to the MFMA kernel in the single-matrix op; a group with such a
+    member is issued matrix by matrix (other arithmetic than the streaming kernel's): still bit-identical to separate calls."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    K = 4096
+    x = torch.randn(M, K, device=DEV).bfloat16()
+    ws, sts = [], []
+    for N in (4096, 1024, 1024):
+        W = (torch.randn(N, K, device=DEV) / K**0.5).bfloat16()
+        q, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4")
+        ws.append(q)
+        sts.append(st)
+    assert bnb.lib.bnb_mi355x_gemm_4bit_route(0, 2, M, 4096, K, 64) == 1 and bnb.lib.bnb_mi355x_gemm_4bit_route(0, 2, M, 1024, K, 64) == 0
+    ys = bnb.matmul_4bit_grouped(x, ws, sts, [None] * 3)
+    for y, w, s in zip(ys, ws, sts):
+        assert torch.equal(y, bnb.matmul_4bit(x, w, s))
+
+
+def test_matmul_4bit_double_backward_gpu():
+    """create_graph=True through matmul_4bit: the backward must stay differentiable in grad_output (reference formulation)."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    W = (torch.randn(256, 512, device=DEV) / 512**0.5).bfloat16()
+    q, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4")
+    x = torch.randn(8, 512, device=DEV).bfloat16().requires_grad_(True)
+    y = bnb.matmul_4bit(x, q, st)
+    (gx,) = torch.autograd.grad(y.float().pow(2).sum(), x, create_graph=True)
+    assert gx.requires_grad
+    gx.float().pow(2).sum().backward()       # second derivative reaches x through grad_output
+    assert x.grad is not None and torch.isfinite(x.grad.float()).all()
+
+
 def test_linear4bit_group_forward_gpu():
     from bitsandbytes_amd.nn import Linear4bit, linear4bit_group_forward
 

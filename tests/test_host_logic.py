@@ -455,3 +455,58 @@ def test_blockwise8_threshold_finders_and_byte_table_emulation():
         assert mod.check_code(code.numpy())
     for m in (-2.0, -1.0, 0.0, 1.0, 2.0, float("inf"), float("nan")):
         assert mod.first_bin_above(m) == mod.bisect_threshold(np.float32(m))
+
+
+def test_reference_plugin_point_loads_this_backend():
+    """pyproject.toml declares the entry point the reference discovers in `_import_backends()` (bitsandbytes/__init__.py:52-70,
+    group "bitsandbytes.backends"). A dist-info directory generated from that stanza is put on sys.path (what an installed wheel
+    provides) and the reference's own loader code is run over it: it must find the entry, load it and call it, after which this
+    package is imported and its kernels are registered. Where the reference checkout exists, its package is imported for real -
+    `import bitsandbytes` runs `_import_backends()` at import time."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    import textwrap
+
+    try:
+        import tomllib
+    except ModuleNotFoundError:  # Python 3.10
+        import tomli as tomllib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "pyproject.toml"), "rb") as fh:
+        meta = tomllib.load(fh)
+    eps = meta["project"]["entry-points"]["bitsandbytes.backends"]
+    assert eps == {"mi355x": "bitsandbytes_amd.backends.plugin:register"}
+    site = tempfile.mkdtemp(prefix="bnb_plugin_site_")
+    di = os.path.join(site, "bitsandbytes_amd_mi355x-0.1.0.dist-info")
+    os.makedirs(di)
+    with open(os.path.join(di, "METADATA"), "w") as fh:
+        fh.write("Metadata-Version: 2.1\nName: bitsandbytes-amd-mi355x\nVersion: 0.1.0\n")
+    with open(os.path.join(di, "entry_points.txt"), "w") as fh:
+        fh.write("[bitsandbytes.backends]\n" + "".join(f"{k} = {v}\n" for k, v in eps.items()))
+    ref = os.environ.get("BNB_REFERENCE_DIR", "/root/reference")
+    have_ref = os.path.isdir(os.path.join(ref, "bitsandbytes"))
+    script = textwrap.dedent(f"""
+        import sys
+        sys.dont_write_bytecode = True
+        sys.path[:0] = [{site!r}, {root!r}] + ([{ref!r}] if {have_ref} else [])
+        if {have_ref}:
+            import bitsandbytes as ref                      # runs _import_backends() at import (reference __init__.py:70)
+            assert ref.__file__.startswith({ref!r}), ref.__file__
+        else:
+            # the loader's own statements (reference bitsandbytes/__init__.py:58-67)
+            from importlib.metadata import entry_points
+            for ext in entry_points(group="bitsandbytes.backends"):
+                ext.load()()
+        assert "bitsandbytes_amd" in sys.modules, "the plug-in was not loaded"
+        from bitsandbytes_amd.backends import plugin
+        assert plugin.REGISTERED
+        import torch
+        # the HIP ("cuda" key) kernels of the path are this package's
+        for op in ("quantize_4bit", "dequantize_4bit", "gemm_4bit", "gemv_4bit", "quantize_blockwise", "dequantize_blockwise"):
+            assert torch._C._dispatch_has_kernel_for_dispatch_key("bitsandbytes::" + op, "CUDA"), op
+        print("PLUGIN_OK", {have_ref})
+    """)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PLUGIN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
