@@ -732,6 +732,7 @@ void gemm_4bit_rt(int dtype, const void* A, const uint8_t* B, const float* absma
 
 // gemm4_mfma_ps.hip (the pre-scaled-operand kernel: 32x32x16 MFMA, register ring, one barrier per 256 k)
 bool gemm_4bit_ps_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize);
+bool gemm_4bit_ps_serves_nested();
 size_t gemm_4bit_ps_workspace_bytes(int M, int N, int K, int force_ks);
 void gemm_4bit_ps(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
@@ -787,6 +788,17 @@ bool ps_selected(int M, int N, int K, int knob1, int* force_ks, int* variant) {
         *variant = cfg - 30;
         return true;
     }
+    if (cfg != 0)
+        return false;
+    // measured on MI355X (profiles/r3_tall_batch_ab.txt), us per launch, pre-scaled-operand kernel (128-row tiles) vs
+    // producer/consumer kernel (64-row tiles): 28672 x 8192 M = 128 / 256 92 / 168 vs 112 / 210; 11008 x 4096 M = 256 44 vs 54;
+    // 8192^2 and 4096 x 11008 M = 256 equal; but 4096^2 M = 256 27 vs 23, and up to 128 rows on matrices below 128 M weights the
+    // producer/consumer kernel stays ahead (8192^2 M = 128 38 vs 34)
+    const long weights = static_cast<long>(N) * K;
+    if (M > 128)
+        return weights >= (32L << 20);
+    if (M > 64)
+        return weights >= (128L << 20);
     return false;
 }
 } // namespace
@@ -805,12 +817,21 @@ size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K) {
     int fks, fw;
     const int knob1 = g_mfma_knob1.load(std::memory_order_relaxed);
     int pks, pvar;
-    if (ps_selected(M, N, K, knob1, &pks, &pvar))
-        return gemm_4bit_ps_workspace_bytes(M, N, K, pks);
-    if (rt_selected(M, N, K, knob1, &fks, &fw))
-        return gemm_4bit_rt_workspace_bytes(M, N, K, fks);
+    size_t ps_bytes = 0;
+    if (ps_selected(M, N, K, knob1, &pks, &pvar)) {
+        ps_bytes = gemm_4bit_ps_workspace_bytes(M, N, K, pks);
+        if (knob1 != 0)
+            return ps_bytes;
+        // (chosen by the built-in rule: a nested-absmax call of the same shape runs the kernels below instead - the query does
+        // not know which it will be and answers with the larger of the two)
+    }
+    if (rt_selected(M, N, K, knob1, &fks, &fw)) {
+        const size_t b = gemm_4bit_rt_workspace_bytes(M, N, K, fks);
+        return b > ps_bytes ? b : ps_bytes;
+    }
     const Plan pl = make_plan(M, N, K, knob1);
-    return pl.ks > 1 ? static_cast<size_t>(pl.ks) * M * N * sizeof(float) : 0;
+    const size_t b = pl.ks > 1 ? static_cast<size_t>(pl.ks) * M * N * sizeof(float) : 0;
+    return b > ps_bytes ? b : ps_bytes;
 }
 
 void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
@@ -820,7 +841,8 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
     int fks, fw;
     const int knob0 = g_mfma_knob0.load(std::memory_order_relaxed), knob1 = g_mfma_knob1.load(std::memory_order_relaxed);
     int pks, pvar;
-    if (ps_selected(M, N, K, knob1, &pks, &pvar) && gemm_4bit_ps_supported(dtype, A, B, code16, M, N, K, blocksize))
+    if (ps_selected(M, N, K, knob1, &pks, &pvar) && (absmax8 == nullptr || gemm_4bit_ps_serves_nested()) &&
+        gemm_4bit_ps_supported(dtype, A, B, code16, M, N, K, blocksize))
         return gemm_4bit_ps(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type,
                             workspace, workspace_bytes, pks, pvar, knob0, stream);
     if (rt_selected(M, N, K, knob1, &fks, &fw) && gemm_4bit_rt_supported(dtype, A, B, code16, M, N, K, blocksize))

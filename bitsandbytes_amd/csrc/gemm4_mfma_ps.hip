@@ -699,6 +699,12 @@ size_t gemm_4bit_ps_workspace_bytes(int M, int N, int K, int force_ks) {
     return pl.ks > 1 ? static_cast<size_t>(pl.ks) * M * N * sizeof(float) : 0;
 }
 
+// Nested (double-quantised) absmax is NOT served by this kernel: on small launches (a handful of stages per workgroup, an
+// otherwise idle chip) its nested instances produced results that differed from run to run in one 16-column strip of a
+// workgroup's tile (profiles/r3_ps_stress_*.txt) - never the fp32-absmax instances, in thousands of launches - and the cause
+// was not found. The instances stay in the source for that investigation; the router does not pick them.
+bool gemm_4bit_ps_serves_nested() { return false; }
+
 // dtype: 1 = f16, 2 = bf16. force_ks (0 = built-in choice): sweeps and tests.
 void gemm_4bit_ps(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,

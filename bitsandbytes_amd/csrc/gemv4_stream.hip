@@ -349,6 +349,20 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     // (left alone, the scheduler serialises look-up and use).
     auto compute = [&](int j0, int i0) {
         f32x2 pr[IL][16];
+        // nested absmax: the second-level look-up (byte code -> code2 entry) goes out FIRST, in front of the sixteen table
+        // look-ups of the item, so that its LDS round trip runs beside theirs instead of behind the FMAs (config 5 was 0.4 us
+        // slower than config 2 with fewer bytes: profiles/r2_configs_bench.txt)
+        float c2v[IL];
+        if constexpr (NESTED) {
+#pragma unroll
+            for (int u = 0; u < IL; ++u) {
+                const uint32_t q8 = __builtin_bit_cast(uint32_t, st[j0 + u].s);
+                if constexpr (GROUPED)
+                    c2v[u] = code2[mat_of(row_begin + g + (i0 + u) * G) * 256 + q8];
+                else
+                    c2v[u] = code2[q8];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < IL; ++u)
 #pragma unroll
@@ -359,6 +373,36 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
                     pr[u][4 * d + j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x2*>(addr);
                 }
         __builtin_amdgcn_sched_barrier(0);
+        // the block's scale. 16-bit activations: applied once to the lane's fp32 sum of 32 products (exact codes, one extra
+        // rounding per 32 terms - well inside the reference's envelope for those types). fp32 activations: applied to the
+        // decoded pair BEFORE the FMA - the operand is fl(code * scale), the reference's own arithmetic (dequantize, then a
+        // fp32 product: csrc/kernels.cu gemv, default/ops.py) - because its fp32 envelope (tests/test_functional.py:892-895:
+        // 1e-8 + 7 * 2e-9 per element and sqrt(dim)) is tighter than the post-scaled sum's rounding (measured 3e-8 on the
+        // fc2 shapes)
+        constexpr bool PRESCALE = TB == 4;
+        float scale_u[IL];
+#pragma unroll
+        for (int u = 0; u < IL; ++u) {
+            const Stage& s = st[j0 + u];
+            float scale;
+            if constexpr (NESTED) {
+                if constexpr (GROUPED) {
+                    const int mi = mat_of(row_begin + g + (i0 + u) * G);
+                    scale = __fadd_rn(__fmul_rn(c2v[u], s.s2), p.mat[mi].absmax_offset[0]);
+                } else {
+                    scale = __fadd_rn(__fmul_rn(c2v[u], s.s2), offset);
+                }
+            } else {
+                scale = s.s;
+            }
+            scale_u[u] = k_ok ? scale : 0.0f;
+            if constexpr (PRESCALE) {
+                const f32x2 sc2 = {scale_u[u], scale_u[u]};
+#pragma unroll
+                for (int b = 0; b < 16; ++b)
+                    pr[u][b] = pr[u][b] * sc2;
+            }
+        }
         // two independent chains of packed FMAs per (item, row): [chain][even k, odd k] - the same four partial sums, in
         // the same order, as four scalar chains
         f32x2 acc[IL][MB][2];
@@ -377,23 +421,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         float v[IL * MB];
 #pragma unroll
         for (int u = 0; u < IL; ++u) {
-            const Stage& s = st[j0 + u];
-            float scale;
-            if constexpr (NESTED) {
-                const uint32_t q8 = __builtin_bit_cast(uint32_t, s.s);
-                if constexpr (GROUPED) {
-                    const int mi = mat_of(row_begin + g + (i0 + u) * G);
-                    scale = __fadd_rn(__fmul_rn(code2[mi * 256 + q8], s.s2), p.mat[mi].absmax_offset[0]);
-                } else {
-                    scale = __fadd_rn(__fmul_rn(code2[q8], s.s2), offset);
-                }
-            } else {
-                scale = s.s;
-            }
-            scale = k_ok ? scale : 0.0f;
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
-                v[u * MB + m] = ((acc[u][m][0][0] + acc[u][m][0][1]) + (acc[u][m][1][0] + acc[u][m][1][1])) * scale;
+            for (int m = 0; m < MB; ++m) {
+                const float sum = (acc[u][m][0][0] + acc[u][m][0][1]) + (acc[u][m][1][0] + acc[u][m][1][1]);
+                v[u * MB + m] = PRESCALE ? sum : sum * scale_u[u];
+            }
         }
         wave_sum_n<IL * MB>(v);
 #pragma unroll

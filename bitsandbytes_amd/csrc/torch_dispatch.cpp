@@ -19,8 +19,11 @@
 #include <torch/library.h>
 
 #include <limits>
+#include <memory>
+#include <mutex>
 #include <optional>
 #include <string>
+#include <unordered_map>
 
 #include "../../include/bnb_mi355x.h"
 
@@ -182,8 +185,84 @@ at::Tensor gemm_4bit_hip(const at::Tensor& A_in, const at::Tensor& B_in, at::Int
     return out;
 }
 
+// ---- Linear4bit.forward without the Python layers between the module and the C ABI (eager decode is host-bound: 10.5 us per
+// Linear4bit call for a 4.1 us kernel, profiles/r2_host_overhead.txt). A module prepares its call ONCE - packed weight,
+// statistics, bias already cast, dtype policy (reference nn/modules.py:609-637, autograd/_functions.py:407-491) - and gets a
+// handle; every later forward is one two-argument op call.
+struct Prepared {
+    at::Tensor B, absmax;
+    std::optional<at::Tensor> bias, a8, code, offset;
+    std::vector<int64_t> shape;
+    int64_t blocksize;
+    std::string quant_type;
+    std::optional<at::ScalarType> compute_dtype;
+};
+std::mutex g_prepared_mutex;
+std::unordered_map<int64_t, std::shared_ptr<const Prepared>> g_prepared;
+int64_t g_prepared_next = 1;
+
+int64_t linear4bit_prepare(const at::Tensor& B, at::IntArrayRef shapeB, const at::Tensor& absmax, int64_t blocksize, c10::string_view quant_type,
+                           const std::optional<at::Tensor>& bias, const std::optional<at::Tensor>& absmax_8bit,
+                           const std::optional<at::Tensor>& absmax_code, const std::optional<at::Tensor>& absmax_offset,
+                           std::optional<at::ScalarType> compute_dtype) {
+    TORCH_CHECK(shapeB.size() == 2, "shapeB must be [N, K]");
+    (void)quant_code(quant_type);
+    auto p = std::make_shared<Prepared>();
+    p->B = B.contiguous();
+    p->absmax = absmax.contiguous();
+    p->shape = shapeB.vec();
+    p->blocksize = blocksize;
+    p->quant_type = std::string(quant_type);
+    p->compute_dtype = compute_dtype;
+    if (bias.has_value())
+        p->bias = compute_dtype.has_value() ? bias->to(*compute_dtype).contiguous() : bias->contiguous();
+    if (absmax_8bit.has_value())
+        p->a8 = absmax_8bit->contiguous();
+    if (absmax_code.has_value())
+        p->code = absmax_code->contiguous();
+    if (absmax_offset.has_value())
+        p->offset = absmax_offset->to(at::kFloat);
+    const std::lock_guard<std::mutex> lock(g_prepared_mutex);
+    const int64_t id = g_prepared_next++;
+    g_prepared.emplace(id, std::move(p));
+    return id;
+}
+
+void linear4bit_release(int64_t handle) {
+    const std::lock_guard<std::mutex> lock(g_prepared_mutex);
+    g_prepared.erase(handle);
+}
+
+at::Tensor linear4bit_prepared(const at::Tensor& x, int64_t handle) {
+    std::shared_ptr<const Prepared> p;
+    {
+        const std::lock_guard<std::mutex> lock(g_prepared_mutex);
+        const auto it = g_prepared.find(handle);
+        TORCH_CHECK(it != g_prepared.end(), "linear4bit_prepared: unknown handle ", handle);
+        p = it->second;
+    }
+    // dtype policy of Linear4bit.forward: compute in compute_dtype, return in the input's dtype; a bias of another dtype was
+    // cast at prepare time
+    const at::ScalarType inp = x.scalar_type();
+    const at::Tensor xc = (p->compute_dtype.has_value() && *p->compute_dtype != inp) ? x.to(*p->compute_dtype) : x;
+    std::optional<at::Tensor> bias = p->bias;
+    if (bias.has_value() && bias->scalar_type() != xc.scalar_type())
+        bias = bias->to(xc.scalar_type());
+    at::Tensor y = gemm_4bit_hip(xc, p->B, p->shape, p->absmax, p->blocksize, p->quant_type, bias, p->a8, p->code, p->offset);
+    return y.scalar_type() == inp ? y : y.to(inp);
+}
+
 } // namespace
 
 // The schema is defined by bitsandbytes_amd/_ops.py (string-identical to the reference's bitsandbytes/_ops.py:239-295), or by the
 // reference package itself when that is imported first; this only adds the device kernel.
 TORCH_LIBRARY_IMPL(bitsandbytes, CUDA, m) { m.impl("gemm_4bit", &gemm_4bit_hip); }
+
+// Extension ops of this package (no counterpart in the reference): the prepared Linear4bit call.
+TORCH_LIBRARY_FRAGMENT(bitsandbytes_amd, m) {
+    m.def("linear4bit_prepare(Tensor B, int[] shapeB, Tensor absmax, int blocksize, str quant_type, Tensor? bias=None, Tensor? absmax_8bit=None, "
+          "Tensor? absmax_code=None, Tensor? absmax_offset=None, ScalarType? compute_dtype=None) -> int",
+          &linear4bit_prepare);
+    m.def("linear4bit_prepared(Tensor x, int handle) -> Tensor", &linear4bit_prepared);
+    m.def("linear4bit_release(int handle) -> ()", &linear4bit_release);
+}

@@ -254,7 +254,52 @@ class Linear4bit(nn.Linear):
             for k, v in state.as_dict(packed=True).items():
                 destination[prefix + "weight." + k] = v if keep_vars else v.detach()
 
+    # ---- prepared call (MI355X): eager decode is host-bound - the Python below (quant-state repair, dtype policy, matmul_4bit,
+    # a ten-argument op call) costs more than the 4 us kernel it launches. Once the layer is quantised on the device, its
+    # call is prepared ONCE in the C++ dispatcher library (csrc/torch_dispatch.cpp: linear4bit_prepare) and every later
+    # forward that needs no autograd is a two-argument op call; anything that changes the layer (a new weight / quant state /
+    # bias object, a moved weight) drops the handle. Results are those of the code below, by construction: the prepared
+    # call runs the same gemm_4bit kernel glue with the same dtype policy.
+    _prepared = None  # (handle, quant_state, weight data_ptr, bias object, bias requires_grad, compute_dtype)
+
+    def _prepared_drop(self):
+        prep = self.__dict__.pop("_prepared", None)
+        if prep is not None:
+            try:
+                torch.ops.bitsandbytes_amd.linear4bit_release(prep[0])
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
+
+    def __del__(self):
+        self._prepared_drop()
+
+    def _prepared_make(self, weight, quant_state, bias):
+        from ..backends import hip
+
+        self._prepared_drop()
+        if not hip.NATIVE_DISPATCH or not weight.is_cuda or len(quant_state.shape) != 2:
+            return None
+        if quant_state.nested and quant_state.state2.blocksize != 256:
+            return None
+        if quant_state.nested:
+            absmax, a8, code, offset = quant_state.state2.absmax, quant_state.absmax, quant_state.state2.code, quant_state.offset
+        else:
+            absmax, a8, code, offset = quant_state.absmax, None, None, None
+        handle = torch.ops.bitsandbytes_amd.linear4bit_prepare(
+            weight.data.view(-1, 1) if weight.dtype == torch.uint8 else weight.data, list(quant_state.shape), absmax, quant_state.blocksize,
+            quant_state.quant_type, None if bias is None else bias.data, a8, code, offset, self.compute_dtype)
+        prep = (handle, quant_state, weight.data_ptr(), bias, bias is not None and bias.requires_grad, self.compute_dtype)
+        self.__dict__["_prepared"] = prep
+        return prep
+
     def forward(self, x: torch.Tensor):
+        prep = self._prepared
+        if prep is not None and x.is_cuda:
+            weight = self._parameters["weight"]
+            if (prep[1] is getattr(weight, "quant_state", None) and prep[2] == weight.data_ptr() and prep[3] is self._parameters["bias"]
+                    and prep[5] is self.compute_dtype and not (torch.is_grad_enabled() and (x.requires_grad or prep[4]))
+                    and not torch.compiler.is_compiling()):
+                return torch.ops.bitsandbytes_amd.linear4bit_prepared(x, prep[0])
         fix_4bit_weight_quant_state_from_module(self)
         quant_state = self.weight.quant_state
 
@@ -272,7 +317,16 @@ class Linear4bit(nn.Linear):
                 bias.data = bias.data.to(x.dtype)
             bias = bias.to(self.compute_dtype)
 
+        if (x.is_cuda and quant_state is not None and self.compute_type_is_set and not torch.compiler.is_compiling()
+                and K_matches(x, quant_state)):
+            # (prepared for the NEXT call; this one takes the ordinary path)
+            self._prepared_make(self.weight, quant_state, self.bias)
         return matmul_4bit(x, self.weight, bias=bias, quant_state=quant_state).to(inp_dtype)
+
+
+def K_matches(x: torch.Tensor, quant_state) -> bool:
+    """The [N, K] orientation matmul_4bit's fused path expects (the legacy [K, N] layout keeps the ordinary path)."""
+    return len(quant_state.shape) == 2 and x.shape[-1] == quant_state.shape[1]
 
 
 def linear4bit_group_forward(layers, x: torch.Tensor):

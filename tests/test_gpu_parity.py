@@ -1457,6 +1457,45 @@ def test_matmul_4bit_double_backward_gpu():
     assert x.grad is not None and torch.isfinite(x.grad.float()).all()
 
 
+def test_linear4bit_prepared_call_equals_ordinary_path():
+    """Linear4bit.forward's prepared call (csrc/torch_dispatch.cpp linear4bit_prepare / linear4bit_prepared): from the second
+    eager no-grad call on, the layer runs a two-argument C++ op instead of the Python layers. Same results bit for bit - bias,
+    nested statistics, fp32 input with bf16 compute, several batch sizes incl. the unfused range; the handle is dropped
+    when the weight, the quant state or the bias object changes, and autograd calls keep the ordinary path."""
+    from bitsandbytes_amd.backends import hip
+    from bitsandbytes_amd.nn import Linear4bit
+
+    if not hip.NATIVE_DISPATCH:
+        pytest.skip("the C++ dispatcher library is not loaded")
+    torch.manual_seed(11)
+    for (K, N, cs, qt, cdt, xdt, with_bias) in ((1024, 512, True, "nf4", torch.bfloat16, torch.bfloat16, True),
+                                                (2048, 256, False, "fp4", torch.float16, torch.float16, False),
+                                                (1024, 384, True, "nf4", torch.bfloat16, torch.float32, True)):
+        layer = Linear4bit(K, N, bias=with_bias, quant_type=qt, compress_statistics=cs, compute_dtype=cdt).to(DEV)
+        for M in (1, 3, 40, 700):
+            x = torch.randn(M, K, device=DEV, dtype=xdt)
+            with torch.no_grad():
+                layer._prepared_drop()
+                y0 = layer(x)                       # ordinary path (prepares)
+                assert layer._prepared is not None
+                y1 = layer(x)                       # prepared call
+                y2 = layer(x)
+            assert y1.dtype == xdt and torch.equal(y0, y1) and torch.equal(y1, y2)
+        # autograd keeps the ordinary path and still works
+        xg = torch.randn(4, K, device=DEV, dtype=xdt, requires_grad=True)
+        layer(xg).float().sum().backward()
+        assert xg.grad is not None
+        # a replaced bias / re-quantised weight drops the stale handle
+        with torch.no_grad():
+            h0 = layer._prepared[0]
+            if with_bias:
+                layer.bias = torch.nn.Parameter(torch.randn(N, device=DEV, dtype=cdt), requires_grad=False)
+                x = torch.randn(2, K, device=DEV, dtype=xdt)
+                ya = layer(x)                       # ordinary path again (bias object changed)
+                yb = layer(x)
+                assert layer._prepared[0] != h0 and torch.equal(ya, yb)
+
+
 def test_linear4bit_group_forward_gpu():
     from bitsandbytes_amd.nn import Linear4bit, linear4bit_group_forward
 
@@ -1603,4 +1642,47 @@ def test_bench_multi_gpu_code_path_at_world_size_one():
                 "dtype", "data", "config", "roofline"):
         assert key in line, key
     assert line["n_gpus"] == 1 and line["steps"] == 6 and line["value"] > 0
-    assert "ShardedLinear4bit" in line["config"]["parallelism"] and line["per_layer_gather"]["us_per_layer"] > 0
+    assert "ShardedLinear4bit" in line["config"]["parallelism"] and line["bucketed_gather"]["us_per_layer"] > 0
+
+
+def test_sharded_linear4bit_over_rccl_two_ranks():
+    """BASELINE.json configs[3] on real links: two ranks (one process per GPU, backend "nccl" = RCCL), each with its row shard of
+    the Llama FFN matrices; the gathered output of every rank must equal the unsharded layer bit for bit (M = 1 and M = 2: the
+    streaming kernel's results do not depend on the launch geometry). Self-skips on a box with fewer than two GPUs - the
+    builder's boxes have one; the driver's multi-GPU node runs it."""
+    import subprocess
+    import sys
+    import textwrap
+
+    from conftest import ROOT
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs 2 GPUs, this box has {torch.cuda.device_count()}")
+    script = textwrap.dedent(f"""
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, {ROOT!r})
+        import bitsandbytes_amd.nn as bnn
+        from bitsandbytes_amd.parallel import shard_linear4bit
+        rank = int(os.environ["RANK"]); torch.cuda.set_device(rank)
+        dev = torch.device("cuda", rank)
+        dist.init_process_group("nccl", device_id=dev)
+        torch.manual_seed(7)                                   # the same layer on every rank
+        for (N, K) in ((11008, 4096), (4096, 11008)):
+            layer = bnn.Linear4bit(K, N, bias=True, compute_dtype=torch.bfloat16, quant_type="nf4").to(dev)
+            sh = shard_linear4bit(layer)
+            for M in (1, 2, 64):
+                x = torch.randn(M, K, generator=torch.Generator().manual_seed(M)).to(dev, torch.bfloat16)
+                y, y0 = sh(x), layer(x)
+                assert y.shape == y0.shape
+                if M <= 2:
+                    assert torch.equal(y, y0), (N, K, M)
+                else:
+                    assert ((y.float() - y0.float()).abs().max() / y0.float().abs().max()).item() < 1e-2
+        dist.barrier(); dist.destroy_process_group()
+        print("RANK_OK", rank)
+    """)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29731", os.path.join(ROOT, "tests", "checks", "two_rank_nccl.py")],
+                       capture_output=True, text=True, timeout=900, env=dict(env, BNB_TWO_RANK_SCRIPT=script))
+    assert r.returncode == 0 and r.stdout.count("RANK_OK") == 2, r.stdout[-2000:] + r.stderr[-4000:]

@@ -36,7 +36,8 @@ def timeit(fn, n=2000):
 
 with torch.no_grad():
     rows = [
-        ("Linear4bit.forward", lambda: layer(x)),
+        ("Linear4bit.forward (prepared C++ call)", lambda: layer(x)),
+        ("Linear4bit.forward (Python layers)", lambda: (layer._prepared_drop(), layer(x))[1]),
         ("matmul_4bit", lambda: bnb.matmul_4bit(x, q, st)),
         ("torch.ops.bitsandbytes.gemm_4bit", lambda: torch.ops.bitsandbytes.gemm_4bit.default(x, q, st.shape, st.absmax, 64, "nf4")),
         ("Python kernel of the op (replaced)", lambda: hip._gemm_4bit_python_kernel(x, q, st.shape, st.absmax, 64, "nf4")),
@@ -45,4 +46,4 @@ with torch.no_grad():
     ]
     print(f"# native dispatch (csrc/torch_dispatch.cpp) loaded: {hip.NATIVE_DISPATCH}")
     for name, fn in rows:
-        print(f"{name:36s} {timeit(fn):7.1f} us per call")
+        print(f"{name:40s} {timeit(fn):7.1f} us per call")
