@@ -157,7 +157,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     constexpr int TB = TypeInfo<T>::bytes;
     constexpr int CH = 2 * TB;  // 16-byte chunks of activations per lane and segment (= 1-KiB DMA pieces per segment)
     constexpr int EPC = 16 / TB; // elements per chunk
-    constexpr int LPS = NESTED ? 3 : 2; // vector loads per ring stage
+    constexpr int LPS = 2; // vector loads per ring stage (weights + scale / 8-bit scale code)
     // The wavefronts of a workgroup start ~90 cycles apart (the last of 16 about 1400 cycles after the first, measured
     // with s_memtime): everything that has to be finished before the first barrier - activation copy, decode table -
     // is given to the first half of them, which have that time to spare; the late ones only issue their loads.
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
 
     // LDS map: table | nested code(s) (1 KiB per matrix) | activation image [MB][SW][2048] T | segment partials [R][S][MB]
     // (the image sits at a compile-time offset: its address is needed before the first loads go out)
-    constexpr int kCode2Bytes = (GROUPED ? kMaxGroup : 1) * 1024;
+    constexpr int kCode2Bytes = (GROUPED ? kMaxGroup : 1) * 1024 + 64; // + the matrices' absmax offsets (grouped launches)
     float* const code2 = reinterpret_cast<float*>(smem + kLutBytes);
     unsigned char* const ximg = smem + kLutBytes + kCode2Bytes;
     float* const part = reinterpret_cast<float*>(ximg + MB * SW * kSegK * TB);
@@ -205,13 +205,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     float code2_v[NESTED ? C2PASS : 1];
     float cv = 0.0f;
     const int nmat = GROUPED ? p.nmat : 1;
+    float offset = 0.0f;
     if constexpr (NESTED) {
 #pragma unroll
         for (int i = 0; i < C2PASS; ++i) {
             const int t = i * THREADS + tid;
             code2_v[i] = (t < nmat * 256) ? p.mat[GROUPED ? (t >> 8) : 0].absmax_code[t & 255] : 0.0f;
         }
+        // the absmax offset(s): requested HERE, in front of the weight stream. Fetched after the ring (as this kernel did
+        // until round 3) the load is the youngest of the queue, and the wait for it in front of the first decode is a wait
+        // for every ring stage: the nested configurations ran 0.5 us behind the fp32-absmax ones
+        offset = p.mat[GROUPED ? (tid < nmat ? tid : 0) : 0].absmax_offset[0];
     }
+    float* const offs = reinterpret_cast<float*>(smem + kLutBytes + kCode2Bytes - 64);
     if constexpr (CODEPTR)
         cv = p.code16[lane & 15];
 
@@ -251,8 +257,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     // loads its wait insertion merges the paths and falls back to draining the queue.
     struct Stage {
         u32x4 w;
-        float s;  // fp32 absmax of the lane's block (nested: the uint8 code in the low byte)
-        float s2; // nested: second-level absmax
+        float s;      // fp32 absmax of the lane's block (nested: the uint8 code in the low byte)
+        float s2a, s2b; // nested: second-level absmax of the item's first / last block (wave-uniform: SCALAR loads)
+        uint32_t grp;   // nested: second-level group (block >> 8) of the item's first block
     };
     Stage st[NS];
     constexpr uint32_t kOob = 0xFFFFFFF0u; // beyond num_records
@@ -302,9 +309,22 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         const uint32_t blk = (static_cast<uint32_t>(row) * static_cast<uint32_t>(K) + k0) >> bs_shift;
         if constexpr (NESTED) {
             const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(am8), 0, kRecords, kRsrcFlags);
-            const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(am), 0, kRecords, kRsrcFlags);
             s.s = __builtin_bit_cast(float, static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b8(rs_q, blk | inval, 0, 0)));
-            s.s2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, ((blk >> 8) * 4u) | inval, 0, 0));
+            // second level: the <= 2048 / bs blocks of an item lie in at most TWO groups of 256 blocks (in ONE when K is a
+            // multiple of 2048): two scalar loads per item instead of a third vector-memory instruction per ring stage - the
+            // nested configurations ran 0.5 us behind the fp32-absmax ones on 4096^2 (profiles/r3_configs_bench_mid_round.txt)
+            const uint32_t e0 = static_cast<uint32_t>(row) * static_cast<uint32_t>(K) + static_cast<uint32_t>(seg * kSegK);
+            uint32_t k_last = static_cast<uint32_t>(seg * kSegK + kSegK - 1);
+            k_last = k_last < static_cast<uint32_t>(K) ? k_last : static_cast<uint32_t>(K - 1);
+            const uint32_t e1 = static_cast<uint32_t>(row) * static_cast<uint32_t>(K) + k_last;
+            const uint32_t ga = valid && seg < S ? (e0 >> bs_shift) >> 8 : 0u, gb = valid && seg < S ? (e1 >> bs_shift) >> 8 : 0u;
+            s.grp = ga;
+            // (constant address space: the statistics are read-only for the kernel, a uniform index then compiles to s_load_dword;
+            // through the generic pointer hipcc emits a vector load per lane)
+            typedef const float __attribute__((address_space(4))) * cfloat_ptr;
+            const cfloat_ptr amc = (cfloat_ptr)(reinterpret_cast<uintptr_t>(am));
+            s.s2a = amc[__builtin_amdgcn_readfirstlane(ga)];
+            s.s2b = amc[__builtin_amdgcn_readfirstlane(gb)];
         } else {
             const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(am), 0, kRecords, kRsrcFlags);
             s.s = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, (blk * 4u) | inval, 0, 0));
@@ -313,7 +333,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
 
     uint32_t perm_sel = 0x0C0C0400u; // v_perm_b32 selector {lane offset, weight byte j, 0, 0}
     const uint32_t lane_off = static_cast<uint32_t>(lane & 31) * 8u;
-    float offset = 0.0f;
     // the lane's 32 activations of each row as 16 fp32 PAIRS (k, k + 1): a packed byte decodes to the pair (code[hi],
     // code[lo]) and one v_pk_fma_f32 multiplies pair by pair - half the VALU issue slots of two v_fma_f32 (the decode is
     // VALU-bound at streaming rate: ~80 wave-instructions per KiB of weights against ~1 per cycle and CU)
@@ -386,12 +405,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             const Stage& s = st[j0 + u];
             float scale;
             if constexpr (NESTED) {
+                // the lane's second-level group against the item's first: which of the two scalars is this lane's
+                int rowl = row_begin + g + (i0 + u) * G;
+                int mi = 0;
                 if constexpr (GROUPED) {
-                    const int mi = mat_of(row_begin + g + (i0 + u) * G);
-                    scale = __fadd_rn(__fmul_rn(c2v[u], s.s2), p.mat[mi].absmax_offset[0]);
-                } else {
-                    scale = __fadd_rn(__fmul_rn(c2v[u], s.s2), offset);
+                    mi = mat_of(rowl);
+                    rowl -= p.mat[mi].row_start;
                 }
+                const uint32_t lane_grp = ((static_cast<uint32_t>(rowl) * static_cast<uint32_t>(K) + k0) >> bs_shift) >> 8;
+                const float s2 = lane_grp == s.grp ? s.s2a : s.s2b;
+                if constexpr (GROUPED)
+                    scale = __fadd_rn(__fmul_rn(c2v[u], s2), offs[mi]);
+                else
+                    scale = __fadd_rn(__fmul_rn(c2v[u], s2), offset);
             } else {
                 scale = s.s;
             }
@@ -497,8 +523,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
                     if (t < nmat * 256)
                         code2[t] = code2_v[i];
                 }
-                if constexpr (!GROUPED)
-                    offset = p.mat[0].absmax_offset[0];
+                if constexpr (GROUPED)
+                    if (tid < nmat)
+                        offs[tid] = offset;
             }
         }
         // (3) the activation DMAs are older than the NS ring stages: wait until only those remain in flight
@@ -663,7 +690,7 @@ Geometry make_geometry(int rows_total, int K, int mb, int waves, int tbytes, boo
     int sw = S < waves ? S : waves;
     if (tune_sw > 0 && tune_sw < sw)
         sw = tune_sw;
-    const size_t fixed = kLutBytes + (grouped ? kMaxGroup : 1) * 1024;
+    const size_t fixed = kLutBytes + (grouped ? kMaxGroup : 1) * 1024 + 64;
     const size_t ximg_cap = 80 * 1024;
     while (sw > 1 && static_cast<size_t>(mb) * sw * kSegK * tbytes > ximg_cap)
         --sw;
