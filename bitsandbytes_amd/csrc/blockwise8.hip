@@ -69,13 +69,13 @@ __device__ __forceinline__ unsigned bin_of(float x, float inv) {
 template <typename T> __device__ __forceinline__ void load4(const T* __restrict__ A, long i, long n, bool vec_ok, float (&x)[4]) {
     if (vec_ok && i + 4 <= n) {
         if constexpr (sizeof(T) == 4) {
-            const f32x4_t r = *reinterpret_cast<const f32x4_t*>(A + i);
+            const f32x4_t r = stream_load<true>(reinterpret_cast<const f32x4_t*>(A + i));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 x[j] = r[j];
         } else {
             typedef T v4 __attribute__((ext_vector_type(4)));
-            const v4 r = *reinterpret_cast<const v4*>(A + i);
+            const v4 r = stream_load<true>(reinterpret_cast<const v4*>(A + i));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 x[j] = static_cast<float>(r[j]);
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void quantize8_kernel(const float* __restrict_
             }
             const long i = base + sp * 256L;
             if (vec_ok && i + 4 <= n) {
-                *reinterpret_cast<uint32_t*>(out + i) = q4;
+                stream_store<true>(q4, reinterpret_cast<uint32_t*>(out + i));
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kQ8LutThreads) void quantize8_lut_kernel(const floa
                 }
                 const long i = base + sp * 256L;
                 if (vec_ok && i + 4 <= n) {
-                    *reinterpret_cast<uint32_t*>(out + i) = q4;
+                    stream_store<true>(q4, reinterpret_cast<uint32_t*>(out + i));
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -354,21 +354,21 @@ __global__ __launch_bounds__(256) void dequantize8_kernel(const float* __restric
     const long stride = static_cast<long>(gridDim.x) * 256 * 4;
     for (long i = (static_cast<long>(blockIdx.x) * 256 + threadIdx.x) * 4; i < n; i += stride) {
         if (vec_ok && i + 4 <= n) {
-            const uint32_t q4 = *reinterpret_cast<const uint32_t*>(A + i);
+            const uint32_t q4 = stream_load<true>(reinterpret_cast<const uint32_t*>(A + i));
             const float s = absmax[i >> bs_shift]; // blocksize >= 4 and i % 4 == 0: one block for the four
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 v[j] = rounded_f32(lut[(q4 >> (8 * j)) & 0xFFu] * s);
             if constexpr (sizeof(T) == 4) {
-                *reinterpret_cast<f32x4_t*>(out + i) = f32x4_t{v[0], v[1], v[2], v[3]};
+                stream_store<true>((f32x4_t{v[0], v[1], v[2], v[3]}), reinterpret_cast<f32x4_t*>(out + i));
             } else {
                 typedef T v4 __attribute__((ext_vector_type(4)));
                 v4 r;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     r[j] = static_cast<T>(v[j]);
-                *reinterpret_cast<v4*>(out + i) = r;
+                stream_store<true>(r, reinterpret_cast<v4*>(out + i));
             }
         } else {
             for (long e = i; e < i + 4 && e < n; ++e)

@@ -13,6 +13,24 @@
 
 namespace bnb {
 
+// Loads / stores of the standalone streaming kernels (quantize / dequantize: every byte is touched once). NT selects the
+// non-temporal cache policy. Measured on MI355X at 16.7 M elements (profiles/r3_stream_nt_policy_ab.txt): 16-bit quantize4
+// 12.4 -> 11.0 us, dequantize4 10.0 -> 9.0, FP4 quantize 15.2 -> 13.3, the 8-bit pair -4 ... -5 %; but fp32 dequantize4
+// 20.1 -> 26.7 us (a lane's 32 bytes leave as two 16-byte stores at a 32-byte stride: half lines written around the L2) and
+// fp32 quantize4 +2.5 % - so the 4-bit kernels use it for 16-bit tensors only.
+template <bool NT, typename V> __device__ __forceinline__ V stream_load(const V* ptr) {
+    if constexpr (NT)
+        return __builtin_nontemporal_load(ptr);
+    else
+        return *ptr;
+}
+template <bool NT, typename V> __device__ __forceinline__ void stream_store(V val, V* ptr) {
+    if constexpr (NT)
+        __builtin_nontemporal_store(val, ptr);
+    else
+        *ptr = val;
+}
+
 constexpr int kWave = 64;
 
 // quant_type codes on the C ABI (reference csrc/common.h:3-7)

@@ -21,14 +21,15 @@ constexpr int kDqThreads = 256;
 constexpr int kDqUnroll = 4;                              // packed dwords per lane
 constexpr int kDqTile = kDqThreads * kDqUnroll * 8;       // outputs per workgroup (8192)
 
-template <typename T> __device__ __forceinline__ void store8(T* __restrict__ out, long base, const float (&v)[8]) {
+// NT: non-temporal stores (the standalone stream; the row gather keeps the default policy - its output is read next)
+template <typename T, bool NT> __device__ __forceinline__ void store8(T* __restrict__ out, long base, const float (&v)[8]) {
     if constexpr (sizeof(T) == 2) {
         using V = __attribute__((ext_vector_type(8))) T;
         V r;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             r[i] = static_cast<T>(v[i]);
-        *reinterpret_cast<V*>(out + base) = r;
+        stream_store<NT>(r, reinterpret_cast<V*>(out + base));
     } else {
         using V = __attribute__((ext_vector_type(4))) float;
         V r0, r1;
@@ -37,8 +38,8 @@ template <typename T> __device__ __forceinline__ void store8(T* __restrict__ out
             r0[i] = v[i];
             r1[i] = v[4 + i];
         }
-        *reinterpret_cast<V*>(out + base) = r0;
-        *reinterpret_cast<V*>(out + base + 4) = r1;
+        stream_store<NT>(r0, reinterpret_cast<V*>(out + base));
+        stream_store<NT>(r1, reinterpret_cast<V*>(out + base + 4));
     }
 }
 
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(kDqThreads) void dequantize4_kernel(const uint8_t* 
 #pragma unroll
         for (int u = 0; u < kDqUnroll; ++u) {
             const long base = tile_base + (static_cast<long>(u) * kDqThreads + tid) * 8;
-            w[u] = *reinterpret_cast<const uint32_t*>(A + (base >> 1));
+            w[u] = stream_load<sizeof(T) == 2>(reinterpret_cast<const uint32_t*>(A + (base >> 1)));
             s[u] = absmax[base >> bs_shift];
         }
         __syncthreads();
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(kDqThreads) void dequantize4_kernel(const uint8_t* 
                 v[2 * b] = rounded_f32(code[byte >> 4] * s[u]);
                 v[2 * b + 1] = rounded_f32(code[byte & 0xF] * s[u]);
             }
-            store8<T>(out, base, v);
+            store8<T, sizeof(T) == 2>(out, base, v);
         }
     } else {
         __syncthreads();
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(kDqThreads) void dequantize4_rows_kernel(const uint
         v[2 * b] = valid ? rounded_f32(code[byte >> 4] * s) : __builtin_nanf("");
         v[2 * b + 1] = valid ? rounded_f32(code[byte & 0xF] * s) : __builtin_nanf("");
     }
-    store8<T>(out, t * row_len + col, v);
+    store8<T, false>(out, t * row_len + col, v);
 }
 
 template <typename T>

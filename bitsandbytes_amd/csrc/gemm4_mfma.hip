@@ -465,8 +465,9 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
                 const long o = static_cast<long>(m) * N + col;
                 if (hot_kslices == 1)
                     out[o] = static_cast<T>(acc[mt][t][r] + bv);
-                else
-                    p.ws[static_cast<long>(blockIdx.y) * M * N + o] = acc[mt][t][r];
+                else // (slabs go around the L2: less dirty data to write back at the kernel boundary - with the finalize kernel's
+                     // non-temporal loads C3 24.1 -> 23.4 us, 8192^2 M = 32 19.5 -> 18.4, profiles/r3_slab_cache_policy_ab.txt)
+                    __builtin_nontemporal_store(acc[mt][t][r], &p.ws[static_cast<long>(blockIdx.y) * M * N + o]);
             }
         }
     }
@@ -492,7 +493,8 @@ __global__ __launch_bounds__(256) void gemm4_finalize_kernel(const float* __rest
 #pragma unroll
             for (int j = 0; j < BATCH; ++j) {
                 const int sl = (s0 + j < kslices) ? s0 + j : kslices - 1; // clamp: a re-read, never out of range
-                w[j] = *reinterpret_cast<const f32x4*>(ws + static_cast<long>(sl) * total + i);
+                // (read once, written by another launch: non-temporal - 28672 x 8192 M = 64 62.3 -> 59.6 us)
+                w[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ws + static_cast<long>(sl) * total + i));
             }
 #pragma unroll
             for (int j = 0; j < BATCH; ++j) {
@@ -728,7 +730,7 @@ size_t gemm_4bit_rt_workspace_bytes(int M, int N, int K, int force_ks);
 void gemm_4bit_rt(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int force_waves,
-                  hipStream_t stream);
+                  int variant, hipStream_t stream);
 
 // gemm4_mfma_ps.hip (the pre-scaled-operand kernel: 32x32x16 MFMA, register ring, one barrier per 256 k)
 bool gemm_4bit_ps_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize);
@@ -847,7 +849,7 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
                             workspace, workspace_bytes, pks, pvar, knob0, stream);
     if (rt_selected(M, N, K, knob1, &fks, &fw) && gemm_4bit_rt_supported(dtype, A, B, code16, M, N, K, blocksize))
         return gemm_4bit_rt(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize,
-                            quant_type, workspace, workspace_bytes, fks, fw, stream);
+                            quant_type, workspace, workspace_bytes, fks, fw, knob0 & 3, stream);
     GemmArgs p;
     p.A = A;
     p.B = B;

@@ -120,7 +120,16 @@ __device__ __forceinline__ float rt_code_literal(int i, bool fp4) {
 // lanes of rows < M fetch (the rest is exec-masked), so a load instruction touches at most 16 lines either way - the
 // fragment-shaped load is only expensive when all 64 lanes take part - and 8 ds_write_b128 + 8 ds_read_b128 per chunk and
 // wavefront disappear from the LDS store path (13 cycles per wave-instruction).
-template <typename T, int MT, int WAVES, bool NESTED, bool DIRECT>
+//
+// BL (the M <= 4 instances; bnb_mi355x_set_tuning knob0 bit 0 switches it off for A/B runs): weights and activations are fetched through buffer descriptors - a 32-bit
+// per-lane offset computed once plus a scalar offset per chunk / row tile instead of 64-bit per-lane address arithmetic in
+// front of every load (16 wavefronts share four VALUs when the kernel starts).
+//
+// BS64 (nested instances only; the others decide at run time): the blocksize is 64 - one dword of 8-bit codes per chunk and row
+// instead of two bytes. A compile-time choice: as a run-time branch the two paths loaded into the same registers, and at their
+// join the compiler drained the queue (vmcnt(0) between a chunk's weight request and its scale / activation requests: every
+// chunk of a nested call paid an extra memory round trip - 4096^2 M = 3 6.7 us nested against 6.25 plain).
+template <typename T, int MT, int WAVES, bool NESTED, bool DIRECT, bool BL, bool BS64>
 __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     // hot arguments as separate scalars: preloaded into SGPRs by the command processor (14 dwords)
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, int hot_M, int hot_N,
@@ -161,6 +170,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     const int arow_l = DIRECT ? ln : r, ag_l = DIRECT ? lg : pp;
     const T* const abase = static_cast<const T*>(hot_A) + (ag_l & 1) * 32 + (ag_l >> 1) * 16;
     const long e0 = static_cast<long>(wrow) * K; // flat element index of the row start
+    // (BL: byte offsets are 32-bit and stay below the descriptors' 2^31 records - gemm_4bit_rt_supported)
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hot_B), 0, 0x7FFFFFFF, 0x00020000);
+    const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(hot_A), 0, 0x7FFFFFFF, 0x00020000);
+    const uint32_t w_off = static_cast<uint32_t>(wrow) * static_cast<uint32_t>(K >> 1) + static_cast<uint32_t>(pp * 16);
+    const uint32_t a_off = (static_cast<uint32_t>(m_base + arow_l) * static_cast<uint32_t>(K) +
+                            static_cast<uint32_t>((ag_l & 1) * 32 + (ag_l >> 1) * 16)) * static_cast<uint32_t>(sizeof(T));
 
     struct Raw {
         u32x4 w[2]; // 128 k each: lane (r, pp) holds k [128 h + 32 pp, + 32) of row r
@@ -171,6 +186,21 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     // full tile); those lanes hold zeros and the MFMA rows they feed are never stored.
     auto load_a_step = [&](Raw& raw, int c, int mt, int s) {
         const int row = m_base + mt * 16 + arow_l;
+        if constexpr (BL) {
+            if (row < M)
+                raw.a[s] = __builtin_bit_cast(
+                    u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                               rs_a, a_off + static_cast<uint32_t>((128 * (s >> 2) + 64 * ((s >> 1) & 1) + 8 * (s & 1)) * sizeof(T)),
+                               // (wavefront-uniform by construction; said explicitly, or the scalar offset arrives in a VGPR and every
+                               // load is wrapped in a readfirstlane loop - seen in the ISA of the first build)
+                               __builtin_amdgcn_readfirstlane((static_cast<uint32_t>(c) * static_cast<uint32_t>(kRtChunk) +
+                                                               static_cast<uint32_t>(mt * 16) * static_cast<uint32_t>(K)) *
+                                                              static_cast<uint32_t>(sizeof(T))),
+                               0));
+            else
+                raw.a[s] = u32x4{0, 0, 0, 0};
+            return;
+        }
         if (row < M)
             raw.a[s] = *reinterpret_cast<const u32x4*>(abase + static_cast<long>(row) * K + static_cast<long>(c) * kRtChunk +
                                                        128 * (s >> 2) + 64 * ((s >> 1) & 1) + 8 * (s & 1));
@@ -184,10 +214,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     };
     auto issue = [&](Raw& raw, int c) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-            raw.w[h] = *reinterpret_cast<const u32x4*>(wsrc + static_cast<long>(c) * 128 + h * 64);
+        for (int h = 0; h < 2; ++h) {
+            if constexpr (BL)
+                raw.w[h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         rs_w, w_off, __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(c) * 128u + static_cast<uint32_t>(h * 64)), 0));
+            else
+                raw.w[h] = *reinterpret_cast<const u32x4*>(wsrc + static_cast<long>(c) * 128 + h * 64);
+        }
         const long e = e0 + (static_cast<long>(c) << 8);
-        if (bs_shift == 6) {
+        if (NESTED ? BS64 : bs_shift == 6) {
             if constexpr (NESTED) {
                 raw.s[0] = *reinterpret_cast<const uint32_t*>(hot_absmax8 + (e >> 6));
                 raw.s[1] = __builtin_bit_cast(uint32_t, hot_absmax[e >> 14]);
@@ -197,13 +232,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
             }
         } else {
             if constexpr (NESTED) {
-                uint32_t q = 0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    q |= static_cast<uint32_t>(hot_absmax8[(e + b * 64) >> bs_shift]) << (8 * b);
-                raw.s[0] = q;
+                // The bytes stay apart until the chunk is consumed: packed here, the wavefront waited for them here - right
+                // behind their own request and in front of the activation loads (nested blocksize-128 calls ran 0.5 us behind
+                // blocksize 64, profiles/r3_rt_prefetch_ab.txt). A chunk's four 64-k sub-blocks lie in two blocks at blocksize
+                // 128 and in one above: sub-blocks 0 and 2 are fetched, 1 = 0 and 3 = 2.
+                raw.s[0] = hot_absmax8[e >> bs_shift];
+                raw.s[2] = hot_absmax8[(e + 128) >> bs_shift];
                 raw.s[1] = __builtin_bit_cast(uint32_t, hot_absmax[(e >> bs_shift) >> 8]);
-                raw.s[2] = raw.s[3] = 0;
+                raw.s[3] = 0;
             } else {
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
@@ -294,7 +330,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             // (copies first: __builtin_bit_cast applied to a vector-element lvalue reads element 0 - hipcc 7.2)
-            const uint32_t sb = sraw[b], s0 = sraw[0], s1 = sraw[1];
+            const uint32_t sb = sraw[b], s1 = sraw[1];
+            // (nested, blocksize >= 128: the two bytes fetched for sub-blocks 0 and 2 become the four codes here)
+            const uint32_t s0 = BS64 ? sraw[0] : sraw[0] * 0x0101u + sraw[2] * 0x01010000u;
             if constexpr (NESTED)
                 scale[b] = __fadd_rn(__fmul_rn(code2[(s0 >> (8 * b)) & 0xFFu], __builtin_bit_cast(float, s1)), offset);
             else
@@ -381,6 +419,7 @@ int rt_cu_count() { return device_cu_count_or_default(); }
 
 struct RtPlan {
     int ks, cps, waves, mt;
+    int bl = 0; // buffer-load addressing (template parameter BL)
 };
 
 // K slices only when the column tiles alone would leave nearly all of the chip idle (a second launch and a slab round trip
@@ -420,22 +459,39 @@ RtPlan rt_plan(int M, int N, int K, int force_ks) {
     return pl;
 }
 
-template <typename T, int MT, int WAVES, bool DIRECT = false>
-void rt_launch(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
-               const RtPlan& pl, const RtArgs& a, hipStream_t stream) {
+template <typename T, int MT, int WAVES, bool DIRECT, bool BL>
+void rt_launch_bl(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
+                  const RtPlan& pl, const RtArgs& a, hipStream_t stream) {
     const size_t lds = kRtLut + static_cast<size_t>(WAVES) * kRtScratch + 1024 + static_cast<size_t>(WAVES) * MT * 1024;
     dim3 grid((N + 15) / 16, pl.ks, (M + 16 * MT - 1) / (16 * MT));
-    if (absmax8 != nullptr) {
-        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, true, DIRECT>;
+    if (absmax8 != nullptr && (flags & 31) == 6) {
+        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, true, DIRECT, BL, true>;
+        static LdsLimit lim;
+        ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
+        hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, M, N, K, flags, pl.cps, pl.ks, a);
+    } else if (absmax8 != nullptr) {
+        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, true, DIRECT, BL, false>;
         static LdsLimit lim;
         ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
         hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, M, N, K, flags, pl.cps, pl.ks, a);
     } else {
-        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, false, DIRECT>;
+        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, false, DIRECT, BL, false>;
         static LdsLimit lim;
         ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
         hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, M, N, K, flags, pl.cps, pl.ks, a);
     }
+}
+
+template <typename T, int MT, int WAVES, bool DIRECT = false>
+void rt_launch(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
+               const RtPlan& pl, const RtArgs& a, hipStream_t stream) {
+    // buffer-load addressing: the direct-fragment instances only (M <= 4: 4096^2 6.25 -> 5.75 us, 8192^2 14.8 -> 13.7, 1376 x 4096
+    // 4.8 -> 4.5; with transposed fragments it measured neutral to +1 us - profiles/r3_rt_buffer_load_ab.txt)
+    if constexpr (DIRECT) {
+        if (pl.bl)
+            return rt_launch_bl<T, MT, WAVES, DIRECT, true>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+    }
+    return rt_launch_bl<T, MT, WAVES, DIRECT, false>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
 }
 
 template <typename T> void rt_launch_mt(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N,
@@ -460,7 +516,9 @@ template <typename T> void rt_launch_mt(const void* A, const uint8_t* B, const f
 
 bool gemm_4bit_rt_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize) {
     return dtype != 0 && code16 == nullptr && M >= 1 && N >= 1 && K >= kRtChunk && (K % kRtChunk) == 0 && blocksize >= 64 && is_pow2(blocksize) &&
-           aligned_to(A, 16) && aligned_to(B, 16);
+           aligned_to(A, 16) && aligned_to(B, 16) &&
+           // (byte offsets of the buffer loads are 32-bit and must stay below the descriptors' 2^31 records)
+           static_cast<long long>(N) * K < (1LL << 32) && static_cast<long long>(M) * K < (1LL << 30);
 }
 
 size_t gemm_4bit_rt_workspace_bytes(int M, int N, int K, int force_ks) {
@@ -474,10 +532,11 @@ size_t gemm_4bit_rt_workspace_bytes(int M, int N, int K, int force_ks) {
 void gemm_4bit_rt(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int force_waves,
-                  hipStream_t stream) {
+                  int variant, hipStream_t stream) {
     RtPlan pl = rt_plan(M, N, K, force_ks);
     if (force_waves == 8 || (force_waves == 16 && pl.mt == 1))
         pl.waves = force_waves;
+    pl.bl = (variant & 1) ? 0 : 1; // (knob0 bit 0 switches it OFF: A/B runs)
     float* ws = static_cast<float*>(workspace);
     const size_t slab = static_cast<size_t>(M) * N * sizeof(float);
     if (pl.ks > 1) {

@@ -236,10 +236,10 @@ __device__ __forceinline__ void load8(const T* __restrict__ A, long base, long n
     if (vec_ok) { // caller guarantees base + 8 <= n
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const u32x4* p = reinterpret_cast<const u32x4*>(A + base);
-        const u32x4 a = p[0];
+        const u32x4 a = stream_load<sizeof(T) == 2>(p);
         r.w[0] = a.x, r.w[1] = a.y, r.w[2] = a.z, r.w[3] = a.w;
         if constexpr (sizeof(T) == 4) {
-            const u32x4 b = p[1];
+            const u32x4 b = stream_load<sizeof(T) == 2>(p + 1);
             r.w[4] = b.x, r.w[5] = b.y, r.w[6] = b.z, r.w[7] = b.w;
         }
     } else {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void quantize4_kernel(const T* __restrict__ A,
             wq |= ((q[2 * i] << 4) | q[2 * i + 1]) << (8 * i);
 
         if (base + 8 <= n) {
-            *reinterpret_cast<uint32_t*>(out + (base >> 1)) = wq;
+            stream_store<sizeof(T) == 2>(wq, reinterpret_cast<uint32_t*>(out + (base >> 1)));
         } else {
             // ragged end: byte stores; an odd n pads the last low nibble with the code of s = 0
             const uint32_t pad = encode4<QT>(0.0f);
