@@ -79,6 +79,14 @@ def _declare(dll: ct.CDLL) -> None:
     sig(["bnb_mi355x_gemm_4bit_grad_input"], [_I32] + [_VOID_P] * 7 + [_I32] * 5 + [_VOID_P, ct.c_size_t, _VOID_P])
     sig(["bnb_mi355x_gemm_4bit_grad_input_workspace_bytes"], [_I32] * 3, ct.c_size_t)
     sig(["bnb_mi355x_gemm_4bit_grad_input_supported"], [_I32] * 5, _I32)
+    sig(["bnb_mi355x_peer_buffer_bytes"], [_I32, ct.c_size_t], ct.c_size_t)
+    sig(["bnb_mi355x_peer_alloc"], [ct.c_size_t], _VOID_P)
+    sig(["bnb_mi355x_peer_free", "bnb_mi355x_peer_close"], [_VOID_P])
+    sig(["bnb_mi355x_peer_export"], [_VOID_P, _VOID_P], _I32)
+    sig(["bnb_mi355x_peer_open"], [_VOID_P], _VOID_P)
+    # (bufs[], world, rank, src, out, bytes, max_bytes, stream)
+    sig(["bnb_mi355x_peer_allgather"], [_VOID_P, _I32, _I32, _VOID_P, _VOID_P, ct.c_size_t, ct.c_size_t, _VOID_P])
+    sig(["bnb_mi355x_peer_status"], [_VOID_P], _I32)
     sig(["bnb_mi355x_set_stream_tuning"], [_I32] * 5)
     sig(["bnb_mi355x_set_tuning"], [_I32] * 4)
     sig(["bnb_mi355x_set_stamp_buffer"], [_VOID_P])
@@ -110,5 +118,7 @@ EXPORTED_SYMBOLS = tuple(
     + ["get_context", "cget_managed_ptr", "bnb_mi355x_quantize_4bit", "bnb_mi355x_quantize_8bit", "bnb_mi355x_dequantize_4bit_rows",
        "bnb_mi355x_gemm_4bit", "bnb_mi355x_gemm_4bit_workspace_bytes", "bnb_mi355x_gemm_4bit_route", "bnb_mi355x_gemm_4bit_grouped",
        "bnb_mi355x_gemm_4bit_grad_input", "bnb_mi355x_gemm_4bit_grad_input_workspace_bytes", "bnb_mi355x_gemm_4bit_grad_input_supported",
+       "bnb_mi355x_peer_buffer_bytes", "bnb_mi355x_peer_alloc", "bnb_mi355x_peer_free", "bnb_mi355x_peer_export", "bnb_mi355x_peer_open",
+       "bnb_mi355x_peer_close", "bnb_mi355x_peer_allgather", "bnb_mi355x_peer_status",
        "bnb_mi355x_set_stream_tuning", "bnb_mi355x_set_tuning", "bnb_mi355x_set_stamp_buffer", "bnb_mi355x_version"]
 )

@@ -165,11 +165,16 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
     const int c_begin = blockIdx.y * per_wg;
     const int c_end = (c_begin + per_wg < chunks_total) ? c_begin + per_wg : chunks_total;
     const int n = (c_end > c_begin) ? c_end - c_begin : 0;
-    // profiling only (bnb_mi355x_set_stamp_buffer): 16 s_memtime stamps per wavefront
+    // profiling builds only (bnb_mi355x_set_stamp_buffer): 16 s_memtime stamps per wavefront. (Until round 3 the product build
+    // carried them as run-time branches on a NULL pointer - three of them inside the chunk loop.)
+#ifdef BNB_PROFILING
 #define BNB_PC_STAMP(i)                                                                            \
     if (p.dbg && lane == 0)                                                                        \
         p.dbg[((((static_cast<long>(blockIdx.x) * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (CW + kPcProducers)) + wave) * 16 + (i)] = \
             __builtin_amdgcn_s_memtime();
+#else
+#define BNB_PC_STAMP(i) {}
+#endif
     BNB_PC_STAMP(0)
 
     if (wave >= CW) {
@@ -849,7 +854,7 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
                             workspace, workspace_bytes, pks, pvar, knob0, stream);
     if (rt_selected(M, N, K, knob1, &fks, &fw) && gemm_4bit_rt_supported(dtype, A, B, code16, M, N, K, blocksize))
         return gemm_4bit_rt(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize,
-                            quant_type, workspace, workspace_bytes, fks, fw, knob0 & 3, stream);
+                            quant_type, workspace, workspace_bytes, fks, fw, knob0 & 1, stream);
     GemmArgs p;
     p.A = A;
     p.B = B;

@@ -76,7 +76,6 @@ template <> struct RtMma<f16> {
 constexpr int kRtLut = 32768;            // 256 entries x 32 copies x 4 B, at LDS address 0
 constexpr int kRtScratch = 2 * 1024 + 256; // per wavefront: two transposition tiles + the scale tile (16 x 16 B)
 constexpr int kRtChunk = 256;            // k per wavefront step: four 64-k MFMA pairs
-constexpr int kRtDirectMaxM = 4;         // batches up to this many rows load their activation fragments directly (see DIRECT)
 
 struct RtArgs {
 #ifdef BNB_PROFILING
@@ -116,14 +115,14 @@ __device__ __forceinline__ float rt_code_literal(int i, bool fp4) {
 // tile t + 1 refill the same registers); WAVES wavefronts split the workgroup's K range chunk by chunk (chunk c of the slice
 // goes to wavefront c % WAVES). grid = (ceil(N / 16), kslices, ceil(M / (16 MT))).
 //
-// DIRECT (M <= 4, one row tile): the activation fragments are loaded straight in MFMA shape, no transposition. Only the 16
-// lanes of rows < M fetch (the rest is exec-masked), so a load instruction touches at most 16 lines either way - the
-// fragment-shaped load is only expensive when all 64 lanes take part - and 8 ds_write_b128 + 8 ds_read_b128 per chunk and
-// wavefront disappear from the LDS store path (13 cycles per wave-instruction).
+// DIRECT (M <= 6, M <= 8 on small matrices - RtPlan::direct_max; one row tile): the activation fragments are loaded straight in
+// MFMA shape, no transposition. Only the lanes of rows < M fetch (the rest is exec-masked), so a load instruction touches few
+// lines either way - the fragment-shaped load is only expensive when all 64 lanes take part - and 8 ds_write_b128 +
+// 8 ds_read_b128 per chunk and wavefront disappear from the LDS store path (13 cycles per wave-instruction).
 //
-// BL (the M <= 4 instances; bnb_mi355x_set_tuning knob0 bit 0 switches it off for A/B runs): weights and activations are fetched through buffer descriptors - a 32-bit
-// per-lane offset computed once plus a scalar offset per chunk / row tile instead of 64-bit per-lane address arithmetic in
-// front of every load (16 wavefronts share four VALUs when the kernel starts).
+// BL (the DIRECT instances; bnb_mi355x_set_tuning knob0 bit 0 switches it off for A/B runs): weights and activations are
+// fetched through buffer descriptors - a 32-bit per-lane offset computed once plus a scalar offset per chunk / row tile instead
+// of 64-bit per-lane address arithmetic in front of every load (16 wavefronts share four VALUs when the kernel starts).
 //
 // BS64 (nested instances only; the others decide at run time): the blocksize is 64 - one dword of 8-bit codes per chunk and row
 // instead of two bytes. A compile-time choice: as a run-time branch the two paths loaded into the same registers, and at their
@@ -420,6 +419,7 @@ int rt_cu_count() { return device_cu_count_or_default(); }
 struct RtPlan {
     int ks, cps, waves, mt;
     int bl = 0; // buffer-load addressing (template parameter BL)
+    int direct_max = 4; // batches up to this many rows load their activation fragments directly (see DIRECT)
 };
 
 // K slices only when the column tiles alone would leave nearly all of the chip idle (a second launch and a slab round trip
@@ -456,6 +456,10 @@ RtPlan rt_plan(int M, int N, int K, int force_ks) {
     // (4096^2 M = 5 / 8: 6.40 / 6.47 vs 6.51 / 6.58 us; M = 16: 6.90 vs 6.78)
     if (M <= 8 && wgs * pl.ks <= cus && pl.cps >= 16)
         pl.waves = 16;
+    // direct activation fragments (measured, profiles/r3_rt_direct_fragments_m8_ab.txt, us direct vs transposed): M = 5 / 6 win on
+    // every shape (4096^2 5.7 / 5.8 vs 6.4, 11008 x 4096 11.1 / 11.6 vs 12.0, 8192^2 nested 14.1 / 14.8 vs 15.4 / 15.0); M = 8 wins
+    // on 4096^2 (6.05 vs 6.46) and loses 0.5 - 0.7 us on the larger matrices
+    pl.direct_max = static_cast<long>(N) * K <= (20L << 20) ? 8 : 6;
     return pl;
 }
 
@@ -487,6 +491,7 @@ void rt_launch(const void* A, const uint8_t* B, const float* absmax, const uint8
                const RtPlan& pl, const RtArgs& a, hipStream_t stream) {
     // buffer-load addressing: the direct-fragment instances only (M <= 4: 4096^2 6.25 -> 5.75 us, 8192^2 14.8 -> 13.7, 1376 x 4096
     // 4.8 -> 4.5; with transposed fragments it measured neutral to +1 us - profiles/r3_rt_buffer_load_ab.txt)
+    // (with transposed fragments the buffer-load addressing measured neutral: profiles/r3_rt_buffer_load_all_instances_ab.txt)
     if constexpr (DIRECT) {
         if (pl.bl)
             return rt_launch_bl<T, MT, WAVES, DIRECT, true>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
@@ -498,7 +503,7 @@ template <typename T> void rt_launch_mt(const void* A, const uint8_t* B, const f
                                         int K, int flags, const RtPlan& pl, const RtArgs& a, hipStream_t stream) {
     switch (pl.mt) {
     case 1:
-        if (M <= kRtDirectMaxM) { // activation fragments loaded straight in MFMA shape
+        if (M <= pl.direct_max) { // activation fragments loaded straight in MFMA shape
             if (pl.waves == 16)
                 return rt_launch<T, 1, 16, true>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
             return rt_launch<T, 1, 8, true>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
@@ -536,7 +541,10 @@ void gemm_4bit_rt(int dtype, const void* A, const uint8_t* B, const float* absma
     RtPlan pl = rt_plan(M, N, K, force_ks);
     if (force_waves == 8 || (force_waves == 16 && pl.mt == 1))
         pl.waves = force_waves;
-    pl.bl = (variant & 1) ? 0 : 1; // (knob0 bit 0 switches it OFF: A/B runs)
+    // knob0 bit 0 (A/B runs, tools/rt_variant_ab.py): round 2's form - direct fragments up to 4 rows, no buffer-load addressing
+    pl.bl = (variant & 1) ? 0 : 1;
+    if (variant & 1)
+        pl.direct_max = 4;
     float* ws = static_cast<float*>(workspace);
     const size_t slab = static_cast<size_t>(M) * N * sizeof(float);
     if (pl.ks > 1) {

@@ -144,9 +144,28 @@ void bnb_mi355x_gemm_4bit_grad_input(int dtype, const void* grad_out, const uint
 size_t bnb_mi355x_gemm_4bit_grad_input_workspace_bytes(int M, int N, int K);
 int bnb_mi355x_gemm_4bit_grad_input_supported(int dtype, int M, int N, int K, int blocksize);
 
+/* One-shot all-gather of small per-rank outputs over peer-mapped buffers (bitsandbytes_amd/csrc/peer_gather.hip): the exchange
+ * step of the N-sharded 4-bit linear layer at decode sizes (2.7 KB per rank), one kernel per collective, capturable in a hipGraph.
+ * Nothing in the reference to mirror (it has no collective code); bitsandbytes_amd/peer.py is the host side.
+ *   buffer_bytes : size of one rank's buffer for shards of up to max_bytes in a group of `world` (<= 8) ranks
+ *   alloc / free : fine-grained device memory on the current device, zeroed
+ *   export       : 64-byte hipIpc handle of an allocated buffer (0 = ok); open / close: map / unmap a peer's buffer
+ *   allgather    : bufs = HOST array of `world` device pointers (rank r's buffer as mapped into this process, bufs[rank] local);
+ *                  src = this rank's shard (bytes <= max_bytes), out = world x bytes, rank-major (all_gather_into_tensor's layout).
+ *                  Every rank of the group must call it the same number of times with the same `bytes`.
+ *   status       : 0, or 1 once a wait ran into its ~1 s bound because a peer never arrived (synchronises the device). */
+size_t bnb_mi355x_peer_buffer_bytes(int world, size_t max_bytes);
+void* bnb_mi355x_peer_alloc(size_t bytes);
+void bnb_mi355x_peer_free(void* buffer);
+int bnb_mi355x_peer_export(void* buffer, void* handle64);
+void* bnb_mi355x_peer_open(const void* handle64);
+void bnb_mi355x_peer_close(void* mapped);
+void bnb_mi355x_peer_allgather(void* const* bufs, int world, int rank, const void* src, void* out, size_t bytes, size_t max_bytes, bnb_stream_t stream);
+int bnb_mi355x_peer_status(const void* local_buffer);
+
 /* Tuning overrides for sweeps and tests (0 = built-in heuristic). reserved0: encoder of the 8-bit blockwise quantize - 1 =
  * cell-table kernel, 2 = byte-table kernel, anything else = by input size; reserved1: N slices of the fused backward (> 0; the
- * workspace-size query follows it). MFMA kernels: knob0 reserved,
+ * workspace-size query follows it). MFMA kernels: knob0 bit 0 = round 2's form of the register-transposed kernel (A/B runs),
  * knob1 = 100 * cfg + K-slice count (cfg 11-14 producer/consumer geometries, 20/21/22
  * register-transposed kernel with built-in / 8 / 16 wavefronts, 30 pre-scaled-operand kernel). Every setting
  * computes correct results - the knobs only choose a launch geometry. THREAD-LOCAL: a setting applies to the calls the

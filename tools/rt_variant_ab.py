@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--m", default="3,4,5,8,16,32,64")
     ap.add_argument("--repeat", type=int, default=1, help="measure every cell this many times (alternating), print the minimum")
+    ap.add_argument("--knobs", default="0,1", help="the two knob0 values to compare")
     args = ap.parse_args()
     print(torch.cuda.get_device_name(0), bnb.lib.bnb_mi355x_version().decode())
     cases = [(4096, 4096, 64, False), (4096, 4096, 64, True), (4096, 4096, 128, True), (8192, 8192, 64, False),
@@ -37,7 +38,8 @@ def main():
     if args.quick:
         cases = cases[:4]
     ms = tuple(int(v) for v in args.m.split(","))
-    print(f"{'N x K':>14s} {'bs':>4s} {'dq':>2s} {'M':>3s} {'knob0 = 0':>13s} {'knob0 = 1':>9s} {'same bits':>10s}   GB/s (%HBM)")
+    knobs = tuple(int(v) for v in args.knobs.split(","))
+    print(f"{'N x K':>14s} {'bs':>4s} {'dq':>2s} {'M':>3s} {'knob0 = ' + str(knobs[0]):>13s} {'knob0 = ' + str(knobs[1]):>9s} {'same bits':>10s}   GB/s (%HBM)")
     for (N, K, bs, dq) in cases:
         layers = make_layers(N, K, bs, "nf4", dq)
         for M in ms:
@@ -45,15 +47,15 @@ def main():
                 continue  # (routed to the producer/consumer kernel)
             x = torch.randn(M, K, device="cuda").bfloat16()
             row, outs = [], []
-            for knob0 in (0, 1):
+            for _ in knobs:
                 row.append(float("inf"))
                 outs.append(None)
             for _ in range(args.repeat):
-                for knob0 in (0, 1):
+                for i, knob0 in enumerate(knobs):
                     try:
                         bnb.lib.bnb_mi355x_set_tuning(0, 0, knob0, 0)
-                        row[knob0] = min(row[knob0], run(layers, x, 2))
-                        outs[knob0] = one(*layers[0], x).clone()
+                        row[i] = min(row[i], run(layers, x, 2))
+                        outs[i] = one(*layers[0], x).clone()
                     finally:
                         bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
             gbs = alg_bytes(M, N, K, bs, dq) / min(row) / 1e3
