@@ -156,13 +156,15 @@ def matmul_4bit(
     return result
 
 
-def matmul_4bit_grouped(A: torch.Tensor, weights, quant_states, biases=None):
+def matmul_4bit_grouped(A: torch.Tensor, weights, quant_states, biases=None, outs=None):
     """``[matmul_4bit(A, B_i, state_i, bias=bias_i) for i]`` for 4-bit weights that share their input - the Q/K/V
     projections of an attention block, the gate/up projections of an MLP. On MI355X a decode-sized batch (M <= 4) is
     ONE launch of the streaming kernel over the concatenated output rows (``bnb_mi355x_gemm_4bit_grouped``): one
     kernel boundary, one decode-table build and one activation copy per CU instead of one per matrix. Outputs are
     bit-identical to the separate calls; anything the grouped launch does not cover (autograd, mixed statistics
     formats, legacy [K, N] weights, CPU tensors) takes the separate calls.
+    ``outs``: optional pre-allocated contiguous result tensors (slices of one communication buffer - the sharded block of
+    ``parallel.py`` gathers a whole group with one collective); they are filled and returned.
     New functionality on top of the reference (which issues one gemm_4bit per Linear4bit, nn/modules.py:609-637)."""
     n = len(weights)
     biases = [None] * n if biases is None else list(biases)
@@ -170,7 +172,12 @@ def matmul_4bit_grouped(A: torch.Tensor, weights, quant_states, biases=None):
         raise ValueError("weights, quant_states and biases must have the same length")
 
     def separate():
-        return [matmul_4bit(A, w, s, bias=b) for w, s, b in zip(weights, quant_states, biases)]
+        res = [matmul_4bit(A, w, s, bias=b) for w, s, b in zip(weights, quant_states, biases)]
+        if outs is None:
+            return res
+        for o, r in zip(outs, res):
+            o.copy_(r.reshape(o.shape))
+        return list(outs)
 
     if n == 0:
         return []
@@ -193,4 +200,4 @@ def matmul_4bit_grouped(A: torch.Tensor, weights, quant_states, biases=None):
             mats.append((w.view(-1, 1), s.shape, s.state2.absmax, b, s.absmax, s.state2.code, s.offset))
         else:
             mats.append((w.view(-1, 1), s.shape, s.absmax, b, None, None, None))
-    return hip.gemm_4bit_grouped(A, mats, s0.blocksize, s0.quant_type)
+    return hip.gemm_4bit_grouped(A, mats, s0.blocksize, s0.quant_type, outs=outs)

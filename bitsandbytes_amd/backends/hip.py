@@ -370,12 +370,13 @@ def _(grad_out, B, shapeB: Sequence[int], absmax, blocksize: int, quant_type: st
     return out
 
 
-def gemm_4bit_grouped(A: torch.Tensor, mats, blocksize: int, quant_type: str):
+def gemm_4bit_grouped(A: torch.Tensor, mats, blocksize: int, quant_type: str, outs=None):
     """``[A @ dequant(B_i).T (+ bias_i) for i]`` for several packed weights that share the activations, in ONE launch
     of the streaming kernel when M <= 4 (``bnb_mi355x_gemm_4bit_grouped``; larger M and odd shapes are issued matrix
     by matrix inside the library). ``mats``: sequence of ``(B, shapeB, absmax, bias, absmax_8bit, absmax_code,
     absmax_offset)`` with the argument meaning of the ``gemm_4bit`` op; all matrices share K, blocksize, quant_type
-    and nested-ness. Results are bit-identical to separate ``gemm_4bit`` calls."""
+    and nested-ness. Results are bit-identical to separate ``gemm_4bit`` calls. ``outs``: optional pre-allocated contiguous
+    ``[*, N_i]`` result tensors (e.g. slices of one communication buffer); they are returned."""
     import ctypes as ct
 
     K = A.shape[-1]
@@ -393,9 +394,17 @@ def gemm_4bit_grouped(A: torch.Tensor, mats, blocksize: int, quant_type: str):
         # outside the grouped kernel's range - or a member that the single-matrix op hands to the MFMA kernels (three or four
         # rows on a big matrix: other arithmetic, and faster there): the single-matrix op (its own routing, its own split-K
         # workspace from torch's allocator)
-        return [torch.ops.bitsandbytes.gemm_4bit.default(A, B, shapeB, absmax, blocksize, quant_type, bias, a8, ac, ao)
-                for (B, shapeB, absmax, bias, a8, ac, ao) in mats]
+        res = [torch.ops.bitsandbytes.gemm_4bit.default(A, B, shapeB, absmax, blocksize, quant_type, bias, a8, ac, ao)
+               for (B, shapeB, absmax, bias, a8, ac, ao) in mats]
+        if outs is None:
+            return res
+        for o, r in zip(outs, res):
+            o.copy_(r.view(o.shape))
+        return list(outs)
     A = A.contiguous()
+    given = None if outs is None else list(outs)
+    if given is not None and len(given) != count:
+        raise ValueError("outs must have one tensor per matrix")
     keep, outs = [], []
     cols = {k: [] for k in ("B", "absmax", "a8", "ac", "ao", "out", "bias")}
     Ns = []
@@ -413,7 +422,12 @@ def gemm_4bit_grouped(A: torch.Tensor, mats, blocksize: int, quant_type: str):
             bias = bias.contiguous()
         B = B.contiguous()
         absmax = absmax.contiguous()
-        out = torch.empty((*A.shape[:-1], N), dtype=A.dtype, device=A.device)
+        if given is None:
+            out = torch.empty((*A.shape[:-1], N), dtype=A.dtype, device=A.device)
+        else:
+            out = given[len(outs)]
+            if out.dtype != A.dtype or out.device != A.device or out.numel() != M * N or not out.is_contiguous():
+                raise ValueError("outs[i] must be a contiguous [*, N_i] tensor of A's dtype on A's device")
         a8 = None if a8 is None else a8.contiguous()
         ac = None if ac is None else ac.contiguous()
         ao = None if ao is None else ao.to(dtype=torch.float32)

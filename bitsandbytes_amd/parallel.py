@@ -11,6 +11,12 @@ the backend is ``"nccl"``, gloo in the CPU tests) reassembles ``y[M, N]``. Nothi
 never split across ranks.
 
 One process per GPU; the process group is whatever the caller initialised.
+
+For a tensor-parallel decode (every shard launch is 3 - 4 us, every gather 2.7 KB per rank - boundaries and
+latency, not bandwidth) three more pieces: ``peer=`` (a :class:`bitsandbytes_amd.peer.PeerAllGather`: the gather as ONE kernel
+over peer-mapped buffers instead of a ring collective), :class:`ShardedLinear4bitGroup` (layers that share ``x`` - Q/K/V,
+gate/up: one grouped launch and ONE gather for the whole group) and :class:`GraphedBlock` (a whole block of such calls captured
+in one hipGraph per rank and replayed per token).
 """
 from __future__ import annotations
 
@@ -21,8 +27,17 @@ import torch.distributed as dist
 from torch import nn
 
 from . import functional as F
-from .autograd import matmul_4bit
+from .autograd import matmul_4bit, matmul_4bit_grouped
 from .functional import QuantState
+
+
+def _all_gather_rows(y2: torch.Tensor, world: int, group, peer) -> torch.Tensor:
+    """``[m, ns] -> [G * m, ns]`` rank-major: the one-shot peer kernel when given and the message fits, else the group's own."""
+    if peer is not None and y2.numel() * y2.element_size() <= peer.max_bytes:
+        return peer.all_gather(y2)
+    buf = torch.empty((world * y2.shape[0], y2.shape[1]), dtype=y2.dtype, device=y2.device)
+    dist.all_gather_into_tensor(buf, y2, group=group)
+    return buf
 
 
 def shard_quant_state(packed: torch.Tensor, state: QuantState, rank: int, world_size: int):
@@ -70,8 +85,11 @@ class ShardedLinear4bit(nn.Module):
 
     def __init__(self, packed_shard: torch.Tensor, quant_state: QuantState, out_features: int,
                  bias_shard: Optional[torch.Tensor] = None, group=None, gather_output: bool = True,
-                 always_gather: bool = False):
+                 always_gather: bool = False, peer=None):
         super().__init__()
+        # peer: a bitsandbytes_amd.peer.PeerAllGather of the same group - the gather of a decode-sized output is then one
+        # kernel over peer-mapped buffers (messages above its max_bytes still take the group's all-gather)
+        self.peer = peer
         # always_gather: issue the collective even in a group of one (a single-GPU smoke test of the RCCL path)
         self.always_gather = always_gather
         self.register_buffer("weight", packed_shard, persistent=False)
@@ -100,8 +118,7 @@ class ShardedLinear4bit(nn.Module):
         ns = y_local.shape[-1]
         y2 = y_local.reshape(-1, ns).contiguous()
         m = y2.shape[0]
-        buf = torch.empty((G * m, ns), dtype=y2.dtype, device=y2.device)  # rank-major concatenation
-        dist.all_gather_into_tensor(buf, y2, group=self.group)
+        buf = _all_gather_rows(y2, G, self.group, self.peer)  # rank-major concatenation
         if m == 1:
             return buf.view(*lead, G * ns)  # M == 1: rank-major already is feature-major
         return buf.view(G, m, ns).permute(1, 0, 2).reshape(*lead, G * ns)
@@ -112,7 +129,7 @@ class ShardedLinear4bit(nn.Module):
 
 
 def shard_linear4bit(layer, rank: Optional[int] = None, world_size: Optional[int] = None, group=None,
-                     gather_output: bool = True, always_gather: bool = False) -> ShardedLinear4bit:
+                     gather_output: bool = True, always_gather: bool = False, peer=None) -> ShardedLinear4bit:
     """Build this rank's :class:`ShardedLinear4bit` from an already-quantised ``Linear4bit``."""
     if rank is None:
         rank = dist.get_rank(group)
@@ -128,4 +145,93 @@ def shard_linear4bit(layer, rank: Optional[int] = None, world_size: Optional[int
     if layer.bias is not None:
         bias = layer.bias.data[rank * ns : (rank + 1) * ns].clone()
     return ShardedLinear4bit(packed_shard, shard_state, N, bias, group=group, gather_output=gather_output,
-                             always_gather=always_gather)
+                             always_gather=always_gather, peer=peer)
+
+
+class ShardedLinear4bitGroup(nn.Module):
+    """Row shards of several 4-bit linear layers that consume the SAME input (Q/K/V, gate/up): ``forward(x)`` returns the list of
+    full outputs, from ONE grouped launch (``matmul_4bit_grouped``: one kernel boundary for a decode-sized batch) writing straight
+    into one communication buffer and ONE all-gather of that buffer - instead of a launch and a collective per layer.
+    Values are those of the members called one by one."""
+
+    def __init__(self, shards, always_gather: bool = False):
+        super().__init__()
+        shards = list(shards)
+        if not shards:
+            raise ValueError("empty group")
+        self.shards = nn.ModuleList(shards)
+        self.group = shards[0].group
+        self.peer = shards[0].peer
+        self.always_gather = always_gather or any(s.always_gather for s in shards)
+        if any(s.group is not self.group for s in shards):
+            raise ValueError("all members must live in the same process group")
+
+    @property
+    def world_size(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def forward(self, x: torch.Tensor):
+        shards = list(self.shards)
+        lead = x.shape[:-1]
+        m = x.numel() // x.shape[-1] if x.shape[-1] else 0
+        ns = [int(s.quant_state.shape[0]) for s in shards]
+        # one buffer, member blocks [m, ns_i] one after the other: every block is a dense result tensor for the launch
+        flat = torch.empty((1, m * sum(ns)), dtype=x.dtype, device=x.device)
+        outs, off = [], 0
+        for n in ns:
+            outs.append(flat[0, off * m : (off + n) * m].view(m, n))
+            off += n
+        biases = [None if s.bias is None else (s.bias if s.bias.dtype == x.dtype else s.bias.to(x.dtype)) for s in shards]
+        matmul_4bit_grouped(x.reshape(m, -1), [s.weight for s in shards], [s.quant_state for s in shards], biases, outs=outs)
+        G = self.world_size
+        if G == 1 and not (self.always_gather and dist.is_initialized()):
+            return [o.view(*lead, n) for o, n in zip(outs, ns)]
+        buf = _all_gather_rows(flat, G, self.group, self.peer)  # [G, m * sum(ns)]
+        res, off = [], 0
+        for n in ns:
+            blk = buf[:, off * m : (off + n) * m]  # rank g's [m, n] block of this member
+            if m == 1:
+                res.append(blk.reshape(*lead, G * n))  # rank-major is feature-major
+            else:
+                res.append(blk.reshape(G, m, n).permute(1, 0, 2).reshape(*lead, G * n))
+            off += n
+        return res
+
+
+class GraphedBlock:
+    """A block of stream-ordered work - sharded launches, grouped launches, peer gathers, anything capturable - recorded ONCE into
+    a hipGraph per rank and replayed per call: the per-kernel boundary is paid by the GPU's command processor instead of by
+    Python and the launch path (at 3 - 4 us per shard launch the host is the bound otherwise - SURVEY §8e).
+    ``fn(*tensors) -> tensor | sequence of tensors``; the example inputs fix shapes and dtypes. Every rank must build and call its
+    GraphedBlock in the same order (the collectives inside are replayed, not renegotiated). Inference only."""
+
+    def __init__(self, fn, *example_inputs: torch.Tensor, warmup: int = 2):
+        self._static_in = [t.clone() for t in example_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.no_grad(), torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):  # lazy initialisation (workspaces, RCCL channels) happens outside the capture
+                fn(*self._static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            out = fn(*self._static_in)
+        self._single = isinstance(out, torch.Tensor)
+        self._static_out = [out] if self._single else list(out)
+
+    def __call__(self, *inputs: torch.Tensor):
+        if len(inputs) != len(self._static_in):
+            raise ValueError(f"expected {len(self._static_in)} inputs")
+        for dst, src in zip(self._static_in, inputs):
+            if dst.shape != src.shape or dst.dtype != src.dtype:
+                raise ValueError("GraphedBlock inputs must keep the shapes and dtypes of the example inputs")
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        self.graph.replay()
+        return self._static_out[0] if self._single else list(self._static_out)
+
+    @property
+    def inputs(self):
+        """The graph's own input tensors: write into them directly to skip the copy in ``__call__``."""
+        return list(self._static_in)

@@ -24,13 +24,6 @@ MAX_WORLD = 8
 DEFAULT_MAX_BYTES = 64 * 1024  # per rank; larger messages are bandwidth-bound: use the group's own all-gather
 
 
-class _RawDeviceBuffer:
-    """Zero-copy torch view of device memory the library allocated (``__cuda_array_interface__``)."""
-
-    def __init__(self, ptr: int, nbytes: int):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
-
-
 class PeerAllGather:
     """``all_gather(y_local) -> [G * m, ns]`` (rank-major, the layout of ``dist.all_gather_into_tensor``) for shards of at
     most ``max_bytes`` bytes. Every rank of ``group`` constructs one (collectively: the handles travel through the group) and

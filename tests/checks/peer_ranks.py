@@ -1,0 +1,85 @@
+"""Per-rank body of tests/test_gpu_peer.py: WORLD processes that share ONE GPU (cuda:0), rendezvous over gloo, gather buffers mapped
+into each other by hipIpc. Exercises bitsandbytes_amd.peer.PeerAllGather, ShardedLinear4bit(peer=), ShardedLinear4bitGroup and
+GraphedBlock with the peer kernel inside the graph. Prints "PEER_OK <rank>" on success."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bitsandbytes_amd as bnb  # noqa: E402
+import bitsandbytes_amd.nn as bnn  # noqa: E402
+from bitsandbytes_amd.peer import PeerAllGather  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    peer = PeerAllGather(max_bytes=64 * 1024)
+    try:
+        # ---- the collective itself: several sizes, aligned and not, many rounds (the double buffer turns over)
+        for it, (m, ns, dt) in enumerate([(1, 1376, torch.bfloat16), (1, 1376, torch.bfloat16), (4, 1376, torch.float16), (1, 7, torch.bfloat16),
+                                          (3, 129, torch.float32), (1, 16384, torch.float32)] * 3):
+            y = (torch.arange(m * ns, device=dev, dtype=torch.float32) % 251 + 1000 * rank + it).to(dt).view(m, ns)
+            got = peer.all_gather(y)
+            want = torch.cat([(torch.arange(m * ns, device=dev, dtype=torch.float32) % 251 + 1000 * r + it).to(dt).view(m, ns)
+                              for r in range(world)])
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (it, m, ns, dt)
+        peer.check()
+
+        # ---- the sharded layer through the peer kernel == the full layer, bit for bit
+        torch.manual_seed(3)  # same weights on every rank
+        for (N, K, M, dq) in ((1024, 2048, 1, False), (1024, 2048, 3, True), (11008, 4096, 1, False)):
+            layer = bnn.Linear4bit(K, N, bias=True, compute_dtype=torch.bfloat16, quant_type="nf4", compress_statistics=dq).to(dev)
+            x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+            sharded = bnb.shard_linear4bit(layer, rank, world, peer=peer)
+            y = sharded(x)
+            torch.cuda.synchronize()
+            y_full = layer(x)
+            assert y.shape == (M, N) and torch.equal(y, y_full), (N, K, M, dq)
+
+        # ---- a group (Q/K/V-like): one grouped launch + ONE gather == the members one by one
+        torch.manual_seed(5)
+        K = 2048
+        layers = [bnn.Linear4bit(K, n, bias=b, compute_dtype=torch.bfloat16, quant_type="nf4").to(dev) for n, b in ((2048, True), (512, False), (512, True))]
+        shards = [bnb.shard_linear4bit(layer, rank, world, peer=peer) for layer in layers]
+        group = bnb.ShardedLinear4bitGroup(shards)
+        for M in (1, 2, 5):
+            x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+            ys = group(x)
+            torch.cuda.synchronize()
+            for y, layer in zip(ys, layers):
+                assert torch.equal(y, layer(x)), M
+
+        # ---- the same group + one more sharded layer as ONE hipGraph per rank, replayed with fresh inputs
+        down = bnn.Linear4bit(512 * 1, 1024, bias=False, compute_dtype=torch.bfloat16, quant_type="nf4").to(dev)
+        down_s = bnb.shard_linear4bit(down, rank, world, peer=peer)
+
+        def block(x):
+            q, k, v = group(x)
+            return down_s(k * v) + q[..., :1024]
+
+        x0 = torch.randn(1, K, device=dev, dtype=torch.bfloat16)
+        graphed = bnb.GraphedBlock(block, x0)
+        for seed in range(4):
+            torch.manual_seed(100 + seed)  # same input on every rank
+            x = torch.randn(1, K, device=dev, dtype=torch.bfloat16)
+            y = graphed(x).clone()
+            torch.cuda.synchronize()
+            q, k, v = [layer(x) for layer in layers]
+            want = down(k * v) + q[..., :1024]
+            assert torch.equal(y, want), seed
+        peer.check()
+        print(f"PEER_OK {rank}", flush=True)
+    finally:
+        peer.close()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,17 @@ def _worker(rank, world, port, results):
                 y_loc = sharded.local_forward(x)
                 ns = N // world
                 ok &= bool(torch.equal(y_loc, y_full[:, rank * ns:(rank + 1) * ns]))
+        # a group of layers that share x: one buffer, one gather, the members' values
+        torch.manual_seed(11)
+        K = 256
+        layers = [Linear4bit(K, n, bias=b, quant_type="nf4", compress_statistics=dq).to("cpu") for n, b, dq in
+                  ((64, True, False), (32, False, False), (96, True, False))]
+        group = bnb.ShardedLinear4bitGroup([bnb.shard_linear4bit(layer, rank, world) for layer in layers])
+        for M in (1, 3):
+            x = torch.randn(M, K)
+            ys = group(x)
+            for y, layer in zip(ys, layers):
+                ok &= y.shape == (M, layer.out_features) and bool(torch.equal(y, layer(x)))
         results[rank] = ok
     finally:
         dist.destroy_process_group()

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Latency of the one-shot peer all-gather (bitsandbytes_amd/peer.py) per collective: WORLD processes sharing cuda:0 (what a 1-GPU
+box can run: same kernel, flags and ordering as across xGMI, without the link), hipGraph of 200 dependent collectives, next to
+torch.distributed's all_gather_into_tensor on an RCCL group of ONE rank (the protocol's fixed cost on this stack).
+    python tools/peer_gather_bench.py [world]          (spawns its own ranks)"""
+import os
+import socket
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def graph_us(fn, n=200, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (reps * n) * 1e3
+
+
+def rank_main():
+    import torch.distributed as dist
+
+    from bitsandbytes_amd.peer import PeerAllGather
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    peer = PeerAllGather(max_bytes=64 * 1024)
+    try:
+        for i, nbytes in enumerate((2752, 2752, 8192, 65536)):
+            y = torch.zeros(1, nbytes // 2, device="cuda", dtype=torch.bfloat16)
+            out = torch.empty(world, nbytes // 2, device="cuda", dtype=torch.bfloat16)
+            dist.barrier()
+            t = graph_us(lambda: peer.all_gather(y, out))
+            peer.check()
+            if rank == 0 and i > 0:  # (the first pass pays the processes' start-up skew)
+                print(f"peer all-gather, {world} process(es) on one GPU, {nbytes:6d} B per rank: {t:6.2f} us per collective", flush=True)
+    finally:
+        peer.close()
+        dist.destroy_process_group()
+
+
+def rccl_world_one():
+    import torch.distributed as dist
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        for nbytes in (2752, 65536):
+            y = torch.zeros(1, nbytes // 2, device="cuda", dtype=torch.bfloat16)
+            out = torch.empty(1, nbytes // 2, device="cuda", dtype=torch.bfloat16)
+            try:
+                t = graph_us(lambda: dist.all_gather_into_tensor(out, y))
+                how = "hipGraph"
+            except Exception:  # capture of the collective refused: eager enqueue
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(1000):
+                    dist.all_gather_into_tensor(out, y)
+                e1.record()
+                torch.cuda.synchronize()
+                t, how = e0.elapsed_time(e1), "eager"
+            print(f"RCCL all_gather_into_tensor, group of ONE rank, {nbytes:6d} B: {t:6.2f} us per collective ({how})", flush=True)
+    finally:
+        dist.destroy_process_group()
+
+
+def main():
+    if os.environ.get("PEER_BENCH_RANK") == "1":
+        return rank_main()
+    if os.environ.get("PEER_BENCH_RANK") == "rccl":
+        return rccl_world_one()
+    # (more than ~4 processes on ONE device are time-sliced by the driver - 10 ms per collective at 8: not a property of the kernel)
+    worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4]
+    for world in worlds:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)],
+                                  env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world),
+                                           PEER_BENCH_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(world)]
+        for p in procs:
+            p.wait(timeout=300)
+    subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, PEER_BENCH_RANK="rccl"), timeout=300)
+
+
+if __name__ == "__main__":
+    main()
