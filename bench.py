@@ -338,6 +338,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--no-rocprof", action="store_true", help="skip the rocprofv3 kernel-trace pass (roofline then falls back to HIP events)")
     ap.add_argument("--profile-out", default=None, help="copy the rocprofv3 kernel_stats.csv of the roofline pass here (e.g. profiles/r2_bench_kernel_stats.csv)")
+    ap.add_argument("--no-peer-gather", action="store_true", help="multi-GPU: RCCL all_gather_into_tensor per layer instead of the one-shot peer kernel")
     ap.add_argument("--sharded-path", action="store_true",
                     help="run the multi-GPU code path (ShardedLinear4bit shards, bucketed RCCL all-gather, per-layer "
                          "gather) even at world size 1: how that path is exercised on a 1-GPU box")
@@ -386,6 +387,7 @@ def main():
     flops_step = LAYERS * 2 * M * N * K
 
     # ---- one step = the 128 layers, each its own launch through the public op
+    peer = None
     if not multi:
         def step_fn():
             for q, st in layers:
@@ -395,7 +397,35 @@ def main():
         # layer the shard kernel, then the all-gather of that layer's shard outputs - the next layer needs the whole y -
         # i.e. LAYERS kernels + LAYERS collectives in stream order. (The bucketed form - one all-gather per step, legal only
         # because this benchmark's layers do not feed each other - is timed separately and reported as a side key.)
-        shards = [ShardedLinear4bit(q, st, out_features=world * N, group=None, always_gather=True) for q, st in layers]
+        # The gather: the one-shot peer kernel (bitsandbytes_amd.peer: 8 KB per rank is latency, not bandwidth) when it constructs
+        # on this node AND reproduces the group's own all-gather bit for bit on live data - its authors could only run it between
+        # processes sharing one GPU - else RCCL's all_gather_into_tensor. Every rank takes the same branch.
+        if not args.no_peer_gather:
+            try:
+                from bitsandbytes_amd.peer import PeerAllGather
+
+                peer = PeerAllGather(max_bytes=64 * 1024)
+                same = True
+                for i in range(16):
+                    t_chk = (torch.randn(M, N, device=device) + rank + i).bfloat16()
+                    want = torch.empty(world * M, N, device=device, dtype=torch.bfloat16)
+                    dist.all_gather_into_tensor(want, t_chk)
+                    same &= bool(torch.equal(peer.all_gather(t_chk), want))
+                peer.check()
+                agree = torch.tensor([1 if same else 0], device=device)
+                dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+                if int(agree.item()) != 1:
+                    raise RuntimeError("the peer all-gather does not reproduce the group's all-gather on this node")
+            except Exception as exc:  # noqa: BLE001
+                if rank == 0:
+                    print(f"bench: peer all-gather not used ({type(exc).__name__}: {exc}); RCCL all_gather_into_tensor per layer", file=sys.stderr)
+                if peer is not None:
+                    try:
+                        peer.close()
+                    except Exception:  # noqa: BLE001
+                        pass
+                peer = None
+        shards = [ShardedLinear4bit(q, st, out_features=world * N, group=None, always_gather=True, peer=peer) for q, st in layers]
         buckets = [torch.empty(LAYERS, M, N, device=device, dtype=torch.bfloat16) for _ in range(2)]
         gathered = [torch.empty(world * LAYERS, M, N, device=device, dtype=torch.bfloat16) for _ in range(2)]
 
@@ -583,9 +613,11 @@ def main():
                 "launch": (f"hipGraph replay per step ({LAYERS} dependent launches of bitsandbytes_amd.matmul_4bit), every step of warm-up and timed region"
                            if not multi else f"{LAYERS} x (shard kernel + all-gather) per step"),
                 "timed_region_s": round(elapsed, 6),
-                "parallelism": (f"rows sharded x{world} (parallel.ShardedLinear4bit.forward per layer: shard kernel + all_gather_into_tensor of "
-                                f"that layer's outputs over RCCL, in stream order, {'one hipGraph per step' if step_graph is not None else 'eager'}); "
-                                "N > 1 is unmeasured on hardware by the builder (1-GPU boxes only)") if multi else "single GPU",
+                "parallelism": (f"rows sharded x{world} (parallel.ShardedLinear4bit.forward per layer: shard kernel + the all-gather of "
+                                f"that layer's outputs, in stream order, {'one hipGraph per step' if step_graph is not None else 'eager'}; gather = "
+                                + ("one-shot peer kernel over hipIpc-mapped buffers (bitsandbytes_amd.peer), checked against RCCL's result at start-up"
+                                   if peer is not None else "RCCL all_gather_into_tensor")
+                                + "); N > 1 is unmeasured on hardware by the builder (1-GPU boxes only)") if multi else "single GPU",
             },
             "roofline": {
                 "bound": "hbm",
@@ -620,6 +652,8 @@ def main():
             except Exception as exc:  # baseline is informational; never lose the GPU line over it
                 line["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {exc}"}
     if multi:
+        if peer is not None:
+            peer.close()
         dist.destroy_process_group()
     if rank == 0:
         # the JSON line is the LAST line of stdout: RCCL prints its version banner through C stdio, which is block-buffered

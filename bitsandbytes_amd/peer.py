@@ -41,30 +41,44 @@ class PeerAllGather:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._mapped = []
         self._local = None
+        # Every step below is collective and none may leave the ranks disagreeing about whether the object exists: failures are
+        # carried to the exchanges as values, and every rank raises - or none does.
+        handle = ct.create_string_buffer(64)
         with torch.cuda.device(self.device):
             nbytes = lib.bnb_mi355x_peer_buffer_bytes(self.world, self.max_bytes)
             self._local = lib.bnb_mi355x_peer_alloc(nbytes)
-            if not self._local:
-                raise RuntimeError("PeerAllGather: could not allocate fine-grained device memory")
-            handle = ct.create_string_buffer(64)
-            if lib.bnb_mi355x_peer_export(ct.c_void_p(self._local), handle) != 0:
-                raise RuntimeError("PeerAllGather: hipIpcGetMemHandle failed")
-            mine = (handle.raw, torch.cuda.get_device_properties(self.device).name)
-            everyone = [None] * self.world
-            dist.all_gather_object(everyone, mine, group=group)
-            ptrs = []
-            for r, (raw, _name) in enumerate(everyone):
-                if r == self.rank:
-                    ptrs.append(self._local)
-                    continue
-                p = lib.bnb_mi355x_peer_open(ct.create_string_buffer(raw, 64))
-                if not p:
-                    raise RuntimeError(f"PeerAllGather: could not map the buffer of rank {r} (no peer access between the devices?)")
-                self._mapped.append(p)
-                ptrs.append(p)
-            self._bufs = (ct.c_void_p * self.world)(*ptrs)
-        # nobody may store into a buffer that its owner has not finished zeroing / exporting
-        dist.barrier(group=group)
+            exported = bool(self._local) and lib.bnb_mi355x_peer_export(ct.c_void_p(self._local), handle) == 0
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, handle.raw if exported else None, group=group)
+        ptrs, problem = [], None
+        if any(raw is None for raw in everyone):
+            problem = "a rank could not allocate or export its fine-grained buffer"
+        else:
+            with torch.cuda.device(self.device):
+                for r, raw in enumerate(everyone):
+                    if r == self.rank:
+                        ptrs.append(self._local)
+                        continue
+                    p = lib.bnb_mi355x_peer_open(ct.create_string_buffer(raw, 64))
+                    if not p:
+                        problem = f"rank {self.rank} could not map the buffer of rank {r} (no peer access between the devices?)"
+                        break
+                    self._mapped.append(p)
+                    ptrs.append(p)
+        problems = [None] * self.world
+        dist.all_gather_object(problems, problem, group=group)  # also: nobody stores into a buffer its owner has not zeroed yet
+        problems = [q for q in problems if q]
+        if problems:
+            self._release()
+            raise RuntimeError("PeerAllGather: " + "; ".join(problems))
+        self._bufs = (ct.c_void_p * self.world)(*ptrs)
+
+    def _release(self) -> None:
+        for p in self._mapped:
+            lib.bnb_mi355x_peer_close(ct.c_void_p(p))
+        if self._local:
+            lib.bnb_mi355x_peer_free(ct.c_void_p(self._local))
+        self._mapped, self._local = [], None
 
     def all_gather(self, y_local: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         y2 = y_local.reshape(-1, y_local.shape[-1]).contiguous()
@@ -97,17 +111,10 @@ class PeerAllGather:
             dist.barrier(group=self.group)  # no peer is still storing into a buffer that is about to go away
         except Exception:  # the group may already be gone at interpreter exit
             pass
-        for p in self._mapped:
-            lib.bnb_mi355x_peer_close(ct.c_void_p(p))
-        lib.bnb_mi355x_peer_free(ct.c_void_p(self._local))
-        self._mapped, self._local = [], None
+        self._release()
 
     def __del__(self):
         try:
-            if self._local is not None:
-                for p in self._mapped:
-                    lib.bnb_mi355x_peer_close(ct.c_void_p(p))
-                lib.bnb_mi355x_peer_free(ct.c_void_p(self._local))
-                self._mapped, self._local = [], None
+            self._release()
         except Exception:
             pass

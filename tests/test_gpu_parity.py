@@ -1667,6 +1667,8 @@ def test_bench_multi_gpu_code_path_at_world_size_one():
         assert key in line, key
     assert line["n_gpus"] == 1 and line["steps"] == 6 and line["value"] > 0
     assert "ShardedLinear4bit" in line["config"]["parallelism"] and line["bucketed_gather"]["us_per_layer"] > 0
+    # the per-layer gather is the one-shot peer kernel wherever it constructs and reproduces RCCL's result (it must, here)
+    assert "one-shot peer kernel" in line["config"]["parallelism"], (line["config"]["parallelism"], r.stderr[-2000:])
 
 
 def test_sharded_linear4bit_over_rccl_two_ranks():
