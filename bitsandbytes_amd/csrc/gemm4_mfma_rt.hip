@@ -458,7 +458,8 @@ RtPlan rt_plan(int M, int N, int K, int force_ks) {
         pl.waves = 16;
     // direct activation fragments (measured, profiles/r3_rt_direct_fragments_m8_ab.txt, us direct vs transposed): M = 5 / 6 win on
     // every shape (4096^2 5.7 / 5.8 vs 6.4, 11008 x 4096 11.1 / 11.6 vs 12.0, 8192^2 nested 14.1 / 14.8 vs 15.4 / 15.0); M = 8 wins
-    // on 4096^2 (6.05 vs 6.46) and loses 0.5 - 0.7 us on the larger matrices
+    // on 4096^2 (6.05 vs 6.46) and loses 0.5 - 0.7 us on the larger matrices; above 8 rows the direct form loses everywhere
+    // (4096^2 M = 12 / 16 7.1 / 7.7 vs 6.65 / 6.74, profiles/r3_rt_direct_fragments_m16_ab.txt)
     pl.direct_max = static_cast<long>(N) * K <= (20L << 20) ? 8 : 6;
     return pl;
 }
