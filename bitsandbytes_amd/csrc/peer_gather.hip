@@ -20,7 +20,7 @@
 //    to finish e, and the peer sends that at the start of its own launch e, i.e. after everything it enqueued before - its
 //    reads of the result of e - 2 included).
 //  * Order: payload stores (16-byte where alignment allows), system-scope release fence, barrier, then ONE system-scope
-//    atomic store of the flag; the reader polls its own flag word with system-scope acquire loads (bounded: ~1 s, then the
+//    atomic store of the flag; the reader polls its own flag word with system-scope acquire loads (bounded - tens of seconds by default - then the
 //    status word is set and the launch ends instead of hanging the queue) and only then lets the launch end - whatever runs
 //    next on the stream sees complete data.
 #include "bnb_common.h"
@@ -178,8 +178,14 @@ void bnb_mi355x_peer_allgather(void* const* bufs, int world, int rank, const voi
     for (int r = 0; r < kPeerMaxWorld; ++r)
         b.base[r] = static_cast<unsigned char*>(r < world ? bufs[r] : nullptr);
     const uint32_t stride = static_cast<uint32_t>((max_bytes + 255) & ~static_cast<size_t>(255));
-    // ~1 s: s_sleep 8 = 512 cycles plus the load round trip, ~1 us per poll
-    const uint32_t spin_bound = 1000000u;
+    // A poll is s_sleep 8 (512 cycles) plus a system-scope load round trip: ~1 us. 30 M polls = tens of seconds: long enough for
+    // any skew between healthy ranks (a rank that is still compiling, logging, loading), short enough that a dead peer ends as
+    // an error (status word, PeerAllGather.check()) instead of a queue that never drains. BNB_MI355X_PEER_WAIT_POLLS overrides.
+    static const uint32_t spin_bound = [] {
+        const char* e = getenv("BNB_MI355X_PEER_WAIT_POLLS");
+        const long long v = e ? atoll(e) : 0;
+        return static_cast<uint32_t>(v > 0 && v < 4000000000LL ? v : 30000000LL);
+    }();
     hipLaunchKernelGGL(peer_allgather_kernel, dim3(world), dim3(kPeerThreads), 0, static_cast<hipStream_t>(stream), b,
                        static_cast<const unsigned char*>(src), static_cast<unsigned char*>(out), static_cast<uint32_t>(bytes), stride, rank,
                        world, spin_bound);

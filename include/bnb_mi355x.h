@@ -153,7 +153,8 @@ int bnb_mi355x_gemm_4bit_grad_input_supported(int dtype, int M, int N, int K, in
  *   allgather    : bufs = HOST array of `world` device pointers (rank r's buffer as mapped into this process, bufs[rank] local);
  *                  src = this rank's shard (bytes <= max_bytes), out = world x bytes, rank-major (all_gather_into_tensor's layout).
  *                  Every rank of the group must call it the same number of times with the same `bytes`.
- *   status       : 0, or 1 once a wait ran into its ~1 s bound because a peer never arrived (synchronises the device). */
+ *   status       : 0, or 1 once a wait ran into its bound (tens of seconds; BNB_MI355X_PEER_WAIT_POLLS) because a peer never arrived
+ *                  (synchronises the device). */
 size_t bnb_mi355x_peer_buffer_bytes(int world, size_t max_bytes);
 void* bnb_mi355x_peer_alloc(size_t bytes);
 void bnb_mi355x_peer_free(void* buffer);
