@@ -854,7 +854,7 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
                             workspace, workspace_bytes, pks, pvar, knob0, stream);
     if (rt_selected(M, N, K, knob1, &fks, &fw) && gemm_4bit_rt_supported(dtype, A, B, code16, M, N, K, blocksize))
         return gemm_4bit_rt(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize,
-                            quant_type, workspace, workspace_bytes, fks, fw, knob0 & 3, stream);
+                            quant_type, workspace, workspace_bytes, fks, fw, knob0 & 1, stream);
     GemmArgs p;
     p.A = A;
     p.B = B;

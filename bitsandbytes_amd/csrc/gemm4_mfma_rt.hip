@@ -75,8 +75,6 @@ template <> struct RtMma<f16> {
 
 constexpr int kRtLut = 32768;            // 256 entries x 32 copies x 4 B, at LDS address 0
 constexpr int kRtScratch = 2 * 1024 + 256; // per wavefront: two transposition tiles + the scale tile (16 x 16 B)
-constexpr int kRtImage = 8 * 512;          // (AL == 2) + the activation image: 8 rows x 256 k
-constexpr int rt_scratch(int al) { return kRtScratch + (al == 2 ? kRtImage : 0); }
 constexpr int kRtChunk = 256;            // k per wavefront step: four 64-k MFMA pairs
 
 struct RtArgs {
@@ -122,20 +120,21 @@ __device__ __forceinline__ float rt_code_literal(int i, bool fp4) {
 // lines either way - the fragment-shaped load is only expensive when all 64 lanes take part - and 8 ds_write_b128 +
 // 8 ds_read_b128 per chunk and wavefront disappear from the LDS store path (13 cycles per wave-instruction).
 //
-// AL (activation loads of the DIRECT instances; bnb_mi355x_set_tuning knob0 selects 0 / 1 for A/B runs): 0 = pointer loads; 1 =
-// weights and activations through buffer descriptors - a 32-bit per-lane offset computed once plus a scalar offset per chunk
-// instead of 64-bit per-lane address arithmetic in front of every load (16 wavefronts share four VALUs when the kernel starts);
-// 2 = 1 with the chunk's activations fetched COALESCED (a load instruction = two rows x 512 contiguous bytes, at most four
-// instructions for up to eight rows) into a wavefront-private LDS image from which the lanes of rows < M gather their eight
-// fragments: the fragment-shaped loads of 1 cost the CU's address unit one look-up per 16-byte piece - 16 wavefronts x 8
-// instructions x 4 M pieces, ~2000 (M = 4) to ~4000 (M = 8) cycles before the last wavefront's requests are out
-// (profiles/r3_timeline_rt_direct.txt: loads issued 4000 cycles after the wavefront's start, median).
+// BL (every instance; bnb_mi355x_set_tuning knob0 bit 0 selects round 2's form for A/B runs): weights and activations are
+// fetched through buffer descriptors - a 32-bit per-lane offset computed once plus a scalar offset per chunk / row tile instead
+// of 64-bit per-lane address arithmetic in front of every load (16 wavefronts share four VALUs when the kernel starts) - and,
+// what matters more, WITHOUT branches: a row past the end of the batch, or a wavefront without a chunk, is an out-of-range
+// offset (zeros, nothing fetched) instead of an exec-masked region. With branches around the loads the compiler cannot count
+// what is in flight at the top of the chunk loop and drains the queue there (vmcnt(1), vmcnt(0) in the ISA of round 2's loop):
+// the weights - requested first - were not transposed and looked up before the activation fragments - requested last, ~4000
+// cycles into the kernel (profiles/r3_timeline_rt_direct.txt) - had landed too. Now the top of the loop waits vmcnt(9), (8)
+// for the weights and 7 ... 0 fragment by fragment (profiles/r3_rt_branch_free_loads_ab.txt).
 //
 // BS64 (nested instances only; the others decide at run time): the blocksize is 64 - one dword of 8-bit codes per chunk and row
 // instead of two bytes. A compile-time choice: as a run-time branch the two paths loaded into the same registers, and at their
 // join the compiler drained the queue (vmcnt(0) between a chunk's weight request and its scale / activation requests: every
 // chunk of a nested call paid an extra memory round trip - 4096^2 M = 3 6.7 us nested against 6.25 plain).
-template <typename T, int MT, int WAVES, bool NESTED, bool DIRECT, int AL, bool BS64>
+template <typename T, int MT, int WAVES, bool NESTED, bool DIRECT, bool BL, bool BS64>
 __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     // hot arguments as separate scalars: preloaded into SGPRs by the command processor (14 dwords)
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, int hot_M, int hot_N,
@@ -159,15 +158,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     ce = (ce < (K >> 8)) ? ce : (K >> 8);
 
     // LDS map: table | per-wavefront scratch (tile 0, tile 1, scale tile) | nested absmax code (1 KiB) | parked partial tiles
-    constexpr int SCR = rt_scratch(AL);
-    constexpr bool BL = AL != 0;
-    unsigned char* const sc = smem + kRtLut + wave * SCR;
-    u32x4* const image = reinterpret_cast<u32x4*>(sc + kRtScratch); // (AL == 2) [8 rows][32 pieces of 16 B], swizzled
+    unsigned char* const sc = smem + kRtLut + wave * kRtScratch;
     u32x4* const tile0 = reinterpret_cast<u32x4*>(sc);
     u32x4* const tile1 = reinterpret_cast<u32x4*>(sc + 1024);
     u32x4* const stile = reinterpret_cast<u32x4*>(sc + 2048);
-    float* const code2 = reinterpret_cast<float*>(smem + kRtLut + WAVES * SCR);
-    unsigned char* const red = smem + kRtLut + WAVES * SCR + 1024; // [WAVES][MT][64 lanes][16 B]
+    float* const code2 = reinterpret_cast<float*>(smem + kRtLut + WAVES * kRtScratch);
+    unsigned char* const red = smem + kRtLut + WAVES * kRtScratch + 1024; // [WAVES][MT][64 lanes][16 B]
 
     // ---- sources. Rows past the end (ragged N or M) re-read the last row: MFMA rows / columns are independent and those
     // results are never stored, so no masking instructions are needed.
@@ -219,27 +215,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
         else
             raw.a[s] = u32x4{0, 0, 0, 0};
     };
-    // (AL == 2) instruction i fetches rows 2i, 2i + 1 of the chunk: lane l = 16-byte piece l % 32 of row 2i + l / 32
-    const int cl_row = lane >> 5, cl_piece = lane & 31;
-    const uint32_t cl_off = (static_cast<uint32_t>(m_base + cl_row) * static_cast<uint32_t>(K)) * static_cast<uint32_t>(sizeof(T)) +
-                            static_cast<uint32_t>(cl_piece * 16);
     auto load_a = [&](Raw& raw, int c, int mt) {
-        if constexpr (AL == 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                {
-                    const uint32_t inval = (m_base + 2 * i + cl_row < M && c < ce) ? 0u : kOob;
-                    raw.a[i] = __builtin_bit_cast(
-                        u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                   rs_a, cl_off | inval,
-                                   __builtin_amdgcn_readfirstlane((static_cast<uint32_t>(c) * static_cast<uint32_t>(kRtChunk) +
-                                                                   static_cast<uint32_t>(2 * i) * static_cast<uint32_t>(K)) *
-                                                                  static_cast<uint32_t>(sizeof(T))),
-                                   0));
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int s = 0; s < 8; ++s)
             load_a_step(raw, c, mt, s);
@@ -379,27 +355,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
         }
         if (c == cb + wave)
             BNB_RT_STAMP(4)
-        u32x4 afd[8]; // (AL == 2) the lane's eight fragments, gathered from the wavefront's image
-        if constexpr (AL == 2) {
-            // piece p of row m sits at slot p ^ f(m), f(m) = (m & 1) | (m & 2) << 2: rows 0 .. 3 read four different 16-byte
-            // positions mod 16 for the same fragment (a row is 512 B = a whole number of bank rounds: unswizzled, every row
-            // would hit the same banks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = 2 * i + cl_row;
-                if (m_base + m < M)
-                    image[m * 32 + (cl_piece ^ ((m & 1) | ((m & 2) << 2)))] = raw.a[i];
-            }
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                // fragment s of lane (ln, lg) = k [128 (s >> 2) + 64 ((s >> 1) & 1) + 8 (s & 1) + 32 (lg & 1) + 16 (lg >> 1), + 8)
-                const int piece = 16 * (s >> 2) + 8 * ((s >> 1) & 1) + (s & 1) + 4 * (lg & 1) + 2 * (lg >> 1);
-                if (ln < 8 && m_base + ln < M)
-                    afd[s] = image[ln * 32 + (piece ^ ((ln & 1) | ((ln & 2) << 2)))];
-                else
-                    afd[s] = u32x4{0, 0, 0, 0};
-            }
-        }
         u32x4 bfr[8]; // decoded weight fragments of the chunk: produced with the first activation tile, reused by the others
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -411,9 +366,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
                     const int h = blk >> 1, j = 2 * (blk & 1) + i, s = 4 * h + j;
                     u32x4* const tile = (s & 1) ? tile1 : tile0;
                     u32x4 af;
-                    if constexpr (AL == 2) {
-                        af = afd[s];
-                    } else if constexpr (DIRECT) {
+                    if constexpr (DIRECT) {
                         af = raw.a[s];
                     } else {
                         tile[wslot] = raw.a[s];
@@ -481,7 +434,7 @@ int rt_cu_count() { return device_cu_count_or_default(); }
 
 struct RtPlan {
     int ks, cps, waves, mt;
-    int bl = 0; // activation loads of the direct instances (template parameter AL)
+    int bl = 0; // branch-free buffer loads (template parameter BL)
     int direct_max = 4; // batches up to this many rows load their activation fragments directly (see DIRECT)
 };
 
@@ -527,23 +480,23 @@ RtPlan rt_plan(int M, int N, int K, int force_ks) {
     return pl;
 }
 
-template <typename T, int MT, int WAVES, bool DIRECT, int AL>
+template <typename T, int MT, int WAVES, bool DIRECT, bool BL>
 void rt_launch_bl(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
                   const RtPlan& pl, const RtArgs& a, hipStream_t stream) {
-    const size_t lds = kRtLut + static_cast<size_t>(WAVES) * rt_scratch(AL) + 1024 + static_cast<size_t>(WAVES) * MT * 1024;
+    const size_t lds = kRtLut + static_cast<size_t>(WAVES) * kRtScratch + 1024 + static_cast<size_t>(WAVES) * MT * 1024;
     dim3 grid((N + 15) / 16, pl.ks, (M + 16 * MT - 1) / (16 * MT));
     if (absmax8 != nullptr && (flags & 31) == 6) {
-        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, true, DIRECT, AL, true>;
+        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, true, DIRECT, BL, true>;
         static LdsLimit lim;
         ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
         hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, M, N, K, flags, pl.cps, pl.ks, a);
     } else if (absmax8 != nullptr) {
-        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, true, DIRECT, AL, false>;
+        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, true, DIRECT, BL, false>;
         static LdsLimit lim;
         ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
         hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, M, N, K, flags, pl.cps, pl.ks, a);
     } else {
-        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, false, DIRECT, AL, false>;
+        auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, false, DIRECT, BL, false>;
         static LdsLimit lim;
         ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
         hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, M, N, K, flags, pl.cps, pl.ks, a);
@@ -553,16 +506,9 @@ void rt_launch_bl(const void* A, const uint8_t* B, const float* absmax, const ui
 template <typename T, int MT, int WAVES, bool DIRECT = false>
 void rt_launch(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
                const RtPlan& pl, const RtArgs& a, hipStream_t stream) {
-    // buffer-load addressing: the direct-fragment instances only (M <= 4: 4096^2 6.25 -> 5.75 us, 8192^2 14.8 -> 13.7, 1376 x 4096
-    // 4.8 -> 4.5; with transposed fragments it measured neutral to +1 us - profiles/r3_rt_buffer_load_ab.txt)
-    // (with transposed fragments the buffer-load addressing measured neutral: profiles/r3_rt_buffer_load_all_instances_ab.txt)
-    if constexpr (DIRECT) {
-        if (pl.bl == 2 && M <= 8)
-            return rt_launch_bl<T, MT, WAVES, DIRECT, 2>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
-    }
     if (pl.bl)
-        return rt_launch_bl<T, MT, WAVES, DIRECT, 1>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
-    return rt_launch_bl<T, MT, WAVES, DIRECT, 0>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+        return rt_launch_bl<T, MT, WAVES, DIRECT, true>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+    return rt_launch_bl<T, MT, WAVES, DIRECT, false>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
 }
 
 template <typename T> void rt_launch_mt(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N,
@@ -608,7 +554,7 @@ void gemm_4bit_rt(int dtype, const void* A, const uint8_t* B, const float* absma
     if (force_waves == 8 || (force_waves == 16 && pl.mt == 1))
         pl.waves = force_waves;
     // knob0 bit 0 (A/B runs, tools/rt_variant_ab.py): round 2's form - direct fragments up to 4 rows, no buffer-load addressing
-    pl.bl = (variant & 1) ? 0 : (variant & 2) ? 2 : 1;
+    pl.bl = (variant & 1) ? 0 : 1;
     if (variant & 1)
         pl.direct_max = 4;
     float* ws = static_cast<float*>(workspace);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of a build variant of the register-transposed MFMA kernel (bnb_mi355x_set_tuning knob0 bit 0; in round 3: BL = buffer-load
-addressing; the prefetching loop measured with this tool is recorded in profiles/r3_rt_prefetch_ab.txt) against the shipped
-loop (knob0 = 0), built-in routing otherwise: us per launch over an HBM-resident rotation of distinct layers, hipGraph-replayed
+"""A/B of two forms of the register-transposed MFMA kernel selected by bnb_mi355x_set_tuning knob0: 0 = shipped, 1 = round 2's
+form (pointer loads, exec-masked rows, direct fragments up to 4 rows); other values were one-off experiment builds whose tables
+are in profiles/r3_rt_*_ab.txt. Built-in routing otherwise: us per launch over an HBM-resident rotation of distinct layers, hipGraph-replayed
 (launch-to-launch time in a dependent stream), plus a bit comparison of the two results (same arithmetic, same order of the
 sums: they must be equal)."""
 import argparse
