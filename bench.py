@@ -401,30 +401,42 @@ def main():
         # on this node AND reproduces the group's own all-gather bit for bit on live data - its authors could only run it between
         # processes sharing one GPU - else RCCL's all_gather_into_tensor. Every rank takes the same branch.
         if not args.no_peer_gather:
+            # (a wait bound of a few seconds instead of the default tens: a node on which the kernel cannot work must fall back
+            # quickly; read once by the library, before its first collective)
+            os.environ.setdefault("BNB_MI355X_PEER_WAIT_POLLS", "3000000")
+            why = None
             try:
                 from bitsandbytes_amd.peer import PeerAllGather
 
-                peer = PeerAllGather(max_bytes=64 * 1024)
+                peer = PeerAllGather(max_bytes=64 * 1024)  # (raises on every rank or on none)
+            except Exception as exc:  # noqa: BLE001
+                peer, why = None, f"{type(exc).__name__}: {exc}"
+            if peer is not None:
                 same = True
-                for i in range(16):
-                    t_chk = (torch.randn(M, N, device=device) + rank + i).bfloat16()
-                    want = torch.empty(world * M, N, device=device, dtype=torch.bfloat16)
-                    dist.all_gather_into_tensor(want, t_chk)
-                    same &= bool(torch.equal(peer.all_gather(t_chk), want))
-                peer.check()
+                try:
+                    for i in range(8):
+                        t_chk = (torch.randn(M, N, device=device) + rank + i).bfloat16()
+                        want = torch.empty(world * M, N, device=device, dtype=torch.bfloat16)
+                        dist.all_gather_into_tensor(want, t_chk)
+                        got = peer.all_gather(t_chk)
+                        torch.cuda.synchronize()
+                        same = same and bool(torch.equal(got, want)) and peer.status() == 0
+                        if not same:
+                            break
+                except Exception as exc:  # noqa: BLE001
+                    same, why = False, f"{type(exc).__name__}: {exc}"
+                # the decision is collective: every rank reaches this reduction, whatever happened to it above
                 agree = torch.tensor([1 if same else 0], device=device)
                 dist.all_reduce(agree, op=dist.ReduceOp.MIN)
                 if int(agree.item()) != 1:
-                    raise RuntimeError("the peer all-gather does not reproduce the group's all-gather on this node")
-            except Exception as exc:  # noqa: BLE001
-                if rank == 0:
-                    print(f"bench: peer all-gather not used ({type(exc).__name__}: {exc}); RCCL all_gather_into_tensor per layer", file=sys.stderr)
-                if peer is not None:
+                    why = why or "it does not reproduce the group's all-gather on this node"
                     try:
                         peer.close()
                     except Exception:  # noqa: BLE001
                         pass
-                peer = None
+                    peer = None
+            if peer is None and rank == 0:
+                print(f"bench: peer all-gather not used ({why}); RCCL all_gather_into_tensor per layer", file=sys.stderr)
         shards = [ShardedLinear4bit(q, st, out_features=world * N, group=None, always_gather=True, peer=peer) for q, st in layers]
         buckets = [torch.empty(LAYERS, M, N, device=device, dtype=torch.bfloat16) for _ in range(2)]
         gathered = [torch.empty(world * LAYERS, M, N, device=device, dtype=torch.bfloat16) for _ in range(2)]

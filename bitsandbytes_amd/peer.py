@@ -97,9 +97,13 @@ class PeerAllGather:
                                           nbytes, self.max_bytes, ct.c_void_p(stream))
         return out
 
+    def status(self) -> int:
+        """0 while every wait of every collective found its peer, 1 once one gave up (synchronises the device)."""
+        return int(lib.bnb_mi355x_peer_status(ct.c_void_p(self._local)))
+
     def check(self) -> None:
         """Raises if any collective so far gave up waiting for a peer (synchronises the device)."""
-        st = lib.bnb_mi355x_peer_status(ct.c_void_p(self._local))
+        st = self.status()
         if st != 0:
             raise RuntimeError("PeerAllGather: a rank did not arrive at a collective within the wait bound (status %d)" % st)
 
