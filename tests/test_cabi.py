@@ -167,6 +167,75 @@ def test_no_kernel_spills_to_scratch():
     assert not spilled, f"kernels using scratch: {spilled[:5]}"
 
 
+def _device_disassembly(symbol_substring: str):
+    """{kernel symbol: [instruction lines]} for the kernels of the library's gfx950 code objects whose name contains
+    `symbol_substring` (llvm-objdump; no GPU needed)."""
+    import re
+    import subprocess
+    import tempfile
+    from pathlib import Path
+
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    tools = [llvm / "llvm-objcopy", llvm / "clang-offload-bundler", llvm / "llvm-objdump"]
+    if not all(t.exists() for t in tools):
+        pytest.skip("ROCm LLVM binutils not available")
+    from bitsandbytes_amd.cextension import LIB_PATH
+
+    kernels = {}
+    with tempfile.TemporaryDirectory() as td:
+        fat = Path(td) / "fat.bin"
+        subprocess.check_call([str(tools[0]), "-O", "binary", "--only-section=.hip_fatbin", str(LIB_PATH), str(fat)])
+        blob = fat.read_bytes()
+        starts = [m.start() for m in re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), blob)]
+        for i, s0 in enumerate(starts):
+            piece = Path(td) / f"bundle{i}.bin"
+            piece.write_bytes(blob[s0 : starts[i + 1] if i + 1 < len(starts) else len(blob)])
+            co = Path(td) / f"dev{i}.co"
+            subprocess.check_call([str(tools[1]), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                                   f"--input={piece}", f"--output={co}"], stderr=subprocess.DEVNULL)
+            syms = subprocess.run([str(tools[2]), "-t", str(co)], capture_output=True, text=True).stdout
+            if symbol_substring not in syms:
+                continue
+            text = subprocess.run([str(tools[2]), "-d", "--no-show-raw-insn", str(co)], capture_output=True, text=True).stdout
+            cur = None
+            for line in text.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                if m:
+                    cur = m.group(1) if symbol_substring in m.group(1) and not m.group(1).endswith(".kd") else None
+                    if cur:
+                        kernels[cur] = []
+                elif cur and line.strip():
+                    kernels[cur].append(line.strip())
+    return kernels
+
+
+def test_rt_kernel_isa_keeps_its_loads_in_flight():
+    """gemm4_mfma_rt_kernel leaves every wait to the compiler. Round 3 read its ISA and found three source patterns that made
+    hipcc drain the in-order memory queue or serialise the loads: branches around loads (exec-masked rows), a
+    run-time blocksize branch whose sides load into the same registers, scalar offsets that end up in VGPRs (every buffer load
+    wrapped in a v_readfirstlane loop). This pins the repaired state on the shipped (branch-free, BL) instances:
+      * no readfirstlane loop around a load anywhere in the kernel;
+      * the first vector-memory wait behind the table barrier - the top of the chunk loop - is a COUNTED one that leaves at
+        least the chunk's eight activation loads in flight (round 2's loop had vmcnt(1) / vmcnt(0) there)."""
+    import re
+
+    kernels = _device_disassembly("gemm4_mfma_rt_kernel")
+    shipped = {k: v for k, v in kernels.items()
+               if re.search(r"rt_kernelI\w+?Li\dELi\d+ELb[01]ELb[01]ELb1ELb[01]E", k)}  # <T, MT, WAVES, NESTED, DIRECT, BL = true, BS64>
+    assert len(shipped) >= 28, f"expected the branch-free instances of the kernel, found {len(shipped)} of {len(kernels)}"
+    for name, lines in shipped.items():
+        ops = [ln.split()[0] for ln in lines]
+        for i, op in enumerate(ops):
+            if op == "v_readfirstlane_b32":
+                window = ops[i : i + 10]
+                assert not ("s_cbranch_execnz" in window and any(o.startswith("buffer_load") for o in window)), \
+                    f"{name}: a buffer load inside a readfirstlane loop (scalar offset not uniform for the compiler)"
+        first_barrier = ops.index("s_barrier")
+        first_wait = next(ln for ln in lines[first_barrier:] if ln.startswith("s_waitcnt") and "vmcnt(" in ln)
+        n = int(re.search(r"vmcnt\((\d+)\)", first_wait).group(1))
+        assert n >= 8, f"{name}: the top of the chunk loop waits `{first_wait}` - the queue is drained there"
+
+
 def test_launch_plan_workspace_query_is_pure_host_logic():
     """bnb_mi355x_gemm_4bit_workspace_bytes runs the launch plans on the host (no GPU needed): for every BASELINE
     shape the split-K workspace is a whole number of fp32 [M, N] slabs, bounded by one slab per 512 k of K
