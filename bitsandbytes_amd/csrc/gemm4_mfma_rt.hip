@@ -120,7 +120,8 @@ __device__ __forceinline__ float rt_code_literal(int i, bool fp4) {
 // lines either way - the fragment-shaped load is only expensive when all 64 lanes take part - and 8 ds_write_b128 +
 // 8 ds_read_b128 per chunk and wavefront disappear from the LDS store path (13 cycles per wave-instruction).
 //
-// BL (every instance; bnb_mi355x_set_tuning knob0 bit 0 selects round 2's form for A/B runs): weights and activations are
+// BL (every instance of the product library; the measurement build also has BL = false, round 2's form, for A/B runs -
+// bnb_mi355x_set_tuning knob0 bit 0): weights and activations are
 // fetched through buffer descriptors - a 32-bit per-lane offset computed once plus a scalar offset per chunk / row tile instead
 // of 64-bit per-lane address arithmetic in front of every load (16 wavefronts share four VALUs when the kernel starts) - and,
 // what matters more, WITHOUT branches: a row past the end of the batch, or a wavefront without a chunk, is an out-of-range
@@ -506,9 +507,13 @@ void rt_launch_bl(const void* A, const uint8_t* B, const float* absmax, const ui
 template <typename T, int MT, int WAVES, bool DIRECT = false>
 void rt_launch(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
                const RtPlan& pl, const RtArgs& a, hipStream_t stream) {
-    if (pl.bl)
-        return rt_launch_bl<T, MT, WAVES, DIRECT, true>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
-    return rt_launch_bl<T, MT, WAVES, DIRECT, false>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+#ifdef BNB_PROFILING
+    // (round 2's form - pointer loads, exec-masked rows - exists in the measurement build only: the A/B partner of
+    // tools/rt_variant_ab.py, run with BNB_MI355X_LIBRARY=.../libbitsandbytes_mi355x_prof.so)
+    if (!pl.bl)
+        return rt_launch_bl<T, MT, WAVES, DIRECT, false>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
+#endif
+    return rt_launch_bl<T, MT, WAVES, DIRECT, true>(A, B, absmax, absmax8, M, N, K, flags, pl, a, stream);
 }
 
 template <typename T> void rt_launch_mt(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N,
@@ -553,10 +558,16 @@ void gemm_4bit_rt(int dtype, const void* A, const uint8_t* B, const float* absma
     RtPlan pl = rt_plan(M, N, K, force_ks);
     if (force_waves == 8 || (force_waves == 16 && pl.mt == 1))
         pl.waves = force_waves;
-    // knob0 bit 0 (A/B runs, tools/rt_variant_ab.py): round 2's form - direct fragments up to 4 rows, no buffer-load addressing
-    pl.bl = (variant & 1) ? 0 : 1;
-    if (variant & 1)
+    pl.bl = 1;
+#ifdef BNB_PROFILING
+    // knob0 bit 0 (measurement build only, tools/rt_variant_ab.py): round 2's form - pointer loads, direct fragments up to 4 rows
+    if (variant & 1) {
+        pl.bl = 0;
         pl.direct_max = 4;
+    }
+#else
+    (void)variant;
+#endif
     float* ws = static_cast<float*>(workspace);
     const size_t slab = static_cast<size_t>(M) * N * sizeof(float);
     if (pl.ks > 1) {

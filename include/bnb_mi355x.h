@@ -166,7 +166,7 @@ int bnb_mi355x_peer_status(const void* local_buffer);
 
 /* Tuning overrides for sweeps and tests (0 = built-in heuristic). reserved0: encoder of the 8-bit blockwise quantize - 1 =
  * cell-table kernel, 2 = byte-table kernel, anything else = by input size; reserved1: N slices of the fused backward (> 0; the
- * workspace-size query follows it). MFMA kernels: knob0 bit 0 = round 2's form of the register-transposed kernel (A/B runs),
+ * workspace-size query follows it). MFMA kernels: knob0 bit 0 = round 2's form of the register-transposed kernel (measurement build only; ignored by the product library),
  * knob1 = 100 * cfg + K-slice count (cfg 11-14 producer/consumer geometries, 20/21/22
  * register-transposed kernel with built-in / 8 / 16 wavefronts, 30 pre-scaled-operand kernel). Every setting
  * computes correct results - the knobs only choose a launch geometry. THREAD-LOCAL: a setting applies to the calls the

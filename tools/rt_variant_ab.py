@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B of two forms of the register-transposed MFMA kernel selected by bnb_mi355x_set_tuning knob0: 0 = shipped, 1 = round 2's
 form (pointer loads, exec-masked rows, direct fragments up to 4 rows); other values were one-off experiment builds whose tables
-are in profiles/r3_rt_*_ab.txt. Built-in routing otherwise: us per launch over an HBM-resident rotation of distinct layers, hipGraph-replayed
+are in profiles/r3_rt_*_ab.txt. Round 2's form only exists in the measurement build: run with
+BNB_MI355X_LIBRARY=<repo>/bitsandbytes_amd/libbitsandbytes_mi355x_prof.so (the product library ignores the knob). Built-in routing otherwise: us per launch over an HBM-resident rotation of distinct layers, hipGraph-replayed
 (launch-to-launch time in a dependent stream), plus a bit comparison of the two results (same arithmetic, same order of the
 sums: they must be equal)."""
 import argparse
