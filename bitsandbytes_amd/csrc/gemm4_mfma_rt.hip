@@ -10,7 +10,7 @@
 //
 //  * ONE workgroup of 16 wavefronts per 16 output columns, no split-K between workgroups when N / 16 fills the chip (no
 //    slab round trip, no second launch); the wavefronts split K in 256-k chunks and combine once through LDS.
-//  * Every global load is a plain, fully coalesced 16-byte-per-lane load whose four neighbouring lanes cover 64 contiguous
+//  * Every global load is a fully coalesced 16-byte-per-lane load whose four neighbouring lanes cover 64 contiguous
 //    bytes of ONE row (lane 4r + p: row r, piece p): 16 L1 tag look-ups per instruction. The MFMA operand layout wants the
 //    row index in the LOW lane bits (lane r + 16 g) - loading in that shape costs 64 tag look-ups per instruction (four
 //    different rows per lane quad), which is what made round 1's fragment-shaped loads crawl. The transposition
@@ -24,7 +24,10 @@
 //    128-byte line), so no data is ever permuted on the A side.
 //  * The decode table (byte -> the pair (code[hi], code[lo]) in T, 32 bank-private copies) is built from compile-time
 //    literals while the loads fly: no memory dependency in front of it. Loads are issued before anything else.
-//  * No LDS-DMA and no inline-asm waits: every wait is the compiler's counted vmcnt on ordinary loads.
+//  * No LDS-DMA and no inline-asm waits: every wait is the compiler's counted vmcnt - which it can only compute for
+//    straight-line code, so every load is a BRANCH-FREE buffer load (round 3, see BL / BS64 below and DESIGN.md 6b: what
+//    branches around loads, run-time format branches and non-uniform scalar offsets did to the waits of round 2's loop);
+//    tests/test_cabi.py::test_rt_kernel_isa_keeps_its_loads_in_flight checks the disassembly of the built library.
 //
 // Results are bit-reproducible: partial tiles are combined in wavefront order, K slices (only when N / 16 workgroups would
 // leave most of the chip idle) through fp32 slabs added in slice order by gemm4_finalize (gemm4_mfma.hip).
