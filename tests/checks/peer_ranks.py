@@ -1,5 +1,5 @@
-"""Per-rank body of tests/test_gpu_peer.py: WORLD processes that share ONE GPU (cuda:0), rendezvous over gloo, gather buffers mapped
-into each other by hipIpc. Exercises bitsandbytes_amd.peer.PeerAllGather, ShardedLinear4bit(peer=), ShardedLinear4bitGroup and
+"""Per-rank body of tests/test_gpu_peer.py: WORLD processes that share ONE GPU (cuda:0, rendezvous over gloo) - or, with
+PEER_DEVICE_PER_RANK=1, one GPU per rank (backend nccl = RCCL; needs WORLD GPUs) - gather buffers mapped into each other by hipIpc. Exercises bitsandbytes_amd.peer.PeerAllGather, ShardedLinear4bit(peer=), ShardedLinear4bitGroup and
 GraphedBlock with the peer kernel inside the graph. Prints "PEER_OK <rank>" on success."""
 import os
 import sys
@@ -16,9 +16,13 @@ from bitsandbytes_amd.peer import PeerAllGather  # noqa: E402
 
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda:0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per_rank = os.environ.get("PEER_DEVICE_PER_RANK") == "1"
+    torch.cuda.set_device(rank if per_rank else 0)
+    dev = torch.device("cuda", rank if per_rank else 0)
+    if per_rank:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     peer = PeerAllGather(max_bytes=64 * 1024)
     try:
         # ---- the collective itself: several sizes, aligned and not, many rounds (the double buffer turns over)
