@@ -119,9 +119,9 @@ __device__ __forceinline__ float rt_code_literal(int i, bool fp4) {
 // goes to wavefront c % WAVES). grid = (ceil(N / 16), kslices, ceil(M / (16 MT))).
 //
 // DIRECT (M <= 6, M <= 8 on small matrices - RtPlan::direct_max; one row tile): the activation fragments are loaded straight in
-// MFMA shape, no transposition. Only the lanes of rows < M fetch (the rest is exec-masked), so a load instruction touches few
-// lines either way - the fragment-shaped load is only expensive when all 64 lanes take part - and 8 ds_write_b128 +
-// 8 ds_read_b128 per chunk and wavefront disappear from the LDS store path (13 cycles per wave-instruction).
+// MFMA shape, no transposition. Only the lanes of rows < M fetch (the others carry an out-of-range offset, see BL), so a load
+// instruction touches few lines either way - the fragment-shaped load is only expensive when all 64 lanes take part - and
+// 8 ds_write_b128 + 8 ds_read_b128 per chunk and wavefront disappear from the LDS store path (13 cycles per wave-instruction).
 //
 // BL (every instance of the product library; the measurement build also has BL = false, round 2's form, for A/B runs -
 // bnb_mi355x_set_tuning knob0 bit 0): weights and activations are
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
         u32x4 s;    // the row's scales of the chunk's four 64-k sub-blocks (nested: {4 x uint8, second-level absmax})
         u32x4 a[8]; // step (h, j): lane (r, pp) holds A[r][128 h + 64 (j >> 1) + 8 (j & 1) + 32 (pp & 1) + 16 (pp >> 1) + 0..7]
     };
-    // Activation rows past the end of the batch are not fetched at all (exec-masked: the loads then cost the L1 M / 16 of a
-    // full tile); those lanes hold zeros and the MFMA rows they feed are never stored.
+    // Activation rows past the end of the batch are not fetched at all (an out-of-range offset - exec-masked in round 2's form:
+    // the loads then cost the L1 M / 16 of a full tile); those lanes hold zeros and the MFMA rows they feed are never stored.
     auto load_a_step = [&](Raw& raw, int c, int mt, int s) {
         const int row = m_base + mt * 16 + arow_l;
         if constexpr (BL) {
