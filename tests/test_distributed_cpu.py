@@ -53,6 +53,17 @@ def _worker(rank, world, port, results):
             ys = group(x)
             for y, layer in zip(ys, layers):
                 ok &= y.shape == (M, layer.out_features) and bool(torch.equal(y, layer(x)))
+            # leading batch dimensions survive the gather
+            x3 = torch.randn(2, M, K)
+            for y, layer in zip(group(x3), layers):
+                ok &= y.shape == (2, M, layer.out_features) and bool(torch.equal(y, layer(x3)))
+        # double-quantised members (the Linear4bit default)
+        torch.manual_seed(12)
+        layers_dq = [Linear4bit(512, n, bias=b, quant_type="nf4", compress_statistics=True).to("cpu") for n, b in ((64, False), (128, True))]
+        group_dq = bnb.ShardedLinear4bitGroup([bnb.shard_linear4bit(layer, rank, world) for layer in layers_dq])
+        x = torch.randn(2, 512)
+        for y, layer in zip(group_dq(x), layers_dq):
+            ok &= bool(torch.equal(y, layer(x)))
         results[rank] = ok
     finally:
         dist.destroy_process_group()
