@@ -334,6 +334,15 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
                 BNB_PC_STAMP(2 + 3 * k)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier(); // #k: A(k) is in LDS (and, the first time, the tables)
+#ifdef BNB_PROFILING
+            // (experiment queued for the next round, measurement build only, tools/pc_phase_shift_ab.py: the second consumer
+            // wavefront of every SIMD - wavefronts 4 .. 7 - runs (knob0 >> 4) x 128 cycles behind the first, so that the two stop
+            // doing their table look-ups, their MFMAs and their scale FMAs at the same time: the chunk time of this kernel equals
+            // the SUM of LDS, matrix-pipe and VALU time)
+            if ((p.knob0 >> 4) != 0 && (wave & 4) != 0)
+                for (int i = 0; i < (p.knob0 >> 4); ++i)
+                    __builtin_amdgcn_s_sleep(2);
+#endif
             if (k < 4)
                 BNB_PC_STAMP(3 + 3 * k)
             if (first) {
