@@ -755,6 +755,13 @@ void gemm_4bit_ps(int dtype, const void* A, const uint8_t* B, const float* absma
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int variant,
                   int ablate, hipStream_t stream);
 
+// gemm4_mfma_kq.hip (the K-quarter kernel: 32x32x16 MFMA, shares of a chunk copied to registers, 17 ... 64-row batches)
+bool gemm_4bit_kq_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize);
+size_t gemm_4bit_kq_workspace_bytes(int M, int N, int K, int force_ks);
+void gemm_4bit_kq(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
+                  const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
+                  int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, hipStream_t stream);
+
 // shared with gemm4_mfma_rt.hip / gemm4_mfma_ps.hip: the slab finalize launch and the library-owned workspace
 void gemm_4bit_finalize(int dtype, const float* ws, const void* bias, void* out, int M, int N, int kslices, hipStream_t stream) {
     const long total = static_cast<long>(M) * N;
@@ -817,6 +824,16 @@ bool ps_selected(int M, int N, int K, int knob1, int* force_ks, int* variant) {
         return weights >= (128L << 20);
     return false;
 }
+// Which problems go to the K-quarter kernel (tuning knob cfg 40 forces it; knob % 100 = K slices).
+bool kq_selected(int M, int N, int K, int knob1, int* force_ks) {
+    const int cfg = knob1 / 100;
+    *force_ks = 0;
+    if (cfg == 40) {
+        *force_ks = knob1 % 100;
+        return true;
+    }
+    return false;
+}
 } // namespace
 
 // Preconditions of the MFMA kernel: 16-bit activations, K a multiple of 256, blocksize >= 64
@@ -832,8 +849,10 @@ size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K) {
         return 0;
     int fks, fw;
     const int knob1 = g_mfma_knob1.load(std::memory_order_relaxed);
-    int pks, pvar;
+    int pks, pvar, qks;
     size_t ps_bytes = 0;
+    if (kq_selected(M, N, K, knob1, &qks))
+        return gemm_4bit_kq_workspace_bytes(M, N, K, qks);
     if (ps_selected(M, N, K, knob1, &pks, &pvar)) {
         ps_bytes = gemm_4bit_ps_workspace_bytes(M, N, K, pks);
         if (knob1 != 0)
@@ -856,7 +875,10 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
                     size_t workspace_bytes, hipStream_t stream) {
     int fks, fw;
     const int knob0 = g_mfma_knob0.load(std::memory_order_relaxed), knob1 = g_mfma_knob1.load(std::memory_order_relaxed);
-    int pks, pvar;
+    int pks, pvar, qks;
+    if (kq_selected(M, N, K, knob1, &qks) && gemm_4bit_kq_supported(dtype, A, B, code16, M, N, K, blocksize))
+        return gemm_4bit_kq(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type,
+                            workspace, workspace_bytes, qks, stream);
     if (ps_selected(M, N, K, knob1, &pks, &pvar) && (absmax8 == nullptr || gemm_4bit_ps_serves_nested()) &&
         gemm_4bit_ps_supported(dtype, A, B, code16, M, N, K, blocksize))
         return gemm_4bit_ps(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type,

@@ -214,8 +214,11 @@ int64_t linear4bit_prepare(const at::Tensor& B, at::IntArrayRef shapeB, const at
     p->blocksize = blocksize;
     p->quant_type = std::string(quant_type);
     p->compute_dtype = compute_dtype;
+    // The bias is kept as handed over - an alias of the module's storage, never a converted copy: an in-place update of the
+    // live bias is seen by the next call (the cast to the compute dtype, when one is needed, happens per call below); a
+    // REPLACED bias storage changes data_ptr(), which the module keys the handle on.
     if (bias.has_value())
-        p->bias = compute_dtype.has_value() ? bias->to(*compute_dtype).contiguous() : bias->contiguous();
+        p->bias = bias->contiguous();
     if (absmax_8bit.has_value())
         p->a8 = absmax_8bit->contiguous();
     if (absmax_code.has_value())
@@ -241,8 +244,8 @@ at::Tensor linear4bit_prepared(const at::Tensor& x, int64_t handle) {
         TORCH_CHECK(it != g_prepared.end(), "linear4bit_prepared: unknown handle ", handle);
         p = it->second;
     }
-    // dtype policy of Linear4bit.forward: compute in compute_dtype, return in the input's dtype; a bias of another dtype was
-    // cast at prepare time
+    // dtype policy of Linear4bit.forward: compute in compute_dtype, return in the input's dtype; a bias of another dtype is
+    // cast here, per call
     const at::ScalarType inp = x.scalar_type();
     const at::Tensor xc = (p->compute_dtype.has_value() && *p->compute_dtype != inp) ? x.to(*p->compute_dtype) : x;
     std::optional<at::Tensor> bias = p->bias;

@@ -216,6 +216,55 @@ def fix_4bit_weight_quant_state_from_module(module: "Linear4bit") -> None:
     module.weight.quant_state = module.quant_state
 
 
+class _PreparedCall:
+    """Owner of one handle of the C++ dispatcher's prepared-call table (csrc/torch_dispatch.cpp: linear4bit_prepare). The handle is
+    released when THIS object dies, and the object never travels: ``copy.deepcopy`` / pickling of a module yield ``None`` in its
+    place, so a copy (or a module loaded in another process) can never release - or call - the original's handle. The key is
+    everything the prepared call captured: the quant state object, the STORAGE of weight and bias (``layer.bias.data = new`` keeps
+    the Parameter object but changes ``data_ptr()``; in-place updates write the storage the prepared call aliases), dtypes."""
+
+    __slots__ = ("handle", "quant_state", "weight_ptr", "bias_obj", "bias_ptr", "bias_dtype", "bias_grad", "compute_dtype")
+
+    def __init__(self, handle, quant_state, weight, bias, compute_dtype):
+        self.handle = handle
+        self.quant_state = quant_state
+        self.weight_ptr = weight.data_ptr()
+        self.bias_obj = bias
+        self.bias_ptr = None if bias is None else bias.data_ptr()
+        self.bias_dtype = None if bias is None else bias.dtype
+        self.bias_grad = bias is not None and bias.requires_grad
+        self.compute_dtype = compute_dtype
+
+    def matches(self, weight, bias, compute_dtype) -> bool:
+        if self.handle is None or self.quant_state is not getattr(weight, "quant_state", None) or self.weight_ptr != weight.data_ptr():
+            return False
+        if bias is not self.bias_obj or self.compute_dtype is not compute_dtype:
+            return False
+        return bias is None or (bias.data_ptr() == self.bias_ptr and bias.dtype is self.bias_dtype
+                                and bias.requires_grad == self.bias_grad)
+
+    def release(self):
+        handle, self.handle = self.handle, None
+        if handle is not None:
+            try:
+                torch.ops.bitsandbytes_amd.linear4bit_release(handle)
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
+
+    def __del__(self):
+        self.release()
+
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (_no_prepared_call, ())
+
+
+def _no_prepared_call():
+    return None
+
+
 class Linear4bit(nn.Linear):
     """QLoRA-style 4-bit linear layer (reference modules.py:504-637). Load fp weights into it, then
     ``.to("cuda")`` quantises them on the MI355X."""
@@ -260,18 +309,18 @@ class Linear4bit(nn.Linear):
     # forward that needs no autograd is a two-argument op call; anything that changes the layer (a new weight / quant state /
     # bias object, a moved weight) drops the handle. Results are those of the code below, by construction: the prepared
     # call runs the same gemm_4bit kernel glue with the same dtype policy.
-    _prepared = None  # (handle, quant_state, weight data_ptr, bias object, bias requires_grad, compute_dtype)
+    _prepared = None  # a _PreparedCall (below) or None
 
     def _prepared_drop(self):
         prep = self.__dict__.pop("_prepared", None)
         if prep is not None:
-            try:
-                torch.ops.bitsandbytes_amd.linear4bit_release(prep[0])
-            except Exception:  # noqa: BLE001  (interpreter shutdown)
-                pass
+            prep.release()
 
-    def __del__(self):
+    def _apply(self, fn, recurse=True):
+        # .to() / .cuda() / .cpu() / .half(): the prepared call holds the packed weight and its statistics alive on the device
+        # they were on - drop it before anything moves, the next eager forward prepares again
         self._prepared_drop()
+        return super()._apply(fn, recurse)
 
     def _prepared_make(self, weight, quant_state, bias):
         from ..backends import hip
@@ -288,18 +337,17 @@ class Linear4bit(nn.Linear):
         handle = torch.ops.bitsandbytes_amd.linear4bit_prepare(
             weight.data.view(-1, 1) if weight.dtype == torch.uint8 else weight.data, list(quant_state.shape), absmax, quant_state.blocksize,
             quant_state.quant_type, None if bias is None else bias.data, a8, code, offset, self.compute_dtype)
-        prep = (handle, quant_state, weight.data_ptr(), bias, bias is not None and bias.requires_grad, self.compute_dtype)
+        prep = _PreparedCall(handle, quant_state, weight, bias, self.compute_dtype)
         self.__dict__["_prepared"] = prep
         return prep
 
     def forward(self, x: torch.Tensor):
         prep = self._prepared
         if prep is not None and x.is_cuda:
-            weight = self._parameters["weight"]
-            if (prep[1] is getattr(weight, "quant_state", None) and prep[2] == weight.data_ptr() and prep[3] is self._parameters["bias"]
-                    and prep[5] is self.compute_dtype and not (torch.is_grad_enabled() and (x.requires_grad or prep[4]))
+            if (prep.matches(self._parameters["weight"], self._parameters["bias"], self.compute_dtype)
+                    and not (torch.is_grad_enabled() and (x.requires_grad or prep.bias_grad))
                     and not torch.compiler.is_compiling()):
-                return torch.ops.bitsandbytes_amd.linear4bit_prepared(x, prep[0])
+                return torch.ops.bitsandbytes_amd.linear4bit_prepared(x, prep.handle)
         fix_4bit_weight_quant_state_from_module(self)
         quant_state = self.weight.quant_state
 

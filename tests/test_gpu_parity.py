@@ -1511,13 +1511,82 @@ def test_linear4bit_prepared_call_equals_ordinary_path():
         assert xg.grad is not None
         # a replaced bias / re-quantised weight drops the stale handle
         with torch.no_grad():
-            h0 = layer._prepared[0]
+            h0 = layer._prepared.handle
             if with_bias:
                 layer.bias = torch.nn.Parameter(torch.randn(N, device=DEV, dtype=cdt), requires_grad=False)
                 x = torch.randn(2, K, device=DEV, dtype=xdt)
                 ya = layer(x)                       # ordinary path again (bias object changed)
                 yb = layer(x)
-                assert layer._prepared[0] != h0 and torch.equal(ya, yb)
+                assert layer._prepared.handle != h0 and torch.equal(ya, yb)
+
+
+def test_linear4bit_prepared_call_never_serves_a_stale_bias_or_a_foreign_handle():
+    """Round-3 review items: (a) `layer.bias.data = new` keeps the Parameter object - the prepared call must not keep serving the
+    old values (it aliases the live storage and is keyed on its data_ptr), nor after an in-place update; (b) the handle is an
+    owning object that never travels: deepcopy / pickle of a module carry no handle, and collecting the copy leaves the
+    original's call intact; (c) `.to()` drops the handle (it holds the packed weight alive on the device)."""
+    import copy
+    import gc
+    import io
+
+    from bitsandbytes_amd.backends import hip
+    from bitsandbytes_amd.nn import Linear4bit
+
+    if not hip.NATIVE_DISPATCH:
+        pytest.skip("the C++ dispatcher library is not loaded")
+    torch.manual_seed(12)
+    K, N = 1024, 256
+    for (bias_dtype, cdt) in ((torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16)):
+        layer = Linear4bit(K, N, bias=True, quant_type="nf4", compute_dtype=cdt).to(DEV)
+        layer.bias.data = layer.bias.data.to(bias_dtype)
+        x = torch.randn(1, K, device=DEV, dtype=torch.bfloat16)
+        with torch.no_grad():
+            y0 = layer(x)
+            y1 = layer(x)
+            assert layer._prepared is not None and torch.equal(y0, y1)
+            # (a) swapped storage, same Parameter object
+            new_bias = torch.randn(N, device=DEV, dtype=layer.bias.dtype)
+            layer.bias.data = new_bias
+            ya = layer(x)
+            want = (y0.float() - (y0.float() * 0 + 0)).clone()  # placeholder shape
+            layer._prepared_drop()
+            yb = layer(x)                              # ordinary path on the same state
+            assert torch.equal(ya, yb), "prepared call served a stale bias after `bias.data = new`"
+            assert not torch.equal(ya, y0)
+            # in-place update of the live storage
+            layer(x)
+            assert layer._prepared is not None
+            layer.bias.data.add_(1.0)
+            yc = layer(x)
+            layer._prepared_drop()
+            yd = layer(x)
+            assert torch.equal(yc, yd), "prepared call served a stale bias after an in-place update"
+            del want
+            # (b) deepcopy / pickle carry no handle; collecting the copy leaves the original's handle valid
+            layer(x)
+            h = layer._prepared.handle
+            twin = copy.deepcopy(layer)
+            assert twin.__dict__.get("_prepared") is None
+            yt = twin(x)
+            yt2 = twin(x)
+            assert torch.equal(yt, yd) and torch.equal(yt2, yd)
+            assert twin._prepared is None or twin._prepared.handle != h
+            del twin
+            gc.collect()
+            assert torch.equal(layer(x), yd) and layer._prepared.handle == h
+            buf = io.BytesIO()
+            torch.save(layer, buf)
+            buf.seek(0)
+            loaded = torch.load(buf, weights_only=False)
+            assert loaded.__dict__.get("_prepared") is None
+            assert torch.equal(loaded(x), yd)
+            del loaded
+            gc.collect()
+            assert torch.equal(layer(x), yd)
+            # (c) a move drops the handle
+            layer.to(DEV)
+            assert layer.__dict__.get("_prepared") is None
+            assert torch.equal(layer(x), yd)
 
 
 def test_linear4bit_group_forward_gpu():
