@@ -758,9 +758,10 @@ void gemm_4bit_ps(int dtype, const void* A, const uint8_t* B, const float* absma
 // gemm4_mfma_kq.hip (the K-quarter kernel: 32x32x16 MFMA, shares of a chunk copied to registers, 17 ... 64-row batches)
 bool gemm_4bit_kq_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize);
 size_t gemm_4bit_kq_workspace_bytes(int M, int N, int K, int force_ks);
+bool gemm_4bit_kq_serves(const float* absmax, const uint8_t* absmax8, int blocksize, int K);
 void gemm_4bit_kq(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
-                  int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, hipStream_t stream);
+                  int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int ablate, hipStream_t stream);
 
 // shared with gemm4_mfma_rt.hip / gemm4_mfma_ps.hip: the slab finalize launch and the library-owned workspace
 void gemm_4bit_finalize(int dtype, const float* ws, const void* bias, void* out, int M, int N, int kslices, hipStream_t stream) {
@@ -876,9 +877,10 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
     int fks, fw;
     const int knob0 = g_mfma_knob0.load(std::memory_order_relaxed), knob1 = g_mfma_knob1.load(std::memory_order_relaxed);
     int pks, pvar, qks;
-    if (kq_selected(M, N, K, knob1, &qks) && gemm_4bit_kq_supported(dtype, A, B, code16, M, N, K, blocksize))
+    if (kq_selected(M, N, K, knob1, &qks) && gemm_4bit_kq_supported(dtype, A, B, code16, M, N, K, blocksize) &&
+        gemm_4bit_kq_serves(absmax, absmax8, blocksize, K))
         return gemm_4bit_kq(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type,
-                            workspace, workspace_bytes, qks, stream);
+                            workspace, workspace_bytes, qks, knob0, stream);
     if (ps_selected(M, N, K, knob1, &pks, &pvar) && (absmax8 == nullptr || gemm_4bit_ps_serves_nested()) &&
         gemm_4bit_ps_supported(dtype, A, B, code16, M, N, K, blocksize))
         return gemm_4bit_ps(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type,

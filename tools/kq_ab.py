@@ -47,7 +47,9 @@ def main():
     print("# us per launch (kernel + finalize): shipped routing | cfg 11 (producer/consumer) | cfg 40 (K-quarter)")
     cases = [(8192, 8192, (64, 32)), (4096, 4096, (64, 32)), (11008, 4096, (64,)), (4096, 11008, (64,))]
     if not quick:
-        cases += [(28672, 8192, (64,)), (8192, 8192, (17, 48, 128)), (1376, 4096, (64,))]
+        cases = [(8192, 8192, (17, 24, 32, 48, 64, 128)), (28672, 8192, (17, 32, 64)), (11008, 4096, (17, 32, 64)), (4096, 11008, (17, 32, 64)),
+                 (14336, 4096, (32, 64)), (4096, 14336, (32, 64)), (5120, 5120, (32, 64)), (6144, 4096, (32, 64)), (4096, 4096, (32, 64)),
+                 (8192, 2048, (64,)), (2048, 8192, (64,))]
     for (N, K, Ms) in cases:
         for dq in (False, True):
             layers = make_layers(N, K, 64, "nf4", dq, cap=24)

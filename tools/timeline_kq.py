@@ -19,6 +19,7 @@ ap.add_argument("--k", type=int, default=8192)
 ap.add_argument("--m", type=int, default=64)
 ap.add_argument("--cfg", type=int, default=4000)
 ap.add_argument("--nested", type=int, default=0)
+ap.add_argument("--ablate", type=int, default=0, help="ablation bits of the stamped instance (3: no DMA in the loop, 16: no LDS -> register reads)")
 a = ap.parse_args()
 N, K, M = a.n, a.k, a.m
 L = max(4, int(700e6 // (N * K // 2)))
@@ -40,15 +41,13 @@ def step(i):
     return hip._gemm_4bit_fused(x, q, st.shape, st.absmax, st.blocksize, st.quant_type, None, None, None, None, kernel=2)
 
 
-names = {0: "start", 1: "prologue DMA issued", 14: "chunk loop done", 15: "end"}
-for _i in range(2):
-    names[2 + 5 * _i] = f"chunk {2 + _i} top"
-    names[3 + 5 * _i] = f"chunk {2 + _i} own DMA landed"
-    names[4 + 5 * _i] = f"chunk {2 + _i} shares in registers (past barrier 2)"
-    names[5 + 5 * _i] = f"chunk {2 + _i} computed"
-ORDER = [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 14, 15]
+names = {0: "start", 1: "start-up DMA issued", 2: "LAST half: load phase starts", 3: "share read, batch requested, first look-ups issued",
+         9: "  reads issued", 
+         4: "own requests landed (all but this phase's weights)", 5: "past the barrier: compute phase starts", 6: "computed", 7: "first barrier passed: half 0 in the LDS, table built", 13: "epilogue: partial sums exchanged through the LDS",
+         8: "past the barrier", 14: "chunk loop done", 15: "end"}
+ORDER = [0, 1, 7, 2, 3, 5, 6, 4, 8, 14, 15]
 
-bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, a.cfg)
+bnb.lib.bnb_mi355x_set_tuning(0, 0, 64 + a.ablate, a.cfg)  # knob0 = 64: the stamped instance of the kernel
 try:
     for i in range(L):
         step(i)
@@ -66,19 +65,32 @@ t = t[used]
 if t.shape[0] == 0:
     print("no stamps: not a profiling build?")
     sys.exit(0)
-print(f"# kq kernel cfg={a.cfg} nested={a.nested} M={M} N={N} K={K}: {t.shape[0]} workgroups x {waves} wavefronts; s_memtime ticks relative to the "
+print(f"# kq kernel cfg={a.cfg} ablate={a.ablate} nested={a.nested} M={M} N={N} K={K}: {t.shape[0]} workgroups x {waves} wavefronts; s_memtime ticks relative to the "
       f"wavefront's own start")
-print(f"{'stamp':44s} {'min':>7s} {'median':>7s} {'max':>7s}   median delta to previous stamp")
+wg0 = torch.where(t[:, :, 0] > 0, t[:, :, 0], torch.full_like(t[:, :, 0], float("inf"))).min(dim=1, keepdim=True).values  # first wavefront start of the WORKGROUP (one XCD, one clock)
+print(f"{'stamp':52s} {'median time since the workgroup started':>40s}   {'median delta to the previous stamp':>36s}")
+print(f"{'':52s} {'all':>8s} {'group 0':>8s} {'group 1':>8s} {'min':>8s} {'max':>8s}   {'all':>8s} {'group 0':>8s} {'group 1':>8s}")
 prev = None
 for i in ORDER:
     ok = (t[:, :, i] > 0) & (t[:, :, 0] > 0)
     if ok.sum() == 0:
         continue
-    rel = (t[:, :, i] - t[:, :, 0])[ok]
-    line = f"{names[i]:44s} {rel.min().item():7.0f} {rel.median().item():7.0f} {rel.max().item():7.0f}"
+    rel = t[:, :, i] - wg0
+    med = lambda x, m: x[m].median().item() if m.sum() else float("nan")  # noqa: E731
+    line = (f"{names[i]:52s} {med(rel, ok):8.0f} {med(rel[:, :4], ok[:, :4]):8.0f} {med(rel[:, 4:], ok[:, 4:]):8.0f} "
+            f"{rel[ok].min().item():8.0f} {rel[ok].max().item():8.0f}")
     if prev is not None:
         both = ok & (t[:, :, prev] > 0)
         d = (t[:, :, i] - t[:, :, prev])
-        line += f"   {d[both].median().item():8.0f}"
+        line += f"   {med(d, both):8.0f} {med(d[:, :4], both[:, :4]):8.0f} {med(d[:, 4:], both[:, 4:]):8.0f}"
     print(line)
     prev = i
+ok0 = t[:, :, 0] > 0
+for idx, what in ((13, 'of load-phase work'), (10, 'at the barrier ending the load phases'), (9, 'of compute-phase work'), (11, 'waiting for own DMA'), (12, 'at the barrier ending the compute phases')):
+    v = t[:, :, idx]
+    print(f'SUM over the slice, cycles {what:42s}: median {v[ok0].median().item():7.0f}  group 0 {v[:, :4][ok0[:, :4]].median().item():7.0f}  group 1 {v[:, 4:][ok0[:, 4:]].median().item():7.0f}')
+# one workgroup in full: every wavefront's stamps, relative to the workgroup's start
+w = t.shape[0] // 2
+print(f"# workgroup {w}: rows = wavefronts 0..7 (group 0 = 0-3, group 1 = 4-7), columns = stamps {ORDER}")
+for wv in range(waves):
+    print("   " + " ".join(f"{(t[w, wv, i] - wg0[w, 0]).item():7.0f}" if t[w, wv, i] > 0 else "      -" for i in ORDER))
