@@ -19,27 +19,41 @@ from conftest import ROOT, gpu_ready
 
 COMPILED = os.path.join(ROOT, "oracle", "_ref", "ref_tests")
 
-# (file, -k expression, minimum number of tests that must pass, regex of test ids that may fail - with the reason)
+# The EXACT ids expected to fail, one per line (dtype x blocksize x nested x signed spelled out): a regression in a case that passes
+# today (e.g. fp32 / blocksize 256 of the 8-bit quantizer, which the 4-bit double quantisation uses) is a new failure and fails
+# the gate; a listed id that starts passing fails it too, so the list cannot go stale.
+EXPECTED_FAILURES_FILE = os.path.join(ROOT, "tests", "golden", "reference_suite_expected_failures.txt")
+
+
+def expected_failures():
+    with open(EXPECTED_FAILURES_FILE) as fh:
+        return {ln.strip() for ln in fh if ln.strip() and not ln.startswith("#")}
+
+
+# (file, -k expression, EXACT number of tests that must pass (round 3's counts, profiles/r3_reference_suite_on_gpu.txt), regex that
+# every expected-failure id of the selection must match - with the reason)
 SELECTIONS = [
-    ("tests/test_ops.py", "4bit", 200, None),
+    ("tests/test_ops.py", "4bit", 304, None),
     # test_gemv_4bit's fp32 envelope (tests/test_functional.py:892-895) bounds the mean difference between gemv_4bit and
     # F.linear(A, dequantize_4bit(B)) ON THE DEVICE, i.e. between two fp32 summation orders, with numbers measured for cuBLAS vs
     # the reference's CUDA kernel on an RTX 4090 (1e-8 / 2e-8 per element and sqrt(dim), 7 sigma of 2e-9). Against rocBLAS's
     # fp32 gemv this kernel lands at 3e-8 / 5e-8 on the "fc2" shapes (K = 4 dim) at dim = 128 and 1024 - 2-3 fp32 ulps of the
     # output - and inside the envelope everywhere else (320 of 328 gemv cases). Which of the two orders is closer to the exact sum
     # is checked in tests/test_gpu_parity.py::test_gemv_fp32_summation_is_as_accurate_as_the_blas_library (fp64 reference).
-    ("tests/test_functional.py", "4bit and not bench", 1400, r"test_gemv_4bit\[dim=(128|1024)-fp32-fc2-"),
+    ("tests/test_functional.py", "4bit and not bench", 1421, r"test_gemv_4bit\[dim=(128|1024)-fp32-fc2-"),
     # The 8-bit blockwise quantizer of this package reproduces the reference's CPU rule bit for bit (north star: "outputs match
     # the reference CPU backend"; csrc/cpu_ops.cpp: a 65536-bin table look-up, not the nearest-code search of csrc/kernels.cu).
     # test_dynamic_blockwise_quantization's thresholds are calibrated on the CUDA rule: the mean RELATIVE error it measures is
     # dominated by the elements closest to zero - exact zeros of 16-bit inputs, which the CPU rule sends to the smallest non-zero
     # code - and exceeds them for fp16 / bf16 inputs and for blocksizes >= 1024 (the oracle itself measures the same numbers on
-    # the same data: tests/test_oracle_golden.py pins the rule). Those ids may fail; every other test of the class must pass.
-    ("tests/test_functional.py", "Test8BitBlockwiseQuantizeFunctional and not bench", 20, r"test_dynamic_blockwise_quantization\["),
-    ("tests/test_autograd.py", "matmul_4bit", 380, None),
-    ("tests/test_linear4bit.py", "not fsdp", 300, None),
-    ("tests/test_parametrize.py", "", 80, None),
-    ("tests/test_modules.py", "(embedding or 4bit or NF4 or FP4) and not 8bit and not Int8 and not int8", 40, None),
+    # the same data: tests/test_oracle_golden.py pins the rule). The 68 ids that fail for that reason are listed one by one in
+    # tests/golden/reference_suite_expected_failures.txt (all fp16 / bf16 ids, and fp32 at blocksize >= 1024); the fp32 ids at
+    # blocksize 64 ... 512 - the cases the 4-bit double quantisation uses - and every other test of the class must pass.
+    ("tests/test_functional.py", "Test8BitBlockwiseQuantizeFunctional and not bench", 41, r"test_dynamic_blockwise_quantization\["),
+    ("tests/test_autograd.py", "matmul_4bit", 384, None),
+    ("tests/test_linear4bit.py", "not fsdp", 310, None),
+    ("tests/test_parametrize.py", "", 82, None),
+    ("tests/test_modules.py", "(embedding or 4bit or NF4 or FP4) and not 8bit and not Int8 and not int8", 46, None),
 ]
 
 
@@ -72,10 +86,16 @@ def test_reference_test_file_passes_on_the_hip_device(shim_root, path, expr, min
         for ln in lines:
             if ln.startswith("FAILED"):
                 fh.write("    " + ln + "\n")
-    failed = [ln.split()[1] for ln in lines if ln.startswith("FAILED ")]
-    unexpected = [f for f in failed if not (may_fail and re.search(may_fail, f))]
+    failed = {ln.split()[1] for ln in lines if ln.startswith("FAILED ")}
+    # the listed ids of THIS selection: those of its file that match its regex (the two test_functional.py selections overlap in
+    # nothing: "4bit" does not select the 8-bit class)
+    expected = {f for f in expected_failures() if may_fail and f.startswith(path + "::") and re.search(may_fail, f)}
+    unexpected = sorted(failed - expected)
+    recovered = sorted(expected - failed)
     tail = "\n".join(lines[-40:])
-    assert not unexpected, f"{path} -k '{expr}': {len(unexpected)} unexpected failures:\n" + "\n".join(unexpected[:20]) + f"\n{tail}\n{proc.stderr[-1500:]}"
     assert proc.returncode in (0, 1), f"{path} -k '{expr}' did not run:\n{tail}\n{proc.stderr[-1500:]}"
+    assert not unexpected, f"{path} -k '{expr}': {len(unexpected)} NEW failures:\n" + "\n".join(unexpected[:20]) + f"\n{tail}\n{proc.stderr[-1500:]}"
+    assert not recovered, (f"{path} -k '{expr}': {len(recovered)} ids listed in {os.path.basename(EXPECTED_FAILURES_FILE)} pass now - remove them "
+                           "from the list:\n" + "\n".join(recovered[:20]))
     m = re.search(r"(\d+) passed", summary)
-    assert m and int(m.group(1)) >= min_passed, summary
+    assert m and int(m.group(1)) >= min_passed, f"expected >= {min_passed} passed: {summary}"

@@ -44,19 +44,19 @@ def main():
             err, same = check(N, K, M, dq, qt, bs, dt, knob)
             print(f"  {N:5d} x {K:5d} M = {M:3d} {qt} bs {bs:3d} nested {int(dq)} {str(dt)[6:]:>8s} knob {knob}: err {err:.2e} same {same}"
                   + ("" if err < 1e-2 and same else "   <-- FAIL"), flush=True)
-    print("# us per launch (kernel + finalize): shipped routing | cfg 11 (producer/consumer) | cfg 40 (K-quarter)")
+    print("# us per launch (kernel + finalize): shipped routing | cfg 20 (register-transposed) | cfg 11 (producer/consumer, 128 columns) | cfg 14 (64 columns) | cfg 40 (K-quarter)")
     cases = [(8192, 8192, (64, 32)), (4096, 4096, (64, 32)), (11008, 4096, (64,)), (4096, 11008, (64,))]
     if not quick:
-        cases = [(8192, 8192, (17, 24, 32, 48, 64, 128)), (28672, 8192, (17, 32, 64)), (11008, 4096, (17, 32, 64)), (4096, 11008, (17, 32, 64)),
-                 (14336, 4096, (32, 64)), (4096, 14336, (32, 64)), (5120, 5120, (32, 64)), (6144, 4096, (32, 64)), (4096, 4096, (32, 64)),
-                 (8192, 2048, (64,)), (2048, 8192, (64,))]
+        cases = [(8192, 8192, (17, 32, 40, 48, 64)), (28672, 8192, (17, 32, 64)), (11008, 4096, (17, 32, 48, 64)), (4096, 11008, (17, 32, 48, 64)),
+                 (14336, 4096, (32, 64)), (4096, 14336, (32, 64)), (5120, 5120, (17, 32, 64)), (6144, 4096, (17, 32, 64)), (4096, 4096, (17, 32, 64)),
+                 (8192, 2048, (32, 64)), (2048, 8192, (32, 64)), (1376, 4096, (32, 64)), (3072, 3072, (32, 64))]
     for (N, K, Ms) in cases:
-        for dq in (False, True):
+        for dq in ((False, True) if quick else (False,)):
             layers = make_layers(N, K, 64, "nf4", dq, cap=24)
             for M in Ms:
                 x = torch.randn(M, K, device="cuda").bfloat16()
                 row = []
-                for knob in (0, 1100, 4000):
+                for knob in (0, 2000, 1100, 1400, 4000):
                     try:
                         bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, knob)
                         row.append(min(run(layers, x, 2) for _ in range(2)))
