@@ -28,11 +28,11 @@ _DT_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 _QT_CODE = {"fp4": 1, "nf4": 2}
 
 # Largest M routed to the fused kernels; above it one dequantize + hipBLASLt GEMM moves fewer bytes
-# per FLOP than re-streaming the packed weight per 64-row slab. Calibrated on MI355X (profiles/r3_tall_batch_ab.txt,
-# us per launch, fused vs dequantize + hipBLASLt): 4096^2 M = 256 / 512 23 / 29 vs 30 / 37; 8192^2 M = 256 53 vs 92 but
-# M = 512 104 vs 94; 11008 x 4096 M = 256 52 vs 61, M = 512 80 vs 69. So: 256 rows everywhere, 512 on matrices of up to
-# FUSED_SMALL_WEIGHTS weights (one dequantize pass over a small matrix is cheap, but so is re-streaming it).
-FUSED_MAX_M = 256
+# per FLOP than re-streaming the packed weight per 64-row slab. Calibrated on MI355X (profiles/r4_route_ab.txt, us per launch,
+# fused (K-quarter kernel) vs dequantize + hipBLASLt at M = 512: 4096^2 24 vs 41, 8192^2 89 vs 111, 11008 x 4096 70 vs 78,
+# 4096 x 11008 59 vs 94; at M = 1024 (profiles/r3_tall_batch_ab.txt: 49 / 144 / 105 / 116 unfused) twice the fused M = 512 time is
+# level at best. So: 512 rows everywhere (the two constants are kept apart: they are calibrated separately).
+FUSED_MAX_M = 512
 FUSED_MAX_M_SMALL = 512
 FUSED_SMALL_WEIGHTS = 20 << 20
 _REFERENCE_CUSTOM_MAX_M = 256  # reference backends/cuda/ops.py:816 (_gemm_4bit_custom_max_m on ROCm)

@@ -90,6 +90,12 @@ struct TlsKnob {
     void store(int x, std::memory_order = std::memory_order_relaxed) { v = x; }
 };
 
+// Which kernel family the calling thread's last gemm_4bit / gemv_4bit call launched (bnb_mi355x_last_gemm_kernel: tests assert
+// that the kernel they name is the kernel that ran - a forced geometry that silently falls back to another family is not
+// coverage). Written by the launchers themselves, at the point of the launch.
+enum GemmKernelId { kKernelNone = 0, kKernelStream = 1, kKernelGeneric = 2, kKernelRt = 3, kKernelPc = 4, kKernelPs = 5, kKernelKq = 6 };
+extern thread_local int g_last_gemm_kernel;
+
 // ---------------------------------------------------------------------------------------------
 // Element types. fp16/bf16 travel as their native clang types so that conversions lower to the
 // gfx950 hardware converts (v_cvt_f16_f32 / v_cvt_pk_bf16_f32, both round-to-nearest-even).

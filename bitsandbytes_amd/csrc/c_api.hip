@@ -32,6 +32,7 @@ bool gemv_4bit_grouped(int dtype, const void* A, int count, const uint8_t* const
                        void* const* out, const void* const* bias, const int* N, int M, int K, int blocksize, int quant_type,
                        hipStream_t stream);
 void gemv_4bit_stream_tuning(int ns, int sw, int rows_per_wg, int nt, int waves);
+thread_local int g_last_gemm_kernel = kKernelNone;
 #ifdef BNB_PROFILING
 unsigned long long* g_dbg_buf = nullptr; // profiling builds only: device buffer for the kernels' s_memtime stamps
 #endif
@@ -283,6 +284,7 @@ size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N,
         return 0;
     return gemm_4bit_mfma_workspace_bytes(M, N, K);
 }
+int bnb_mi355x_last_gemm_kernel(void) { return g_last_gemm_kernel; }
 int bnb_mi355x_gemm_4bit_route(int kernel, int dtype, int M, int N, int K, int blocksize) {
     // (alignment of A / B is unknown here; the aligned - fast - case is assumed, as in the workspace query)
     static const int dummy_aligned[4] __attribute__((aligned(16))) = {0, 0, 0, 0};

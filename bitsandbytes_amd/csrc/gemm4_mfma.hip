@@ -627,8 +627,11 @@ Plan make_plan(int M, int N, int K, int knob1) {
         // Calibrated on MI355X (profiles/r1_sweep_mfma_variants.txt): 8 consumer wavefronts x 16 columns share one A tile;
         // on a small matrix with a tall tile 64-column workgroups need half the K slices, i.e. half the slab traffic
         // (4096^2 M = 64: 14.6 vs 15.4 us), on large matrices 128 columns win
+        // (64-column workgroups only while they fit one round of workgroups: 4096^2 M = 512 ran 39.6 us in 512 of them against
+        // 27.5 in 256 of 128 columns, profiles/r4_route_ab.txt)
         const bool big = static_cast<long>(N) * K >= (32L << 20) && N >= 1024;
-        cfg = (pl.mt >= 3 && !big) ? 14 : 11;
+        const long wgs14 = static_cast<long>((N + 63) / 64) * gz;
+        cfg = (pl.mt >= 3 && !big && wgs14 <= device_cu_count_or_default()) ? 14 : 11;
     }
     if (cfg == 13 && pl.mt > 2)
         cfg = 11; // 8 x 2 consumers with a > 32-row A tile do not fit the 160 KiB of LDS
@@ -696,6 +699,7 @@ template <typename T, int MT> void launch_mfma(GemmArgs& p, int cfg, hipStream_t
 }
 
 template <typename T> void dispatch_mfma(GemmArgs& p, float* ws, size_t ws_bytes, int knob1, hipStream_t stream) {
+    g_last_gemm_kernel = kKernelPc;
     Plan pl = make_plan(p.M, p.N, p.K, knob1);
     const size_t slab = static_cast<size_t>(p.M) * p.N * sizeof(float);
     if (pl.ks > 1) {
@@ -746,15 +750,6 @@ void gemm_4bit_rt(int dtype, const void* A, const uint8_t* B, const float* absma
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int force_waves,
                   int variant, hipStream_t stream);
 
-// gemm4_mfma_ps.hip (the pre-scaled-operand kernel: 32x32x16 MFMA, register ring, one barrier per 256 k)
-bool gemm_4bit_ps_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize);
-bool gemm_4bit_ps_serves_nested();
-size_t gemm_4bit_ps_workspace_bytes(int M, int N, int K, int force_ks);
-void gemm_4bit_ps(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
-                  const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
-                  int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int variant,
-                  int ablate, hipStream_t stream);
-
 // gemm4_mfma_kq.hip (the K-quarter kernel: 32x32x16 MFMA, shares of a chunk copied to registers, 17 ... 64-row batches)
 bool gemm_4bit_kq_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize);
 size_t gemm_4bit_kq_workspace_bytes(int M, int N, int K, int force_ks);
@@ -763,7 +758,7 @@ void gemm_4bit_kq(int dtype, const void* A, const uint8_t* B, const float* absma
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int ablate, hipStream_t stream);
 
-// shared with gemm4_mfma_rt.hip / gemm4_mfma_ps.hip: the slab finalize launch and the library-owned workspace
+// shared with gemm4_mfma_rt.hip: the slab finalize launch and the library-owned workspace
 void gemm_4bit_finalize(int dtype, const float* ws, const void* bias, void* out, int M, int N, int kslices, hipStream_t stream) {
     const long total = static_cast<long>(M) * N;
     if (dtype == 2)
@@ -797,32 +792,16 @@ bool rt_selected(int M, int N, int K, int knob1, int* force_ks, int* force_waves
         return weights <= (96L << 20);
     if (M <= 32)
         return weights <= (20L << 20);
+    // 33 ... 64 rows (two row tiles): round 4's table (profiles/r4_route_ab.txt), register-transposed vs producer/consumer:
+    //   M = 40 / 48: 4096^2 8.9 / 9.1 vs 9.4 / 9.5, 3072^2 8.3 vs 8.8, 1376 x 4096 7.5 vs 8.6, 2048 x 4096 6.8 vs 8.6 - but the
+    //     elongated 8192 x 2048 10.6 vs 9.7 and 2048 x 8192 11.1 vs 10.1
+    //   M = 64: 1376 x 4096 7.8 vs 9.4, 2048 x 4096 8.0 vs 9.5 - but 3072^2 11.8 vs 9.7, 8192 x 2048 12.7 vs 10.9, 2048 x 8192
+    //     13.4 vs 11.0, 4096^2 10.8 vs 10.5
+    const long longer = N > K ? N : K, shorter = N > K ? K : N;
+    if (M <= 48)
+        return weights <= (12L << 20) || (weights <= (20L << 20) && longer < 2 * shorter);
     if (M <= 64)
-        return weights <= (20L << 20);
-    return false;
-}
-// Which problems go to the pre-scaled-operand kernel (tuning knob cfg 30 / 31 forces it: two / three ring slots;
-// knob % 100 = K slices).
-bool ps_selected(int M, int N, int K, int knob1, int* force_ks, int* variant) {
-    const int cfg = knob1 / 100;
-    *force_ks = 0;
-    *variant = 0;
-    if (cfg == 30 || cfg == 31) {
-        *force_ks = knob1 % 100;
-        *variant = cfg - 30;
-        return true;
-    }
-    if (cfg != 0)
-        return false;
-    // measured on MI355X (profiles/r3_tall_batch_ab.txt), us per launch, pre-scaled-operand kernel (128-row tiles) vs
-    // producer/consumer kernel (64-row tiles): 28672 x 8192 M = 128 / 256 92 / 168 vs 112 / 210; 11008 x 4096 M = 256 44 vs 54;
-    // 8192^2 and 4096 x 11008 M = 256 equal; but 4096^2 M = 256 27 vs 23, and up to 128 rows on matrices below 128 M weights the
-    // producer/consumer kernel stays ahead (8192^2 M = 128 38 vs 34)
-    const long weights = static_cast<long>(N) * K;
-    if (M > 128)
-        return weights >= (32L << 20);
-    if (M > 64)
-        return weights >= (128L << 20);
+        return weights <= (17L << 19);
     return false;
 }
 // Which problems go to the K-quarter kernel (tuning knob cfg 40 forces it; knob % 100 = K slices).
@@ -833,6 +812,26 @@ bool kq_selected(int M, int N, int K, int knob1, int* force_ks) {
         *force_ks = knob1 % 100;
         return true;
     }
+    if (cfg != 0)
+        return false;
+    // measured on MI355X (profiles/r4_kq_ab.txt), us per launch pair, K-quarter vs producer/consumer kernel, M = 17 / 32 / 64:
+    // 8192^2 15.3 / 15.9 / 20.0 vs 17.1 / 17.6 / 21.8; 11008 x 4096 13.5 / 14.0 / 17.6 vs 15.1 / 15.5 / 19.3; 4096 x 11008 12.5 /
+    // 13.0 / 16.7 vs 14.2 / 14.6 / 17.7; 28672 x 8192 38 / 40 / 47 vs 41 / 42 / 53; 5120^2 and 6144 x 4096 (25 M weights) 0.5 - 0.9
+    // ahead; 4096^2 and below: behind the register-transposed kernel (17 ... 32 rows) or level with the producer/consumer one
+    // 33 ... 48 rows (a quarter of the second row tile is padding; the producer/consumer kernel has 48-row tiles): 5120^2 13.8 vs
+    // 13.2, 8192^2 and 11008 x 4096 level or 0.5 ahead. Taller batches (64-row passes; profiles/r4_route_ab.txt, M = 128 / 256 /
+    // 512): 4096^2 13.0 / 17.9 / 24.0 vs 13.5 / 19.7 / 27.5, 8192^2 28.9 / 45.1 / 88.9 vs 32.4 / 52.4 / 101, 11008 x 4096 23.0 /
+    // 43.2 / 69.8 vs 26.9 / 50.9 / 80.2, 28672 x 8192 89 / 171 vs 109 / 199 - and level with or ahead of round 3's pre-scaled-operand
+    // kernel (same table, column ps), which left the library for it
+    const long weights = static_cast<long>(N) * K;
+    if (M >= 17 && M <= 32)
+        return weights >= (24L << 20);
+    if (M >= 33 && M <= 48)
+        return weights >= (40L << 20);
+    if (M >= 49 && M <= 64)
+        return weights >= (24L << 20);
+    if (M >= 65)
+        return weights >= (16L << 20);
     return false;
 }
 } // namespace
@@ -850,24 +849,20 @@ size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K) {
         return 0;
     int fks, fw;
     const int knob1 = g_mfma_knob1.load(std::memory_order_relaxed);
-    int pks, pvar, qks;
-    size_t ps_bytes = 0;
-    if (kq_selected(M, N, K, knob1, &qks))
-        return gemm_4bit_kq_workspace_bytes(M, N, K, qks);
-    if (ps_selected(M, N, K, knob1, &pks, &pvar)) {
-        ps_bytes = gemm_4bit_ps_workspace_bytes(M, N, K, pks);
-        if (knob1 != 0)
-            return ps_bytes;
-        // (chosen by the built-in rule: a nested-absmax call of the same shape runs the kernels below instead - the query does
-        // not know which it will be and answers with the larger of the two)
+    int qks;
+    size_t kq_bytes = 0;
+    if (kq_selected(M, N, K, knob1, &qks)) {
+        kq_bytes = gemm_4bit_kq_workspace_bytes(M, N, K, qks);
+        // (a call whose statistics or alignment the K-quarter kernel does not serve - gemm_4bit_kq_serves / _supported - runs the
+        // kernels below: the query does not know and answers with the larger of the two)
     }
     if (rt_selected(M, N, K, knob1, &fks, &fw)) {
         const size_t b = gemm_4bit_rt_workspace_bytes(M, N, K, fks);
-        return b > ps_bytes ? b : ps_bytes;
+        return b > kq_bytes ? b : kq_bytes;
     }
     const Plan pl = make_plan(M, N, K, knob1);
     const size_t b = pl.ks > 1 ? static_cast<size_t>(pl.ks) * M * N * sizeof(float) : 0;
-    return b > ps_bytes ? b : ps_bytes;
+    return b > kq_bytes ? b : kq_bytes;
 }
 
 void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
@@ -876,15 +871,11 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
                     size_t workspace_bytes, hipStream_t stream) {
     int fks, fw;
     const int knob0 = g_mfma_knob0.load(std::memory_order_relaxed), knob1 = g_mfma_knob1.load(std::memory_order_relaxed);
-    int pks, pvar, qks;
+    int qks;
     if (kq_selected(M, N, K, knob1, &qks) && gemm_4bit_kq_supported(dtype, A, B, code16, M, N, K, blocksize) &&
         gemm_4bit_kq_serves(absmax, absmax8, blocksize, K))
         return gemm_4bit_kq(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type,
                             workspace, workspace_bytes, qks, knob0, stream);
-    if (ps_selected(M, N, K, knob1, &pks, &pvar) && (absmax8 == nullptr || gemm_4bit_ps_serves_nested()) &&
-        gemm_4bit_ps_supported(dtype, A, B, code16, M, N, K, blocksize))
-        return gemm_4bit_ps(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type,
-                            workspace, workspace_bytes, pks, pvar, knob0, stream);
     if (rt_selected(M, N, K, knob1, &fks, &fw) && gemm_4bit_rt_supported(dtype, A, B, code16, M, N, K, blocksize))
         return gemm_4bit_rt(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize,
                             quant_type, workspace, workspace_bytes, fks, fw, knob0 & 1, stream);

@@ -735,8 +735,17 @@ __global__ __launch_bounds__(kKqWaves * 64) void gemm4_mfma_kq_kernel(
         }
     }
     const uint32_t row_bytes = static_cast<uint32_t>(N) * esz;
-    void* const st_base = hot_kslices == 1 ? p.out : static_cast<void*>(p.ws + static_cast<long>(blockIdx.y) * M * N);
-    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(st_base, 0, static_cast<int>(static_cast<uint32_t>(M) * row_bytes), 0x00020000);
+    // K slices across workgroups: the slab is NOT a row-major [M][N] matrix but the accumulator layout itself - per workgroup
+    // tile [column group][tile nt * MT + mt][register quad j][lane] 16 bytes (rows 8 j + 4 h + 0..3 of column n): a lane's four
+    // consecutive registers leave as ONE 16-byte store, 1 KiB contiguous per wavefront instruction (the row-major form needs four
+    // 4-byte stores of two 128-byte row segments each: the store tail of the kernel was bound by the number of store
+    // instructions the CU's address unit takes, 128 per workgroup). gemm4_finalize_kq_kernel below reads that layout.
+    const long slab_floats = static_cast<long>(gridDim.z) * gridDim.x * (4096 * MT);
+    void* const st_base = hot_kslices == 1
+                              ? p.out
+                              : static_cast<void*>(p.ws + static_cast<long>(blockIdx.y) * slab_floats +
+                                                   (static_cast<long>(blockIdx.z) * gridDim.x + blockIdx.x) * (4096 * MT));
+    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(st_base, 0, hot_kslices == 1 ? static_cast<int>(static_cast<uint32_t>(M) * row_bytes) : 16384 * MT, 0x00020000);
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         if (q != o) {
@@ -764,6 +773,7 @@ __global__ __launch_bounds__(kKqWaves * 64) void gemm4_mfma_kq_kernel(
 #pragma unroll
                 for (int src = 0; src < 3; ++src)
                     x[src] = *reinterpret_cast<const f32x4*>(smem + ((((c * 4 + o) * 3 + src) * CH + ch) * 64 + lane) * 16);
+                f32x4 v4;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int f = o * RS + ch * 4 + k;
@@ -774,15 +784,20 @@ __global__ __launch_bounds__(kKqWaves * 64) void gemm4_mfma_kq_kernel(
 #pragma unroll
                     for (int qq2 = 1; qq2 < 4; ++qq2)
                         v += qq2 == o ? own : x[qq2 < o ? qq2 : qq2 - 1][k];
-                    // 32x32 accumulator layout: register i of lane (n, h) = row (i & 3) + 8 (i >> 2) + 4 h, column n
-                    const int mrel = 32 * mt + (i & 3) + 8 * (i >> 2);
-                    const uint32_t voff = st_lane[nt] + static_cast<uint32_t>(mrel) * row_bytes;
+                    v4[k] = v;
                     if (hot_kslices == 1) {
+                        // 32x32 accumulator layout: register i of lane (n, h) = row (i & 3) + 8 (i >> 2) + 4 h, column n
+                        const int mrel = 32 * mt + (i & 3) + 8 * (i >> 2);
+                        const uint32_t voff = st_lane[nt] + static_cast<uint32_t>(mrel) * row_bytes;
                         const T tv = static_cast<T>(v + bv[nt]);
                         __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, tv), rs_o, voff, 0, 0);
-                    } else {
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs_o, voff, 0, 2 /* nt: read once, by another launch */);
                     }
+                }
+                if (hot_kslices != 1) {
+                    const int f0 = o * RS + ch * 4; // tile f0 / 16, register quad (f0 % 16) / 4
+                    const uint32_t voff = static_cast<uint32_t>(lane) * 16u + static_cast<uint32_t>(((f0 / 16) * 4 + (f0 % 16) / 4) * 1024);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), rs_o, voff, static_cast<uint32_t>(c) * (8192u * MT),
+                                                           2 /* nt: read once, by another launch */);
                 }
             }
         }
@@ -799,9 +814,74 @@ __global__ __launch_bounds__(kKqWaves * 64) void gemm4_mfma_kq_kernel(
 #endif
 }
 
+// out = T(sum over the K slices + bias) from slabs in the accumulator layout the kernel above stores (see its epilogue): one
+// thread per 16-byte piece = rows row0 .. row0 + 3 of one column; slices added in slice order (bit-reproducible); the rows and
+// columns of a ragged tile are dropped here.
+template <typename T, int BATCH>
+__global__ __launch_bounds__(256) void gemm4_finalize_kq_kernel(const float* __restrict__ ws, const T* __restrict__ bias, T* __restrict__ out,
+                                                                long slab_floats, int M, int N, int gx, int mt, int kslices) {
+    const long idx = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+    if (idx * 4 >= slab_floats)
+        return;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (all loads of a batch in flight before the first add - gemm4_finalize_kernel)
+    for (int s0 = 0; s0 < kslices; s0 += BATCH) {
+        f32x4 w[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const int sl = (s0 + j < kslices) ? s0 + j : kslices - 1;
+            w[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ws + static_cast<long>(sl) * slab_floats + idx * 4));
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const bool live = s0 + j < kslices;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                v[k] = live ? v[k] + w[j][k] : v[k];
+        }
+    }
+    const int lane = static_cast<int>(idx & 63);
+    long r = idx >> 6;
+    const int j = static_cast<int>(r & 3);
+    r >>= 2;
+    const int t = static_cast<int>(r % (2 * mt));
+    r /= (2 * mt);
+    const int c = static_cast<int>(r & 1);
+    const long wg = r >> 1;
+    const int bx = static_cast<int>(wg % gx), bz = static_cast<int>(wg / gx);
+    const int col = bx * kKqCols + 64 * c + 32 * (t / mt) + (lane & 31);
+    const int row0 = bz * 32 * mt + 32 * (t % mt) + 8 * j + 4 * (lane >> 5);
+    if (col >= N)
+        return;
+    const float b = bias ? static_cast<float>(bias[col]) : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (row0 + k < M)
+            out[static_cast<long>(row0 + k) * N + col] = static_cast<T>(v[k] + b);
+}
+
+template <typename T>
+void kq_finalize(const float* ws, const void* bias, void* out, long slab_floats, int M, int N, int gx, int mt, int kslices, hipStream_t stream) {
+    const dim3 grid(static_cast<unsigned>((slab_floats / 4 + 255) / 256));
+    const T* const b = static_cast<const T*>(bias);
+    T* const o = static_cast<T*>(out);
+    if (kslices <= 2)
+        hipLaunchKernelGGL((gemm4_finalize_kq_kernel<T, 2>), grid, dim3(256), 0, stream, ws, b, o, slab_floats, M, N, gx, mt, kslices);
+    else if (kslices <= 4)
+        hipLaunchKernelGGL((gemm4_finalize_kq_kernel<T, 4>), grid, dim3(256), 0, stream, ws, b, o, slab_floats, M, N, gx, mt, kslices);
+    else
+        hipLaunchKernelGGL((gemm4_finalize_kq_kernel<T, 8>), grid, dim3(256), 0, stream, ws, b, o, slab_floats, M, N, gx, mt, kslices);
+}
+
 struct KqPlan {
     int mt, ks, cps;
 };
+
+// floats of one K slice's slab: whole workgroup tiles (128 columns x 32 MT rows), in the accumulator layout
+long kq_slab_floats(int M, int N, int mt) {
+    const long gx = (N + kKqCols - 1) / kKqCols, gz = (M + 32 * mt - 1) / (32 * mt);
+    return gx * gz * 4096L * mt;
+}
 
 // Row tiles, K slices and chunks per slice: a pure function of (M, N, K) and the forced slice count, shared by the launch
 // and the workspace-size query. One workgroup per CU (~150 KiB of LDS): K slices fill the chip without spilling into a second
@@ -907,16 +987,17 @@ size_t gemm_4bit_kq_workspace_bytes(int M, int N, int K, int force_ks) {
     if (M < 1 || N < 1 || K < kKqChunk)
         return 0;
     const KqPlan pl = kq_plan(M, N, K, force_ks);
-    return pl.ks > 1 ? static_cast<size_t>(pl.ks) * M * N * sizeof(float) : 0;
+    return pl.ks > 1 ? static_cast<size_t>(pl.ks) * kq_slab_floats(M, N, pl.mt) * sizeof(float) : 0;
 }
 
 // dtype: 1 = f16, 2 = bf16. force_ks (0 = built-in choice): sweeps and tests.
 void gemm_4bit_kq(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int ablate, hipStream_t stream) {
+    g_last_gemm_kernel = kKernelKq;
     KqPlan pl = kq_plan(M, N, K, force_ks);
     float* ws = static_cast<float*>(workspace);
-    const size_t slab = static_cast<size_t>(M) * N * sizeof(float);
+    const size_t slab = static_cast<size_t>(kq_slab_floats(M, N, pl.mt)) * sizeof(float);
     if (pl.ks > 1) {
         if (ws == nullptr) {
             ws = gemm_4bit_internal_workspace(slab * pl.ks, stream);
@@ -951,8 +1032,14 @@ void gemm_4bit_kq(int dtype, const void* A, const uint8_t* B, const float* absma
     else
         kq_launch<f16>(A, B, absmax, absmax8, M, N, K, flags, sfast, pl, a, stream);
     BNB_CHECK_LAUNCH();
-    if (pl.ks > 1)
-        gemm_4bit_finalize(dtype, ws, bias, out, M, N, pl.ks, stream);
+    if (pl.ks > 1) {
+        const int gx = (N + kKqCols - 1) / kKqCols;
+        if (dtype == 2)
+            kq_finalize<bf16>(ws, bias, out, kq_slab_floats(M, N, pl.mt), M, N, gx, pl.mt, pl.ks, stream);
+        else
+            kq_finalize<f16>(ws, bias, out, kq_slab_floats(M, N, pl.mt), M, N, gx, pl.mt, pl.ks, stream);
+        BNB_CHECK_LAUNCH();
+    }
 }
 
 } // namespace bnb

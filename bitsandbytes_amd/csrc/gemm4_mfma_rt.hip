@@ -558,6 +558,7 @@ void gemm_4bit_rt(int dtype, const void* A, const uint8_t* B, const float* absma
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int force_waves,
                   int variant, hipStream_t stream) {
+    g_last_gemm_kernel = kKernelRt;
     RtPlan pl = rt_plan(M, N, K, force_ks);
     if (force_waves == 8 || (force_waves == 16 && pl.mt == 1))
         pl.waves = force_waves;

@@ -891,8 +891,10 @@ void gemv_4bit_stream(int dtype, const void* A, const uint8_t* B, const float* a
         for (int i = 0; i < kMaxGroup; ++i)
             a.mat[i] = StreamMat{B, absmax, absmax8, absmax_code, absmax_offset, out, bias, N, i == 0 ? 0 : 0x7FFFFFFF};
         launch_stream_any(dtype, a, quant_type, false, stream);
+        g_last_gemm_kernel = kKernelStream;
         return;
     }
+    g_last_gemm_kernel = kKernelGeneric;
     GenericArgs p{A, B, absmax, absmax8, absmax_code, absmax_offset, code16, out, bias, M, N, K, ilog2(blocksize), quant_type};
     if (dtype == 0)
         launch_generic<float>(p, stream);
@@ -945,6 +947,7 @@ bool gemv_4bit_grouped(int dtype, const void* A, int count, const uint8_t* const
         make_geometry(a.rows_total, K, mb, 8, dtype == 0 ? 4 : 2, true, 0, 0).P > 1)
         return false; // rows longer than one workgroup's segment columns: the single-matrix path has the phase loop
     launch_stream_any(dtype, a, quant_type, true, stream);
+    g_last_gemm_kernel = kKernelStream;
     return true;
 }
 

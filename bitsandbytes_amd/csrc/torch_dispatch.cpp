@@ -32,7 +32,7 @@ namespace {
 // keep in step with bitsandbytes_amd/backends/hip.py (FUSED_MAX_M, FUSED_MAX_M_SMALL, FUSED_SMALL_WEIGHTS,
 // _REFERENCE_CUSTOM_MAX_M, _gemm_4bit_route); the GPU test tests/test_gpu_parity.py::test_native_dispatch_matches_python_kernel
 // runs both over fused and unfused shapes, tests/test_cabi.py pins the constants
-constexpr int64_t kFusedMaxM = 256;
+constexpr int64_t kFusedMaxM = 512;
 constexpr int64_t kFusedMaxMSmall = 512;
 constexpr int64_t kFusedSmallWeights = 20971520; // 20 << 20
 constexpr int64_t kFusedMaxMFp32 = 4;

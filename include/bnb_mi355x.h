@@ -122,6 +122,12 @@ size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N,
 /* Which kernel family bnb_mi355x_gemm_4bit(kernel, ...) runs for this problem (aligned pointers assumed): 0 = streaming
  * kernel, 1 = MFMA kernels. The grouped entry point below goes matrix by matrix when any member answers 1. */
 int bnb_mi355x_gemm_4bit_route(int kernel, int dtype, int M, int N, int K, int blocksize);
+/* Which kernel family the calling thread's LAST gemm_4bit / gemv_4bit call (any entry point) launched: 0 none yet, 1 streaming
+ * kernel (gemv4_stream_kernel), 2 generic scalar kernel (odd shapes), 3 register-transposed MFMA kernel (gemm4_mfma_rt_kernel),
+ * 4 producer/consumer MFMA kernel (gemm4_mfma_pc_kernel), 6 K-quarter MFMA kernel (gemm4_mfma_kq_kernel). Debug / test query:
+ * a test that forces a kernel with bnb_mi355x_set_tuning asserts here that it ran (a geometry the forced kernel does not
+ * serve falls back to another family by design). */
+int bnb_mi355x_last_gemm_kernel(void);
 
 /* Grouped gemm_4bit: `count` weight matrices applied to the SAME activations A[M, K] in one launch -
  *   out[i][M, N[i]] = A * dequant(B[i])^T (+ bias[i])        i = 0 .. count-1
@@ -168,7 +174,7 @@ int bnb_mi355x_peer_status(const void* local_buffer);
  * cell-table kernel, 2 = byte-table kernel, anything else = by input size; reserved1: N slices of the fused backward (> 0; the
  * workspace-size query follows it). MFMA kernels: knob0 bit 0 = round 2's form of the register-transposed kernel (measurement build only; ignored by the product library),
  * knob1 = 100 * cfg + K-slice count (cfg 11-14 producer/consumer geometries, 20/21/22
- * register-transposed kernel with built-in / 8 / 16 wavefronts, 30 pre-scaled-operand kernel). Every setting
+ * register-transposed kernel with built-in / 8 / 16 wavefronts, 40 K-quarter kernel). Every setting
  * computes correct results - the knobs only choose a launch geometry. THREAD-LOCAL: a setting applies to the calls the
  * SAME host thread makes afterwards and to nothing else in the process. */
 void bnb_mi355x_set_tuning(int reserved0, int reserved1, int mfma_knob0, int mfma_knob1);

@@ -238,7 +238,8 @@ def test_rt_kernel_isa_keeps_its_loads_in_flight():
 
 def test_launch_plan_workspace_query_is_pure_host_logic():
     """bnb_mi355x_gemm_4bit_workspace_bytes runs the launch plans on the host (no GPU needed): for every BASELINE
-    shape the split-K workspace is a whole number of fp32 [M, N] slabs, bounded by one slab per 512 k of K
+    shape the split-K workspace is a whole number of fp32 slabs - [M, N] ones, or the K-quarter kernel's (whole 128-column x
+    32 / 64-row workgroup tiles in the accumulator layout: gemm4_mfma_kq.hip) - bounded by one slab per 512 k of K
     (>= 2 chunks of 256 k per slice), zero where no MFMA split-K launch can happen, and the query is a pure
     function (same answer twice)."""
     from bitsandbytes_amd import cextension as ce
@@ -254,18 +255,21 @@ def test_launch_plan_workspace_query_is_pure_host_logic():
                 w = q(kernel, BF16, M, N, K, 64)
                 assert w == q(kernel, BF16, M, N, K, 64)
                 slab = M * N * 4
-                assert w % slab == 0, (M, N, K, w)
-                ks = w // slab
+                rows = 64 if M > 32 else 32
+                slab_kq = -(-M // rows) * rows * -(-N // 128) * 128 * 4
+                assert w % slab == 0 or w % slab_kq == 0, (M, N, K, w)
+                ks = w // slab if w % slab == 0 else w // slab_kq
                 assert ks == 0 or 2 <= ks <= max(2, K // 512), (M, N, K, ks)
                 if kernel == 0 and M <= 2:
                     assert w == 0, "M <= 2 runs the dot kernel: no workspace"
         assert q(1, BF16, 64, N, K, 64) == 0, "explicit dot kernel never needs a workspace"
         assert q(0, 0, 64, N, K, 64) == 0, "fp32 activations never take the MFMA path"
         assert q(0, BF16, 64, N, K, 32) == 0, "blocksize 32 is outside the MFMA kernels' preconditions"
-    # headline shape: single-launch plans (no finalize pass) for every batch up to 64 rows (the register-transposed kernel:
+    # headline shape: single-launch plans (no finalize pass) for every batch up to 48 rows (the register-transposed kernel:
     # 256 column tiles fill the chip without K slices); large matrices with tall tiles split K
     assert q(0, BF16, 16, 4096, 4096, 64) == 0
-    assert q(0, BF16, 64, 4096, 4096, 64) == 0
+    assert q(0, BF16, 48, 4096, 4096, 64) == 0
+    assert q(0, BF16, 64, 4096, 4096, 64) > 0
     assert q(0, BF16, 64, 8192, 8192, 64) > 0
     assert q(0, BF16, 64, 4096, 4100, 64) == 0, "K % 256 != 0 falls back to the dot kernel"
 

@@ -400,24 +400,6 @@ def test_rt_mfma_lane_algebra_emulation():
 
 
 
-def test_ps_mfma_lane_algebra_emulation():
-    """The index algebra of csrc/gemm4_mfma_ps.hip (LDS-DMA instructions with source-side XOR swizzles, the weight / scale /
-    activation ring slots, the ds_read_b128 + v_permlane32_swap that deals the packed weights to the two column tiles of a
-    lane, the k order of the 32x32x16 MFMA steps across K quarters and lane halves, the accumulator layout and the split of the
-    accumulator registers among the K quarters in the epilogue, K slices) replayed lane by lane against the hardware semantics -
-    see tests/checks/emulate_ps_mfma.py. Every 16-byte LDS read is also checked against the lane groups one ds_read_b128 pass
-    serves (no bank conflicts), every ring read against the stage the slot must hold."""
-    import importlib.util
-    import os
-
-    spec = importlib.util.spec_from_file_location(
-        "emulate_ps_mfma", os.path.join(os.path.dirname(__file__), "checks", "emulate_ps_mfma.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    for (M, K, MT, sps) in ((40, 768, 2, None), (64, 1024, 2, 3), (17, 512, 2, None), (100, 640, 4, 2)):
-        assert mod.emulate(M=M, K=K, MT=MT, seed=M, sps=sps) < 1e-12
-
-
 def test_grad_input_lane_algebra_emulation():
     """The index algebra of csrc/gemm4_grad_input.hip (one dword per weight row and lane, nibble j = B operand of the strided
     column tile {8 c + j}, the swizzled private grad_out patch, the scale patch, the output mapping, the dealing of the final

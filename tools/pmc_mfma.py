@@ -16,7 +16,7 @@ ap.add_argument("--n", type=int, default=8192)
 ap.add_argument("--k", type=int, default=8192)
 ap.add_argument("--m", type=int, default=64)
 ap.add_argument("--layers", type=int, default=8)
-ap.add_argument("--knob", type=int, default=0, help="bnb_mi355x_set_tuning mfma_knob1 (e.g. 3000 = ps kernel)")
+ap.add_argument("--knob", type=int, default=0, help="bnb_mi355x_set_tuning mfma_knob1 (e.g. 4000 = K-quarter kernel)")
 a = ap.parse_args()
 g = torch.Generator(device="cuda").manual_seed(0)
 layers = []
