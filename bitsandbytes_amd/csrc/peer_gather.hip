@@ -97,13 +97,18 @@ __global__ __launch_bounds__(kPeerThreads) void peer_allgather_kernel(PeerBufs b
     __syncthreads();
     // ---- rank p's shard goes to the caller's output (every lane orders its reads behind the flag it did not read itself)
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    unsigned char* const o = out + static_cast<size_t>(p) * bytes;
     if (landed) {
         const unsigned char* const slot = local + kPeerDataOffset + (static_cast<size_t>(e & 1u) * world + p) * slot_stride;
-        unsigned char* const o = out + static_cast<size_t>(p) * bytes;
         if (vec)
             peer_copy<V16>(o, slot, bytes, tid);
         else
             peer_copy<unsigned char>(o, slot, bytes, tid);
+    } else {
+        // the peer never arrived (status word set above): its rows of the result become all-ones bytes - a NaN in fp16, bf16 and
+        // fp32 - instead of whatever the caller's buffer held: a timeout cannot pass for data downstream
+        for (uint32_t i = tid; i < bytes; i += kPeerThreads)
+            o[i] = 0xFFu;
     }
 }
 

@@ -205,7 +205,13 @@ class GraphedBlock:
     ``fn(*tensors) -> tensor | sequence of tensors``; the example inputs fix shapes and dtypes. Every rank must build and call its
     GraphedBlock in the same order (the collectives inside are replayed, not renegotiated). Inference only."""
 
-    def __init__(self, fn, *example_inputs: torch.Tensor, warmup: int = 2):
+    def __init__(self, fn, *example_inputs: torch.Tensor, warmup: int = 2, peers=(), check_every: int = 1024):
+        # peers: the PeerAllGather objects the block uses. A peer kernel that gives up waiting marks the missing rows NaN and sets a
+        # sticky status word; nothing on the device raises. The block reads the word every `check_every` replays (a device
+        # synchronisation each time) and in check(): a dead rank surfaces as an exception instead of NaNs far downstream.
+        self._peers = [p for p in peers if p is not None]
+        self._check_every = max(1, int(check_every))
+        self._replays = 0
         self._static_in = [t.clone() for t in example_inputs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -229,7 +235,15 @@ class GraphedBlock:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
         self.graph.replay()
+        self._replays += 1
+        if self._peers and self._replays % self._check_every == 0:
+            self.check()
         return self._static_out[0] if self._single else list(self._static_out)
+
+    def check(self) -> None:
+        """Raises if a peer collective of this block ever gave up waiting for a rank (synchronises the device)."""
+        for p in self._peers:
+            p.check()
 
     @property
     def inputs(self):

@@ -7,6 +7,10 @@ then runs ONE kernel per collective in which each rank stores its shard straight
 xGMI, publishes a flag and waits for the peers' flags (``csrc/peer_gather.hip``). It is a plain stream-ordered launch: no host
 synchronisation, capturable in a hipGraph with the kernels around it (``parallel.GraphedBlock``).
 
+A wait that runs into its bound does not hang the queue: the launch ends, the missing rank's rows of the result are NaN (all-ones
+bytes) and a sticky status word is set. Nothing on the device raises: callers poll :meth:`PeerAllGather.check` at their natural
+synchronisation points (``parallel.GraphedBlock`` does every ``check_every`` replays; ``bench.py`` before it trusts the kernel).
+
 Nothing in the reference to mirror (it has no collective code). Exercised here with two processes sharing one GPU
 and in-process at world size 1; **not measured on a multi-GPU node by us**.
 """
@@ -118,7 +122,16 @@ class PeerAllGather:
         self._release()
 
     def __del__(self):
+        # (garbage collection is not collective: no barrier here. The local work is drained before the buffer goes away; peers
+        # that may still store into it are the reason `close()` exists - an object that is dropped while the process group is
+        # alive and no barrier has run keeps its memory mapped rather than freeing it under a peer's stores)
         try:
+            if self._local is None:
+                return
+            torch.cuda.synchronize(self.device)
+            if self.world > 1 and dist.is_initialized():
+                self._mapped, self._local = [], None   # leaked on purpose: see above
+                return
             self._release()
         except Exception:
             pass
