@@ -15,13 +15,15 @@ Timed region: each step is one replay of a hipGraph holding the step's 128 launc
 (bitsandbytes_amd.matmul_4bit) - for ANY --steps / --warmup value, so a short driver run measures the same thing as
 a long one. Bracketed by barrier + synchronize; MAX over ranks.
 
---gpus N > 1 (weak scaling, bitsandbytes_amd.parallel semantics: rows sharded, x replicated, no reduction): every
-rank owns a full-size 4096-row shard of an (N*4096)-row layer, held in parallel.ShardedLinear4bit modules. A step is
-what a tensor-parallel decode does: per layer the shard kernel and then the all-gather of THAT layer's 8 KB of outputs
-(the next layer needs the whole y) - 128 kernels + 128 collectives in stream order, one hipGraph per step; `value` is
-this per-layer form. The gather is the one-shot peer kernel (bitsandbytes_amd.peer) when it reproduces RCCL's result
-at start-up, else RCCL's all_gather_into_tensor. The bucketed form (ONE all-gather per step - legal only because the
-benchmark's layers do not feed each other) is timed as well and reported as the side key "bucketed_gather".
+--gpus N > 1 (weak scaling, bitsandbytes_amd.parallel semantics: rows sharded, x replicated, no reduction): a decode step
+through an N-sharded MLP stack - up (H -> F) / down (F -> H) layers, each sharded by output features, each layer's
+gathered y the next layer's x; H x F = N x 4096^2, so every rank's shard of every layer holds 4096^2 weights, the
+headline layer's bytes, at every N (1: 4096 / 4096, 2: 4096 / 8192, 4: 8192 / 8192, 8: 8192 / 16384). A step is what a
+tensor-parallel decode does: 128 x (shard kernel + the all-gather of THAT layer's outputs), one hipGraph per step.
+`value` takes the fused form (bitsandbytes_amd.peer.PeerChain: the gather inside the gemv launches, one launch per
+layer) when it reproduces the separate form bit for bit at start-up on every rank, else kernel + a collective per layer
+(the one-shot peer kernel when IT reproduces RCCL, else RCCL's all_gather_into_tensor); the other forms and the shard
+kernels alone are timed beside it ("sharded_chain"). N > 1 was never run on real links by the builder.
 
 Extra objects on the JSON line:
   "roofline"      dominant kernel; achieved = algorithmic bytes / kernel_us, frac = achieved / 8 TB/s. THREE clocks are
@@ -391,30 +393,49 @@ def main():
     assert bnb.lib, "native HIP library missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
 
     M, N, K, bs, qt = args.m, args.n, args.k, args.blocksize, args.quant_type
-    layers, x = build_layers(device, LAYERS, N, K, M, bs, qt, seed=1234 + rank)
-    nbytes_layer = algorithmic_bytes(M, N, K, bs)
-    nbytes_step = LAYERS * nbytes_layer
-    flops_step = LAYERS * 2 * M * N * K
-
-    # ---- one step = the 128 layers, each its own launch through the public op
-    peer = None
+    peer = chain = None
+    chain_info = None
     if not multi:
+        layers, x = build_layers(device, LAYERS, N, K, M, bs, qt, seed=1234 + rank)
+        nbytes_layer = algorithmic_bytes(M, N, K, bs)
+        nbytes_step = LAYERS * nbytes_layer
+        flops_step = LAYERS * 2 * M * N * K
+
+        # ---- one step = the 128 layers, each its own launch through the public op
         def step_fn():
             for q, st in layers:
                 bnb.matmul_4bit(x, q, st)
     else:
-        # this rank's shards as product modules (parallel.ShardedLinear4bit). A step is what a tensor-parallel decode does: per
-        # layer the shard kernel, then the all-gather of that layer's shard outputs - the next layer needs the whole y -
-        # i.e. LAYERS kernels + LAYERS collectives in stream order. (The bucketed form - one all-gather per step, legal only
-        # because this benchmark's layers do not feed each other - is timed separately and reported as a side key.)
-        # The gather: the one-shot peer kernel (bitsandbytes_amd.peer: 8 KB per rank is latency, not bandwidth) when it constructs
-        # on this node AND reproduces the group's own all-gather bit for bit on live data - its authors could only run it between
-        # processes sharing one GPU - else RCCL's all_gather_into_tensor. Every rank takes the same branch.
+        # ---- N-sharded decode chain (bitsandbytes_amd.parallel semantics: rows sharded, x replicated, no reduction). The model
+        # is an MLP stack, up (H -> F) / down (F -> H), every layer sharded by output features over the ranks and every layer's
+        # gathered y the next layer's x. H x F = world x 4096^2, so that EVERY rank's shard of EVERY layer holds 4096^2 weights - the
+        # headline layer's bytes - at any world size (weak scaling): world 1: 4096 / 4096, 2: 4096 / 8192, 4: 8192 / 8192, 8: 8192 /
+        # 16384. One step = one activation row through LAYERS such layers = LAYERS x (shard kernel + all-gather of y).
+        lg = max(0, world.bit_length() - 1)
+        H = N << (lg // 2)
+        Fd = (N * K * world) // H
+        if (H * Fd != N * K * world) or Fd % world or H % world:
+            sys.exit(f"bench.py: cannot build the sharded chain for world size {world} (needs a power of two)")
+        dims = [(Fd // world, H), (H // world, Fd)]      # (rows of this rank's shard, K) of an up / a down layer
+        g = torch.Generator(device=device).manual_seed(1234 + rank)
+        import bitsandbytes_amd.functional as F4
+
+        shard_mods = []
+        for li in range(LAYERS):
+            ns_l, k_l = dims[li & 1]
+            W = (torch.randn(ns_l, k_l, device=device, generator=g) / k_l**0.5).to(torch.bfloat16)
+            q, st = F4.quantize_4bit(W, blocksize=bs, quant_type=qt)
+            shard_mods.append((q, st, world * ns_l))
+            del W
+        x = torch.randn(M, H, device=device, generator=torch.Generator(device=device).manual_seed(99)).to(torch.bfloat16)  # same on every rank
+        nbytes_step = sum(algorithmic_bytes(M, int(st.shape[0]), int(st.shape[1]), bs) for _, st, _ in shard_mods)
+        nbytes_layer = nbytes_step // LAYERS
+        flops_step = sum(2 * M * int(st.shape[0]) * int(st.shape[1]) for _, st, _ in shard_mods)
+        os.environ.setdefault("BNB_MI355X_PEER_WAIT_POLLS", "3000000")  # (a few seconds: a node on which the peer kernels cannot work falls back quickly)
+        why = None
+        # the separate-gather form (kernel, then a collective per layer): the one-shot peer kernel when it constructs and
+        # reproduces RCCL's all-gather on live data, else RCCL's all_gather_into_tensor. Every rank takes the same branch.
         if not args.no_peer_gather:
-            # (a wait bound of a few seconds instead of the default tens: a node on which the kernel cannot work must fall back
-            # quickly; read once by the library, before its first collective)
-            os.environ.setdefault("BNB_MI355X_PEER_WAIT_POLLS", "3000000")
-            why = None
             try:
                 from bitsandbytes_amd.peer import PeerAllGather
 
@@ -435,7 +456,6 @@ def main():
                         same = same and bool(torch.equal(got, want)) and peer.status() == 0
                 except Exception as exc:  # noqa: BLE001
                     same, why = False, f"{type(exc).__name__}: {exc}"
-                # the decision is collective: every rank reaches this reduction, whatever happened to it above
                 agree = torch.tensor([1 if same else 0], device=device)
                 dist.all_reduce(agree, op=dist.ReduceOp.MIN)
                 if int(agree.item()) != 1:
@@ -447,20 +467,66 @@ def main():
                     peer = None
             if peer is None and rank == 0:
                 print(f"bench: peer all-gather not used ({why}); RCCL all_gather_into_tensor per layer", file=sys.stderr)
-        shards = [ShardedLinear4bit(q, st, out_features=world * N, group=None, always_gather=True, peer=peer) for q, st in layers]
-        buckets = [torch.empty(LAYERS, M, N, device=device, dtype=torch.bfloat16) for _ in range(2)]
-        gathered = [torch.empty(world * LAYERS, M, N, device=device, dtype=torch.bfloat16) for _ in range(2)]
+        separate = [ShardedLinear4bit(q, st, out_features=nf, group=None, always_gather=True, peer=peer) for q, st, nf in shard_mods]
+
+        def separate_fn():
+            y = x
+            for sh in separate:
+                y = sh(y)
+            return y
+
+        # the fused form (bitsandbytes_amd.peer.PeerChain: the gather inside the gemv launches - one launch per layer): used for
+        # `value` when it constructs on this node AND reproduces the separate form bit for bit on live data - its authors could only
+        # run it between processes sharing one GPU. The decision is collective.
+        fused_mod = None
+        why_chain = None
+        if not args.no_peer_gather:
+            try:
+                from bitsandbytes_amd.parallel import ShardedLinear4bitChain
+                from bitsandbytes_amd.peer import PeerChain
+
+                chain = PeerChain(max_values=max(H, Fd))
+                fused_mod = ShardedLinear4bitChain([ShardedLinear4bit(q, st, out_features=nf, group=None) for q, st, nf in shard_mods], chain)
+            except Exception as exc:  # noqa: BLE001
+                chain, fused_mod, why_chain = None, None, f"{type(exc).__name__}: {exc}"
+            ok = chain is not None
+            if ok:
+                try:
+                    ok = bool(fused_mod.fused(x))
+                    if not ok:
+                        why_chain = "the chain's shapes are outside the fused form"
+                    else:
+                        y_sep = separate_fn()
+                        for _ in range(3):
+                            y_fus = fused_mod(x)
+                            torch.cuda.synchronize()
+                            ok = ok and bool(torch.equal(y_fus, y_sep)) and chain.status() == 0
+                        if not ok:
+                            why_chain = "it does not reproduce the separate-gather form on this node"
+                except Exception as exc:  # noqa: BLE001
+                    ok, why_chain = False, f"{type(exc).__name__}: {exc}"
+            agree = torch.tensor([1 if ok else 0], device=device)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if int(agree.item()) != 1:
+                why_chain = why_chain or "another rank could not use it"
+                if chain is not None:
+                    try:
+                        chain.close()
+                    except Exception:  # noqa: BLE001
+                        pass
+                chain = fused_mod = None
+            if chain is None and rank == 0:
+                print(f"bench: fused peer chain not used ({why_chain}); kernel + separate all-gather per layer", file=sys.stderr)
+        chain_info = {"H": H, "F": Fd, "up_shard": list(dims[0]), "down_shard": list(dims[1]),
+                      "gather": "fused into the gemv launches (peer.PeerChain)" if chain is not None else
+                                ("separate one-shot peer kernel per layer (peer.PeerAllGather)" if peer is not None else "RCCL all_gather_into_tensor per layer"),
+                      "fused_chain_not_used_because": why_chain}
 
         def step_fn():
-            for sh in shards:
-                sh(x)
-
-        def make_bucketed_step(b):
-            def fn():
-                # (one stack kernel per step moves the 128 shard outputs into the gather bucket: the public op allocates its own
-                # output, and an out= copy per layer would add 128 launches)
-                torch.stack([sh.local_forward(x) for sh in shards], out=buckets[b])
-            return fn
+            if fused_mod is not None:
+                fused_mod(x)
+            else:
+                separate_fn()
 
     if args.prof_child:
         if args.prof_eager:
@@ -532,39 +598,37 @@ def main():
                 bnb.matmul_4bit(xm, q, st)
         return graph_us_per_launch(fn, LAYERS, reps)
 
-    kernel_us_events = per_launch_us(M)
+    side_forms = None
+    if not multi:
+        kernel_us_events = per_launch_us(M)
+    else:
+        # the same chain in its other forms, beside `value` (every rank enqueues the same work; MAX over ranks):
+        #   kernels alone: the shard kernels of the chain on resident inputs, no exchange at all - what a layer costs without the gather
+        #   separate gather: shard kernel, then a collective per layer (round 3's form)
+        def alone_fn():
+            for (q, st, _nf) in shard_mods:
+                bnb.matmul_4bit(xs_by_k[int(st.shape[1])], q, st)
 
-    bucketed_gather = None
-    if multi:
-        # the bucketed form: one all-gather per step. On the SAME stream: a cross-stream event wait behind a graph launch stalls
-        # the queue for ~190 us per step on this stack (measured on MI355X at world size 1: 5.7 us per layer against 4.2 with
-        # the gather in-stream, profiles/r2_sharded_path_probe.txt) - more than the 1 MB-per-rank gather it would hide.
-        bgraphs = [capture(make_bucketed_step(b)) for b in range(2)]
+        xs_by_k = {int(st.shape[1]): torch.randn(M, int(st.shape[1]), device=device).to(torch.bfloat16) for _, st, _ in shard_mods}
 
-        def run_bucketed(nsteps):
-            for c in range(nsteps):
-                b = c & 1
-                bgraphs[b].replay()
-                dist.all_gather_into_tensor(gathered[b].view(world * LAYERS * M, N), buckets[b].view(LAYERS * M, N))
+        def timed_form(fn):
+            barrier()
+            try:
+                us = graph_us_per_launch(fn, LAYERS, reps=5)
+            except Exception:  # noqa: BLE001  (a collective that cannot be captured here)
+                torch.cuda.synchronize()
+                return None
+            t_ = torch.tensor([us], device=device, dtype=torch.float64)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return round(float(t_.item()), 3)
 
-        n_b = max(8, min(args.steps, 200))
-        run_bucketed(4)
-        torch.cuda.synchronize()
-        barrier()
-        t1 = time.perf_counter()
-        run_bucketed(n_b)
-        torch.cuda.synchronize()
-        barrier()
-        dt = time.perf_counter() - t1
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        bucketed_gather = {"us_per_layer": round(float(tt.item()) / (n_b * LAYERS) * 1e6, 3),
-                           "GBps_whole_job": round(nbytes_step * world * n_b / float(tt.item()) / 1e9, 1),
-                           "what": f"the same {LAYERS} shard kernels per step as one hipGraph + ONE all_gather_into_tensor per step (informational: "
-                                   "legal only because this benchmark's layers are independent; `value` is the per-layer-gather form)"}
+        kernel_us_events = timed_form(alone_fn) or round(elapsed / args.steps / LAYERS * 1e6, 3)
+        side_forms = {"us_per_layer_kernels_alone": kernel_us_events,
+                      "us_per_layer_kernel_plus_separate_gather": timed_form(separate_fn),
+                      "us_per_layer_timed_region": round(elapsed / args.steps / LAYERS * 1e6, 3)}
 
     sweep = grouped = None
-    if (args.sweep or (not multi and not args.no_sweep)) and rank == 0:
+    if not multi and (args.sweep or not args.no_sweep) and rank == 0:
         sweep = []
         for m_rows in (1, 2, 4, 8, 16, 32, 64):
             t_us = per_launch_us(m_rows, reps=5)
@@ -626,20 +690,22 @@ def main():
             "data": "synthetic",
             "tflops": round(flops_step * total_steps / elapsed / 1e12, 4),
             "config": {
-                "workload": f"gemv_4bit {qt.upper()} bf16 M={M} N=K={N}x{K} blocksize={bs} fp32-absmax (BASELINE.json configs[1]); "
-                            f"one step = one activation row through {LAYERS} distinct layers, one launch per layer",
+                "workload": (f"gemv_4bit {qt.upper()} bf16 M={M} N=K={N}x{K} blocksize={bs} fp32-absmax (BASELINE.json configs[1]); "
+                             f"one step = one activation row through {LAYERS} distinct layers, one launch per layer") if not multi else
+                            (f"gemv_4bit {qt.upper()} bf16 M={M} blocksize={bs} fp32-absmax, N-sharded x{world}: decode step through {LAYERS} layers of an "
+                             f"MLP stack H={chain_info['H']} / F={chain_info['F']} (up shard {chain_info['up_shard'][0]}x{chain_info['up_shard'][1]}, down shard "
+                             f"{chain_info['down_shard'][0]}x{chain_info['down_shard'][1]}: {N}x{K} weights per rank and layer = BASELINE.json configs[1]'s layer at every N)"),
                 "layers_per_step": LAYERS,
                 "bytes_per_layer": nbytes_layer,
                 "bytes_per_step": nbytes_step,
                 "us_per_layer": round(elapsed / args.steps / LAYERS * 1e6, 3),
                 "launch": (f"hipGraph replay per step ({LAYERS} dependent launches of bitsandbytes_amd.matmul_4bit), every step of warm-up and timed region"
-                           if not multi else f"{LAYERS} x (shard kernel + all-gather) per step"),
+                           if not multi else f"{LAYERS} x (shard kernel + all-gather of its outputs) per step, "
+                                             f"{'one hipGraph per step' if step_graph is not None else 'eager'}; gather = {chain_info['gather']}"),
                 "timed_region_s": round(elapsed, 6),
-                "parallelism": (f"rows sharded x{world} (parallel.ShardedLinear4bit.forward per layer: shard kernel + the all-gather of "
-                                f"that layer's outputs, in stream order, {'one hipGraph per step' if step_graph is not None else 'eager'}; gather = "
-                                + ("one-shot peer kernel over hipIpc-mapped buffers (bitsandbytes_amd.peer), checked against RCCL's result at start-up"
-                                   if peer is not None else "RCCL all_gather_into_tensor")
-                                + "); N > 1 is unmeasured on hardware by the builder (1-GPU boxes only)") if multi else "single GPU",
+                "parallelism": (f"rows (output features) sharded x{world}, x replicated, one all-gather of y per layer, no reduction "
+                                f"(bitsandbytes_amd.parallel); gather = {chain_info['gather']}, checked bit for bit against the next simpler form at "
+                                "start-up on every rank; N > 1 is unmeasured on hardware by the builder (1-GPU boxes only)") if multi else "single GPU",
             },
             "roofline": {
                 "bound": "hbm",
@@ -665,8 +731,8 @@ def main():
             traffic, detail = pmc_traffic(extra)
             line["roofline"]["traffic"] = None if traffic is None else round(traffic)
             line["roofline"]["traffic_detail"] = detail
-        if bucketed_gather is not None:
-            line["bucketed_gather"] = bucketed_gather
+        if side_forms is not None:
+            line["sharded_chain"] = {**chain_info, **side_forms}
         if sweep is not None:
             line["headline_sweep_N4096_K4096"] = sweep
         if grouped is not None:
@@ -677,8 +743,9 @@ def main():
             except Exception as exc:  # baseline is informational; never lose the GPU line over it
                 line["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {exc}"}
     if multi:
-        if peer is not None:
-            peer.close()
+        for obj in (chain, peer):
+            if obj is not None:
+                obj.close()
         dist.destroy_process_group()
     if rank == 0:
         # the JSON line is the LAST line of stdout: RCCL prints its version banner through C stdio, which is block-buffered

@@ -32,6 +32,12 @@ bool gemv_4bit_grouped(int dtype, const void* A, int count, const uint8_t* const
                        void* const* out, const void* const* bias, const int* N, int M, int K, int blocksize, int quant_type,
                        hipStream_t stream);
 void gemv_4bit_stream_tuning(int ns, int sw, int rows_per_wg, int nt, int waves);
+bool gemv_4bit_peer(void* const* bufs, void* epoch_word, int world, int rank, int dtype, const void* A, const uint8_t* B, const float* absmax,
+                    const uint8_t* absmax8, const float* absmax_code, const float* absmax_offset, const void* bias, void* out_local,
+                    int ns, int K, int blocksize, int quant_type, int mode, long max_values, int wg_limit, uint32_t epoch_offset,
+                    uint32_t spin_bound, hipStream_t stream);
+void peer_chain_read(void* const* bufs, void* epoch_word, int world, int rank, int dtype, void* out, int nvalues, long max_values, uint32_t epoch_offset,
+                     uint32_t spin_bound, hipStream_t stream);
 thread_local int g_last_gemm_kernel = kKernelNone;
 #ifdef BNB_PROFILING
 unsigned long long* g_dbg_buf = nullptr; // profiling builds only: device buffer for the kernels' s_memtime stamps
@@ -285,6 +291,57 @@ size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N,
     return gemm_4bit_mfma_workspace_bytes(M, N, K);
 }
 int bnb_mi355x_last_gemm_kernel(void) { return g_last_gemm_kernel; }
+
+// ------------------------------------------------------------------ peer chain (the all-gather fused into the gemv launches)
+static uint32_t peer_chain_spin_bound() {
+    // a re-fetch is s_sleep 4 (256 cycles) + a system-scope load round trip: ~1 us. BNB_MI355X_PEER_WAIT_POLLS as in peer_gather.hip
+    static const uint32_t bound = [] {
+        const char* e = getenv("BNB_MI355X_PEER_WAIT_POLLS");
+        const long long v = e ? atoll(e) : 0;
+        return static_cast<uint32_t>(v > 0 && v < 4000000000LL ? v : 30000000LL);
+    }();
+    return bound;
+}
+size_t bnb_mi355x_peer_chain_buffer_bytes(long max_values) {
+    // header + 64 regions (gemv4_stream.hip: kChainRegions) of max_values / 2 granules of 8 bytes
+    return 256 + 64 * 4 * static_cast<size_t>(max_values > 0 ? max_values + (max_values & 1) : 0);
+}
+void* bnb_mi355x_peer_chain_alloc(size_t bytes) {
+    // ordinary (cacheable) device memory, zeroed; exported / mapped / freed with the bnb_mi355x_peer_* functions
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(p);
+        return nullptr;
+    }
+    return p;
+}
+int bnb_mi355x_gemv_4bit_peer(void* const* bufs, void* epoch_word, int world, int rank, int dtype, const void* A, const uint8_t* B, const float* absmax,
+                              const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, const void* bias,
+                              void* out_local, int ns, int K, int blocksize, int quant_type, int mode, long max_values, int wg_limit,
+                              int epoch_offset, bnb_stream_t s) {
+    if (quant_type != kFP4 && quant_type != kNF4) {
+        fprintf(stderr, "bitsandbytes_amd: gemv_4bit_peer: quant_type must be 1 (FP4) or 2 (NF4), got %d\n", quant_type);
+        exit(1);
+    }
+    return gemv_4bit_peer(bufs, epoch_word, world, rank, dtype, A, B, absmax, absmax_8bit, absmax_code, absmax_offset, bias, out_local, ns, K,
+                          blocksize, quant_type, mode, max_values, wg_limit, static_cast<uint32_t>(epoch_offset), peer_chain_spin_bound(), S(s))
+               ? 1
+               : 0;
+}
+void bnb_mi355x_peer_chain_read(void* const* bufs, void* epoch_word, int world, int rank, int dtype, void* out, int nvalues, long max_values, int epoch_offset,
+                                bnb_stream_t s) {
+    if (epoch_word == nullptr || world < 1 || world > 8 || rank < 0 || rank >= world || (dtype != 1 && dtype != 2) || nvalues < 2 || (nvalues & 1) || nvalues > max_values) {
+        fprintf(stderr, "bitsandbytes_amd: peer_chain_read: bad arguments (world %d, rank %d, dtype %d, %d values of %ld)\n", world, rank, dtype,
+                nvalues, max_values);
+        exit(1);
+    }
+    peer_chain_read(bufs, epoch_word, world, rank, dtype, out, nvalues, max_values, static_cast<uint32_t>(epoch_offset), peer_chain_spin_bound(), S(s));
+}
 int bnb_mi355x_gemm_4bit_route(int kernel, int dtype, int M, int N, int K, int blocksize) {
     // (alignment of A / B is unknown here; the aligned - fast - case is assumed, as in the workspace query)
     static const int dummy_aligned[4] __attribute__((aligned(16))) = {0, 0, 0, 0};

@@ -57,7 +57,8 @@ enum StreamFlags : int {
     kFp4 = 4,     // literal table = FP4 (else NF4)
     kNT = 8,      // non-temporal weight loads
     kGrouped = 16, // several matrices over one concatenated row space
-    kMulti = 32    // rows longer than the workgroup's segment columns: several phases (a loop around the whole body)
+    kMulti = 32,   // rows longer than the workgroup's segment columns: several phases (a loop around the whole body)
+    kPeer = 64     // "peer chain" form (M = 1): x taken from / y delivered to the ranks' exchange buffers - see PeerChain
 };
 
 // One weight matrix of a launch.
@@ -88,10 +89,50 @@ struct StreamMat {
 #define BNB_ST_STAMP(i) {}
 #endif
 
+// Peer chain (kPeer instances; bitsandbytes_amd/peer.py PeerChain): the all-gather that re-assembles y of an
+// N-sharded layer is FUSED into the kernels on either side of it. Every rank owns an exchange buffer (ordinary device memory,
+// mapped into every process of the node by hipIpc; every store into it is a system-scope write-through store):
+//     [4] u32 status  sticky, 1 = a wait ran into its bound          [8] u32 done  workgroups of the running read-out that finished
+// and, in ORDINARY (cacheable) device memory that only its own launches touch, one epoch word: exchanges completed on this rank up
+// to the last read-out. It lives on the DEVICE because a replayed hipGraph re-runs its launches; the launches of a chain carry
+// their distance from it as an argument, and only the read-out that ends a chain - a handful of workgroups - advances it (an
+// arrival counter over the 256 workgroups of every gemv launch cost 3 us per layer: 12 ns per atomic on one address; the word
+// inside the fine-grained buffer cost ~1 us per launch: an uncached scalar load in front of the granule fetches and another one
+// in front of the stores - profiles/r4_peer_chain.txt).
+//     [256] granule[64][max_granules]  8 bytes each = {two consecutive T values of y, u32 tag}; exchange e in region e % 64
+// Producer (mode bit 1): the thread that holds an even output row packs it with its neighbour's and stores the granule - ONE
+// 8-byte system-scope store, data and tag indivisible - into slot (rank * ns + row) / 2 of EVERY rank's buffer, tag = epoch + 1.
+// No fence, no flag, no counter: a granule is valid when its tag says so. Consumer (mode bit 0; the NEXT layer's launch): after
+// its weight ring is requested, the builder wavefronts fetch the K / 2 granules of the current epoch with system-scope loads,
+// re-fetch the ones whose tag is not there yet, and write the values into the activation image in the LDS - the exchange
+// latency runs under the ~1.5 us the first weight bytes need anyway. Two parities are enough: a rank can start exchange e + 2
+// (same parity as e) only after it consumed ALL of e + 1, which every peer stores at the END of the launch that consumed e.
+struct PeerChain {
+    unsigned char* base[8]; // the ranks' exchange buffers as mapped into this process; base[rank] = the local one
+    unsigned char* local;   // = base[rank]
+    uint32_t* epoch_word;   // this rank's epoch word (cacheable memory)
+    int world, rank;
+    uint32_t max_granules;  // granules per parity region
+    uint32_t spin_bound;    // re-fetches of a granule before the launch gives up (status word, NaN)
+    uint32_t epoch_offset;  // exchanges produced by earlier launches since the buffer's epoch word was last advanced
+    int mode;               // bit 0: x = the current exchange (A is ignored); bit 1: y goes to the exchange (+ to out when non-NULL);
+                            // bit 2: rows come in fours (ns and the rows per workgroup are multiples of 4): two granules per store
+};
+constexpr size_t kChainDataOffset = 256;
+// Exchange e lives in region e % kChainRegions. Two regions are what CORRECTNESS needs (see above); 64 are there for speed: the
+// buffers are ordinary cacheable memory and the consumer's FIRST fetch of a granule is a plain load, so that the 32 workgroups of an
+// XCD share one copy in their L2 instead of each pulling the same 16 KiB through one memory channel (system-scope fetches by all
+// 256 workgroups cost +1.2 us per layer: 256 readers x 128 bytes per line on one channel). A plain load may hit a STALE line - this
+// XCD's copy of the region's previous use - whose tags then do not match and which is re-fetched at system scope like a granule
+// that has not arrived: with 64 regions a line's previous use is 64 layers of streamed weights old and gone from the L2.
+constexpr uint32_t kChainRegions = 64;
+constexpr int kChainRounds = 8; // 16-byte fetches per builder lane: K <= 8 * 8 KiB / 4 B = 16384 values
+
 struct StreamArgs {
 #ifdef BNB_PROFILING
     unsigned long long* dbg;
 #endif
+    PeerChain peer{};
     const void* A;
     const float* code16;
     int M, K, bs_shift;
@@ -153,6 +194,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     int hot_inv /* ceil(256 / SW) */, const StreamArgs p) {
     constexpr bool NESTED = FLAGS & kNested, CODEPTR = FLAGS & kCodePtr, NT = FLAGS & kNT, GROUPED = FLAGS & kGrouped;
     constexpr bool MULTI = FLAGS & kMulti;
+    constexpr bool PEER = (FLAGS & kPeer) != 0;
+    static_assert(!PEER || (MB == 1 && !MULTI && !GROUPED && WAVES == 16), "the peer-chain form is the M = 1, single-phase kernel");
     constexpr int THREADS = WAVES * 64;
     constexpr int TB = TypeInfo<T>::bytes;
     constexpr int CH = 2 * TB;  // 16-byte chunks of activations per lane and segment (= 1-KiB DMA pieces per segment)
@@ -465,13 +508,36 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         }
     };
 
+    uint32_t epoch = 0; // (peer chain) exchanges completed when this launch started
     for (int ph = 0; ph < P; ++ph) {
         if (ph > 0)
             __syncthreads(); // everyone is done with the previous activation image
         // (1) this phase's activation image (LDS-DMA, oldest in the queue), then the first NS ring stages
         if (ph == 0)
             BNB_ST_STAMP(9)
-        issue_x(ph);
+        // (peer chain) x = the current exchange: 16 bytes = two granules = four values per lane and round, fetched by the wavefronts
+        // that do NOT build the decode table (8 ... 15: they start last and have nothing else to do before the first barrier), IN
+        // FRONT of their weight ring - so that tags can be checked and the image written while the ring is still in flight (behind the
+        // ring, the in-order counter made x wait for every weight byte: +1.2 us per layer, profiles/r4_peer_chain.txt). The epoch
+        // they depend on is one scalar load; a lane past the end of x is out of range (zeros, no traffic).
+        bool x_from_peer = false;
+        u32x4 gx[PEER ? kChainRounds : 1];
+        if constexpr (PEER) {
+            x_from_peer = (p.peer.mode & 1) != 0;
+            if (x_from_peer && wave >= BUILDERS) {
+                // (only the fetching wavefronts wait for the epoch word here; the others must not stall in front of their ring)
+                typedef const uint32_t __attribute__((address_space(4))) * cu32_ptr;
+                epoch = *(cu32_ptr)(reinterpret_cast<uintptr_t>(p.peer.epoch_word)) + p.peer.epoch_offset;
+                unsigned char* const src = p.peer.local + kChainDataOffset + static_cast<size_t>(epoch & (kChainRegions - 1u)) * p.peer.max_granules * 8u;
+                const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(src, 0, K * 4, kRsrcFlags);
+#pragma unroll
+                for (int r = 0; r < kChainRounds; ++r)
+                    gx[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                          rs_x, static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave - BUILDERS) * 64 + lane) * 16u, 0, 0 /* plain: see kChainRegions */));
+            }
+        }
+        if (!x_from_peer)
+            issue_x(ph);
         if (ph == 0)
             BNB_ST_STAMP(10)
         seg = ph * SW + sw;
@@ -531,7 +597,38 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         // (3) the activation DMAs are older than the NS ring stages: wait until only those remain in flight
         if (ph == 0)
             BNB_ST_STAMP(2)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS * LPS) : "memory");
+        if (!x_from_peer)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS * LPS) : "memory");
+        if constexpr (PEER) {
+            if (x_from_peer && wave >= BUILDERS) {
+                unsigned char* const src = p.peer.local + kChainDataOffset + static_cast<size_t>(epoch & (kChainRegions - 1u)) * p.peer.max_granules * 8u;
+#pragma unroll
+                for (int r = 0; r < kChainRounds; ++r) {
+                    const uint32_t off = static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave - BUILDERS) * 64 + lane) * 16u;
+                    if (off < static_cast<uint32_t>(K) * 4u) {
+                        u32x4 gr = gx[r];
+                        // (the re-fetch loop is spelled in asm: a loop with loads in it makes the compiler's wait insertion
+                        // forget what is in flight behind it. Slow path only - a peer that is late.)
+                        uint32_t spins = 0;
+                        while (gr[1] != epoch || gr[3] != epoch) {
+                            __builtin_amdgcn_s_sleep(4);
+                            const unsigned char* const addr = src + off;
+                            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(gr) : "v"(addr) : "memory");
+                            if (++spins > p.peer.spin_bound) {
+                                __hip_atomic_store(reinterpret_cast<uint32_t*>(p.peer.local) + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                gr = u32x4{0xFFFFFFFFu, epoch, 0xFFFFFFFFu, epoch}; // NaN in fp16 / bf16: a timeout cannot pass for data
+                            }
+                        }
+                        // four values = half of the 16-byte chunk c of x; chunk (l', q) of a segment lives at slot CH l' + (q ^ swz(l'))
+                        const uint32_t c = off >> 5, half = (off >> 4) & 1u;
+                        const uint32_t sg = c >> 8, cs = c & 255u, lp = cs / CH, q = cs % CH;
+                        using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+                        *reinterpret_cast<u32x2*>(ximg + ((sg * CH * 64 + CH * lp + (q ^ static_cast<uint32_t>(swz(static_cast<int>(lp))))) * 16 + half * 8)) =
+                            u32x2{gr[0], gr[2]};
+                    }
+                }
+            }
+        }
         __syncthreads();
         if (ph == 0)
             BNB_ST_STAMP(3)
@@ -576,6 +673,12 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         __builtin_trap();
 
     // ---- combine the segment partials of every row in segment order, bias, one rounding
+    [[maybe_unused]] uint32_t epoch_out = 0;
+    if constexpr (PEER) {
+        // (a fresh scalar load: nothing before this point depends on it in the wavefronts that did not fetch x)
+        typedef const uint32_t __attribute__((address_space(4))) * cu32_ptr;
+        epoch_out = *(cu32_ptr)(reinterpret_cast<uintptr_t>(p.peer.epoch_word)) + p.peer.epoch_offset + 1u;
+    }
     __syncthreads();
     BNB_ST_STAMP(7)
     for (int idx = tid; idx < nrows * MB; idx += THREADS) {
@@ -593,7 +696,41 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         }
         const T* bias = static_cast<const T*>(p.mat[mi].bias);
         const float b = bias ? static_cast<float>(bias[row]) : 0.0f;
-        static_cast<T*>(p.mat[mi].out)[static_cast<long>(m0 + m) * p.mat[mi].N + row] = static_cast<T>(v + b);
+        const T tv = static_cast<T>(v + b);
+        if constexpr (PEER) {
+            if (p.mat[mi].out != nullptr)
+                static_cast<T*>(p.mat[mi].out)[row] = tv;
+            if (p.peer.mode & 2) {
+                // (rows come in pairs: the host keeps ns and the rows per workgroup even, so a thread and its neighbour are in the
+                // loop together and the even one stores both values)
+                const uint32_t own = static_cast<uint32_t>(__builtin_bit_cast(unsigned short, tv));
+                const uint32_t other = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((lane ^ 1) << 2, static_cast<int>(own)));
+                const uint32_t pair = own | (other << 16);                                                           // (even lanes: rows r, r + 1)
+                const uint32_t pair2 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((lane ^ 2) << 2, static_cast<int>(pair))); // rows r + 2, r + 3
+                const size_t slot = kChainDataOffset + (static_cast<size_t>(epoch_out & (kChainRegions - 1u)) * p.peer.max_granules +
+                                                        ((static_cast<size_t>(p.peer.rank) * static_cast<size_t>(rows_total) + static_cast<size_t>(row)) >> 1)) * 8u;
+                if (p.peer.mode & 4) {
+                    // two granules per store: a 16-byte system-scope store costs the fabric what an 8-byte one does (each aligned
+                    // 8-byte half carries its own tag, so the two need not land together)
+                    if (!(row & 3)) {
+                        const u32x4 granules = {pair, epoch_out, pair2, epoch_out};
+                        for (int pr = 0; pr < p.peer.world; ++pr) {
+                            unsigned char* const dst = p.peer.base[pr] + slot;
+                            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(granules) : "memory");
+                        }
+                    }
+                } else if (!(row & 1)) {
+                    using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+                    const u32x2 granule = {pair, epoch_out};
+                    for (int pr = 0; pr < p.peer.world; ++pr) {
+                        unsigned char* const dst = p.peer.base[pr] + slot;
+                        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(granule) : "memory");
+                    }
+                }
+            }
+        } else {
+            static_cast<T*>(p.mat[mi].out)[static_cast<long>(m0 + m) * p.mat[mi].N + row] = tv;
+        }
     }
     BNB_ST_STAMP(8)
 #ifdef BNB_PROFILING
@@ -857,7 +994,145 @@ void launch_stream_any(int dtype, const StreamArgs& a, int quant_type, bool grou
     BNB_CHECK_LAUNCH();
 }
 
+// (peer chain) the launch: the M = 1, 16-wavefront, single-phase instance with the kPeer paths compiled in
+template <typename T, int FLAGS> void launch_peer(const StreamArgs& a, const Geometry& ge, hipStream_t stream) {
+    auto kern = gemv4_stream_kernel<T, 1, 16, kRing, FLAGS | kNT | kPeer>;
+    static LdsLimit lds_limit;
+    ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), ge.lds);
+    const StreamMat& m0 = a.mat[0];
+    hipLaunchKernelGGL(kern, dim3(ge.grid_x, 1), dim3(16 * 64), ge.lds, stream, a.A, m0.B, m0.absmax, m0.absmax8, m0.N, a.K,
+                       (1 & 0x3FFFF) | (a.bs_shift << 18) | (ge.P << 23), ge.R | (ge.SW << 16) | (ge.G << 21), (256 + ge.SW - 1) / ge.SW, a);
+}
+template <typename T> void launch_peer_flags(const StreamArgs& a, const Geometry& ge, int quant_type, hipStream_t stream) {
+    const int sel = (a.mat[0].absmax8 != nullptr ? 1 : 0) | (quant_type == kFP4 ? 2 : 0);
+    switch (sel) {
+    case 0: return launch_peer<T, 0>(a, ge, stream);
+    case 1: return launch_peer<T, kNested>(a, ge, stream);
+    case 2: return launch_peer<T, kFp4>(a, ge, stream);
+    default: return launch_peer<T, kFp4 | kNested>(a, ge, stream);
+    }
+}
+
+// (peer chain) the current exchange as a plain [nvalues] tensor: one granule per lane, re-fetched until its tag is there
+template <typename T>
+__global__ __launch_bounds__(256) void peer_chain_read_kernel(PeerChain pc, T* __restrict__ out, int nvalues) {
+    uint32_t* const hdr = reinterpret_cast<uint32_t*>(pc.local);
+    const uint32_t epoch = pc.epoch_word[0] + pc.epoch_offset;
+    const unsigned char* const src = pc.local + kChainDataOffset + static_cast<size_t>(epoch & (kChainRegions - 1u)) * pc.max_granules * 8u;
+    using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+    for (int gi = blockIdx.x * 256 + threadIdx.x; 2 * gi < nvalues; gi += gridDim.x * 256) {
+        const unsigned char* const addr = src + static_cast<size_t>(gi) * 8u;
+        u32x2 gr;
+        uint32_t spins = 0;
+        for (;;) {
+            asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(gr) : "v"(addr) : "memory");
+            if (gr[1] == epoch)
+                break;
+            if (++spins > pc.spin_bound) {
+                __hip_atomic_store(hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                gr[0] = 0xFFFFFFFFu;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        *reinterpret_cast<uint32_t*>(out + 2 * gi) = gr[0];
+    }
+    // the last workgroup (of at most 8) advances the buffer's epoch past the chain that ends here (visible to the next launch on
+    // this device: kernel boundary)
+    if (threadIdx.x == 0) {
+        const uint32_t prev = __hip_atomic_fetch_add(hdr + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1u) {
+            hdr[2] = 0u;
+            pc.epoch_word[0] = epoch;
+        }
+    }
+}
+
 } // namespace
+
+// Peer-chain form of the M = 1 gemv (see PeerChain). mode bit 0: x = the current exchange (A ignored, K values), bit 1: y goes
+// to every rank's exchange buffer (and to out_local when non-NULL). Returns false - nothing launched - when the problem is
+// outside the form's preconditions; the caller then takes the unfused path (kernel + all-gather).
+bool gemv_4bit_peer(void* const* bufs, void* epoch_word, int world, int rank, int dtype, const void* A, const uint8_t* B, const float* absmax,
+                    const uint8_t* absmax8, const float* absmax_code, const float* absmax_offset, const void* bias, void* out_local,
+                    int ns, int K, int blocksize, int quant_type, int mode, long max_values, int wg_limit, uint32_t epoch_offset,
+                    uint32_t spin_bound, hipStream_t stream) {
+    if (epoch_word == nullptr || (dtype != 1 && dtype != 2) || world < 1 || world > 8 || rank < 0 || rank >= world || ns < 2 || (ns & 1) || K < 32 || (K % 32) != 0 ||
+        blocksize < 32 || !is_pow2(blocksize) || !aligned_to(B, 16) || (mode & 3) == 0 || max_values < 2 || max_values >= (1L << 28))
+        return false;
+    if ((mode & 1) ? (K > kChainRounds * 2048 || K > max_values) : !aligned_to(A, 16))
+        return false;
+    if ((mode & 2) && static_cast<long>(world) * ns > max_values)
+        return false;
+    if (!(mode & 2) && out_local == nullptr)
+        return false;
+    // rows per workgroup: even (granules are row pairs), and no more workgroups than the caller allows (ranks that share one
+    // device - a test set-up - must be co-resident: a launch that waits for its peers may not fill the device alone)
+    int cus = device_cu_count();
+    if (wg_limit > 0 && wg_limit < cus)
+        cus = wg_limit;
+    int R = (ns + cus - 1) / cus;
+    R += R & 1;
+    if ((ns & 3) == 0)
+        R = (R + 3) & ~3; // rows in fours: two granules per store
+    const Geometry ge = make_geometry(ns, K, 1, 16, 2, false, 0, R);
+    if (ge.P != 1 || (ge.R & 1))
+        return false;
+    const bool quads = (ns & 3) == 0 && (ge.R & 3) == 0;
+
+    StreamArgs a;
+#ifdef BNB_PROFILING
+    a.dbg = g_dbg_buf;
+#endif
+    for (int r = 0; r < 8; ++r)
+        a.peer.base[r] = static_cast<unsigned char*>(r < world ? bufs[r] : nullptr);
+    a.peer.local = a.peer.base[rank];
+    a.peer.epoch_word = static_cast<uint32_t*>(epoch_word);
+    a.peer.world = world;
+    a.peer.rank = rank;
+    a.peer.max_granules = static_cast<uint32_t>(max_values / 2);
+    a.peer.spin_bound = spin_bound;
+    a.peer.epoch_offset = epoch_offset;
+    a.peer.mode = (mode & 3) | (quads ? 4 : 0);
+    a.A = A;
+    a.code16 = nullptr;
+    a.M = 1;
+    a.K = K;
+    a.bs_shift = ilog2(blocksize);
+    a.rows_total = ns;
+    a.nmat = 1;
+    for (int i = 0; i < kMaxGroup; ++i)
+        a.mat[i] = StreamMat{B, absmax, absmax8, absmax_code, absmax_offset, out_local, bias, ns, i == 0 ? 0 : 0x7FFFFFFF};
+    if (dtype == 2)
+        launch_peer_flags<bf16>(a, ge, quant_type, stream);
+    else
+        launch_peer_flags<f16>(a, ge, quant_type, stream);
+    BNB_CHECK_LAUNCH();
+    g_last_gemm_kernel = kKernelStream;
+    return true;
+}
+
+void peer_chain_read(void* const* bufs, void* epoch_word, int world, int rank, int dtype, void* out, int nvalues, long max_values, uint32_t epoch_offset,
+                     uint32_t spin_bound, hipStream_t stream) {
+    PeerChain pc;
+    for (int r = 0; r < 8; ++r)
+        pc.base[r] = static_cast<unsigned char*>(r < world ? bufs[r] : nullptr);
+    pc.local = pc.base[rank];
+    pc.epoch_word = static_cast<uint32_t*>(epoch_word);
+    pc.world = world;
+    pc.rank = rank;
+    pc.max_granules = static_cast<uint32_t>(max_values / 2);
+    pc.spin_bound = spin_bound;
+    pc.epoch_offset = epoch_offset;
+    pc.mode = 0;
+    const int granules = (nvalues + 1) / 2;
+    const int grid = (granules + 255) / 256 < 8 ? (granules + 255) / 256 : 8;
+    if (dtype == 2)
+        hipLaunchKernelGGL(peer_chain_read_kernel<bf16>, dim3(grid > 0 ? grid : 1), dim3(256), 0, stream, pc, static_cast<bf16*>(out), nvalues);
+    else
+        hipLaunchKernelGGL(peer_chain_read_kernel<f16>, dim3(grid > 0 ? grid : 1), dim3(256), 0, stream, pc, static_cast<f16*>(out), nvalues);
+    BNB_CHECK_LAUNCH();
+}
 
 // Sweep-only overrides (0 / -1 = built-in choice). Atomics: a sweep thread can never corrupt a concurrent launch,
 // it can only change which (always correct) geometry that launch uses.

@@ -16,7 +16,8 @@ For a tensor-parallel decode (every shard launch is 3 - 4 us, every
 latency, not bandwidth) three more pieces: ``peer=`` (a :class:`bitsandbytes_amd.peer.PeerAllGather`: the gather as ONE kernel
 over peer-mapped buffers instead of a ring collective), :class:`ShardedLinear4bitGroup` (layers that share ``x`` - Q/K/V,
 gate/up: one grouped launch and ONE gather for the whole group) and :class:`GraphedBlock` (a whole block of such calls captured
-in one hipGraph per rank and replayed per token).
+in one hipGraph per rank and replayed per token); and :class:`ShardedLinear4bitChain` (consecutive layers whose all-gathers are
+fused into the gemv launches themselves - ``peer.PeerChain``: one launch per layer, the exchange under the next layer's weight stream).
 """
 from __future__ import annotations
 
@@ -196,6 +197,60 @@ class ShardedLinear4bitGroup(nn.Module):
                 res.append(blk.reshape(G, m, n).permute(1, 0, 2).reshape(*lead, G * n))
             off += n
         return res
+
+
+class ShardedLinear4bitChain(nn.Module):
+    """Consecutive N-sharded layers of a decode step - each one's gathered ``y`` is the next one's ``x`` (up / down projection of
+    an MLP, ``out_features[i] == in_features[i + 1]``) - with every all-gather FUSED into the launches on either side of it
+    (:class:`bitsandbytes_amd.peer.PeerChain`): layer ``i`` stores its shard outputs straight into every rank's exchange buffer,
+    layer ``i + 1`` takes its ``x`` from there behind its own weight requests. One launch per layer + one small read-out at the
+    end, instead of a kernel and a collective per layer; values are bit-identical to calling the layers one by one.
+
+    The fused form serves one activation row (M = 1) of fp16 / bf16 and shapes within ``PeerChain.serves``; anything else -
+    decided from shapes alone, so every rank decides the same - runs the members one by one (``ShardedLinear4bit.forward``).
+    An activation function between two layers breaks the chain there (it needs the plain tensor): build one chain per stretch."""
+
+    def __init__(self, shards, chain):
+        # (All launches of a chain go to ONE stream. Two alternating streams - the exchange is the only real dependency between
+        # consecutive layers, so layer i + 1's workgroups could take the CUs layer i's leave one by one - were tried in round 4 and
+        # dead-locked: nothing orders the DISPATCH of two queues, a later launch can occupy the device before the launch it waits
+        # for has been placed. DESIGN.md 6b.)
+        super().__init__()
+        shards = list(shards)
+        if not shards:
+            raise ValueError("empty chain")
+        for a, b in zip(shards, shards[1:]):
+            if a.out_features != int(b.quant_state.shape[1]):
+                raise ValueError(f"layer outputs {a.out_features} features, the next one takes {int(b.quant_state.shape[1])}")
+        self.shards = nn.ModuleList(shards)
+        self.chain = chain
+        self._bias_cache = {}
+
+    def fused(self, x: torch.Tensor) -> bool:
+        if self.chain is None or x.dtype not in (torch.float16, torch.bfloat16) or x.numel() != x.shape[-1]:
+            return False
+        return all(self.chain.serves(int(s.quant_state.shape[0]), int(s.quant_state.shape[1]), int(s.quant_state.blocksize), i > 0)
+                   and self.chain.world * int(s.quant_state.shape[0]) == s.out_features
+                   for i, s in enumerate(self.shards))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.fused(x):
+            for s in self.shards:
+                x = s(x)
+            return x
+        lead = x.shape[:-1]
+        x1 = x.reshape(-1).contiguous()
+        for i, s in enumerate(self.shards):
+            bias = s.bias
+            if bias is not None and bias.dtype != x.dtype:
+                key = (i, x.dtype, bias.data_ptr(), bias._version)
+                if self._bias_cache.get("key" + str(i)) != key:
+                    self._bias_cache["key" + str(i)], self._bias_cache[i] = key, bias.to(x.dtype)
+                bias = self._bias_cache[i]
+            ok = self.chain.gemv(x1 if i == 0 else None, s.weight, s.quant_state, bias=bias, consume=i > 0, produce=True, dtype=x.dtype)
+            if not ok:
+                raise RuntimeError("PeerChain refused a launch its own serves() accepted")
+        return self.chain.read(self.shards[-1].out_features, x.dtype).view(*lead, self.shards[-1].out_features)
 
 
 class GraphedBlock:

@@ -28,20 +28,20 @@ MAX_WORLD = 8
 DEFAULT_MAX_BYTES = 64 * 1024  # per rank; larger messages are bandwidth-bound: use the group's own all-gather
 
 
-class PeerAllGather:
-    """``all_gather(y_local) -> [G * m, ns]`` (rank-major, the layout of ``dist.all_gather_into_tensor``) for shards of at
-    most ``max_bytes`` bytes. Every rank of ``group`` constructs one (collectively: the handles travel through the group) and
-    calls ``all_gather`` the same number of times with the same shape."""
+class _PeerBuffers:
+    """One fine-grained device buffer per rank, mapped into every process of the group (hipIpc; the handles travel through the
+    ordinary process group). Construction is collective."""
 
-    def __init__(self, group=None, max_bytes: int = DEFAULT_MAX_BYTES, device: Optional[torch.device] = None):
+    def __init__(self, nbytes_of, group=None, device: Optional[torch.device] = None, alloc=None):
+        name = type(self).__name__
+        alloc = alloc or lib.bnb_mi355x_peer_alloc
         if not dist.is_initialized():
-            raise RuntimeError("PeerAllGather needs an initialised process group (the buffer handles travel through it)")
+            raise RuntimeError(f"{name} needs an initialised process group (the buffer handles travel through it)")
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         if self.world > MAX_WORLD:
-            raise ValueError(f"PeerAllGather serves the GPUs of one node (<= {MAX_WORLD} ranks), got {self.world}")
-        self.max_bytes = int(max_bytes)
+            raise ValueError(f"{name} serves the GPUs of one node (<= {MAX_WORLD} ranks), got {self.world}")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._mapped = []
         self._local = None
@@ -49,8 +49,8 @@ class PeerAllGather:
         # carried to the exchanges as values, and every rank raises - or none does.
         handle = ct.create_string_buffer(64)
         with torch.cuda.device(self.device):
-            nbytes = lib.bnb_mi355x_peer_buffer_bytes(self.world, self.max_bytes)
-            self._local = lib.bnb_mi355x_peer_alloc(nbytes)
+            nbytes = nbytes_of(self.world)
+            self._local = alloc(nbytes)
             exported = bool(self._local) and lib.bnb_mi355x_peer_export(ct.c_void_p(self._local), handle) == 0
         everyone = [None] * self.world
         dist.all_gather_object(everyone, handle.raw if exported else None, group=group)
@@ -74,7 +74,7 @@ class PeerAllGather:
         problems = [q for q in problems if q]
         if problems:
             self._release()
-            raise RuntimeError("PeerAllGather: " + "; ".join(problems))
+            raise RuntimeError(f"{name}: " + "; ".join(problems))
         self._bufs = (ct.c_void_p * self.world)(*ptrs)
 
     def _release(self) -> None:
@@ -84,32 +84,15 @@ class PeerAllGather:
             lib.bnb_mi355x_peer_free(ct.c_void_p(self._local))
         self._mapped, self._local = [], None
 
-    def all_gather(self, y_local: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        y2 = y_local.reshape(-1, y_local.shape[-1]).contiguous()
-        nbytes = y2.numel() * y2.element_size()
-        if nbytes > self.max_bytes:
-            raise ValueError(f"shard of {nbytes} bytes exceeds this PeerAllGather's max_bytes ({self.max_bytes})")
-        if y2.device != self.device:
-            raise ValueError(f"tensor on {y2.device}, buffers on {self.device}")
-        if out is None:
-            out = torch.empty((self.world * y2.shape[0], y2.shape[1]), dtype=y2.dtype, device=y2.device)
-        elif out.numel() * out.element_size() != self.world * nbytes or not out.is_contiguous():
-            raise ValueError("out must be a contiguous tensor of world x shard elements")
-        with torch.cuda.device(self.device):
-            stream = torch.cuda.current_stream().cuda_stream
-            lib.bnb_mi355x_peer_allgather(self._bufs, self.world, self.rank, ct.c_void_p(y2.data_ptr()), ct.c_void_p(out.data_ptr()),
-                                          nbytes, self.max_bytes, ct.c_void_p(stream))
-        return out
-
     def status(self) -> int:
-        """0 while every wait of every collective found its peer, 1 once one gave up (synchronises the device)."""
+        """0 while every wait of every launch found its peer, 1 once one gave up (synchronises the device)."""
         return int(lib.bnb_mi355x_peer_status(ct.c_void_p(self._local)))
 
     def check(self) -> None:
-        """Raises if any collective so far gave up waiting for a peer (synchronises the device)."""
+        """Raises if any launch so far gave up waiting for a peer (synchronises the device)."""
         st = self.status()
         if st != 0:
-            raise RuntimeError("PeerAllGather: a rank did not arrive at a collective within the wait bound (status %d)" % st)
+            raise RuntimeError(f"{type(self).__name__}: a rank did not arrive within the wait bound (status {st})")
 
     def close(self) -> None:
         if self._local is None:
@@ -135,3 +118,143 @@ class PeerAllGather:
             self._release()
         except Exception:
             pass
+
+
+class PeerAllGather(_PeerBuffers):
+    """``all_gather(y_local) -> [G * m, ns]`` (rank-major, the layout of ``dist.all_gather_into_tensor``) for shards of at
+    most ``max_bytes`` bytes. Every rank of ``group`` constructs one (collectively: the handles travel through the group) and
+    calls ``all_gather`` the same number of times with the same shape."""
+
+    def __init__(self, group=None, max_bytes: int = DEFAULT_MAX_BYTES, device: Optional[torch.device] = None):
+        self.max_bytes = int(max_bytes)
+        super().__init__(lambda world: lib.bnb_mi355x_peer_buffer_bytes(world, self.max_bytes), group, device)
+
+    def all_gather(self, y_local: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        y2 = y_local.reshape(-1, y_local.shape[-1]).contiguous()
+        nbytes = y2.numel() * y2.element_size()
+        if nbytes > self.max_bytes:
+            raise ValueError(f"shard of {nbytes} bytes exceeds this PeerAllGather's max_bytes ({self.max_bytes})")
+        if y2.device != self.device:
+            raise ValueError(f"tensor on {y2.device}, buffers on {self.device}")
+        if out is None:
+            out = torch.empty((self.world * y2.shape[0], y2.shape[1]), dtype=y2.dtype, device=y2.device)
+        elif out.numel() * out.element_size() != self.world * nbytes or not out.is_contiguous():
+            raise ValueError("out must be a contiguous tensor of world x shard elements")
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            lib.bnb_mi355x_peer_allgather(self._bufs, self.world, self.rank, ct.c_void_p(y2.data_ptr()), ct.c_void_p(out.data_ptr()),
+                                          nbytes, self.max_bytes, ct.c_void_p(stream))
+        return out
+
+
+def _ranks_on_my_device(group, device) -> int:
+    """How many ranks of the group use the device this rank uses (1 on a real node; > 1 where processes share a GPU - the only
+    way a 1-GPU box can run the peer paths). Identified by hostname + PCI address where torch reports it, else by hostname +
+    device index + HIP_VISIBLE_DEVICES."""
+    import os
+    import socket
+
+    props = torch.cuda.get_device_properties(device)
+    pci = tuple(getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    key = (socket.gethostname(), pci) if all(v is not None for v in pci) else \
+        (socket.gethostname(), torch.device(device).index, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"))
+    keys = [None] * dist.get_world_size(group)
+    dist.all_gather_object(keys, key, group=group)
+    return sum(1 for k in keys if k == key)
+
+
+class PeerChain(_PeerBuffers):
+    """The all-gather of an N-sharded decode layer FUSED into the gemv launches on either side of it (``csrc/gemv4_stream.hip``,
+    ``PeerChain``): ``gemv(..., produce=True)`` stores this rank's ``ns`` outputs straight into every rank's exchange buffer as
+    8-byte {two values, tag} granules; the next layer's ``gemv(None, ..., consume=True)`` takes its ``x`` from there - fetched
+    behind its own weight requests, re-fetched until the tags are there - and ``read`` ENDS a chain with the plain tensor (every
+    chain must end with it, a captured block in particular: it is the launch that advances the buffers' epoch). One
+    launch per layer, no collective launch, no host synchronisation; capturable in a hipGraph. M = 1, fp16 / bf16.
+
+    Every rank issues the same sequence of calls. Results are bit-identical to ``ShardedLinear4bit`` layer by layer (the kernel's
+    arithmetic does not depend on the launch geometry). ``max_values``: the longest gathered vector (``world * ns``) and the
+    longest consumed ``x`` (``K``) the chain will see. Exercised between processes sharing one GPU; **not measured on a
+    multi-GPU node by us**."""
+
+    def __init__(self, group=None, max_values: int = 32768, device: Optional[torch.device] = None):
+        self.max_values = int(max_values) + (int(max_values) & 1)
+        super().__init__(lambda world: lib.bnb_mi355x_peer_chain_buffer_bytes(self.max_values), group, device,
+                         alloc=lib.bnb_mi355x_peer_chain_alloc)
+        # ranks that share one device must all be resident at once (a launch that waits for its peers may not fill the device
+        # alone): each gets its share of the CUs. One rank per device - the real case - gets them all.
+        try:
+            sharing = _ranks_on_my_device(group, self.device)
+        except Exception:
+            self._release()
+            raise
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        self.wg_limit = 0 if sharing <= 1 else max(1, cus // sharing)
+        # exchanges produced since the last read-out: the buffer's epoch word lives on the device and only `read` advances it
+        # (a hipGraph captures these offsets; replayed, they are relative to an epoch that has moved on by a whole chain)
+        self._pending = 0
+        self._epoch = torch.zeros(64, dtype=torch.int32, device=self.device)  # ordinary (cacheable) memory: only this rank's launches touch it
+
+    @staticmethod
+    def _dt(dtype: torch.dtype) -> int:
+        if dtype == torch.float16:
+            return 1
+        if dtype == torch.bfloat16:
+            return 2
+        raise ValueError(f"PeerChain serves fp16 / bf16 activations, got {dtype}")
+
+    def serves(self, ns: int, K: int, blocksize: int, consume: bool) -> bool:
+        """The preconditions of the fused form (mirrors ``gemv_4bit_peer`` in csrc/gemv4_stream.hip; shapes only, so every rank
+        answers the same)."""
+        return (ns >= 2 and ns % 2 == 0 and K >= 32 and K % 32 == 0 and blocksize >= 32 and self.world * ns <= self.max_values
+                and (not consume or (K <= 16384 and K <= self.max_values)))
+
+    def gemv(self, x: Optional[torch.Tensor], packed: torch.Tensor, quant_state, bias: Optional[torch.Tensor] = None,
+             out_local: Optional[torch.Tensor] = None, consume: bool = False, produce: bool = True,
+             dtype: Optional[torch.dtype] = None) -> bool:
+        """One layer: ``y_shard = x @ dequant(packed)^T (+ bias)``. ``consume``: x is the current exchange (pass ``x=None``);
+        ``produce``: y goes to every rank's exchange buffer (and to ``out_local`` when given). Returns False - nothing launched -
+        when the fused form does not serve the problem."""
+        st = quant_state
+        ns, K = int(st.shape[0]), int(st.shape[1])
+        if consume:
+            if dtype is None:
+                raise ValueError("consume=True needs the activation dtype")
+            A = None
+        else:
+            if x is None or x.numel() != K or not x.is_contiguous() or x.device != self.device:
+                raise ValueError("x must be one contiguous row of K values on the chain's device")
+            dtype, A = x.dtype, x
+        if not produce and out_local is None:
+            raise ValueError("a launch that does not produce an exchange needs out_local")
+        if out_local is not None and (out_local.numel() != ns or out_local.dtype != dtype or not out_local.is_contiguous()):
+            raise ValueError("out_local must be a contiguous [ns] tensor of the activation dtype")
+        if bias is not None and bias.dtype != dtype:
+            bias = bias.to(dtype)
+        if st.nested:
+            absmax, absmax8, code, offset = st.state2.absmax, st.absmax, st.state2.code, st.offset
+        else:
+            absmax, absmax8, code, offset = st.absmax, None, None, None
+        ptr = lambda t: ct.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            ok = lib.bnb_mi355x_gemv_4bit_peer(self._bufs, ct.c_void_p(self._epoch.data_ptr()), self.world, self.rank, self._dt(dtype), ptr(A), ptr(packed), ptr(absmax),
+                                               ptr(absmax8), ptr(code), ptr(offset), ptr(bias), ptr(out_local), ns, K,
+                                               int(st.blocksize), 1 if st.quant_type == "fp4" else 2,
+                                               (1 if consume else 0) | (2 if produce else 0), self.max_values, self.wg_limit,
+                                               self._pending, ct.c_void_p(stream))
+        if ok and produce:
+            self._pending += 1
+        return bool(ok)
+
+    def read(self, n_values: int, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The current exchange - the gathered y of the last ``produce`` launch, rank-major - as a plain tensor."""
+        if out is None:
+            out = torch.empty(n_values, dtype=dtype, device=self.device)
+        elif out.numel() != n_values or out.dtype != dtype or not out.is_contiguous():
+            raise ValueError("out must be a contiguous tensor of n_values elements of dtype")
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            lib.bnb_mi355x_peer_chain_read(self._bufs, ct.c_void_p(self._epoch.data_ptr()), self.world, self.rank, self._dt(dtype), ct.c_void_p(out.data_ptr()), int(n_values),
+                                           self.max_values, self._pending, ct.c_void_p(stream))
+        self._pending = 0
+        return out

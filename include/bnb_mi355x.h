@@ -170,6 +170,29 @@ void bnb_mi355x_peer_close(void* mapped);
 void bnb_mi355x_peer_allgather(void* const* bufs, int world, int rank, const void* src, void* out, size_t bytes, size_t max_bytes, bnb_stream_t stream);
 int bnb_mi355x_peer_status(const void* local_buffer);
 
+/* Peer chain: the all-gather of the N-sharded layer FUSED into the gemv launches on either side of it (M = 1 decode; fp16 /
+ * bf16). Each rank owns an exchange buffer of bnb_mi355x_peer_chain_buffer_bytes(max_values) bytes from bnb_mi355x_peer_chain_alloc
+ * (ordinary device memory, zeroed), exported / mapped / freed like the gather buffers above; bufs[r] = rank r's buffer as mapped here. y travels as
+ * 8-byte granules {two consecutive values, u32 tag}: the producing launch stores them straight into every rank's buffer, the
+ * consuming launch - the next layer - fetches them behind its weight requests and re-fetches the ones whose tag is not there
+ * yet. No separate collective launch, no flag, no fence (csrc/gemv4_stream.hip, PeerChain).
+ *   mode bit 0: x = the current exchange (K values; A is ignored)     bit 1: y (ns values of this rank, rank-major) goes to the
+ *   exchange; it is also written to out_local[ns] when that is non-NULL. A launch with bit 1 completes one exchange.
+ *   wg_limit: at most that many workgroups (0 = one per CU) - ranks that share ONE device must be co-resident.
+ *   epoch_word: 4 bytes of ORDINARY device memory owned by this rank, zeroed once (exchanges completed up to the last read-out;
+ *   on the device because a replayed hipGraph re-runs its launches; only the read-out advances it).
+ *   epoch_offset: exchanges completed (launches with bit 1) since the last bnb_mi355x_peer_chain_read on these buffers.
+ * Every rank issues the same sequence of launches; a chain ends with bnb_mi355x_peer_chain_read (epoch_offset = the number of
+ * exchanges since the previous read-out, this chain's included). Returns 1 when launched, 0 when the problem is outside the form's
+ * preconditions (ns even, K % 32 == 0, K <= 16384 with bit 0, one phase, blocksize >= 32, 16-byte aligned B / A, world * ns and
+ * K <= max_values) - nothing was launched and the caller takes the unfused path. A wait that runs into its bound
+ * (BNB_MI355X_PEER_WAIT_POLLS) sets the buffer's status word (bnb_mi355x_peer_status) and yields NaN, never a hang.
+ * bnb_mi355x_peer_chain_read: the current exchange as a plain [nvalues] tensor (the end of a chain). */
+size_t bnb_mi355x_peer_chain_buffer_bytes(long max_values);
+void* bnb_mi355x_peer_chain_alloc(size_t bytes);
+int bnb_mi355x_gemv_4bit_peer(void* const* bufs, void* epoch_word, int world, int rank, int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, const void* bias, void* out_local, int ns, int K, int blocksize, int quant_type, int mode, long max_values, int wg_limit, int epoch_offset, bnb_stream_t stream);
+void bnb_mi355x_peer_chain_read(void* const* bufs, void* epoch_word, int world, int rank, int dtype, void* out, int nvalues, long max_values, int epoch_offset, bnb_stream_t stream);
+
 /* Tuning overrides for sweeps and tests (0 = built-in heuristic). reserved0: encoder of the 8-bit blockwise quantize - 1 =
  * cell-table kernel, 2 = byte-table kernel, anything else = by input size; reserved1: N slices of the fused backward (> 0; the
  * workspace-size query follows it). MFMA kernels: knob0 bit 0 = round 2's form of the register-transposed kernel (measurement build only; ignored by the product library),

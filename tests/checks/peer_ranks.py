@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import bitsandbytes_amd as bnb  # noqa: E402
 import bitsandbytes_amd.nn as bnn  # noqa: E402
-from bitsandbytes_amd.peer import PeerAllGather  # noqa: E402
+from bitsandbytes_amd.peer import PeerAllGather, PeerChain  # noqa: E402
 
 
 def main():
@@ -79,6 +79,49 @@ def main():
             want = down(k * v) + q[..., :1024]
             assert torch.equal(y, want), seed
         peer.check()
+
+        # ---- the peer chain: every all-gather fused into the gemv launches (M = 1) == the layers one by one through the
+        # separate gather, bit for bit - an up / down / up stretch, plain and nested statistics, NF4 and FP4, bf16 and fp16,
+        # eagerly (the double buffer turns over many times) and as one hipGraph per rank
+        chain = PeerChain(max_values=16384)
+        try:
+            for (H, F, dt, qt, dq, bias) in ((2048, 8192, torch.bfloat16, "nf4", False, True), (4096, 11008 - 11008 % (2 * world * 32), torch.bfloat16, "nf4", True, False),
+                                            (1024, 4096, torch.float16, "fp4", True, True)):
+                torch.manual_seed(7)  # same weights on every rank
+                dims = [(H, F), (F, H), (H, F), (F, H)]
+                layers = [bnn.Linear4bit(k, n, bias=bias, compute_dtype=dt, quant_type=qt, compress_statistics=dq).to(dev) for k, n in dims]
+                fused = bnb.ShardedLinear4bitChain([bnb.shard_linear4bit(layer, rank, world) for layer in layers], chain)
+                plain = [bnb.shard_linear4bit(layer, rank, world, peer=peer) for layer in layers]
+                x = torch.randn(1, H, device=dev, dtype=dt)
+                assert fused.fused(x), (H, F, dt)
+                for it in range(6):
+                    torch.manual_seed(200 + it)
+                    x = torch.randn(1, H, device=dev, dtype=dt) * 4
+                    y = fused(x)
+                    torch.cuda.synchronize()
+                    want = x
+                    for s in plain:
+                        want = s(want)
+                    assert y.shape == want.shape and torch.equal(y, want), (H, F, dt, qt, dq, it)
+                graphed = bnb.GraphedBlock(fused, x, peers=[chain])
+                for it in range(4):
+                    torch.manual_seed(300 + it)
+                    x = torch.randn(1, H, device=dev, dtype=dt) * 4
+                    y = graphed(x).clone()
+                    torch.cuda.synchronize()
+                    want = x
+                    for s in plain:
+                        want = s(want)
+                    assert torch.equal(y, want), ("graph", H, F, dt, it)
+                # a batch of two rows is outside the fused form: the chain runs its members one by one, same values
+                x2 = torch.randn(2, H, device=dev, dtype=dt)
+                want = x2
+                for s in plain:
+                    want = s(want)
+                assert not fused.fused(x2) and torch.equal(fused(x2), want)
+            chain.check()
+        finally:
+            chain.close()
         print(f"PEER_OK {rank}", flush=True)
     finally:
         peer.close()

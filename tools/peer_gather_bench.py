@@ -2,7 +2,10 @@
 """Latency of the one-shot peer all-gather (bitsandbytes_amd/peer.py) per collective: WORLD processes sharing cuda:0 (what a 1-GPU
 box can run: same kernel, flags and ordering as across xGMI, without the link), hipGraph of 200 dependent collectives, next to
 torch.distributed's all_gather_into_tensor on an RCCL group of ONE rank (the protocol's fixed cost on this stack).
-    python tools/peer_gather_bench.py [world]          (spawns its own ranks)"""
+    python tools/peer_gather_bench.py [world ...]          (spawns its own ranks)
+    python tools/peer_gather_bench.py chain [world ...]    the FUSED form (peer.PeerChain: the gather inside the gemv launches) against
+                                                           kernel + separate gather and against the kernels alone, per layer of an
+                                                           up / down chain whose per-rank shard is 4096^2 weights at every world size"""
 import os
 import socket
 import subprocess
@@ -60,6 +63,89 @@ def rank_main():
         dist.destroy_process_group()
 
 
+def chain_main():
+    """Per layer of a decode chain up (K = 4096 -> world x 4096 features, 4096 per rank) / down (K = world x 4096 -> 4096 features,
+    4096 / world per rank): every shard is 16.8 M weights = the headline layer's bytes, whatever the world size."""
+    import torch.distributed as dist
+
+    import bitsandbytes_amd as bnb
+    import bitsandbytes_amd.nn as bnn
+    from bitsandbytes_amd.peer import PeerAllGather, PeerChain
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, Fd = 4096, 4096 * world
+    pairs = 12
+    peer = PeerAllGather(max_bytes=64 * 1024)
+    chain = PeerChain(max_values=Fd)
+    try:
+        torch.manual_seed(11)
+        shards = []
+        for i in range(pairs):
+            for (k, n) in ((H, Fd), (Fd, H)):
+                layer = bnn.Linear4bit(k, n, bias=False, compute_dtype=torch.bfloat16, quant_type="nf4", compress_statistics=False).to(dev)
+                shards.append((bnb.shard_linear4bit(layer, rank, world), bnb.shard_linear4bit(layer, rank, world, peer=peer)))
+                del layer
+        L = len(shards)
+        x = torch.randn(1, H, device=dev, dtype=torch.bfloat16)
+        xs = {H: x, Fd: torch.randn(1, Fd, device=dev, dtype=torch.bfloat16)}
+        fused = bnb.ShardedLinear4bitChain([a for a, _ in shards], chain)
+        assert fused.fused(x)
+
+        def run_fused():
+            fused(x)
+
+        def run_separate():
+            y = x
+            for _, b in shards:
+                y = b(y)
+
+        def run_alone():  # the shard kernels only, each on a resident input of its K (no exchange at all)
+            for a, _ in shards:
+                a.local_forward(xs[int(a.quant_state.shape[1])])
+
+        y1 = fused(x)
+        y2 = x
+        for _, b in shards:
+            y2 = b(y2)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(y1, y2))
+        res = {}
+        variants = [("kernels alone", run_alone), ("kernel + separate peer gather", run_separate), ("fused chain", run_fused)]
+        if world == 1:
+            # what each half of the protocol costs (one process: every layer is 4096 x 4096, any exchange fits any layer)
+            out_l = torch.empty(H, device=dev, dtype=torch.bfloat16)
+
+            def run_produce_only():
+                for a, _ in shards:
+                    chain.gemv(x.view(-1), a.weight, a.quant_state, consume=False, produce=True)
+                chain.read(H, torch.bfloat16)
+
+            def run_consume_only():
+                a0 = shards[0][0]
+                chain.gemv(x.view(-1), a0.weight, a0.quant_state, consume=False, produce=True)
+                for a, _ in shards:
+                    chain.gemv(None, a.weight, a.quant_state, out_local=out_l, consume=True, produce=False, dtype=torch.bfloat16)
+                chain.read(H, torch.bfloat16)
+
+            variants += [("produce only", run_produce_only), ("consume only (+1 launch)", run_consume_only)]
+        for name, fn in variants:
+            dist.barrier()
+            res[name] = graph_us(fn, n=1, reps=20) / L
+        chain.check()
+        peer.check()
+        if rank == 0:
+            print(f"{world} process(es) on one GPU, {L} layers (up {H} -> {Fd}, down {Fd} -> {H}; 16.8 M weights per rank and layer"
+                  f"{', workgroups capped at ' + str(chain.wg_limit) + ' per rank for the fused form' if chain.wg_limit else ''}), us per layer: "
+                  + " | ".join(f"{k} {v:6.2f}" for k, v in res.items()) + f" | fused == separate bit for bit: {same}", flush=True)
+    finally:
+        chain.close()
+        peer.close()
+        dist.destroy_process_group()
+
+
 def rccl_world_one():
     import torch.distributed as dist
 
@@ -93,6 +179,12 @@ def main():
         return rank_main()
     if os.environ.get("PEER_BENCH_RANK") == "rccl":
         return rccl_world_one()
+    if os.environ.get("PEER_BENCH_RANK") == "chain":
+        return chain_main()
+    mode = "1"
+    if len(sys.argv) > 1 and sys.argv[1] == "chain":
+        mode = "chain"
+        del sys.argv[1]
     # (more than ~4 processes on ONE device are time-sliced by the driver - 10 ms per collective at 8: not a property of the kernel)
     worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4]
     for world in worlds:
@@ -101,9 +193,11 @@ def main():
             port = s.getsockname()[1]
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)],
                                   env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world),
-                                           PEER_BENCH_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(world)]
+                                           PEER_BENCH_RANK=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(world)]
         for p in procs:
             p.wait(timeout=300)
+    if mode == "chain":
+        return
     subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, PEER_BENCH_RANK="rccl"), timeout=300)
 
 
