@@ -64,6 +64,23 @@ def _worker(rank, world, port, results):
         x = torch.randn(2, 512)
         for y, layer in zip(group_dq(x), layers_dq):
             ok &= bool(torch.equal(y, layer(x)))
+        # a chain of layers (each one's gathered y is the next one's x) without a PeerChain - what every rank runs when the fused
+        # form is not available (CPU, shapes outside it): the members one by one, the same values; shape validation at build time
+        torch.manual_seed(13)
+        dims = [(128, 256), (256, 128), (128, 256)]
+        chain_layers = [Linear4bit(k, n, bias=(i == 1), quant_type="nf4", compress_statistics=(i == 2)).to("cpu") for i, (k, n) in enumerate(dims)]
+        chain = bnb.ShardedLinear4bitChain([bnb.shard_linear4bit(layer, rank, world) for layer in chain_layers], None)
+        for M in (1, 3):
+            x = torch.randn(M, 128)
+            want = x
+            for layer in chain_layers:
+                want = layer(want)
+            ok &= not chain.fused(x) and bool(torch.equal(chain(x), want))
+        try:
+            bnb.ShardedLinear4bitChain([bnb.shard_linear4bit(chain_layers[0], rank, world), bnb.shard_linear4bit(chain_layers[0], rank, world)], None)
+            ok = False
+        except ValueError:
+            pass
         results[rank] = ok
     finally:
         dist.destroy_process_group()

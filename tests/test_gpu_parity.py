@@ -1726,10 +1726,10 @@ def test_sharded_linear4bit_over_rccl_world_size_one():
 
 
 def test_bench_multi_gpu_code_path_at_world_size_one():
-    """bench.py's --gpus N > 1 branch (ShardedLinear4bit shards, step graphs writing the gather bucket, RCCL all-gather per
-    step, the per-layer gather timing) cannot run with N > 1 on a 1-GPU box; `--sharded-path` runs the same code with an RCCL
-    group of one rank. The JSON line must be the LAST line of stdout (RCCL prints a banner through C stdio) and carry the
-    contract's keys."""
+    """bench.py's --gpus N > 1 branch (the N-sharded MLP chain: ShardedLinear4bit shards, the fused peer chain checked against the
+    separate-gather form at start-up, the other forms timed beside it) cannot run with N > 1 on a 1-GPU box; `--sharded-path` runs
+    the same code with an RCCL group of one rank. The JSON line must be the LAST line of stdout (RCCL prints a banner through C
+    stdio) and carry the contract's keys."""
     import json
     import subprocess
     import sys
@@ -1744,9 +1744,12 @@ def test_bench_multi_gpu_code_path_at_world_size_one():
                 "dtype", "data", "config", "roofline"):
         assert key in line, key
     assert line["n_gpus"] == 1 and line["steps"] == 6 and line["value"] > 0
-    assert "ShardedLinear4bit" in line["config"]["parallelism"] and line["bucketed_gather"]["us_per_layer"] > 0
-    # the per-layer gather is the one-shot peer kernel wherever it constructs and reproduces RCCL's result (it must, here)
-    assert "one-shot peer kernel" in line["config"]["parallelism"], (line["config"]["parallelism"], r.stderr[-2000:])
+    sc = line["sharded_chain"]
+    assert sc["H"] == 4096 and sc["F"] == 4096 and sc["up_shard"] == [4096, 4096]  # world 1: the headline layer itself
+    assert sc["us_per_layer_kernels_alone"] > 0 and sc["us_per_layer_kernel_plus_separate_gather"] > 0
+    # the gather is fused into the gemv launches wherever the peer chain constructs and reproduces the separate form (it must, here)
+    assert "fused into the gemv launches" in sc["gather"] and sc["fused_chain_not_used_because"] is None, (sc, r.stderr[-2000:])
+    assert "sharded x1" in line["config"]["parallelism"]
 
 
 def test_sharded_linear4bit_over_rccl_two_ranks():
