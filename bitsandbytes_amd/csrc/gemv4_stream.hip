@@ -508,7 +508,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         }
     };
 
-    uint32_t epoch = 0; // (peer chain) exchanges completed when this launch started
+    uint32_t epoch = 0;     // (peer chain) the exchange this launch consumes
+    uint32_t epoch_raw = 0; // ... the epoch word as loaded
     for (int ph = 0; ph < P; ++ph) {
         if (ph > 0)
             __syncthreads(); // everyone is done with the previous activation image
@@ -524,10 +525,17 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         u32x4 gx[PEER ? kChainRounds : 1];
         if constexpr (PEER) {
             x_from_peer = (p.peer.mode & 1) != 0;
+            // the epoch word: requested here by every wavefront, WAITED for here only by the ones that fetch x (the others must not
+            // stall in front of their ring; they need it for the granules they store at the very end - requested there, as this
+            // kernel did first, the scalar load's round trip sat exposed in front of the stores)
+            typedef const uint32_t __attribute__((address_space(4))) * cu32_ptr;
+            epoch_raw = *(cu32_ptr)(reinterpret_cast<uintptr_t>(p.peer.epoch_word));
             if (x_from_peer && wave >= BUILDERS) {
-                // (only the fetching wavefronts wait for the epoch word here; the others must not stall in front of their ring)
-                typedef const uint32_t __attribute__((address_space(4))) * cu32_ptr;
-                epoch = *(cu32_ptr)(reinterpret_cast<uintptr_t>(p.peer.epoch_word)) + p.peer.epoch_offset;
+                // (the first USE of the loaded word - even the addition of the offset - sits inside the branch: the wait for the load
+                // must not be hoisted above it)
+                uint32_t e = epoch_raw;
+                asm volatile("" : "+s"(e));
+                epoch = e + p.peer.epoch_offset;
                 unsigned char* const src = p.peer.local + kChainDataOffset + static_cast<size_t>(epoch & (kChainRegions - 1u)) * p.peer.max_granules * 8u;
                 const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(src, 0, K * 4, kRsrcFlags);
 #pragma unroll
@@ -674,11 +682,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
 
     // ---- combine the segment partials of every row in segment order, bias, one rounding
     [[maybe_unused]] uint32_t epoch_out = 0;
-    if constexpr (PEER) {
-        // (a fresh scalar load: nothing before this point depends on it in the wavefronts that did not fetch x)
-        typedef const uint32_t __attribute__((address_space(4))) * cu32_ptr;
-        epoch_out = *(cu32_ptr)(reinterpret_cast<uintptr_t>(p.peer.epoch_word)) + p.peer.epoch_offset + 1u;
-    }
+    if constexpr (PEER)
+        epoch_out = epoch_raw + p.peer.epoch_offset + 1u;
     __syncthreads();
     BNB_ST_STAMP(7)
     for (int idx = tid; idx < nrows * MB; idx += THREADS) {
