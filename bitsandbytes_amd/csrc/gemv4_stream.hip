@@ -119,12 +119,15 @@ struct PeerChain {
                             // bit 2: rows come in fours (ns and the rows per workgroup are multiples of 4): two granules per store
 };
 constexpr size_t kChainDataOffset = 256;
-// Exchange e lives in region e % kChainRegions. Two regions are what CORRECTNESS needs (see above); 64 are there for speed: the
-// buffers are ordinary cacheable memory and the consumer's FIRST fetch of a granule is a plain load, so that the 32 workgroups of an
-// XCD share one copy in their L2 instead of each pulling the same 16 KiB through one memory channel (system-scope fetches by all
-// 256 workgroups cost +1.2 us per layer: 256 readers x 128 bytes per line on one channel). A plain load may hit a STALE line - this
-// XCD's copy of the region's previous use - whose tags then do not match and which is re-fetched at system scope like a granule
-// that has not arrived: with 64 regions a line's previous use is 64 layers of streamed weights old and gone from the L2.
+// The i-th exchange since the last read-out (i = epoch_offset + 1 of the launch that produces it) lives in region i % kChainRegions:
+// the region of an exchange is its POSITION in the chain - known on the host, identical in every replay of a captured chain -
+// and only its TAG (epoch word + i) tells one chain's use of a region from the next one's. So the consumer's fetch depends on no
+// device-side word: it goes out with the first instructions of the launch (waiting for the epoch word first - a cold scalar load
+// behind a cold kernarg load - put the x fetch 1300 cycles behind the plain kernel's, the whole +0.75 us of the consumer side;
+// profiles/r4_timeline_chain.txt). Safe with chains of AT LEAST TWO exchanges (enforced by the host layer): a rank re-produces
+// region i in the next chain only after its read-out of this one, i.e. after every rank produced the LAST exchange - which it does
+// behind its consumption of all earlier ones; and the last region is re-produced only behind the consumption of the next chain's
+// exchange n - 1, which every rank produces behind its own read-out.
 constexpr uint32_t kChainRegions = 64;
 constexpr int kChainRounds = 8; // 16-byte fetches per builder lane: K <= 8 * 8 KiB / 4 B = 16384 values
 
@@ -516,32 +519,24 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         // (1) this phase's activation image (LDS-DMA, oldest in the queue), then the first NS ring stages
         if (ph == 0)
             BNB_ST_STAMP(9)
-        // (peer chain) x = the current exchange: 16 bytes = two granules = four values per lane and round, fetched by the wavefronts
-        // that do NOT build the decode table (8 ... 15: they start last and have nothing else to do before the first barrier), IN
-        // FRONT of their weight ring - so that tags can be checked and the image written while the ring is still in flight (behind the
+        // (peer chain) x = the current exchange: 16 bytes = two granules = four values per lane and round, fetched by wavefronts
+        // 0 ... 7 (they start first; the decode table is built by 8 ... 15 in this mode), IN FRONT of their weight ring - so that tags can be checked and the image written while the ring is still in flight (behind the
         // ring, the in-order counter made x wait for every weight byte: +1.2 us per layer, profiles/r4_peer_chain.txt). The epoch
         // they depend on is one scalar load; a lane past the end of x is out of range (zeros, no traffic).
         bool x_from_peer = false;
         u32x4 gx[PEER ? kChainRounds : 1];
         if constexpr (PEER) {
-            x_from_peer = (p.peer.mode & 1) != 0;
-            // the epoch word: requested here by every wavefront, WAITED for here only by the ones that fetch x (the others must not
-            // stall in front of their ring; they need it for the granules they store at the very end - requested there, as this
-            // kernel did first, the scalar load's round trip sat exposed in front of the stores)
-            typedef const uint32_t __attribute__((address_space(4))) * cu32_ptr;
-            epoch_raw = *(cu32_ptr)(reinterpret_cast<uintptr_t>(p.peer.epoch_word));
-            if (x_from_peer && wave >= BUILDERS) {
-                // (the first USE of the loaded word - even the addition of the offset - sits inside the branch: the wait for the load
-                // must not be hoisted above it)
-                uint32_t e = epoch_raw;
-                asm volatile("" : "+s"(e));
-                epoch = e + p.peer.epoch_offset;
-                unsigned char* const src = p.peer.local + kChainDataOffset + static_cast<size_t>(epoch & (kChainRegions - 1u)) * p.peer.max_granules * 8u;
-                const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(src, 0, K * 4, kRsrcFlags);
+            // (the mode travels in the spare bits of a PRELOADED argument and, when x comes from the exchange, the address of the
+            // exchange's region in the slot of the unused activation pointer - the region of an exchange is its POSITION in the chain,
+            // which the host knows, only its tag carries the device-side epoch: the fetch depends on no load at all)
+            const int peer_mode = (hot_packed >> 24) & 7;
+            x_from_peer = (peer_mode & 1) != 0;
+            if (x_from_peer && wave < WAVES - BUILDERS) {
+                const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(hot_A), 0, K * 4, kRsrcFlags);
 #pragma unroll
                 for (int r = 0; r < kChainRounds; ++r)
                     gx[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                          rs_x, static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave - BUILDERS) * 64 + lane) * 16u, 0, 0 /* plain: see kChainRegions */));
+                                                          rs_x, static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave) * 64 + lane) * 16u, 0, 17 /* sc0 sc1 */));
             }
         }
         if (!x_from_peer)
@@ -558,6 +553,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             issue(st[j], j);
             __builtin_amdgcn_sched_barrier(0); // keep the queue in stage order: (weights, scale) of stage 0, of stage 1, ...
         }
+        if constexpr (PEER) {
+            // the epoch word (the tags of the exchange consumed here are epoch + offset, of the one produced epoch + offset + 1):
+            // requested BEHIND every load of the prologue - its address comes from the kernarg segment, whose first access is a cold
+            // miss that stalled every wavefront for ~500 cycles in front of its ring when it sat there (profiles/r4_timeline_chain.txt)
+            typedef const uint32_t __attribute__((address_space(4))) * cu32_ptr;
+            epoch_raw = *(cu32_ptr)(reinterpret_cast<uintptr_t>(p.peer.epoch_word));
+            epoch = epoch_raw + p.peer.epoch_offset;
+        }
         if (ph == 0)
             BNB_ST_STAMP(1)
         if (ph == 0) {
@@ -565,7 +568,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             // is shared by the CU's 16 wavefronts, so nothing that is not needed for the loads may run before them
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (ph == 0 && wave < BUILDERS) {
+        // (peer chain, x from the exchange: the wavefronts that start FIRST fetch x - it is the longest pole in front of the barrier -
+        // and the table is built by the second half of the workgroup, tid_b = the builder's index among the builders)
+        const bool table_builder = (PEER && x_from_peer) ? (wave >= WAVES - BUILDERS) : (wave < BUILDERS);
+        const int tid_b = (PEER && x_from_peer) ? tid - (WAVES - BUILDERS) * 64 : tid;
+        if (ph == 0 && table_builder) {
             if constexpr (!CODEPTR)
                 cv = code_literal<(FLAGS & kFp4) != 0>((lane & 15) + opaque_zero()); // (opaque: not hoisted above the loads)
             // (2) decode table, built while the loads fly: entry e (a packed byte) = 32 copies of
@@ -579,15 +586,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             // code[e >> 4] = code[c16 >> 8]. All cross-lane fetches are issued before the first store: written as
             // fetch-fetch-store per pass the build is a chain of LDS round trips (measured: 2400 cycles for 16 passes).
             const int cvb = __builtin_bit_cast(int, cv);
-            const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((tid >> 4) & 15) * 4, cvb));
+            const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((tid_b >> 4) & 15) * 4, cvb));
             float hi[ITERS];
 #pragma unroll
             for (int it = 0; it < ITERS; ++it)
-                hi[it] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((it * BT + tid) >> 8) * 4, cvb));
+                hi[it] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((it * BT + tid_b) >> 8) * 4, cvb));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int it = 0; it < ITERS; ++it)
-                *reinterpret_cast<f32x4*>(smem + (it * BT + tid) * 16) = f32x4{hi[it], lo, hi[it], lo};
+                *reinterpret_cast<f32x4*>(smem + (it * BT + tid_b) * 16) = f32x4{hi[it], lo, hi[it], lo};
         }
         if (ph == 0) {
             if constexpr (NESTED) {
@@ -608,11 +615,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         if (!x_from_peer)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS * LPS) : "memory");
         if constexpr (PEER) {
-            if (x_from_peer && wave >= BUILDERS) {
-                unsigned char* const src = p.peer.local + kChainDataOffset + static_cast<size_t>(epoch & (kChainRegions - 1u)) * p.peer.max_granules * 8u;
+            if (x_from_peer && wave < WAVES - BUILDERS) {
+                const unsigned char* const src = static_cast<const unsigned char*>(hot_A);
 #pragma unroll
                 for (int r = 0; r < kChainRounds; ++r) {
-                    const uint32_t off = static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave - BUILDERS) * 64 + lane) * 16u;
+                    const uint32_t off = static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave) * 64 + lane) * 16u;
                     if (off < static_cast<uint32_t>(K) * 4u) {
                         u32x4 gr = gx[r];
                         // (the re-fetch loop is spelled in asm: a loop with loads in it makes the compiler's wait insertion
@@ -683,7 +690,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     // ---- combine the segment partials of every row in segment order, bias, one rounding
     [[maybe_unused]] uint32_t epoch_out = 0;
     if constexpr (PEER)
-        epoch_out = epoch_raw + p.peer.epoch_offset + 1u;
+        epoch_out = epoch + 1u;
     __syncthreads();
     BNB_ST_STAMP(7)
     for (int idx = tid; idx < nrows * MB; idx += THREADS) {
@@ -712,7 +719,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
                 const uint32_t other = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((lane ^ 1) << 2, static_cast<int>(own)));
                 const uint32_t pair = own | (other << 16);                                                           // (even lanes: rows r, r + 1)
                 const uint32_t pair2 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((lane ^ 2) << 2, static_cast<int>(pair))); // rows r + 2, r + 3
-                const size_t slot = kChainDataOffset + (static_cast<size_t>(epoch_out & (kChainRegions - 1u)) * p.peer.max_granules +
+                const size_t slot = kChainDataOffset + (static_cast<size_t>((p.peer.epoch_offset + 1u) & (kChainRegions - 1u)) * p.peer.max_granules +
                                                         ((static_cast<size_t>(p.peer.rank) * static_cast<size_t>(rows_total) + static_cast<size_t>(row)) >> 1)) * 8u;
                 if (p.peer.mode & 4) {
                     // two granules per store: a 16-byte system-scope store costs the fabric what an 8-byte one does (each aligned
@@ -721,7 +728,12 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
                         const u32x4 granules = {pair, epoch_out, pair2, epoch_out};
                         for (int pr = 0; pr < p.peer.world; ++pr) {
                             unsigned char* const dst = p.peer.base[pr] + slot;
-                            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(granules) : "memory");
+                            // (this rank's OWN copy is consumed by a later launch of this device: the kernel boundary makes an
+                            // ordinary store visible, and the launch does not end behind a write-through acknowledgement for it)
+                            if (pr == p.peer.rank)
+                                asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(granules) : "memory");
+                            else
+                                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(granules) : "memory");
                         }
                     }
                 } else if (!(row & 1)) {
@@ -729,7 +741,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
                     const u32x2 granule = {pair, epoch_out};
                     for (int pr = 0; pr < p.peer.world; ++pr) {
                         unsigned char* const dst = p.peer.base[pr] + slot;
-                        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(granule) : "memory");
+                        if (pr == p.peer.rank)
+                            asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(granule) : "memory");
+                        else
+                            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(granule) : "memory");
                     }
                 }
             }
@@ -1006,7 +1021,8 @@ template <typename T, int FLAGS> void launch_peer(const StreamArgs& a, const Geo
     ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), ge.lds);
     const StreamMat& m0 = a.mat[0];
     hipLaunchKernelGGL(kern, dim3(ge.grid_x, 1), dim3(16 * 64), ge.lds, stream, a.A, m0.B, m0.absmax, m0.absmax8, m0.N, a.K,
-                       (1 & 0x3FFFF) | (a.bs_shift << 18) | (ge.P << 23), ge.R | (ge.SW << 16) | (ge.G << 21), (256 + ge.SW - 1) / ge.SW, a);
+                       (1 & 0x3FFFF) | (a.bs_shift << 18) | (1 << 23) | ((a.peer.mode & 7) << 24), ge.R | (ge.SW << 16) | (ge.G << 21),
+                       (256 + ge.SW - 1) / ge.SW, a);
 }
 template <typename T> void launch_peer_flags(const StreamArgs& a, const Geometry& ge, int quant_type, hipStream_t stream) {
     const int sel = (a.mat[0].absmax8 != nullptr ? 1 : 0) | (quant_type == kFP4 ? 2 : 0);
@@ -1023,7 +1039,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void peer_chain_read_kernel(PeerChain pc, T* __restrict__ out, int nvalues) {
     uint32_t* const hdr = reinterpret_cast<uint32_t*>(pc.local);
     const uint32_t epoch = pc.epoch_word[0] + pc.epoch_offset;
-    const unsigned char* const src = pc.local + kChainDataOffset + static_cast<size_t>(epoch & (kChainRegions - 1u)) * pc.max_granules * 8u;
+    const unsigned char* const src = pc.local + kChainDataOffset + static_cast<size_t>(pc.epoch_offset & (kChainRegions - 1u)) * pc.max_granules * 8u;
     using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
     for (int gi = blockIdx.x * 256 + threadIdx.x; 2 * gi < nvalues; gi += gridDim.x * 256) {
         const unsigned char* const addr = src + static_cast<size_t>(gi) * 8u;
@@ -1099,7 +1115,10 @@ bool gemv_4bit_peer(void* const* bufs, void* epoch_word, int world, int rank, in
     a.peer.spin_bound = spin_bound;
     a.peer.epoch_offset = epoch_offset;
     a.peer.mode = (mode & 3) | (quads ? 4 : 0);
-    a.A = A;
+    // (x from the exchange: the preloaded pointer slot carries the address of the exchange's region - its position in the chain)
+    a.A = (mode & 1) ? static_cast<const void*>(a.peer.local + kChainDataOffset +
+                                                 static_cast<size_t>(epoch_offset & (kChainRegions - 1u)) * a.peer.max_granules * 8u)
+                     : A;
     a.code16 = nullptr;
     a.M = 1;
     a.K = K;

@@ -227,7 +227,7 @@ class ShardedLinear4bitChain(nn.Module):
         self._bias_cache = {}
 
     def fused(self, x: torch.Tensor) -> bool:
-        if self.chain is None or x.dtype not in (torch.float16, torch.bfloat16) or x.numel() != x.shape[-1]:
+        if self.chain is None or len(self.shards) < 2 or x.dtype not in (torch.float16, torch.bfloat16) or x.numel() != x.shape[-1]:
             return False
         return all(self.chain.serves(int(s.quant_state.shape[0]), int(s.quant_state.shape[1]), int(s.quant_state.blocksize), i > 0)
                    and self.chain.world * int(s.quant_state.shape[0]) == s.out_features

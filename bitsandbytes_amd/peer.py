@@ -171,7 +171,8 @@ class PeerChain(_PeerBuffers):
     chain must end with it, a captured block in particular: it is the launch that advances the buffers' epoch). One
     launch per layer, no collective launch, no host synchronisation; capturable in a hipGraph. M = 1, fp16 / bf16.
 
-    Every rank issues the same sequence of calls. Results are bit-identical to ``ShardedLinear4bit`` layer by layer (the kernel's
+    Every rank issues the same sequence of calls; a chain holds at least two exchanges (two ``produce`` launches) before its
+    ``read``. Results are bit-identical to ``ShardedLinear4bit`` layer by layer (the kernel's
     arithmetic does not depend on the launch geometry). ``max_values``: the longest gathered vector (``world * ns``) and the
     longest consumed ``x`` (``K``) the chain will see. Exercised between processes sharing one GPU; **not measured on a
     multi-GPU node by us**."""
@@ -248,6 +249,10 @@ class PeerChain(_PeerBuffers):
 
     def read(self, n_values: int, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The current exchange - the gathered y of the last ``produce`` launch, rank-major - as a plain tensor."""
+        if self._pending < 2:
+            # (the region of an exchange is its position in the chain: a chain of ONE exchange would re-use its region in the very
+            # next chain, before every rank has read it - csrc/gemv4_stream.hip, kChainRegions)
+            raise RuntimeError("a peer chain must hold at least two exchanges before its read-out (use ShardedLinear4bit for a single layer)")
         if out is None:
             out = torch.empty(n_values, dtype=dtype, device=self.device)
         elif out.numel() != n_values or out.dtype != dtype or not out.is_contiguous():

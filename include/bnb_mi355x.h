@@ -183,7 +183,8 @@ int bnb_mi355x_peer_status(const void* local_buffer);
  *   on the device because a replayed hipGraph re-runs its launches; only the read-out advances it).
  *   epoch_offset: exchanges completed (launches with bit 1) since the last bnb_mi355x_peer_chain_read on these buffers.
  * Every rank issues the same sequence of launches; a chain ends with bnb_mi355x_peer_chain_read (epoch_offset = the number of
- * exchanges since the previous read-out, this chain's included). Returns 1 when launched, 0 when the problem is outside the form's
+ * exchanges since the previous read-out, this chain's included) and holds AT LEAST TWO exchanges: an exchange lives in the region
+ * of its position in the chain (epoch_offset + 1 of the producing launch, modulo 64), only its tag carries the epoch. Returns 1 when launched, 0 when the problem is outside the form's
  * preconditions (ns even, K % 32 == 0, K <= 16384 with bit 0, one phase, blocksize >= 32, 16-byte aligned B / A, world * ns and
  * K <= max_values) - nothing was launched and the caller takes the unfused path. A wait that runs into its bound
  * (BNB_MI355X_PEER_WAIT_POLLS) sets the buffer's status word (bnb_mi355x_peer_status) and yields NaN, never a hang.

@@ -126,11 +126,12 @@ def chain_main():
             def run_consume_only():
                 a0 = shards[0][0]
                 chain.gemv(x.view(-1), a0.weight, a0.quant_state, consume=False, produce=True)
+                chain.gemv(x.view(-1), a0.weight, a0.quant_state, consume=False, produce=True)   # (a chain holds >= 2 exchanges)
                 for a, _ in shards:
                     chain.gemv(None, a.weight, a.quant_state, out_local=out_l, consume=True, produce=False, dtype=torch.bfloat16)
                 chain.read(H, torch.bfloat16)
 
-            variants += [("produce only", run_produce_only), ("consume only (+1 launch)", run_consume_only)]
+            variants += [("produce only", run_produce_only), ("consume only (+2 launches)", run_consume_only)]
         for name, fn in variants:
             dist.barrier()
             res[name] = graph_us(fn, n=1, reps=20) / L
