@@ -285,7 +285,12 @@ template <int WIDTH> __device__ __forceinline__ uint32_t group_max_u32(uint32_t 
 
 // One workgroup = 256 threads = CH chunks of 2048 elements. BS <= 2048: a chunk holds 2048/BS blocks;
 // BS = 4096: a block is two chunks (CH even).
-template <typename T, int BS, int QT, int CH>
+// PIPE (whole, aligned tiles only; round 4): a workgroup walks several tiles, grid-strided, with the NEXT tile's loads in
+// flight while it encodes the current one. Built on the theory that the one-tile form - exactly one round of workgroups on the
+// chip for a 4096^2 weight, 8 per CU, all loading, then all encoding, then all storing - adds its three phases up. Measured
+// (profiles/r4_quantize4_pipelined_ab.txt, 4096^2 bf16): NF4 11.26 vs 11.06 us - the theory is wrong there, the NF4 kernel keeps
+// the one-tile form; FP4 (1025-cell table, more encode work per element) 12.33 vs 13.20: FP4 takes the pipelined form.
+template <typename T, int BS, int QT, int CH, bool PIPE = false>
 __global__ __launch_bounds__(256) void quantize4_kernel(const T* __restrict__ A, float* __restrict__ absmax,
                                                         uint8_t* __restrict__ out, long n, int vec_ok) {
     constexpr int TILE = 2048 * CH;
@@ -298,10 +303,13 @@ __global__ __launch_bounds__(256) void quantize4_kernel(const T* __restrict__ A,
     __shared__ uint32_t wave_max[NB][4];
 
     const int tid = threadIdx.x;
-    const long tile_base = static_cast<long>(blockIdx.x) * TILE;
+    long tile_base = static_cast<long>(blockIdx.x) * TILE;
+    const long ntiles = n / TILE; // (PIPE: n is a whole number of tiles)
+    long tile = blockIdx.x;
 
     Raw8<T> x[CH];
-    if (vec_ok != 0 && tile_base + TILE <= n) { // whole tile in range: CH back-to-back vector loads
+    [[maybe_unused]] Raw8<T> xn[PIPE ? CH : 1];
+    if (PIPE || (vec_ok != 0 && tile_base + TILE <= n)) { // whole tile in range: CH back-to-back vector loads
 #pragma unroll
         for (int c = 0; c < CH; ++c)
             load8<T>(A, tile_base + c * 2048 + static_cast<long>(tid) * 8, n, true, x[c]);
@@ -315,6 +323,16 @@ __global__ __launch_bounds__(256) void quantize4_kernel(const T* __restrict__ A,
         const QCell* src = (QT == kNF4) ? kNF4Cells.c : kFP4Cells.c;
         for (int i = tid; i < NCELL; i += 256)
             cells[i] = src[i];
+    }
+  bool more = false;
+  do { // (one pass unless PIPE)
+    if constexpr (PIPE) {
+        // the next tile of this workgroup - or, behind the last one, the same tile again (an L2 hit that is never used): the
+        // loads are unconditional, so the wait in front of the encode stays a counted one (the CH loads just issued may fly on)
+        const long next = tile + gridDim.x < ntiles ? tile + gridDim.x : tile;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            load8<T>(A, next * TILE + c * 2048 + static_cast<long>(tid) * 8, n, true, xn[c]);
     }
 
     // block-wide max of the |x| patterns
@@ -349,8 +367,10 @@ __global__ __launch_bounds__(256) void quantize4_kernel(const T* __restrict__ A,
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const long base = tile_base + c * 2048 + static_cast<long>(tid) * 8;
-        if (base >= n)
-            break;
+        if constexpr (!PIPE) {
+            if (base >= n)
+                break;
+        }
         const long blk = base / BS;
         const bool tail = (rem != 0) && (blk == nblocks - 1);
         const uint32_t pat = mb[c / CPB];
@@ -397,7 +417,21 @@ __global__ __launch_bounds__(256) void quantize4_kernel(const T* __restrict__ A,
             }
         }
     }
+    if constexpr (PIPE) {
+        tile += gridDim.x;
+        more = tile < ntiles;
+        tile_base = tile * TILE;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            x[c] = xn[c];
+        if constexpr (GROUP > 64)
+            __syncthreads(); // wave_max is rewritten by the next pass
+    }
+  } while (PIPE && more);
 }
+
+// (sweeps / tests: 1 = the one-tile form everywhere, anything else = built-in choice; thread-local like the other knobs)
+thread_local TlsKnob g_q4_variant{0};
 
 template <typename T, int QT> void launch_quantize4(const T* A, float* absmax, uint8_t* out, int blocksize, long n,
                                                     hipStream_t stream) {
@@ -407,6 +441,14 @@ template <typename T, int QT> void launch_quantize4(const T* A, float* absmax, u
     // 4 chunks per workgroup once that still leaves >= 4 workgroups per CU (amortises the cell-table fill
     // and puts 4 loads per lane in flight); small inputs keep the smallest tile to spread over the CUs.
     const bool wide = n >= 4L * 256 * 8192;
+    // the pipelined form: whole aligned tiles, and enough of them that every workgroup gets >= 4 (4 workgroups per CU)
+    const int q4_variant = g_q4_variant.load(std::memory_order_relaxed);
+    const long pipe_grid = 4L * device_cu_count_or_default();
+#define BNB_Q4_LAUNCH_PIPE(BS, CH)                                                                 \
+    {                                                                                              \
+        hipLaunchKernelGGL((quantize4_kernel<T, BS, QT, CH, true>), dim3(static_cast<unsigned>(pipe_grid)), dim3(256), 0, stream, A, absmax, \
+                           out, n, vec_ok);                                                        \
+    }
 #define BNB_Q4_LAUNCH(BS, CH)                                                                      \
     {                                                                                              \
         constexpr long TILE = 2048L * CH;                                                          \
@@ -417,7 +459,10 @@ template <typename T, int QT> void launch_quantize4(const T* A, float* absmax, u
 #define BNB_Q4_CASE(BS)                                                                            \
     case BS: {                                                                                     \
         constexpr int MINCH = BS > 2048 ? BS / 2048 : 1;                                           \
-        if (wide)                                                                                  \
+        constexpr int PCH = BS > 2048 ? BS / 2048 : 2;                                             \
+        if (QT == kFP4 && q4_variant != 1 && vec_ok && (n % (2048L * PCH)) == 0 && n / (2048L * PCH) >= 4 * pipe_grid) \
+            BNB_Q4_LAUNCH_PIPE(BS, PCH)                                                            \
+        else if (wide)                                                                             \
             BNB_Q4_LAUNCH(BS, 4)                                                                   \
         else                                                                                       \
             BNB_Q4_LAUNCH(BS, MINCH)                                                               \
@@ -438,10 +483,13 @@ template <typename T, int QT> void launch_quantize4(const T* A, float* absmax, u
     }
 #undef BNB_Q4_CASE
 #undef BNB_Q4_LAUNCH
+#undef BNB_Q4_LAUNCH_PIPE
     BNB_CHECK_LAUNCH();
 }
 
 } // namespace
+
+void quantize_4bit_set_variant(int variant) { g_q4_variant.store(variant, std::memory_order_relaxed); }
 
 void quantize_4bit_f32(const float* A, float* absmax, uint8_t* out, int blocksize, long n, int quant_type,
                        hipStream_t s) {

@@ -121,6 +121,31 @@ def F_code(quant_type):
     return O.get_4bit_code(quant_type).numpy()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+@pytest.mark.parametrize("blocksize", [64, 4096])
+def test_quantize_4bit_fp4_pipelined_form_vs_oracle(dtype, blocksize):
+    """FP4 tensors of whole aligned tiles from 16 M elements up take the grid-strided, prefetching form of quantize4_kernel
+    (csrc/quantize4.hip, PIPE): codes and absmax bit-exact against the oracle at that size, and identical to the one-tile form
+    (tuning knob)."""
+    import bitsandbytes_amd as bnb
+    from oracle import oracle as O
+
+    F = _F()
+    g = torch.Generator().manual_seed(21)
+    n = 4096 * 4096 + (4096 * 64 if blocksize == 64 else 0)
+    A = (torch.randn(n, generator=g) * 0.3).to(dtype)
+    A[::4099] = 0
+    q, st = F.quantize_4bit(A.to(DEV), blocksize=blocksize, quant_type="fp4")
+    q_o, am_o = O.quantize_4bit(A, blocksize, "fp4")
+    assert torch.equal(q.cpu().flatten(), q_o.flatten()) and torch.equal(st.absmax.cpu(), am_o)
+    try:
+        bnb.lib.bnb_mi355x_set_tuning(3, 0, 0, 0)
+        q1, st1 = F.quantize_4bit(A.to(DEV), blocksize=blocksize, quant_type="fp4")
+    finally:
+        bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+    assert torch.equal(q1, q) and torch.equal(st1.absmax, st.absmax)
+
+
 @pytest.mark.parametrize("quant_type", ["nf4", "fp4"])
 def test_quantize_4bit_every_ulp_around_bounds(quant_type):
     """The cell-table encoder must agree with the 15-bound count on every float next to a decision bound or

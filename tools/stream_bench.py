@@ -48,7 +48,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=4096 * 4096)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--q4-one-tile", action="store_true", help="force the one-tile form of quantize4_kernel (A/B of the pipelined form)")
     a = ap.parse_args()
+    if a.q4_one_tile:
+        bnb.lib.bnb_mi355x_set_tuning(3, 0, 0, 0)
     n = a.n
     lib = bnb.lib
     print(f"# n={n} elements; graph of R launches over R distinct tensors (R*bytes > 512 MiB)")
