@@ -400,6 +400,24 @@ def test_rt_mfma_lane_algebra_emulation():
 
 
 
+def test_round4_index_algebra_emulation():
+    """Index algebra added in round 4, replayed on the CPU (tests/checks/emulate_round4_index_algebra.py): (1) the K-quarter
+    kernel's accumulator-layout slabs against gemm4_finalize_kq_kernel's decoding of them - every element of a workgroup tile
+    stored once and attributed to the row / column its lane held; (2) the peer chain's transport - producer granule slot ->
+    consumer fetch -> swizzled activation image -> the element a decoding lane reads: every k of x reaches the lane that
+    multiplies weight k, for every chain shape the bench and the tests use."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location(
+        "emulate_round4_index_algebra", os.path.join(os.path.dirname(__file__), "checks", "emulate_round4_index_algebra.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.check_kq_slabs()
+    for (K, world, ns) in ((4096, 1, 4096), (8192, 2, 4096), (8192, 4, 2048), (11008, 8, 1376), (16384, 4, 4096), (16384, 8, 2048), (4096, 8, 512)):
+        assert mod.check_peer_chain(K, world, ns)
+
+
 def test_grad_input_lane_algebra_emulation():
     """The index algebra of csrc/gemm4_grad_input.hip (one dword per weight row and lane, nibble j = B operand of the strided
     column tile {8 c + j}, the swizzled private grad_out patch, the scale patch, the output mapping, the dealing of the final
