@@ -67,6 +67,18 @@ def algorithmic_bytes(M, N, K, bs, elt=2):
     return N * K // 2 + 4 * (N * K // bs) + elt * M * K + elt * M * N
 
 
+def sharded_chain_dims(world, N, K):
+    """(H, F, [(rows of a rank's shard, K) of an up layer, ... of a down layer]) of the N-sharded MLP chain bench.py --gpus
+    `world` runs: up H -> F, down F -> H, H x F = world x N x K, so every rank's shard of every layer holds N x K weights at
+    every world size (weak scaling). None when `world` does not divide the model evenly (not a power of two)."""
+    lg = max(0, world.bit_length() - 1)
+    H = N << (lg // 2)
+    Fd = (N * K * world) // H
+    if (H * Fd != N * K * world) or Fd % world or H % world:
+        return None
+    return H, Fd, [(Fd // world, H), (H // world, Fd)]
+
+
 def build_layers(device, n_layers, N, K, M, blocksize, quant_type, seed):
     import bitsandbytes_amd.functional as F
 
@@ -411,12 +423,10 @@ def main():
         # gathered y the next layer's x. H x F = world x 4096^2, so that EVERY rank's shard of EVERY layer holds 4096^2 weights - the
         # headline layer's bytes - at any world size (weak scaling): world 1: 4096 / 4096, 2: 4096 / 8192, 4: 8192 / 8192, 8: 8192 /
         # 16384. One step = one activation row through LAYERS such layers = LAYERS x (shard kernel + all-gather of y).
-        lg = max(0, world.bit_length() - 1)
-        H = N << (lg // 2)
-        Fd = (N * K * world) // H
-        if (H * Fd != N * K * world) or Fd % world or H % world:
+        geo = sharded_chain_dims(world, N, K)
+        if geo is None:
             sys.exit(f"bench.py: cannot build the sharded chain for world size {world} (needs a power of two)")
-        dims = [(Fd // world, H), (H // world, Fd)]      # (rows of this rank's shard, K) of an up / a down layer
+        H, Fd, dims = geo                                 # dims: (rows of this rank's shard, K) of an up / a down layer
         g = torch.Generator(device=device).manual_seed(1234 + rank)
         import bitsandbytes_amd.functional as F4
 

@@ -274,6 +274,26 @@ def test_launch_plan_workspace_query_is_pure_host_logic():
     assert q(0, BF16, 64, 4096, 4100, 64) == 0, "K % 256 != 0 falls back to the dot kernel"
 
 
+def test_bench_sharded_chain_geometry():
+    """bench.py --gpus N: every rank's shard of every layer of the N-sharded MLP chain holds the headline layer's 4096^2 weights
+    at N = 1, 2, 4, 8; each layer's gathered y is the next layer's x; every shape lies inside the fused peer chain's
+    preconditions (rows in fours, K <= 16384 for a consumed x); a world size that does not divide the model is refused."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    want = {1: (4096, 4096), 2: (4096, 8192), 4: (8192, 8192), 8: (8192, 16384)}
+    for world, (H, Fd) in want.items():
+        h, f, dims = bench.sharded_chain_dims(world, 4096, 4096)
+        assert (h, f) == (H, Fd)
+        (ns_up, k_up), (ns_dn, k_dn) = dims
+        assert ns_up * k_up == 4096 * 4096 == ns_dn * k_dn
+        assert world * ns_up == k_dn and world * ns_dn == k_up   # gathered y of one = x of the next
+        assert ns_up % 4 == 0 and ns_dn % 4 == 0 and max(k_up, k_dn) <= 16384 and k_up % 256 == 0 and k_dn % 256 == 0
+    assert bench.sharded_chain_dims(3, 4096, 4096) is None and bench.sharded_chain_dims(6, 4096, 4096) is None
+
+
 def test_bench_contract_flags_and_algorithmic_bytes():
     """bench.py keeps the driver's contract (--gpus/--steps/--warmup, defaults that finish in minutes) and
     prices a step with SURVEY section 8(d)'s algorithmic-byte formula."""
