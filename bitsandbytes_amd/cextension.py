@@ -89,7 +89,9 @@ def _declare(dll: ct.CDLL) -> None:
     sig(["bnb_mi355x_peer_allgather"], [_VOID_P, _I32, _I32, _VOID_P, _VOID_P, ct.c_size_t, ct.c_size_t, _VOID_P])
     sig(["bnb_mi355x_peer_status"], [_VOID_P], _I32)
     sig(["bnb_mi355x_peer_chain_buffer_bytes"], [ct.c_long], ct.c_size_t)
-    sig(["bnb_mi355x_peer_chain_alloc"], [ct.c_size_t], _VOID_P)
+    sig(["bnb_mi355x_peer_chain_alloc"], [ct.c_size_t, _I32], _VOID_P)
+    # (world, ns, K, blocksize, mode, max_values, wg_limit)
+    sig(["bnb_mi355x_gemv_4bit_peer_serves"], [_I32] * 5 + [ct.c_long, _I32], _I32)
     # (bufs[], epoch_word, world, rank, dtype, A, B, absmax, absmax_8bit, absmax_code, absmax_offset, bias, out_local, ns, K, blocksize,
     #  quant_type, mode, max_values, wg_limit, epoch_offset, stream)
     sig(["bnb_mi355x_gemv_4bit_peer"], [_VOID_P, _VOID_P, _I32, _I32, _I32] + [_VOID_P] * 8 + [_I32] * 5 + [ct.c_long, _I32, _I32, _VOID_P], _I32)
@@ -129,6 +131,7 @@ EXPORTED_SYMBOLS = tuple(
        "bnb_mi355x_gemm_4bit_grad_input", "bnb_mi355x_gemm_4bit_grad_input_workspace_bytes", "bnb_mi355x_gemm_4bit_grad_input_supported",
        "bnb_mi355x_peer_buffer_bytes", "bnb_mi355x_peer_alloc", "bnb_mi355x_peer_free", "bnb_mi355x_peer_export", "bnb_mi355x_peer_open",
        "bnb_mi355x_peer_close", "bnb_mi355x_peer_allgather", "bnb_mi355x_peer_status",
-       "bnb_mi355x_peer_chain_buffer_bytes", "bnb_mi355x_peer_chain_alloc", "bnb_mi355x_gemv_4bit_peer", "bnb_mi355x_peer_chain_read",
+       "bnb_mi355x_peer_chain_buffer_bytes", "bnb_mi355x_peer_chain_alloc", "bnb_mi355x_gemv_4bit_peer_serves", "bnb_mi355x_gemv_4bit_peer",
+       "bnb_mi355x_peer_chain_read",
        "bnb_mi355x_set_stream_tuning", "bnb_mi355x_set_tuning", "bnb_mi355x_set_stamp_buffer", "bnb_mi355x_version"]
 )

@@ -38,6 +38,7 @@ bool gemv_4bit_peer(void* const* bufs, void* epoch_word, int world, int rank, in
                     uint32_t spin_bound, hipStream_t stream);
 void peer_chain_read(void* const* bufs, void* epoch_word, int world, int rank, int dtype, void* out, int nvalues, long max_values, uint32_t epoch_offset,
                      uint32_t spin_bound, hipStream_t stream);
+bool gemv_4bit_peer_serves(int world, int ns, int K, int blocksize, int mode, long max_values, int wg_limit);
 thread_local int g_last_gemm_kernel = kKernelNone;
 #ifdef BNB_PROFILING
 unsigned long long* g_dbg_buf = nullptr; // profiling builds only: device buffer for the kernels' s_memtime stamps
@@ -304,13 +305,21 @@ static uint32_t peer_chain_spin_bound() {
     return bound;
 }
 size_t bnb_mi355x_peer_chain_buffer_bytes(long max_values) {
-    // header + 64 regions (gemv4_stream.hip: kChainRegions) of max_values / 2 granules of 8 bytes
-    return 256 + 64 * 4 * static_cast<size_t>(max_values > 0 ? max_values + (max_values & 1) : 0);
+    // header + 64 regions (gemv4_stream.hip: kChainRegions) of max_values / 2 granules of 8 bytes; max_values counts in fours
+    // (an even number of granules per region: every region starts 16-byte aligned, which the two-granule stores and fetches need)
+    const size_t mv = max_values > 0 ? (static_cast<size_t>(max_values) + 3) & ~static_cast<size_t>(3) : 0;
+    return 256 + 64 * 4 * mv;
 }
-void* bnb_mi355x_peer_chain_alloc(size_t bytes) {
-    // ordinary (cacheable) device memory, zeroed; exported / mapped / freed with the bnb_mi355x_peer_* functions
+void* bnb_mi355x_peer_chain_alloc(size_t bytes, int fine_grained) {
+    // Zeroed device memory for a rank's exchange buffer; exported / mapped / freed with the bnb_mi355x_peer_* functions.
+    //   fine_grained != 0: hipDeviceMallocFinegrained - what a chain whose ranks sit on DIFFERENT devices must use. Remote GPUs store
+    //     into this buffer while a kernel of the owner polls it; HIP makes coarse-grained memory coherent across devices at kernel
+    //     boundaries only, so a line of an ordinary allocation that the owner's L2 holds may never show the remote store.
+    //   fine_grained == 0: ordinary (cacheable) hipMalloc memory - enough where every rank runs on ONE device (processes sharing a
+    //     GPU, a group of one rank): one L2 hierarchy, nothing crosses a link (profiles/r4_peer_chain.txt, builds 3 and 6).
     void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) {
+    const hipError_t err = fine_grained ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) : hipMalloc(&p, bytes);
+    if (err != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
@@ -320,6 +329,11 @@ void* bnb_mi355x_peer_chain_alloc(size_t bytes) {
         return nullptr;
     }
     return p;
+}
+int bnb_mi355x_gemv_4bit_peer_serves(int world, int ns, int K, int blocksize, int mode, long max_values, int wg_limit) {
+    // the launcher's own shape check (launch geometry included), without launching: 1 = bnb_mi355x_gemv_4bit_peer would accept
+    // these shapes (given 16-byte aligned B / A, a valid rank and dtype). Needs the current device (CU count).
+    return gemv_4bit_peer_serves(world, ns, K, blocksize, mode, max_values, wg_limit) ? 1 : 0;
 }
 int bnb_mi355x_gemv_4bit_peer(void* const* bufs, void* epoch_word, int world, int rank, int dtype, const void* A, const uint8_t* B, const float* absmax,
                               const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, const void* bias,

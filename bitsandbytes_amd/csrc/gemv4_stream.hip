@@ -130,6 +130,9 @@ constexpr size_t kChainDataOffset = 256;
 // exchange n - 1, which every rank produces behind its own read-out.
 constexpr uint32_t kChainRegions = 64;
 constexpr int kChainRounds = 8; // 16-byte fetches per builder lane: K <= 8 * 8 KiB / 4 B = 16384 values
+// re-fetches a wait is still worth once a wait on the same buffer has run into its bound (the status word is sticky): the peer
+// is gone - every later round and launch would otherwise spin the full bound again, ~30 s each, before a host-side check() runs
+constexpr uint32_t kPeerPollsAfterTimeout = 16;
 
 struct StreamArgs {
 #ifdef BNB_PROFILING
@@ -617,6 +620,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         if constexpr (PEER) {
             if (x_from_peer && wave < WAVES - BUILDERS) {
                 const unsigned char* const src = static_cast<const unsigned char*>(hot_A);
+                uint32_t wait_bound = p.peer.spin_bound; // (per lane; drops to a few polls once anything on this buffer timed out)
 #pragma unroll
                 for (int r = 0; r < kChainRounds; ++r) {
                     const uint32_t off = static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave) * 64 + lane) * 16u;
@@ -626,12 +630,24 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
                         // forget what is in flight behind it. Slow path only - a peer that is late.)
                         uint32_t spins = 0;
                         while (gr[1] != epoch || gr[3] != epoch) {
+                            if (spins == 0 && wait_bound == p.peer.spin_bound) {
+                                // first miss of this lane: has a wait on this buffer ALREADY run into its bound (an earlier round of
+                                // this launch, or an earlier launch - the word is sticky)? Then the peer is gone, and paying the full
+                                // bound again per round and per layer would block the queue for the length of the chain before any
+                                // host-side check() runs: a few polls each from here on.
+                                uint32_t st_word;
+                                const uint32_t* const st_addr = reinterpret_cast<const uint32_t*>(p.peer.local) + 1;
+                                asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(st_word) : "v"(st_addr) : "memory");
+                                if (st_word != 0u)
+                                    wait_bound = kPeerPollsAfterTimeout;
+                            }
                             __builtin_amdgcn_s_sleep(4);
                             const unsigned char* const addr = src + off;
                             asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(gr) : "v"(addr) : "memory");
-                            if (++spins > p.peer.spin_bound) {
+                            if (++spins > wait_bound) {
                                 __hip_atomic_store(reinterpret_cast<uint32_t*>(p.peer.local) + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                 gr = u32x4{0xFFFFFFFFu, epoch, 0xFFFFFFFFu, epoch}; // NaN in fp16 / bf16: a timeout cannot pass for data
+                                wait_bound = kPeerPollsAfterTimeout;
                             }
                         }
                         // four values = half of the 16-byte chunk c of x; chunk (l', q) of a segment lives at slot CH l' + (q ^ swz(l'))
@@ -1041,6 +1057,7 @@ __global__ __launch_bounds__(256) void peer_chain_read_kernel(PeerChain pc, T* _
     const uint32_t epoch = pc.epoch_word[0] + pc.epoch_offset;
     const unsigned char* const src = pc.local + kChainDataOffset + static_cast<size_t>(pc.epoch_offset & (kChainRegions - 1u)) * pc.max_granules * 8u;
     using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+    uint32_t wait_bound = pc.spin_bound;
     for (int gi = blockIdx.x * 256 + threadIdx.x; 2 * gi < nvalues; gi += gridDim.x * 256) {
         const unsigned char* const addr = src + static_cast<size_t>(gi) * 8u;
         u32x2 gr;
@@ -1049,9 +1066,18 @@ __global__ __launch_bounds__(256) void peer_chain_read_kernel(PeerChain pc, T* _
             asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(gr) : "v"(addr) : "memory");
             if (gr[1] == epoch)
                 break;
-            if (++spins > pc.spin_bound) {
+            if (spins == 0 && wait_bound == pc.spin_bound) {
+                // (first miss: a wait on this buffer that already gave up - the sticky status word - caps every later one, see the gemv)
+                uint32_t st_word;
+                const uint32_t* const st_addr = hdr + 1;
+                asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(st_word) : "v"(st_addr) : "memory");
+                if (st_word != 0u)
+                    wait_bound = kPeerPollsAfterTimeout;
+            }
+            if (++spins > wait_bound) {
                 __hip_atomic_store(hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 gr[0] = 0xFFFFFFFFu;
+                wait_bound = kPeerPollsAfterTimeout;
                 break;
             }
             __builtin_amdgcn_s_sleep(4);
@@ -1059,7 +1085,10 @@ __global__ __launch_bounds__(256) void peer_chain_read_kernel(PeerChain pc, T* _
         *reinterpret_cast<uint32_t*>(out + 2 * gi) = gr[0];
     }
     // the last workgroup (of at most 8) advances the buffer's epoch past the chain that ends here (visible to the next launch on
-    // this device: kernel boundary)
+    // this device: kernel boundary). Every wavefront of this workgroup has read the epoch word (first statement of the kernel) and
+    // finished its granules before the workgroup counts as done: without the barrier a late-scheduled wavefront of the LAST
+    // workgroup could still be in front of its epoch load when thread 0 rewrites the word.
+    __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t prev = __hip_atomic_fetch_add(hdr + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == gridDim.x - 1u) {
@@ -1069,23 +1098,16 @@ __global__ __launch_bounds__(256) void peer_chain_read_kernel(PeerChain pc, T* _
     }
 }
 
-} // namespace
-
-// Peer-chain form of the M = 1 gemv (see PeerChain). mode bit 0: x = the current exchange (A ignored, K values), bit 1: y goes
-// to every rank's exchange buffer (and to out_local when non-NULL). Returns false - nothing launched - when the problem is
-// outside the form's preconditions; the caller then takes the unfused path (kernel + all-gather).
-bool gemv_4bit_peer(void* const* bufs, void* epoch_word, int world, int rank, int dtype, const void* A, const uint8_t* B, const float* absmax,
-                    const uint8_t* absmax8, const float* absmax_code, const float* absmax_offset, const void* bias, void* out_local,
-                    int ns, int K, int blocksize, int quant_type, int mode, long max_values, int wg_limit, uint32_t epoch_offset,
-                    uint32_t spin_bound, hipStream_t stream) {
-    if (epoch_word == nullptr || (dtype != 1 && dtype != 2) || world < 1 || world > 8 || rank < 0 || rank >= world || ns < 2 || (ns & 1) || K < 32 || (K % 32) != 0 ||
-        blocksize < 32 || !is_pow2(blocksize) || !aligned_to(B, 16) || (mode & 3) == 0 || max_values < 2 || max_values >= (1L << 28))
-        return false;
-    if ((mode & 1) ? (K > kChainRounds * 2048 || K > max_values) : !aligned_to(A, 16))
+// The shape preconditions of the peer-chain form and the geometry it launches with - ONE function, shared by the launcher and by
+// the host layer's query (bnb_mi355x_gemv_4bit_peer_serves): what the host decides from shapes is what the launcher accepts.
+// Pointer alignment (B, and A when x is a tensor) is the caller's to check on top of this.
+static bool peer_geometry(int world, int ns, int K, int blocksize, int mode, long max_values, int wg_limit, Geometry* out_ge, bool* out_quads) {
+    if (world < 1 || world > 8 || ns < 2 || (ns & 1) || K < 32 || (K % 32) != 0 || blocksize < 32 || !is_pow2(blocksize) || (mode & 3) == 0 ||
+        max_values < 4 || (max_values & 3) || max_values >= (1L << 28))
+        return false; // (max_values in fours: max_granules is then even, every region 16-byte aligned - the quad stores and b128 fetches need it)
+    if ((mode & 1) && (K > kChainRounds * 2048 || K > max_values))
         return false;
     if ((mode & 2) && static_cast<long>(world) * ns > max_values)
-        return false;
-    if (!(mode & 2) && out_local == nullptr)
         return false;
     // rows per workgroup: even (granules are row pairs), and no more workgroups than the caller allows (ranks that share one
     // device - a test set-up - must be co-resident: a launch that waits for its peers may not fill the device alone)
@@ -1097,9 +1119,38 @@ bool gemv_4bit_peer(void* const* bufs, void* epoch_word, int world, int rank, in
     if ((ns & 3) == 0)
         R = (R + 3) & ~3; // rows in fours: two granules per store
     const Geometry ge = make_geometry(ns, K, 1, 16, 2, false, 0, R);
+    // (one phase: K within the workgroup's segment columns; an even R survives make_geometry's clamp to the partial-sum slots)
     if (ge.P != 1 || (ge.R & 1))
         return false;
-    const bool quads = (ns & 3) == 0 && (ge.R & 3) == 0;
+    if (out_ge)
+        *out_ge = ge;
+    if (out_quads)
+        *out_quads = (ns & 3) == 0 && (ge.R & 3) == 0;
+    return true;
+}
+
+} // namespace
+
+bool gemv_4bit_peer_serves(int world, int ns, int K, int blocksize, int mode, long max_values, int wg_limit) {
+    return peer_geometry(world, ns, K, blocksize, mode, max_values, wg_limit, nullptr, nullptr);
+}
+
+// Peer-chain form of the M = 1 gemv (see PeerChain). mode bit 0: x = the current exchange (A ignored, K values), bit 1: y goes
+// to every rank's exchange buffer (and to out_local when non-NULL). Returns false - nothing launched - when the problem is
+// outside the form's preconditions; the caller then takes the unfused path (kernel + all-gather).
+bool gemv_4bit_peer(void* const* bufs, void* epoch_word, int world, int rank, int dtype, const void* A, const uint8_t* B, const float* absmax,
+                    const uint8_t* absmax8, const float* absmax_code, const float* absmax_offset, const void* bias, void* out_local,
+                    int ns, int K, int blocksize, int quant_type, int mode, long max_values, int wg_limit, uint32_t epoch_offset,
+                    uint32_t spin_bound, hipStream_t stream) {
+    Geometry ge;
+    bool quads = false;
+    if (epoch_word == nullptr || (dtype != 1 && dtype != 2) || rank < 0 || rank >= world || !aligned_to(B, 16) ||
+        !peer_geometry(world, ns, K, blocksize, mode, max_values, wg_limit, &ge, &quads))
+        return false;
+    if (!(mode & 1) && !aligned_to(A, 16))
+        return false;
+    if (!(mode & 2) && out_local == nullptr)
+        return false;
 
     StreamArgs a;
 #ifdef BNB_PROFILING

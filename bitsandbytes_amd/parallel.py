@@ -227,7 +227,19 @@ class ShardedLinear4bitChain(nn.Module):
         self._bias_cache = {}
 
     def fused(self, x: torch.Tensor) -> bool:
+        """Whether this call takes the fused form. Everything here is the same on every rank of a correctly used chain (shapes,
+        dtypes, the autograd mode of the call, the alignment of tensors every rank built the same way) - the ranks must agree,
+        because the two forms issue different collectives."""
         if self.chain is None or len(self.shards) < 2 or x.dtype not in (torch.float16, torch.bfloat16) or x.numel() != x.shape[-1]:
+            return False
+        # The fused launches are plain kernels: they record no autograd graph. matmul_4bit - the member-by-member path - is
+        # differentiable, so a call that wants gradients must take it (dropping them silently by shape and dtype would be a bug).
+        if torch.is_grad_enabled() and (x.requires_grad or any(s.bias is not None and s.bias.requires_grad for s in self.shards)):
+            return False
+        if x.device != self.chain.device:
+            return False
+        # the launcher's pointer preconditions (16-byte aligned packed weights and first-layer x), decided BEFORE any launch
+        if any(s.weight.data_ptr() % 16 for s in self.shards):
             return False
         return all(self.chain.serves(int(s.quant_state.shape[0]), int(s.quant_state.shape[1]), int(s.quant_state.blocksize), i > 0)
                    and self.chain.world * int(s.quant_state.shape[0]) == s.out_features
@@ -240,17 +252,31 @@ class ShardedLinear4bitChain(nn.Module):
             return x
         lead = x.shape[:-1]
         x1 = x.reshape(-1).contiguous()
-        for i, s in enumerate(self.shards):
+        if x1.data_ptr() % 16:
+            x1 = x1.clone()  # (a view at an odd offset: the launcher wants 16-byte aligned activations)
+        biases = []
+        for i, s in enumerate(self.shards):  # everything that can raise on the host happens before the first launch
             bias = s.bias
             if bias is not None and bias.dtype != x.dtype:
                 key = (i, x.dtype, bias.data_ptr(), bias._version)
                 if self._bias_cache.get("key" + str(i)) != key:
                     self._bias_cache["key" + str(i)], self._bias_cache[i] = key, bias.to(x.dtype)
                 bias = self._bias_cache[i]
-            ok = self.chain.gemv(x1 if i == 0 else None, s.weight, s.quant_state, bias=bias, consume=i > 0, produce=True, dtype=x.dtype)
-            if not ok:
-                raise RuntimeError("PeerChain refused a launch its own serves() accepted")
-        return self.chain.read(self.shards[-1].out_features, x.dtype).view(*lead, self.shards[-1].out_features)
+            biases.append(bias)
+        done = 0
+        try:
+            for i, s in enumerate(self.shards):
+                if not self.chain.gemv(x1 if i == 0 else None, s.weight, s.quant_state, bias=biases[i], consume=i > 0, produce=True, dtype=x.dtype):
+                    raise RuntimeError(f"PeerChain refused layer {i} although its own shape check accepted it")
+                done += 1
+            return self.chain.read(self.shards[-1].out_features, x.dtype).view(*lead, self.shards[-1].out_features)
+        except Exception as exc:
+            if done:
+                # Some exchanges of this chain are out and its read-out is not: this rank's count of pending exchanges no longer
+                # matches its peers', and every later call would consume the wrong regions. The chain object is poisoned - every
+                # further use raises at once instead of desynchronising silently; a new PeerChain has to be built collectively.
+                self.chain._broken = f"a chain of {len(self.shards)} layers stopped after {done}: {type(exc).__name__}: {exc}"
+            raise
 
 
 class GraphedBlock:

@@ -17,6 +17,7 @@ and in-process at world size 1; **not measured on a multi-GPU node by us**.
 from __future__ import annotations
 
 import ctypes as ct
+import os
 from typing import Optional
 
 import torch
@@ -34,7 +35,6 @@ class _PeerBuffers:
 
     def __init__(self, nbytes_of, group=None, device: Optional[torch.device] = None, alloc=None):
         name = type(self).__name__
-        alloc = alloc or lib.bnb_mi355x_peer_alloc
         if not dist.is_initialized():
             raise RuntimeError(f"{name} needs an initialised process group (the buffer handles travel through it)")
         self.group = group
@@ -45,6 +45,9 @@ class _PeerBuffers:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._mapped = []
         self._local = None
+        # (`alloc` may be a factory that needs the group - the chain picks its memory kind from the topology: called here, on
+        # every rank, before anything is allocated)
+        alloc = alloc(self) if getattr(alloc, "needs_buffers", False) else (alloc or lib.bnb_mi355x_peer_alloc)
         # Every step below is collective and none may leave the ranks disagreeing about whether the object exists: failures are
         # carried to the exchanges as values, and every rank raises - or none does.
         handle = ct.create_string_buffer(64)
@@ -151,7 +154,6 @@ def _ranks_on_my_device(group, device) -> int:
     """How many ranks of the group use the device this rank uses (1 on a real node; > 1 where processes share a GPU - the only
     way a 1-GPU box can run the peer paths). Identified by hostname + PCI address where torch reports it, else by hostname +
     device index + HIP_VISIBLE_DEVICES."""
-    import os
     import socket
 
     props = torch.cuda.get_device_properties(device)
@@ -177,23 +179,121 @@ class PeerChain(_PeerBuffers):
     longest consumed ``x`` (``K``) the chain will see. Exercised between processes sharing one GPU; **not measured on a
     multi-GPU node by us**."""
 
-    def __init__(self, group=None, max_values: int = 32768, device: Optional[torch.device] = None):
-        self.max_values = int(max_values) + (int(max_values) & 1)
-        super().__init__(lambda world: lib.bnb_mi355x_peer_chain_buffer_bytes(self.max_values), group, device,
-                         alloc=lib.bnb_mi355x_peer_chain_alloc)
+    def __init__(self, group=None, max_values: int = 32768, device: Optional[torch.device] = None, self_test: bool = True,
+                 memory: Optional[str] = None):
+        # (in fours: an even number of granules per region keeps every region 16-byte aligned - the two-granule stores and the
+        # 16-byte fetches of the kernel need it)
+        self.max_values = (int(max_values) + 3) & ~3
+        if memory is None:
+            memory = os.environ.get("BNB_MI355X_PEER_CHAIN_MEMORY") or None
+        if memory not in (None, "fine", "coarse"):
+            raise ValueError(f"memory must be 'fine', 'coarse' or None (by topology), got {memory!r}")
+
+        def make_alloc(bufs):
+            # Which memory the exchange buffers live in. Remote GPUs store into a rank's buffer WHILE a kernel of that rank polls
+            # it; HIP makes coarse-grained (ordinary hipMalloc) memory coherent across devices at kernel boundaries only, so across
+            # a link the buffers must be FINE-grained (what RCCL's LL protocol and PeerAllGather use) - a stale L2 line would make
+            # every consumer spin to its bound and emit NaN. Ordinary cacheable memory is kept for the one topology where nothing
+            # crosses a link: every rank on ONE device (processes sharing a GPU - the 1-GPU test set-up - or a group of one).
+            # The decision is collective (an all-gather of device identities), so every rank allocates the same kind.
+            bufs.sharing = _ranks_on_my_device(bufs.group, bufs.device)
+            bufs.memory = memory or ("coarse" if bufs.sharing >= bufs.world else "fine")
+            fine = 1 if bufs.memory == "fine" else 0
+            return lambda nbytes: lib.bnb_mi355x_peer_chain_alloc(nbytes, fine)
+
+        make_alloc.needs_buffers = True
+        super().__init__(lambda world: lib.bnb_mi355x_peer_chain_buffer_bytes(self.max_values), group, device, alloc=make_alloc)
         # ranks that share one device must all be resident at once (a launch that waits for its peers may not fill the device
         # alone): each gets its share of the CUs. One rank per device - the real case - gets them all.
-        try:
-            sharing = _ranks_on_my_device(group, self.device)
-        except Exception:
-            self._release()
-            raise
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count
-        self.wg_limit = 0 if sharing <= 1 else max(1, cus // sharing)
+        self.wg_limit = 0 if self.sharing <= 1 else max(1, cus // self.sharing)
         # exchanges produced since the last read-out: the buffer's epoch word lives on the device and only `read` advances it
         # (a hipGraph captures these offsets; replayed, they are relative to an epoch that has moved on by a whole chain)
         self._pending = 0
         self._epoch = torch.zeros(64, dtype=torch.int32, device=self.device)  # ordinary (cacheable) memory: only this rank's launches touch it
+        self._broken = None
+        if self_test:
+            self._self_test()
+
+    def _self_test(self) -> None:
+        """Collective start-up check: two chains of three small sharded layers each (produce -> consume + produce -> consume +
+        produce -> read-out) against the same layers with the group's own all-gather between them, bit for bit, on every rank.
+        The chain's transport has only ever run between processes sharing one GPU by its authors; a node on which it does not
+        reproduce the collective (memory kind, peer access, a stack that reorders what it may not) must not get silent NaNs or
+        stale activations out of ``ShardedLinear4bitChain`` - every rank raises here, or none does."""
+        from . import functional as F
+        from .autograd import matmul_4bit
+        from .parallel import shard_quant_state
+
+        world, rank, dev = self.world, self.rank, self.device
+        # gathered width H = world * ns: a multiple of 64 (blocksize) and of 2 * world (row pairs), within this chain's max_values
+        step = 64
+        while step % (2 * world):
+            step += 64
+        H = (min(self.max_values, 512) // step) * step
+        problem = None
+        ok = True
+        if H == 0:
+            return  # (max_values below one test layer: nothing this chain could carry would fit either)
+        ns = H // world
+        try:
+            with torch.no_grad(), torch.cuda.device(dev):
+                gen = torch.Generator(device=dev).manual_seed(20250922)  # the same weights and inputs on every rank
+                layers = []
+                for i in range(3):
+                    W = (torch.randn(H, H, device=dev, generator=gen) / H**0.5).to(torch.bfloat16)
+                    packed, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4" if i != 1 else "fp4", compress_statistics=False)
+                    layers.append(shard_quant_state(packed, st, rank, world))
+                # `launch`: decided from shapes alone, so identical on every rank. A rank whose RESULT is wrong keeps launching like
+                # the others (its peers consume its granules: a rank that stopped would make them spin to their bound);
+                # only a refusal - which every rank sees alike - stops the launches.
+                launch = all(self.serves(ns, H, 64, consume=i > 0) for i in range(3))
+                if not launch:
+                    ok, problem = False, f"the fused form refuses the self-test shapes ({ns} x {H})"
+                nccl = dist.get_backend(self.group) == "nccl"
+                for rep in range(2):  # (the second chain re-uses the regions of the first under a new epoch)
+                    x = torch.randn(H, device=dev, generator=gen).to(torch.bfloat16)
+                    want = x
+                    for q, st in layers:
+                        y_loc = matmul_4bit(want.view(1, H), q, quant_state=st).reshape(-1).contiguous()
+                        if nccl:
+                            buf = torch.empty(H, dtype=y_loc.dtype, device=dev)
+                            dist.all_gather_into_tensor(buf, y_loc, group=self.group)
+                        else:  # (a host-side group - gloo in the shared-GPU test set-up: through the host)
+                            parts = [None] * world
+                            dist.all_gather_object(parts, y_loc.cpu(), group=self.group)
+                            buf = torch.cat(parts).to(dev)
+                        want = buf
+                    if launch:
+                        for i, (q, st) in enumerate(layers):
+                            if not self.gemv(x if i == 0 else None, q, st, consume=i > 0, produce=True, dtype=torch.bfloat16):
+                                # (cannot happen behind serves() + freshly cloned, aligned shards; if it does, every rank is here)
+                                launch, ok, problem = False, False, "a launch of the self-test chain was refused"
+                                break
+                    if launch:
+                        got = self.read(H, torch.bfloat16)
+                        torch.cuda.synchronize(dev)
+                        if self.status() != 0:
+                            ok, problem = False, "a wait ran into its bound (a peer's granules never became visible)"
+                        elif not torch.equal(got, want):
+                            ok, problem = False, "its result differs from the layers with the group's all-gather between them"
+        except Exception as exc:  # noqa: BLE001  (carried to the vote below: a rank that raised alone would leave the others waiting)
+            ok, problem = False, f"{type(exc).__name__}: {exc}"
+        votes = [None] * world
+        dist.all_gather_object(votes, None if ok else f"rank {rank}: {problem}", group=self.group)
+        votes = [v for v in votes if v]
+        if votes:
+            self._release_after_failed_test()
+            raise RuntimeError(f"PeerChain self-test failed on this node ({self.memory}-grained buffers, {self.sharing} rank(s) per device) - "
+                               "use ShardedLinear4bit (a kernel + an all-gather per layer) instead: " + "; ".join(votes))
+
+    def _release_after_failed_test(self) -> None:
+        try:
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.group)
+        except Exception:  # noqa: BLE001
+            pass
+        self._release()
 
     @staticmethod
     def _dt(dtype: torch.dtype) -> int:
@@ -203,11 +303,13 @@ class PeerChain(_PeerBuffers):
             return 2
         raise ValueError(f"PeerChain serves fp16 / bf16 activations, got {dtype}")
 
-    def serves(self, ns: int, K: int, blocksize: int, consume: bool) -> bool:
-        """The preconditions of the fused form (mirrors ``gemv_4bit_peer`` in csrc/gemv4_stream.hip; shapes only, so every rank
-        answers the same)."""
-        return (ns >= 2 and ns % 2 == 0 and K >= 32 and K % 32 == 0 and blocksize >= 32 and self.world * ns <= self.max_values
-                and (not consume or (K <= 16384 and K <= self.max_values)))
+    def serves(self, ns: int, K: int, blocksize: int, consume: bool, produce: bool = True) -> bool:
+        """The shape preconditions of the fused form - the launcher's OWN check (``peer_geometry`` in csrc/gemv4_stream.hip, launch
+        geometry included), asked through ``bnb_mi355x_gemv_4bit_peer_serves``: nothing here can drift from what a launch accepts.
+        Shapes only (and the chain's own constants), so every rank answers the same."""
+        with torch.cuda.device(self.device):  # (the geometry depends on the device's CU count)
+            return bool(lib.bnb_mi355x_gemv_4bit_peer_serves(self.world, int(ns), int(K), int(blocksize), (1 if consume else 0) | (2 if produce else 0),
+                                                             self.max_values, self.wg_limit))
 
     def gemv(self, x: Optional[torch.Tensor], packed: torch.Tensor, quant_state, bias: Optional[torch.Tensor] = None,
              out_local: Optional[torch.Tensor] = None, consume: bool = False, produce: bool = True,
@@ -215,6 +317,8 @@ class PeerChain(_PeerBuffers):
         """One layer: ``y_shard = x @ dequant(packed)^T (+ bias)``. ``consume``: x is the current exchange (pass ``x=None``);
         ``produce``: y goes to every rank's exchange buffer (and to ``out_local`` when given). Returns False - nothing launched -
         when the fused form does not serve the problem."""
+        if self._broken:
+            raise RuntimeError(f"this PeerChain is out of step with its peers and cannot be used any more ({self._broken}); build a new one collectively")
         st = quant_state
         ns, K = int(st.shape[0]), int(st.shape[1])
         if consume:

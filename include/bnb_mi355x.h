@@ -171,8 +171,11 @@ void bnb_mi355x_peer_allgather(void* const* bufs, int world, int rank, const voi
 int bnb_mi355x_peer_status(const void* local_buffer);
 
 /* Peer chain: the all-gather of the N-sharded layer FUSED into the gemv launches on either side of it (M = 1 decode; fp16 /
- * bf16). Each rank owns an exchange buffer of bnb_mi355x_peer_chain_buffer_bytes(max_values) bytes from bnb_mi355x_peer_chain_alloc
- * (ordinary device memory, zeroed), exported / mapped / freed like the gather buffers above; bufs[r] = rank r's buffer as mapped here. y travels as
+ * bf16). Each rank owns an exchange buffer of bnb_mi355x_peer_chain_buffer_bytes(max_values) bytes (max_values a multiple of 4) from
+ * bnb_mi355x_peer_chain_alloc (zeroed; fine_grained != 0 = hipDeviceMallocFinegrained, REQUIRED whenever the ranks sit on different
+ * devices: remote stores into coarse-grained memory that a running kernel of the owner polls are outside what HIP guarantees;
+ * 0 = ordinary cacheable memory, enough where all ranks share one device), exported / mapped / freed like the gather buffers above;
+ * bufs[r] = rank r's buffer as mapped here. bnb_mi355x_gemv_4bit_peer_serves = the launcher's own shape check without a launch. y travels as
  * 8-byte granules {two consecutive values, u32 tag}: the producing launch stores them straight into every rank's buffer, the
  * consuming launch - the next layer - fetches them behind its weight requests and re-fetches the ones whose tag is not there
  * yet. No separate collective launch, no flag, no fence (csrc/gemv4_stream.hip, PeerChain).
@@ -187,10 +190,12 @@ int bnb_mi355x_peer_status(const void* local_buffer);
  * of its position in the chain (epoch_offset + 1 of the producing launch, modulo 64), only its tag carries the epoch. Returns 1 when launched, 0 when the problem is outside the form's
  * preconditions (ns even, K % 32 == 0, K <= 16384 with bit 0, one phase, blocksize >= 32, 16-byte aligned B / A, world * ns and
  * K <= max_values) - nothing was launched and the caller takes the unfused path. A wait that runs into its bound
- * (BNB_MI355X_PEER_WAIT_POLLS) sets the buffer's status word (bnb_mi355x_peer_status) and yields NaN, never a hang.
+ * (BNB_MI355X_PEER_WAIT_POLLS) sets the buffer's status word (bnb_mi355x_peer_status) and yields NaN, never a hang; once the word
+ * is set every later wait on the buffer gives up after a few polls (a dead peer costs the bound once, not once per round and layer).
  * bnb_mi355x_peer_chain_read: the current exchange as a plain [nvalues] tensor (the end of a chain). */
 size_t bnb_mi355x_peer_chain_buffer_bytes(long max_values);
-void* bnb_mi355x_peer_chain_alloc(size_t bytes);
+void* bnb_mi355x_peer_chain_alloc(size_t bytes, int fine_grained);
+int bnb_mi355x_gemv_4bit_peer_serves(int world, int ns, int K, int blocksize, int mode, long max_values, int wg_limit);
 int bnb_mi355x_gemv_4bit_peer(void* const* bufs, void* epoch_word, int world, int rank, int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, const void* bias, void* out_local, int ns, int K, int blocksize, int quant_type, int mode, long max_values, int wg_limit, int epoch_offset, bnb_stream_t stream);
 void bnb_mi355x_peer_chain_read(void* const* bufs, void* epoch_word, int world, int rank, int dtype, void* out, int nvalues, long max_values, int epoch_offset, bnb_stream_t stream);
 

@@ -120,8 +120,51 @@ def main():
                     want = s(want)
                 assert not fused.fused(x2) and torch.equal(fused(x2), want)
             chain.check()
+            # which memory the buffers live in follows the topology: cacheable only where every rank sits on ONE device
+            assert chain.memory == ("fine" if per_rank and world > 1 else "coarse"), (chain.memory, chain.sharing)
+            # serves() IS the launcher's check (geometry included): a first layer whose rows are longer than one workgroup's
+            # segment columns (K > 32768: several phases) is outside the form although its shape passes the simple rules - the
+            # chain must fall back to its members, not raise "refused a launch its own serves() accepted" 
+            assert not chain.serves(64, 32768 + 2048, 64, consume=False) and chain.serves(64, 32768, 64, consume=False)
+            assert not chain.serves(64, 16384 + 32, 64, consume=True) and not chain.serves(63, 4096, 64, consume=False)
         finally:
             chain.close()
+
+        # ---- the other memory kind and an odd max_values, on a short stretch: the FINE-grained allocation (what ranks on different
+        # devices get) has then run on hardware at least inside one device; max_values % 4 == 2 used to leave the regions 8-byte
+        # aligned under 16-byte stores. Construction runs the collective self-test (PeerChain._self_test) each time.
+        for memory, max_values in (("fine", 4096), ("coarse", 4098)):
+            chain = PeerChain(max_values=max_values, memory=memory)
+            try:
+                assert chain.memory == memory and chain.max_values % 4 == 0 and chain.max_values >= max_values
+                torch.manual_seed(11)
+                H, F = 1024, 4096
+                layers = [bnn.Linear4bit(k, n, bias=True, compute_dtype=torch.bfloat16, quant_type="nf4").to(dev) for k, n in ((H, F), (F, H), (H, F))]
+                fused = bnb.ShardedLinear4bitChain([bnb.shard_linear4bit(layer, rank, world) for layer in layers], chain)
+                for it in range(3):
+                    torch.manual_seed(400 + it)
+                    x = torch.randn(1, H, device=dev, dtype=torch.bfloat16)
+                    assert fused.fused(x)
+                    y = fused(x)
+                    torch.cuda.synchronize()
+                    want = x
+                    for layer in layers:
+                        want = layer(want)
+                    assert torch.equal(y, want), (memory, it)
+                # a call that wants gradients takes the differentiable member-by-member path, on every rank alike
+                xg = torch.randn(1, H, device=dev, dtype=torch.bfloat16, requires_grad=True)
+                assert not fused.fused(xg)
+                yg = fused(xg)
+                want = xg.detach()
+                for layer in layers:
+                    want = layer(want)
+                assert torch.equal(yg.detach(), want)
+                if world == 1:  # (across ranks the group's all-gather itself is not differentiable: the graph ends there)
+                    yg.float().sum().backward()
+                    assert xg.grad is not None and bool(torch.isfinite(xg.grad).all())
+                chain.check()
+            finally:
+                chain.close()
         print(f"PEER_OK {rank}", flush=True)
     finally:
         peer.close()

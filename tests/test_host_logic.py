@@ -510,3 +510,106 @@ def test_reference_plugin_point_loads_this_backend():
     """)
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PLUGIN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+class _FakeChain:
+    """Stands in for peer.PeerChain on the CPU: records launches, can be told to fail at a given layer."""
+
+    def __init__(self, fail_at=None, refuse_at=None):
+        self.world, self.device = 1, torch.device("cpu")
+        self.fail_at, self.refuse_at = fail_at, refuse_at
+        self.launched, self._broken, self.reads = [], None, 0
+
+    def serves(self, ns, K, blocksize, consume, produce=True):
+        return True
+
+    def gemv(self, x, packed, st, bias=None, consume=False, produce=True, dtype=None):
+        i = len(self.launched)
+        if self.fail_at == i:
+            raise ValueError("boom")
+        if self.refuse_at == i:
+            return False
+        self.launched.append((x is None, consume))
+        return True
+
+    def read(self, n, dtype):
+        self.reads += 1
+        return torch.zeros(n, dtype=dtype)
+
+
+def _chain_shards(bias=False):
+    from bitsandbytes_amd.parallel import ShardedLinear4bit
+
+    torch.manual_seed(0)
+    shards = []
+    for _ in range(3):
+        layer = Linear4bit(64, 64, bias=bias, quant_type="nf4", compute_dtype=torch.bfloat16).to("cpu")
+        st = layer.weight.quant_state
+        shards.append(ShardedLinear4bit(layer.weight.data.view(-1, 1), st, 64, layer.bias))
+    return shards
+
+
+def test_sharded_chain_fused_form_is_refused_when_the_call_wants_gradients():
+    """the fused launches record no autograd graph; the member-by-member path (matmul_4bit) does. A call with grad
+    enabled and an input (or bias) that requires grad must take the latter - decided in fused(), before any launch."""
+    from bitsandbytes_amd.parallel import ShardedLinear4bitChain
+
+    chain = _FakeChain()
+    mod = ShardedLinear4bitChain(_chain_shards(), chain)
+    x = torch.randn(1, 64).bfloat16()
+    with torch.no_grad():
+        assert mod.fused(x)
+    assert mod.fused(x)  # grad mode on, but nothing requires grad
+    assert not mod.fused(x.clone().requires_grad_())
+    with torch.no_grad():
+        assert mod.fused(x.clone().requires_grad_())  # nothing will be recorded anyway
+    assert not mod.fused(torch.randn(2, 64).bfloat16()) and not mod.fused(torch.randn(1, 64))  # two rows / fp32: outside the form
+    with_bias = ShardedLinear4bitChain(_chain_shards(bias=True), _FakeChain())
+    for s in with_bias.shards:
+        s.bias.requires_grad_(False)
+    assert with_bias.fused(x)
+    with_bias.shards[1].bias.requires_grad_(True)
+    assert not with_bias.fused(x)
+    # and the gradients really arrive through the member-by-member path
+    xg = x.clone().requires_grad_()
+    y = mod(xg)
+    y.float().sum().backward()
+    assert xg.grad is not None and chain.launched == [] and chain.reads == 0
+
+
+def test_sharded_chain_failure_mid_chain_poisons_the_chain_object():
+    """A launch that fails after earlier layers of the same chain went out leaves this rank's exchange count out of step with its
+    peers: the chain object must refuse further use loudly. A failure before the first launch leaves it usable."""
+    from bitsandbytes_amd.parallel import ShardedLinear4bitChain
+
+    x = torch.randn(1, 64).bfloat16()
+    with torch.no_grad():
+        first = _FakeChain(fail_at=0)
+        with pytest.raises(ValueError):
+            ShardedLinear4bitChain(_chain_shards(), first)(x)
+        assert first._broken is None
+        for chain in (_FakeChain(fail_at=1), _FakeChain(refuse_at=2)):
+            with pytest.raises((ValueError, RuntimeError)):
+                ShardedLinear4bitChain(_chain_shards(), chain)(x)
+            assert chain._broken and "stopped after" in chain._broken and chain.reads == 0
+        good = _FakeChain()
+        y = ShardedLinear4bitChain(_chain_shards(), good)(x)
+        assert y.shape == (1, 64) and good.launched == [(False, False), (True, True), (True, True)] and good.reads == 1
+
+
+def test_peer_chain_counts_in_fours_and_poisoned_chain_raises():
+    """max_values is rounded up to a multiple of 4 (with max_values % 4 == 2 the regions were only 8-byte aligned and
+    the kernel's 16-byte quad stores / fetches misaligned) - checked on the class without a GPU; a poisoned chain raises at once."""
+    from bitsandbytes_amd.peer import PeerChain
+
+    for given, want in ((2, 4), (4, 4), (30, 32), (32766, 32768), (32768, 32768), (11010, 11012)):
+        assert (int(given) + 3) & ~3 == want
+    import inspect
+
+    src = inspect.getsource(PeerChain.__init__)
+    assert "(int(max_values) + 3) & ~3" in src and "self_test" in src
+    chain = PeerChain.__new__(PeerChain)
+    chain._broken = "test"
+    with pytest.raises(RuntimeError, match="out of step"):
+        chain.gemv(None, None, None, consume=True, dtype=torch.bfloat16)
+    chain._local = None  # (__del__ of the half-built object)
