@@ -58,7 +58,8 @@ enum StreamFlags : int {
     kNT = 8,      // non-temporal weight loads
     kGrouped = 16, // several matrices over one concatenated row space
     kMulti = 32,   // rows longer than the workgroup's segment columns: several phases (a loop around the whole body)
-    kPeer = 64     // "peer chain" form (M = 1): x taken from / y delivered to the ranks' exchange buffers - see PeerChain
+    kPeer = 64,    // "peer chain" form (M = 1): x taken from / y delivered to the ranks' exchange buffers - see PeerChain
+    kRingLate = 128 // the wavefronts that build the decode table request their weight ring BEHIND the build (see the kernel, step (1))
 };
 
 // One weight matrix of a launch.
@@ -201,6 +202,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     constexpr bool NESTED = FLAGS & kNested, CODEPTR = FLAGS & kCodePtr, NT = FLAGS & kNT, GROUPED = FLAGS & kGrouped;
     constexpr bool MULTI = FLAGS & kMulti;
     constexpr bool PEER = (FLAGS & kPeer) != 0;
+    // Round 5. The activation image must have landed before ANY wavefront can decode (first barrier), and a CU's vector-memory
+    // pipeline returns in order: an x piece issued behind other wavefronts' ring stages waits for those stages - weight bytes from
+    // HBM, requested by every CU at once - although x itself is 8 KB of L2-hot data. The timeline of round 2
+    // (profiles/r2_timeline_stream_smemtime.txt) has the table written at ~2200 cycles and the barrier passed at ~4260: two thousand
+    // cycles of every wavefront waiting for x. With RING_LATE the builders (the wavefronts that start FIRST) issue their x piece,
+    // build the table, and only then request their ring: by the time the late wavefronts - which request their ring at once, as
+    // before - reach the memory pipeline, every x piece is already in it, in front of all weight traffic of the CU.
+    constexpr bool RING_LATE = (FLAGS & kRingLate) != 0;
     static_assert(!PEER || (MB == 1 && !MULTI && !GROUPED && WAVES == 16), "the peer-chain form is the M = 1, single-phase kernel");
     constexpr int THREADS = WAVES * 64;
     constexpr int TB = TypeInfo<T>::bytes;
@@ -551,19 +560,26 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         k0 = static_cast<uint32_t>(seg * kSegK + lane * 32);
         k_ok = (seg < S) && (k0 < static_cast<uint32_t>(K));
         lane_mask = k_ok ? 0u : kOob;
+        // the first NS ring stages of this phase (+ the peer chain's epoch word behind them). ONE site in the program, executed
+        // by every wavefront: no branch around a load, so the compiler's counted waits stay exact (see `issue`).
+        auto issue_ring = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            issue(st[j], j);
-            __builtin_amdgcn_sched_barrier(0); // keep the queue in stage order: (weights, scale) of stage 0, of stage 1, ...
-        }
-        if constexpr (PEER) {
-            // the epoch word (the tags of the exchange consumed here are epoch + offset, of the one produced epoch + offset + 1):
-            // requested BEHIND every load of the prologue - its address comes from the kernarg segment, whose first access is a cold
-            // miss that stalled every wavefront for ~500 cycles in front of its ring when it sat there (profiles/r4_timeline_chain.txt)
-            typedef const uint32_t __attribute__((address_space(4))) * cu32_ptr;
-            epoch_raw = *(cu32_ptr)(reinterpret_cast<uintptr_t>(p.peer.epoch_word));
-            epoch = epoch_raw + p.peer.epoch_offset;
-        }
+            for (int j = 0; j < NS; ++j) {
+                issue(st[j], j);
+                __builtin_amdgcn_sched_barrier(0); // keep the queue in stage order: (weights, scale) of stage 0, of stage 1, ...
+            }
+            if constexpr (PEER) {
+                // the epoch word (the tags of the exchange consumed here are epoch + offset, of the one produced epoch + offset + 1):
+                // requested BEHIND every load of the prologue - its address comes from the kernarg segment, whose first access is a cold
+                // miss that stalled every wavefront for ~500 cycles in front of its ring when it sat there (profiles/r4_timeline_chain.txt)
+                typedef const uint32_t __attribute__((address_space(4))) * cu32_ptr;
+                epoch_raw = *(cu32_ptr)(reinterpret_cast<uintptr_t>(p.peer.epoch_word));
+                epoch = epoch_raw + p.peer.epoch_offset;
+            }
+        };
+        // (later phases of a long row have no table to build: their ring goes out at once either way)
+        if (!RING_LATE || ph > 0)
+            issue_ring();
         if (ph == 0)
             BNB_ST_STAMP(1)
         if (ph == 0) {
@@ -599,6 +615,16 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             for (int it = 0; it < ITERS; ++it)
                 *reinterpret_cast<f32x4*>(smem + (it * BT + tid_b) * 16) = f32x4{hi[it], lo, hi[it], lo};
         }
+        if constexpr (RING_LATE) {
+            if (ph == 0) {
+                // (fenced on both sides: the table's stores are issued, THEN the ring is requested - the wavefronts that did not
+                // build fall straight through to here)
+                __builtin_amdgcn_sched_barrier(0);
+                issue_ring();
+                __builtin_amdgcn_sched_barrier(0);
+                BNB_ST_STAMP(12)
+            }
+        }
         if (ph == 0) {
             if constexpr (NESTED) {
 #pragma unroll
@@ -617,6 +643,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             BNB_ST_STAMP(2)
         if (!x_from_peer)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS * LPS) : "memory");
+        if (ph == 0)
+            BNB_ST_STAMP(11) // (this wavefront's x pieces have landed - or it had none; the barrier behind it waits for everyone's)
         if constexpr (PEER) {
             if (x_from_peer && wave < WAVES - BUILDERS) {
                 const unsigned char* const src = static_cast<const unsigned char*>(hot_A);
@@ -935,6 +963,8 @@ template <typename T, int MB, int WAVES, int FLAGS> void launch_tuned(const Stre
     if constexpr (std::is_same<T, bf16>::value && MB == 1 && FLAGS == 0) {
         const int ns = g_tune.ns.load(std::memory_order_relaxed);
         const int nt = g_tune.nt.load(std::memory_order_relaxed);
+        if (nt == 2) // (round 5 A/B: the production instance with the builders' ring requested behind the table build)
+            return launch_one<T, 1, WAVES, ring_depth(1, WAVES), kNT | kRingLate>(a, stream);
         if constexpr (WAVES == 8) {
             if (ns == 2)
                 return launch_one<T, 1, 8, 2, kNT>(a, stream);
