@@ -60,7 +60,24 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 LAYERS = 128
-KERNEL_SUBSTR = "gemv4_stream_kernel"
+KERNEL_SUBSTR = "gemv4_stream_kernel"  # the headline (M = 1) kernel; other --m: dominant_kernel() asks the library which family ran
+# bnb_mi355x_last_gemm_kernel() (csrc/bnb_common.h, GemmKernelId) -> the kernel's name as the profiler prints it
+KERNEL_FAMILIES = {1: "gemv4_stream_kernel", 2: "gemv4_generic_kernel", 3: "gemm4_mfma_rt_kernel", 4: "gemm4_mfma_pc_kernel", 6: "gemm4_mfma_kq_kernel"}
+
+
+def dominant_kernel(M, N, K, bs, qt):
+    """(profiler substring, label) of the kernel `matmul_4bit` launches for this shape - asked of the library after one real
+    call (thread-local record of the family that ran), not assumed from M."""
+    import bitsandbytes_amd as bnb
+    import bitsandbytes_amd.functional as F
+
+    W = torch.zeros(N, K, device="cuda", dtype=torch.bfloat16)
+    q, st = F.quantize_4bit(W, blocksize=bs, quant_type=qt)
+    bnb.matmul_4bit(torch.zeros(M, K, device="cuda", dtype=torch.bfloat16), q, st)
+    torch.cuda.synchronize()
+    fam = KERNEL_FAMILIES.get(int(bnb.lib.bnb_mi355x_last_gemm_kernel()), KERNEL_SUBSTR)
+    rows = f"{M} row" + ("" if M == 1 else "s")
+    return fam, f"{fam}<bf16, {rows}>" + (" (+ its split-K finalize launch where the plan has K slices)" if fam.startswith("gemm4_mfma") and fam != "gemm4_mfma_rt_kernel" else "")
 
 
 def algorithmic_bytes(M, N, K, bs, elt=2):
@@ -405,6 +422,8 @@ def main():
     assert bnb.lib, "native HIP library missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
 
     M, N, K, bs, qt = args.m, args.n, args.k, args.blocksize, args.quant_type
+    global KERNEL_SUBSTR
+    KERNEL_SUBSTR, kernel_label = dominant_kernel(M, N, K, bs, qt)
     peer = chain = None
     chain_info = None
     if not multi:
@@ -719,7 +738,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "gemv4_stream_kernel<bf16, 1 row, 16 wavefronts>",
+                "kernel": kernel_label + (", 16 wavefronts" if M == 1 and KERNEL_SUBSTR == "gemv4_stream_kernel" and N * K <= (20 << 20) else ""),
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -963,8 +963,16 @@ template <typename T, int MB, int WAVES, int FLAGS> void launch_tuned(const Stre
     if constexpr (std::is_same<T, bf16>::value && MB == 1 && FLAGS == 0) {
         const int ns = g_tune.ns.load(std::memory_order_relaxed);
         const int nt = g_tune.nt.load(std::memory_order_relaxed);
-        if (nt == 2) // (round 5 A/B: the production instance with the builders' ring requested behind the table build)
+        if (nt == 2) {
+            // (round 5 A/B: the builders' ring requested behind the table build, at the production policy and several ring depths)
+            if constexpr (WAVES == 16) {
+                if (ns == 3)
+                    return launch_one<T, 1, 16, 3, kNT | kRingLate>(a, stream);
+                if (ns == 4)
+                    return launch_one<T, 1, 16, 4, kNT | kRingLate>(a, stream);
+            }
             return launch_one<T, 1, WAVES, ring_depth(1, WAVES), kNT | kRingLate>(a, stream);
+        }
         if constexpr (WAVES == 8) {
             if (ns == 2)
                 return launch_one<T, 1, 8, 2, kNT>(a, stream);
