@@ -58,8 +58,7 @@ enum StreamFlags : int {
     kNT = 8,      // non-temporal weight loads
     kGrouped = 16, // several matrices over one concatenated row space
     kMulti = 32,   // rows longer than the workgroup's segment columns: several phases (a loop around the whole body)
-    kPeer = 64,    // "peer chain" form (M = 1): x taken from / y delivered to the ranks' exchange buffers - see PeerChain
-    kRingLate = 128 // the wavefronts that build the decode table request their weight ring BEHIND the build (see the kernel, step (1))
+    kPeer = 64     // "peer chain" form (M = 1): x taken from / y delivered to the ranks' exchange buffers - see PeerChain
 };
 
 // One weight matrix of a launch.
@@ -197,19 +196,30 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     // hot arguments as separate scalars: the command processor preloads them into SGPRs (kernarg preload, 14 dwords),
     // so a wavefront does not start with a dependent s_load from a cold kernarg buffer
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, int hot_N, int hot_K,
-    int hot_packed /* M | bs_shift << 18 | P << 23 */, int hot_geom /* R | SW << 16 | G << 21 */,
+    int hot_packed /* M | bs_shift << 18 | P << 23 */, int hot_geom /* R | SW << 16 | G << 21 | ring_late << 26 */,
     int hot_inv /* ceil(256 / SW) */, const StreamArgs p) {
     constexpr bool NESTED = FLAGS & kNested, CODEPTR = FLAGS & kCodePtr, NT = FLAGS & kNT, GROUPED = FLAGS & kGrouped;
     constexpr bool MULTI = FLAGS & kMulti;
     constexpr bool PEER = (FLAGS & kPeer) != 0;
     // Round 5. The activation image must have landed before ANY wavefront can decode (first barrier), and a CU's vector-memory
     // pipeline returns in order: an x piece issued behind other wavefronts' ring stages waits for those stages - weight bytes from
-    // HBM, requested by every CU at once - although x itself is 8 KB of L2-hot data. The timeline of round 2
-    // (profiles/r2_timeline_stream_smemtime.txt) has the table written at ~2200 cycles and the barrier passed at ~4260: two thousand
-    // cycles of every wavefront waiting for x. With RING_LATE the builders (the wavefronts that start FIRST) issue their x piece,
-    // build the table, and only then request their ring: by the time the late wavefronts - which request their ring at once, as
-    // before - reach the memory pipeline, every x piece is already in it, in front of all weight traffic of the CU.
-    constexpr bool RING_LATE = (FLAGS & kRingLate) != 0;
+    // HBM, requested by every CU at once - although x itself is a few KB of L2-hot data. With `ring_late` (a host-chosen bit of a
+    // preloaded argument; 16-wavefront workgroups only) the builders - the wavefronts that start FIRST - issue their x piece, build
+    // the table, and only then request their ring: by the time the late wavefronts, which request their ring at once as before,
+    // reach the memory pipeline, every x piece is already in it, in front of all weight traffic of the CU. Measured
+    // (profiles/r5_stream_prologue_ab.txt, round-robin medians): -2 % where a wavefront has two items or more (4096^2 4.21 -> 4.12 us,
+    // 8192^2 8.81 -> 8.61, 28672 x 8192 23.8 -> 23.4), +2 % on the 8-way shard shapes (less than one item per wavefront: the delayed
+    // ring IS the work) and +4 ... 9 % with 8 wavefronts (every wavefront builds, so every ring is delayed) - hence a run-time bit.
+    // Both positions of the ring are in the program, under a wavefront-UNIFORM branch with the same loads on either side: the
+    // compiler's counted waits must come out unchanged (tests/test_cabi.py reads them back from the ISA).
+    // Compiled in only where NO compiler-visible load is pending across the branch: nested instances hold their code-2 / offset
+    // loads there, grouped and multi-phase ones descriptor reads - at the join of the two ring positions hipcc then cannot order the
+    // pending loads and drains the queue (vmcnt(0) in front of the first barrier: found in the ISA of the first build, the lesson of
+    // DESIGN 6a once more). Those instances keep the one ring position they were validated with.
+    // (peer-chain instances likewise: their eight granule fetches are in flight across the branch - with both ring positions compiled
+    // in, the counted waits of the tag checks dropped from vmcnt(11 ... 4) to (7 ... 0), i.e. x would wait for ring stages)
+    constexpr bool RING_LATE_OK = WAVES == 16 && !NESTED && !GROUPED && !MULTI && !CODEPTR && !PEER;
+    const bool ring_late = RING_LATE_OK && ((hot_geom >> 26) & 1) != 0;
     static_assert(!PEER || (MB == 1 && !MULTI && !GROUPED && WAVES == 16), "the peer-chain form is the M = 1, single-phase kernel");
     constexpr int THREADS = WAVES * 64;
     constexpr int TB = TypeInfo<T>::bytes;
@@ -578,7 +588,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             }
         };
         // (later phases of a long row have no table to build: their ring goes out at once either way)
-        if (!RING_LATE || ph > 0)
+        if (!ring_late || ph > 0)
             issue_ring();
         if (ph == 0)
             BNB_ST_STAMP(1)
@@ -615,15 +625,12 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             for (int it = 0; it < ITERS; ++it)
                 *reinterpret_cast<f32x4*>(smem + (it * BT + tid_b) * 16) = f32x4{hi[it], lo, hi[it], lo};
         }
-        if constexpr (RING_LATE) {
-            if (ph == 0) {
-                // (fenced on both sides: the table's stores are issued, THEN the ring is requested - the wavefronts that did not
-                // build fall straight through to here)
-                __builtin_amdgcn_sched_barrier(0);
-                issue_ring();
-                __builtin_amdgcn_sched_barrier(0);
-                BNB_ST_STAMP(12)
-            }
+        if (ring_late && ph == 0) {
+            // (fenced on both sides: the table's stores are issued, THEN the ring is requested - the wavefronts that did not
+            // build fall straight through to here)
+            __builtin_amdgcn_sched_barrier(0);
+            issue_ring();
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (ph == 0) {
             if constexpr (NESTED) {
@@ -873,6 +880,7 @@ template <typename T, bool NESTED> __global__ __launch_bounds__(256) void gemv4_
 int device_cu_count() { return device_cu_count_or_default(); }
 
 constexpr size_t kLdsBudget = 156 * 1024; // largest dynamic allocation that launches (157 KiB is refused)
+static int g_tune_nt_peek();
 
 struct Geometry {
     int R, SW, G, P, grid_x;
@@ -920,6 +928,20 @@ struct StreamTuning {
     TlsKnob ns{0}, sw{0}, rows{0}, nt{-1}, waves{0};
 };
 thread_local StreamTuning g_tune;
+static int g_tune_nt_peek() { return g_tune.nt.load(std::memory_order_relaxed); }
+// Ring-late prologue (see the kernel): on where a wavefront of a 16-wavefront workgroup has at least two items - the measured
+// crossover (profiles/r5_stream_prologue_ab.txt). The nt knob's values 2 / 3 force it on / off for A/B runs (policy: non-temporal).
+static int ring_late_bit(int waves, int rows_total, int K, int grid_x) {
+    if (waves != 16)
+        return 0;
+    const int nt = g_tune_nt_peek();
+    if (nt == 2)
+        return 1 << 26;
+    if (nt == 3)
+        return 0;
+    const long items = static_cast<long>(rows_total) * ((K + kSegK - 1) / kSegK);
+    return items >= 2L * 16 * (grid_x > 0 ? grid_x : 1) ? 1 << 26 : 0;
+}
 
 // Production ring depth: 2 stages with 16 wavefronts per CU (2 KiB x 16 in flight already cover bandwidth x latency;
 // deeper rings only add refill work at the end of a row list), 4 stages - decoded two at a time - with 8.
@@ -937,8 +959,8 @@ template <typename T, int MB, int WAVES, int NS, int FLAGS> void launch_one(cons
             static LdsLimit lds_limit;
             ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), ge.lds);
             hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), ge.lds, stream, a.A, m0.B, m0.absmax, m0.absmax8, m0.N, a.K,
-                               (a.M & 0x3FFFF) | (a.bs_shift << 18) | (ge.P << 23), ge.R | (ge.SW << 16) | (ge.G << 21),
-                               (256 + ge.SW - 1) / ge.SW, a);
+                               (a.M & 0x3FFFF) | (a.bs_shift << 18) | (ge.P << 23),
+                               ge.R | (ge.SW << 16) | (ge.G << 21) | ring_late_bit(WAVES, a.rows_total, a.K, ge.grid_x), (256 + ge.SW - 1) / ge.SW, a);
             return;
         }
     }
@@ -953,8 +975,8 @@ template <typename T, int MB, int WAVES, int NS, int FLAGS> void launch_one(cons
     static LdsLimit lds_limit;
     ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), ge.lds);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), ge.lds, stream, a.A, m0.B, m0.absmax, m0.absmax8, m0.N, a.K,
-                       (a.M & 0x3FFFF) | (a.bs_shift << 18) | (ge.P << 23), ge.R | (ge.SW << 16) | (ge.G << 21),
-                       (256 + ge.SW - 1) / ge.SW, a);
+                       (a.M & 0x3FFFF) | (a.bs_shift << 18) | (ge.P << 23),
+                       ge.R | (ge.SW << 16) | (ge.G << 21) | ring_late_bit(WAVES, a.rows_total, a.K, ge.grid_x), (256 + ge.SW - 1) / ge.SW, a);
 }
 
 // The sweep-only variants (other ring depths, default cache policy) exist for ONE configuration - bf16, one activation
@@ -963,16 +985,6 @@ template <typename T, int MB, int WAVES, int FLAGS> void launch_tuned(const Stre
     if constexpr (std::is_same<T, bf16>::value && MB == 1 && FLAGS == 0) {
         const int ns = g_tune.ns.load(std::memory_order_relaxed);
         const int nt = g_tune.nt.load(std::memory_order_relaxed);
-        if (nt == 2) {
-            // (round 5 A/B: the builders' ring requested behind the table build, at the production policy and several ring depths)
-            if constexpr (WAVES == 16) {
-                if (ns == 3)
-                    return launch_one<T, 1, 16, 3, kNT | kRingLate>(a, stream);
-                if (ns == 4)
-                    return launch_one<T, 1, 16, 4, kNT | kRingLate>(a, stream);
-            }
-            return launch_one<T, 1, WAVES, ring_depth(1, WAVES), kNT | kRingLate>(a, stream);
-        }
         if constexpr (WAVES == 8) {
             if (ns == 2)
                 return launch_one<T, 1, 8, 2, kNT>(a, stream);
@@ -1029,7 +1041,13 @@ template <typename T> void launch_mb(const StreamArgs& a, int quant_type, bool g
         const int S = (a.K + kSegK - 1) / kSegK;
         const long items_per_cu = static_cast<long>((a.rows_total + device_cu_count() - 1) / device_cu_count()) * S;
         const int tw = g_tune.waves.load(std::memory_order_relaxed);
-        const bool eight = tw == 8 || (tw == 0 && a.code16 == nullptr && (8 % S) == 0 && items_per_cu >= 64);
+        // Round 5: with the round-robin harness (profiles/r5_stream_prologue_ab.txt) 16 wavefronts are level or ahead on EVERY shape -
+        // 8192^2 8.81 vs 8.79 us, 11008 x 4096 6.56 vs 7.22, 14336 x 4096 7.81 vs 8.11, 28672 x 8192 23.8 vs 24.4, 4096 x 11008 7.41 vs
+        // 8.17: round 2's crossover (below) came from single timings in a fixed order, which that harness showed to carry an 8 %
+        // first-measured penalty. The 8-wavefront instance stays for the tuning knob (A/B runs).
+        (void)S;
+        (void)items_per_cu;
+        const bool eight = tw == 8;
         if (eight)
             return launch_flags<T, 1, 8>(a, quant_type, grouped, stream);
         return launch_flags<T, 1, 16>(a, quant_type, grouped, stream);
@@ -1075,8 +1093,8 @@ template <typename T, int FLAGS> void launch_peer(const StreamArgs& a, const Geo
     ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), ge.lds);
     const StreamMat& m0 = a.mat[0];
     hipLaunchKernelGGL(kern, dim3(ge.grid_x, 1), dim3(16 * 64), ge.lds, stream, a.A, m0.B, m0.absmax, m0.absmax8, m0.N, a.K,
-                       (1 & 0x3FFFF) | (a.bs_shift << 18) | (1 << 23) | ((a.peer.mode & 7) << 24), ge.R | (ge.SW << 16) | (ge.G << 21),
-                       (256 + ge.SW - 1) / ge.SW, a);
+                       (1 & 0x3FFFF) | (a.bs_shift << 18) | (1 << 23) | ((a.peer.mode & 7) << 24),
+                       ge.R | (ge.SW << 16) | (ge.G << 21) | ring_late_bit(16, a.rows_total, a.K, ge.grid_x), (256 + ge.SW - 1) / ge.SW, a);
 }
 template <typename T> void launch_peer_flags(const StreamArgs& a, const Geometry& ge, int quant_type, hipStream_t stream) {
     const int sel = (a.mat[0].absmax8 != nullptr ? 1 : 0) | (quant_type == kFP4 ? 2 : 0);
