@@ -14,8 +14,9 @@ from .cextension import lib
 from .backends import hip as _hip_backend  # noqa: F401  registers the "cuda"-key (HIP) kernels
 from . import nn  # noqa: F401
 from . import utils  # noqa: F401
-from .parallel import GraphedBlock, ShardedLinear4bit, ShardedLinear4bitChain, ShardedLinear4bitGroup, shard_linear4bit  # noqa: F401
+from .parallel import (GraphedBlock, ShardedFFN4bit, ShardedLinear4bit, ShardedLinear4bitChain, ShardedLinear4bitGroup,  # noqa: F401
+                       shard_ffn4bit, shard_linear4bit)
 
 __version__ = "0.1.0"
 
-__all__ = ["functional", "nn", "utils", "matmul_4bit", "matmul_4bit_grouped", "MatMul4Bit", "lib", "ShardedLinear4bit", "ShardedLinear4bitGroup", "ShardedLinear4bitChain", "GraphedBlock", "shard_linear4bit"]
+__all__ = ["functional", "nn", "utils", "matmul_4bit", "matmul_4bit_grouped", "MatMul4Bit", "lib", "ShardedLinear4bit", "ShardedLinear4bitGroup", "ShardedLinear4bitChain", "ShardedFFN4bit", "GraphedBlock", "shard_linear4bit", "shard_ffn4bit"]

@@ -116,7 +116,8 @@ struct PeerChain {
     uint32_t spin_bound;    // re-fetches of a granule before the launch gives up (status word, NaN)
     uint32_t epoch_offset;  // exchanges produced by earlier launches since the buffer's epoch word was last advanced
     int mode;               // bit 0: x = the current exchange (A is ignored); bit 1: y goes to the exchange (+ to out when non-NULL);
-                            // bit 2: rows come in fours (ns and the rows per workgroup are multiples of 4): two granules per store
+                            // bit 2: rows come in fours (ns and the rows per workgroup are multiples of 4): two granules per store;
+                            // bit 3 (with bit 0): the exchange holds [gate | up] halves per rank, x = silu(gate) * up (kGateRounds)
 };
 constexpr size_t kChainDataOffset = 256;
 // The i-th exchange since the last read-out (i = epoch_offset + 1 of the launch that produces it) lives in region i % kChainRegions:
@@ -130,6 +131,13 @@ constexpr size_t kChainDataOffset = 256;
 // exchange n - 1, which every rank produces behind its own read-out.
 constexpr uint32_t kChainRegions = 64;
 constexpr int kChainRounds = 8; // 16-byte fetches per builder lane: K <= 8 * 8 KiB / 4 B = 16384 values
+// "Gated" consumption (mode bit 3; one Llama-style FFN block on the chain, BASELINE.json configs[3]): the exchange holds the outputs
+// of a launch over the rank's gate rows FOLLOWED BY its up rows - rank-major [rank][gate ns_g | up ns_g], ns_g = K / world - and the
+// consumer's x is  x[j] = T(T(silu(gate[j])) * up[j]),  j = rank * ns_g + r  (torch's own arithmetic for `F.silu(g) * u` on 16-bit
+// tensors: each op in fp32, rounded once). A builder lane fetches the 16 bytes = 4 values of gate and the matching 16 bytes of up per
+// round: kGateRounds rounds of 8 wavefronts x 64 lanes x 4 values = 2048 values each, K <= 14336 (Llama-3-8B's F; 11008 for Llama-2).
+constexpr int kGateRounds = 7;
+constexpr int kFetchVecs = 2 * kGateRounds; // fetch registers of a builder lane: 8 in the plain form, 7 + 7 in the gated one
 // re-fetches a wait is still worth once a wait on the same buffer has run into its bound (the status word is sticky): the peer
 // is gone - every later round and launch would otherwise spin the full bound again, ~30 s each, before a host-side check() runs
 constexpr uint32_t kPeerPollsAfterTimeout = 16;
@@ -196,30 +204,12 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     // hot arguments as separate scalars: the command processor preloads them into SGPRs (kernarg preload, 14 dwords),
     // so a wavefront does not start with a dependent s_load from a cold kernarg buffer
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, int hot_N, int hot_K,
-    int hot_packed /* M | bs_shift << 18 | P << 23 */, int hot_geom /* R | SW << 16 | G << 21 | ring_late << 26 */,
-    int hot_inv /* ceil(256 / SW) */, const StreamArgs p) {
+    int hot_packed /* M | bs_shift << 18 | P << 23 */, int hot_geom /* R | SW << 16 | G << 21 */,
+    int hot_inv /* ceil(256 / SW) | (peer chain, gated) ns_g << 12 */, int hot_aux /* (peer chain, gated) ceil(2^32 / (ns_g / 4)) */,
+    const StreamArgs p) {
     constexpr bool NESTED = FLAGS & kNested, CODEPTR = FLAGS & kCodePtr, NT = FLAGS & kNT, GROUPED = FLAGS & kGrouped;
     constexpr bool MULTI = FLAGS & kMulti;
     constexpr bool PEER = (FLAGS & kPeer) != 0;
-    // Round 5. The activation image must have landed before ANY wavefront can decode (first barrier), and a CU's vector-memory
-    // pipeline returns in order: an x piece issued behind other wavefronts' ring stages waits for those stages - weight bytes from
-    // HBM, requested by every CU at once - although x itself is a few KB of L2-hot data. With `ring_late` (a host-chosen bit of a
-    // preloaded argument; 16-wavefront workgroups only) the builders - the wavefronts that start FIRST - issue their x piece, build
-    // the table, and only then request their ring: by the time the late wavefronts, which request their ring at once as before,
-    // reach the memory pipeline, every x piece is already in it, in front of all weight traffic of the CU. Measured
-    // (profiles/r5_stream_prologue_ab.txt, round-robin medians): -2 % where a wavefront has two items or more (4096^2 4.21 -> 4.12 us,
-    // 8192^2 8.81 -> 8.61, 28672 x 8192 23.8 -> 23.4), +2 % on the 8-way shard shapes (less than one item per wavefront: the delayed
-    // ring IS the work) and +4 ... 9 % with 8 wavefronts (every wavefront builds, so every ring is delayed) - hence a run-time bit.
-    // Both positions of the ring are in the program, under a wavefront-UNIFORM branch with the same loads on either side: the
-    // compiler's counted waits must come out unchanged (tests/test_cabi.py reads them back from the ISA).
-    // Compiled in only where NO compiler-visible load is pending across the branch: nested instances hold their code-2 / offset
-    // loads there, grouped and multi-phase ones descriptor reads - at the join of the two ring positions hipcc then cannot order the
-    // pending loads and drains the queue (vmcnt(0) in front of the first barrier: found in the ISA of the first build, the lesson of
-    // DESIGN 6a once more). Those instances keep the one ring position they were validated with.
-    // (peer-chain instances likewise: their eight granule fetches are in flight across the branch - with both ring positions compiled
-    // in, the counted waits of the tag checks dropped from vmcnt(11 ... 4) to (7 ... 0), i.e. x would wait for ring stages)
-    constexpr bool RING_LATE_OK = WAVES == 16 && !NESTED && !GROUPED && !MULTI && !CODEPTR && !PEER;
-    const bool ring_late = RING_LATE_OK && ((hot_geom >> 26) & 1) != 0;
     static_assert(!PEER || (MB == 1 && !MULTI && !GROUPED && WAVES == 16), "the peer-chain form is the M = 1, single-phase kernel");
     constexpr int THREADS = WAVES * 64;
     constexpr int TB = TypeInfo<T>::bytes;
@@ -250,7 +240,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     const int nrows = (rows_total - row_begin < R) ? rows_total - row_begin : R;
     const int m0 = blockIdx.y * MB;
     // wave -> (segment column sw, row group g): g = wave / SW by a host-made reciprocal (exact for wave < 16 <= 256 / SW)
-    const int g = (wave * hot_inv) >> 8;
+    const int g = (wave * (PEER ? (hot_inv & 0xFFF) : hot_inv)) >> 8;
+    if constexpr (!PEER)
+        (void)hot_aux;
     const int sw = wave - g * SW;
 #ifdef BNB_PROFILING
     if (p.dbg && lane == 0)
@@ -546,19 +538,39 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         // ring, the in-order counter made x wait for every weight byte: +1.2 us per layer, profiles/r4_peer_chain.txt). The epoch
         // they depend on is one scalar load; a lane past the end of x is out of range (zeros, no traffic).
         bool x_from_peer = false;
-        u32x4 gx[PEER ? kChainRounds : 1];
+        [[maybe_unused]] bool gated = false;
+        u32x4 gx[PEER ? kFetchVecs : 1];
         if constexpr (PEER) {
             // (the mode travels in the spare bits of a PRELOADED argument and, when x comes from the exchange, the address of the
             // exchange's region in the slot of the unused activation pointer - the region of an exchange is its POSITION in the chain,
-            // which the host knows, only its tag carries the device-side epoch: the fetch depends on no load at all)
-            const int peer_mode = (hot_packed >> 24) & 7;
+            // which the host knows, only its tag carries the device-side epoch: the fetch depends on no load at all. The gated form's
+            // two constants - ns_g and the reciprocal of ns_g / 4 - arrive in preloaded dwords too.)
+            const int peer_mode = (hot_packed >> 24) & 15;
             x_from_peer = (peer_mode & 1) != 0;
+            gated = (peer_mode & 8) != 0;
             if (x_from_peer && wave < WAVES - BUILDERS) {
-                const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(hot_A), 0, K * 4, kRsrcFlags);
+                if (!gated) {
+                    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(hot_A), 0, K * 4, kRsrcFlags);
 #pragma unroll
-                for (int r = 0; r < kChainRounds; ++r)
-                    gx[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                          rs_x, static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave) * 64 + lane) * 16u, 0, 17 /* sc0 sc1 */));
+                    for (int r = 0; r < kChainRounds; ++r)
+                        gx[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                              rs_x, static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave) * 64 + lane) * 16u, 0, 17 /* sc0 sc1 */));
+                } else {
+                    // values 4 j4 .. 4 j4 + 3 of x belong to rank q = j4 / (ns_g / 4) - exact by one v_mul_hi (the host's reciprocal;
+                    // tests/checks/peer_gated_division.py sweeps every divisor the form admits) - and sit at value offset
+                    // 4 j4 + q ns_g (gate) / + ns_g more (up) of the exchange, 4 bytes of granule per value; past the end of x: out of range
+                    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(hot_A), 0, K * 8, kRsrcFlags);
+                    const uint32_t nsg = static_cast<uint32_t>(hot_inv) >> 12;
+#pragma unroll
+                    for (int r = 0; r < kGateRounds; ++r) {
+                        const uint32_t j4 = static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave) * 64 + lane);
+                        const uint32_t q = __umulhi(j4, static_cast<uint32_t>(hot_aux));
+                        const uint32_t off = (4u * j4 + q * nsg) * 4u;
+                        const uint32_t oob = 4u * j4 < static_cast<uint32_t>(K) ? 0u : kOob;
+                        gx[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off | oob, 0, 17));
+                        gx[kGateRounds + r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (off + nsg * 4u) | oob, 0, 17));
+                    }
+                }
             }
         }
         if (!x_from_peer)
@@ -570,26 +582,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         k0 = static_cast<uint32_t>(seg * kSegK + lane * 32);
         k_ok = (seg < S) && (k0 < static_cast<uint32_t>(K));
         lane_mask = k_ok ? 0u : kOob;
-        // the first NS ring stages of this phase (+ the peer chain's epoch word behind them). ONE site in the program, executed
-        // by every wavefront: no branch around a load, so the compiler's counted waits stay exact (see `issue`).
-        auto issue_ring = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                issue(st[j], j);
-                __builtin_amdgcn_sched_barrier(0); // keep the queue in stage order: (weights, scale) of stage 0, of stage 1, ...
-            }
-            if constexpr (PEER) {
-                // the epoch word (the tags of the exchange consumed here are epoch + offset, of the one produced epoch + offset + 1):
-                // requested BEHIND every load of the prologue - its address comes from the kernarg segment, whose first access is a cold
-                // miss that stalled every wavefront for ~500 cycles in front of its ring when it sat there (profiles/r4_timeline_chain.txt)
-                typedef const uint32_t __attribute__((address_space(4))) * cu32_ptr;
-                epoch_raw = *(cu32_ptr)(reinterpret_cast<uintptr_t>(p.peer.epoch_word));
-                epoch = epoch_raw + p.peer.epoch_offset;
-            }
-        };
-        // (later phases of a long row have no table to build: their ring goes out at once either way)
-        if (!ring_late || ph > 0)
-            issue_ring();
+        for (int j = 0; j < NS; ++j) {
+            issue(st[j], j);
+            __builtin_amdgcn_sched_barrier(0); // keep the queue in stage order: (weights, scale) of stage 0, of stage 1, ...
+        }
+        if constexpr (PEER) {
+            // the epoch word (the tags of the exchange consumed here are epoch + offset, of the one produced epoch + offset + 1):
+            // requested BEHIND every load of the prologue - its address comes from the kernarg segment, whose first access is a cold
+            // miss that stalled every wavefront for ~500 cycles in front of its ring when it sat there (profiles/r4_timeline_chain.txt)
+            typedef const uint32_t __attribute__((address_space(4))) * cu32_ptr;
+            epoch_raw = *(cu32_ptr)(reinterpret_cast<uintptr_t>(p.peer.epoch_word));
+            epoch = epoch_raw + p.peer.epoch_offset;
+        }
         if (ph == 0)
             BNB_ST_STAMP(1)
         if (ph == 0) {
@@ -625,13 +630,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             for (int it = 0; it < ITERS; ++it)
                 *reinterpret_cast<f32x4*>(smem + (it * BT + tid_b) * 16) = f32x4{hi[it], lo, hi[it], lo};
         }
-        if (ring_late && ph == 0) {
-            // (fenced on both sides: the table's stores are issued, THEN the ring is requested - the wavefronts that did not
-            // build fall straight through to here)
-            __builtin_amdgcn_sched_barrier(0);
-            issue_ring();
-            __builtin_amdgcn_sched_barrier(0);
-        }
         if (ph == 0) {
             if constexpr (NESTED) {
 #pragma unroll
@@ -656,41 +654,78 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
             if (x_from_peer && wave < WAVES - BUILDERS) {
                 const unsigned char* const src = static_cast<const unsigned char*>(hot_A);
                 uint32_t wait_bound = p.peer.spin_bound; // (per lane; drops to a few polls once anything on this buffer timed out)
-#pragma unroll
-                for (int r = 0; r < kChainRounds; ++r) {
-                    const uint32_t off = static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave) * 64 + lane) * 16u;
-                    if (off < static_cast<uint32_t>(K) * 4u) {
-                        u32x4 gr = gx[r];
-                        // (the re-fetch loop is spelled in asm: a loop with loads in it makes the compiler's wait insertion
-                        // forget what is in flight behind it. Slow path only - a peer that is late.)
-                        uint32_t spins = 0;
-                        while (gr[1] != epoch || gr[3] != epoch) {
-                            if (spins == 0 && wait_bound == p.peer.spin_bound) {
-                                // first miss of this lane: has a wait on this buffer ALREADY run into its bound (an earlier round of
-                                // this launch, or an earlier launch - the word is sticky)? Then the peer is gone, and paying the full
-                                // bound again per round and per layer would block the queue for the length of the chain before any
-                                // host-side check() runs: a few polls each from here on.
-                                uint32_t st_word;
-                                const uint32_t* const st_addr = reinterpret_cast<const uint32_t*>(p.peer.local) + 1;
-                                asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(st_word) : "v"(st_addr) : "memory");
-                                if (st_word != 0u)
-                                    wait_bound = kPeerPollsAfterTimeout;
-                            }
-                            __builtin_amdgcn_s_sleep(4);
-                            const unsigned char* const addr = src + off;
-                            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(gr) : "v"(addr) : "memory");
-                            if (++spins > wait_bound) {
-                                __hip_atomic_store(reinterpret_cast<uint32_t*>(p.peer.local) + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                gr = u32x4{0xFFFFFFFFu, epoch, 0xFFFFFFFFu, epoch}; // NaN in fp16 / bf16: a timeout cannot pass for data
+                // one fetched vector = two granules {pair, tag, pair2, tag}: re-fetched (system scope, bounded) until both tags are there
+                auto settle = [&](u32x4 gr, uint32_t off) -> u32x4 {
+                    // (the re-fetch loop is spelled in asm: a loop with loads in it makes the compiler's wait insertion
+                    // forget what is in flight behind it. Slow path only - a peer that is late.)
+                    uint32_t spins = 0;
+                    while (gr[1] != epoch || gr[3] != epoch) {
+                        if (spins == 0 && wait_bound == p.peer.spin_bound) {
+                            // first miss of this lane: has a wait on this buffer ALREADY run into its bound (an earlier round of
+                            // this launch, or an earlier launch - the word is sticky)? Then the peer is gone, and paying the full
+                            // bound again per round and per layer would block the queue for the length of the chain before any
+                            // host-side check() runs: a few polls each from here on.
+                            uint32_t st_word;
+                            const uint32_t* const st_addr = reinterpret_cast<const uint32_t*>(p.peer.local) + 1;
+                            asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(st_word) : "v"(st_addr) : "memory");
+                            if (st_word != 0u)
                                 wait_bound = kPeerPollsAfterTimeout;
-                            }
                         }
-                        // four values = half of the 16-byte chunk c of x; chunk (l', q) of a segment lives at slot CH l' + (q ^ swz(l'))
-                        const uint32_t c = off >> 5, half = (off >> 4) & 1u;
-                        const uint32_t sg = c >> 8, cs = c & 255u, lp = cs / CH, q = cs % CH;
-                        using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
-                        *reinterpret_cast<u32x2*>(ximg + ((sg * CH * 64 + CH * lp + (q ^ static_cast<uint32_t>(swz(static_cast<int>(lp))))) * 16 + half * 8)) =
-                            u32x2{gr[0], gr[2]};
+                        __builtin_amdgcn_s_sleep(4);
+                        const unsigned char* const addr = src + off;
+                        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(gr) : "v"(addr) : "memory");
+                        if (++spins > wait_bound) {
+                            __hip_atomic_store(reinterpret_cast<uint32_t*>(p.peer.local) + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            gr = u32x4{0xFFFFFFFFu, epoch, 0xFFFFFFFFu, epoch}; // NaN in fp16 / bf16: a timeout cannot pass for data
+                            wait_bound = kPeerPollsAfterTimeout;
+                        }
+                    }
+                    return gr;
+                };
+                // four values = half of the 16-byte chunk c of x; chunk (l', q) of a segment lives at slot CH l' + (q ^ swz(l'))
+                using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+                auto put4 = [&](uint32_t j4, u32x2 four) {
+                    const uint32_t c = j4 >> 1, half = j4 & 1u;
+                    const uint32_t sg = c >> 8, cs = c & 255u, lp = cs / CH, q = cs % CH;
+                    *reinterpret_cast<u32x2*>(ximg + ((sg * CH * 64 + CH * lp + (q ^ static_cast<uint32_t>(swz(static_cast<int>(lp))))) * 16 + half * 8)) = four;
+                };
+                if (!gated) {
+#pragma unroll
+                    for (int r = 0; r < kChainRounds; ++r) {
+                        const uint32_t off = static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave) * 64 + lane) * 16u;
+                        if (off < static_cast<uint32_t>(K) * 4u) {
+                            const u32x4 gr = settle(gx[r], off);
+                            put4(off >> 4, u32x2{gr[0], gr[2]});
+                        }
+                    }
+                } else {
+                    const uint32_t nsg = static_cast<uint32_t>(hot_inv) >> 12;
+#pragma unroll
+                    for (int r = 0; r < kGateRounds; ++r) {
+                        const uint32_t j4 = static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave) * 64 + lane);
+                        if (4u * j4 < static_cast<uint32_t>(K)) {
+                            const uint32_t q = __umulhi(j4, static_cast<uint32_t>(hot_aux));
+                            const uint32_t off = (4u * j4 + q * nsg) * 4u;
+                            const u32x4 gg = settle(gx[r], off);
+                            const u32x4 gu = settle(gx[kGateRounds + r], off + nsg * 4u);
+                            // x = T(T(silu(g)) * u): silu in fp32 ( g / (1 + exp(-g)) ), rounded to T; the product in fp32, rounded to T
+                            uint32_t outw[2];
+#pragma unroll
+                            for (int w = 0; w < 2; ++w) {
+                                const uint32_t gw = gg[2 * w], uw = gu[2 * w];
+                                unsigned short res[2];
+#pragma unroll
+                                for (int e = 0; e < 2; ++e) {
+                                    const unsigned short gb = static_cast<unsigned short>(gw >> (16 * e)), ub = static_cast<unsigned short>(uw >> (16 * e));
+                                    const float gf = static_cast<float>(__builtin_bit_cast(T, gb)), uf = static_cast<float>(__builtin_bit_cast(T, ub));
+                                    const T st = static_cast<T>(gf / (1.0f + expf(-gf)));
+                                    const T at = static_cast<T>(__fmul_rn(static_cast<float>(st), uf));
+                                    res[e] = __builtin_bit_cast(unsigned short, at);
+                                }
+                                outw[w] = static_cast<uint32_t>(res[0]) | (static_cast<uint32_t>(res[1]) << 16);
+                            }
+                            put4(j4, u32x2{outw[0], outw[1]});
+                        }
                     }
                 }
             }
@@ -880,7 +915,6 @@ template <typename T, bool NESTED> __global__ __launch_bounds__(256) void gemv4_
 int device_cu_count() { return device_cu_count_or_default(); }
 
 constexpr size_t kLdsBudget = 156 * 1024; // largest dynamic allocation that launches (157 KiB is refused)
-static int g_tune_nt_peek();
 
 struct Geometry {
     int R, SW, G, P, grid_x;
@@ -928,20 +962,6 @@ struct StreamTuning {
     TlsKnob ns{0}, sw{0}, rows{0}, nt{-1}, waves{0};
 };
 thread_local StreamTuning g_tune;
-static int g_tune_nt_peek() { return g_tune.nt.load(std::memory_order_relaxed); }
-// Ring-late prologue (see the kernel): on where a wavefront of a 16-wavefront workgroup has at least two items - the measured
-// crossover (profiles/r5_stream_prologue_ab.txt). The nt knob's values 2 / 3 force it on / off for A/B runs (policy: non-temporal).
-static int ring_late_bit(int waves, int rows_total, int K, int grid_x) {
-    if (waves != 16)
-        return 0;
-    const int nt = g_tune_nt_peek();
-    if (nt == 2)
-        return 1 << 26;
-    if (nt == 3)
-        return 0;
-    const long items = static_cast<long>(rows_total) * ((K + kSegK - 1) / kSegK);
-    return items >= 2L * 16 * (grid_x > 0 ? grid_x : 1) ? 1 << 26 : 0;
-}
 
 // Production ring depth: 2 stages with 16 wavefronts per CU (2 KiB x 16 in flight already cover bandwidth x latency;
 // deeper rings only add refill work at the end of a row list), 4 stages - decoded two at a time - with 8.
@@ -960,7 +980,7 @@ template <typename T, int MB, int WAVES, int NS, int FLAGS> void launch_one(cons
             ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), ge.lds);
             hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), ge.lds, stream, a.A, m0.B, m0.absmax, m0.absmax8, m0.N, a.K,
                                (a.M & 0x3FFFF) | (a.bs_shift << 18) | (ge.P << 23),
-                               ge.R | (ge.SW << 16) | (ge.G << 21) | ring_late_bit(WAVES, a.rows_total, a.K, ge.grid_x), (256 + ge.SW - 1) / ge.SW, a);
+                               ge.R | (ge.SW << 16) | (ge.G << 21), (256 + ge.SW - 1) / ge.SW, 0, a);
             return;
         }
     }
@@ -976,7 +996,7 @@ template <typename T, int MB, int WAVES, int NS, int FLAGS> void launch_one(cons
     ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), ge.lds);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), ge.lds, stream, a.A, m0.B, m0.absmax, m0.absmax8, m0.N, a.K,
                        (a.M & 0x3FFFF) | (a.bs_shift << 18) | (ge.P << 23),
-                       ge.R | (ge.SW << 16) | (ge.G << 21) | ring_late_bit(WAVES, a.rows_total, a.K, ge.grid_x), (256 + ge.SW - 1) / ge.SW, a);
+                       ge.R | (ge.SW << 16) | (ge.G << 21), (256 + ge.SW - 1) / ge.SW, 0, a);
 }
 
 // The sweep-only variants (other ring depths, default cache policy) exist for ONE configuration - bf16, one activation
@@ -1041,10 +1061,11 @@ template <typename T> void launch_mb(const StreamArgs& a, int quant_type, bool g
         const int S = (a.K + kSegK - 1) / kSegK;
         const long items_per_cu = static_cast<long>((a.rows_total + device_cu_count() - 1) / device_cu_count()) * S;
         const int tw = g_tune.waves.load(std::memory_order_relaxed);
-        // Round 5: with the round-robin harness (profiles/r5_stream_prologue_ab.txt) 16 wavefronts are level or ahead on EVERY shape -
-        // 8192^2 8.81 vs 8.79 us, 11008 x 4096 6.56 vs 7.22, 14336 x 4096 7.81 vs 8.11, 28672 x 8192 23.8 vs 24.4, 4096 x 11008 7.41 vs
-        // 8.17: round 2's crossover (below) came from single timings in a fixed order, which that harness showed to carry an 8 %
-        // first-measured penalty. The 8-wavefront instance stays for the tuning knob (A/B runs).
+        // Round 5: with the round-robin harness (profiles/r5_stream_prologue_ab.txt, two runs on two boxes) 16 wavefronts are level or
+        // ahead on EVERY shape - 8192^2 8.54 / 8.81 vs 8.69 / 8.79 us, 11008 x 4096 6.42 / 6.56 vs 7.21 / 7.22, 14336 x 4096 7.54 / 7.81 vs
+        // 7.93 / 8.11, 28672 x 8192 22.8 / 23.8 vs 23.6 / 24.4, 4096 x 11008 7.44 / 7.41 vs 8.10 / 8.17: round 2's crossover (below) came
+        // from single timings in a fixed order, which that harness showed to carry an 8 % first-measured penalty. The 8-wavefront
+        // instance stays for the tuning knob (A/B runs).
         (void)S;
         (void)items_per_cu;
         const bool eight = tw == 8;
@@ -1092,9 +1113,16 @@ template <typename T, int FLAGS> void launch_peer(const StreamArgs& a, const Geo
     static LdsLimit lds_limit;
     ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), ge.lds);
     const StreamMat& m0 = a.mat[0];
+    // (gated consumption: ns_g = K / world in the spare bits of the reciprocal's dword, ceil(2^32 / (ns_g / 4)) in the last preloaded one)
+    int inv = (256 + ge.SW - 1) / ge.SW, aux = 0;
+    if (a.peer.mode & 8) {
+        const uint32_t nsg = static_cast<uint32_t>(a.K / a.peer.world), d = nsg / 4u;
+        inv |= static_cast<int>(nsg << 12);
+        aux = static_cast<int>(static_cast<uint32_t>(((1ull << 32) + d - 1) / d));
+    }
     hipLaunchKernelGGL(kern, dim3(ge.grid_x, 1), dim3(16 * 64), ge.lds, stream, a.A, m0.B, m0.absmax, m0.absmax8, m0.N, a.K,
-                       (1 & 0x3FFFF) | (a.bs_shift << 18) | (1 << 23) | ((a.peer.mode & 7) << 24),
-                       ge.R | (ge.SW << 16) | (ge.G << 21) | ring_late_bit(16, a.rows_total, a.K, ge.grid_x), (256 + ge.SW - 1) / ge.SW, a);
+                       (1 & 0x3FFFF) | (a.bs_shift << 18) | (1 << 23) | ((a.peer.mode & 15) << 24),
+                       ge.R | (ge.SW << 16) | (ge.G << 21), inv, aux, a);
 }
 template <typename T> void launch_peer_flags(const StreamArgs& a, const Geometry& ge, int quant_type, hipStream_t stream) {
     const int sel = (a.mat[0].absmax8 != nullptr ? 1 : 0) | (quant_type == kFP4 ? 2 : 0);
@@ -1161,8 +1189,16 @@ static bool peer_geometry(int world, int ns, int K, int blocksize, int mode, lon
     if (world < 1 || world > 8 || ns < 2 || (ns & 1) || K < 32 || (K % 32) != 0 || blocksize < 32 || !is_pow2(blocksize) || (mode & 3) == 0 ||
         max_values < 4 || (max_values & 3) || max_values >= (1L << 28))
         return false; // (max_values in fours: max_granules is then even, every region 16-byte aligned - the quad stores and b128 fetches need it)
-    if ((mode & 1) && (K > kChainRounds * 2048 || K > max_values))
+    if ((mode & 8) && !(mode & 1))
+        return false; // gated is a form of consumption
+    if (mode & 8) {
+        // x = silu(gate) * up from an exchange of [gate ns_g | up ns_g] per rank: 2 K values in the region, whole fours per rank
+        // (a lane's four values never straddle ranks; ns_g / 4 >= 2 keeps the reciprocal inside a dword), K within the fetch rounds
+        if (K % (4 * world) != 0 || K / world < 8 || K > kGateRounds * 2048 || 2L * K > max_values)
+            return false;
+    } else if ((mode & 1) && (K > kChainRounds * 2048 || K > max_values)) {
         return false;
+    }
     if ((mode & 2) && static_cast<long>(world) * ns > max_values)
         return false;
     // rows per workgroup: even (granules are row pairs), and no more workgroups than the caller allows (ranks that share one
@@ -1221,7 +1257,7 @@ bool gemv_4bit_peer(void* const* bufs, void* epoch_word, int world, int rank, in
     a.peer.max_granules = static_cast<uint32_t>(max_values / 2);
     a.peer.spin_bound = spin_bound;
     a.peer.epoch_offset = epoch_offset;
-    a.peer.mode = (mode & 3) | (quads ? 4 : 0);
+    a.peer.mode = (mode & 3) | (quads ? 4 : 0) | (mode & 8);
     // (x from the exchange: the preloaded pointer slot carries the address of the exchange's region - its position in the chain)
     a.A = (mode & 1) ? static_cast<const void*>(a.peer.local + kChainDataOffset +
                                                  static_cast<size_t>(epoch_offset & (kChainRegions - 1u)) * a.peer.max_granules * 8u)

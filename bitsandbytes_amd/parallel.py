@@ -279,6 +279,116 @@ class ShardedLinear4bitChain(nn.Module):
             raise
 
 
+def _plain_absmax(state: QuantState) -> torch.Tensor:
+    """fp32 absmax of a (possibly double-quantised) state: exactly the values the nested kernels reconstruct (two roundings:
+    the product code2[q8] * absmax2 and the sum with the offset - what `dequantize_blockwise` + a torch add compute)."""
+    if not state.nested:
+        return state.absmax.float()
+    return (F.dequantize_blockwise(state.absmax, state.state2) + state.offset).float()
+
+
+class ShardedFFN4bit(nn.Module):
+    """One gated FFN block  ``y = down(act(gate(x)) * up(x))``  (Llama: ``act`` = SiLU) of a decode step, every projection N-sharded
+    over the ranks - BASELINE.json ``configs[3]`` as it states it: the Llama FFN matrices sharded across the GPUs of a node. With a
+    :class:`bitsandbytes_amd.peer.PeerChain` the block is TWO launches and one small read-out per rank and token:
+
+    1. one launch over this rank's gate rows followed by its up rows (the two shards are concatenated into ONE ``[2 ns, H]`` matrix at
+       construction - they share ``x``, and one matrix needs no grouped form of the peer kernel), whose outputs go straight into
+       every rank's exchange buffer, rank-major ``[rank][gate | up]``;
+    2. the down shard's launch, which takes its input from that exchange and computes ``silu(gate) * up`` on the way into its
+       activation image (``gemv(..., gated=True)``: each op in fp32, rounded once to the 16-bit type - torch's arithmetic for
+       ``F.silu(g) * u``), and whose outputs go to the next exchange;
+    3. ``read``: the gathered ``y``.
+
+    Values are bit-identical to the unsharded block (``down(F.silu(gate(x)) * up(x))`` with the three ``Linear4bit`` layers) and to
+    the member-by-member path, which every call outside the fused form takes (more than one activation row, fp32, gradients, shapes
+    ``PeerChain.serves`` refuses): a grouped launch for gate / up, one gather, torch's activation, the down shard, one gather.
+    Decided from shapes, dtypes and the call's autograd mode - the same on every rank. Nothing in the reference to mirror (it has no
+    collective code); the block's arithmetic is the reference's ``Linear4bit`` x 3 (nn/modules.py:609-637)."""
+
+    def __init__(self, gate: ShardedLinear4bit, up: ShardedLinear4bit, down: ShardedLinear4bit, chain=None):
+        super().__init__()
+        sg, su = gate.quant_state, up.quant_state
+        if tuple(sg.shape) != tuple(su.shape) or sg.blocksize != su.blocksize or sg.quant_type != su.quant_type:
+            raise ValueError("gate and up must have the same shard shape, blocksize and quant_type")
+        if gate.out_features != up.out_features or gate.out_features != int(down.quant_state.shape[1]):
+            raise ValueError("down must take what gate / up produce")
+        self.gate, self.up, self.down = gate, up, down
+        self.group = ShardedLinear4bitGroup([gate, up])
+        self.chain = chain
+        ns, H = int(sg.shape[0]), int(sg.shape[1])
+        # ONE matrix [gate rows; up rows]: packed bytes and absmax are row-major over [N, K], so the concatenation of the two shards'
+        # buffers IS the packed form of the stacked matrix. Nested statistics are carried un-nested (the two matrices have their own
+        # offsets and second-level tables; the fp32 values are exactly the ones the nested kernels reconstruct).
+        wg, wu = gate.weight.reshape(-1), up.weight.reshape(-1)
+        if wg.dtype != torch.uint8:
+            wg, wu = wg.view(torch.uint8), wu.view(torch.uint8)
+        self.register_buffer("gu_weight", torch.cat([wg, wu]).view(-1, 1), persistent=False)
+        self.gu_state = QuantState(absmax=torch.cat([_plain_absmax(sg), _plain_absmax(su)]), shape=torch.Size((2 * ns, H)), code=sg.code,
+                                   blocksize=sg.blocksize, quant_type=sg.quant_type, dtype=sg.dtype)
+        self._gu_bias = {}
+
+    def _stacked_bias(self, dtype):
+        bg, bu = self.gate.bias, self.up.bias
+        if bg is None and bu is None:
+            return None
+        key = (dtype, None if bg is None else (bg.data_ptr(), bg._version), None if bu is None else (bu.data_ptr(), bu._version))
+        if self._gu_bias.get("key") != key:
+            ns = int(self.gate.quant_state.shape[0])
+            dev = self.gu_weight.device
+            parts = [(b.to(dtype) if b is not None else torch.zeros(ns, dtype=dtype, device=dev)) for b in (bg, bu)]
+            self._gu_bias = {"key": key, "bias": torch.cat(parts)}
+        return self._gu_bias["bias"]
+
+    def fused(self, x: torch.Tensor) -> bool:
+        chain = self.chain
+        if chain is None or x.dtype not in (torch.float16, torch.bfloat16) or x.numel() != x.shape[-1] or x.device != chain.device:
+            return False
+        members = (self.gate, self.up, self.down)
+        if torch.is_grad_enabled() and (x.requires_grad or any(m.bias is not None and m.bias.requires_grad for m in members)):
+            return False  # (the fused launches record no autograd graph: see ShardedLinear4bitChain.fused)
+        if self.gu_weight.data_ptr() % 16 or self.down.weight.data_ptr() % 16:
+            return False
+        sd = self.down.quant_state
+        ns, H = int(self.gate.quant_state.shape[0]), int(self.gate.quant_state.shape[1])
+        Fdim = int(sd.shape[1])
+        return (chain.world * ns == Fdim == self.gate.out_features and chain.world * int(sd.shape[0]) == self.down.out_features
+                and chain.serves(2 * ns, H, int(self.gu_state.blocksize), consume=False)
+                and chain.serves(int(sd.shape[0]), Fdim, int(sd.blocksize), consume=True, gated=True))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.fused(x):
+            g, u = self.group(x)
+            return self.down(torch.nn.functional.silu(g) * u)
+        lead = x.shape[:-1]
+        x1 = x.reshape(-1).contiguous()
+        if x1.data_ptr() % 16:
+            x1 = x1.clone()
+        gu_bias = self._stacked_bias(x.dtype)  # (everything that can raise on the host happens before the first launch)
+        db = self.down.bias
+        if db is not None and db.dtype != x.dtype:
+            db = db.to(x.dtype)
+        chain, done = self.chain, 0
+        try:
+            if not chain.gemv(x1, self.gu_weight, self.gu_state, bias=gu_bias, consume=False, produce=True):
+                raise RuntimeError("PeerChain refused the gate / up launch although its own shape check accepted it")
+            done = 1
+            if not chain.gemv(None, self.down.weight, self.down.quant_state, bias=db, consume=True, produce=True, dtype=x.dtype, gated=True):
+                raise RuntimeError("PeerChain refused the down launch although its own shape check accepted it")
+            done = 2
+            return chain.read(self.down.out_features, x.dtype).view(*lead, self.down.out_features)
+        except Exception as exc:
+            if done:
+                chain._broken = f"an FFN block stopped after {done} of its 2 launches: {type(exc).__name__}: {exc}"
+            raise
+
+
+def shard_ffn4bit(gate, up, down, rank: Optional[int] = None, world_size: Optional[int] = None, group=None, chain=None, peer=None) -> ShardedFFN4bit:
+    """This rank's :class:`ShardedFFN4bit` from three already-quantised ``Linear4bit`` layers (gate, up: ``H -> F``; down: ``F -> H``)."""
+    members = [shard_linear4bit(layer, rank, world_size, group=group, peer=peer) for layer in (gate, up, down)]
+    return ShardedFFN4bit(*members, chain=chain)
+
+
 class GraphedBlock:
     """A block of stream-ordered work - sharded launches, grouped launches, peer gathers, anything capturable - recorded ONCE into
     a hipGraph per rank and replayed per call: the per-kernel boundary is paid by the GPU's command processor instead of by

@@ -303,20 +303,25 @@ class PeerChain(_PeerBuffers):
             return 2
         raise ValueError(f"PeerChain serves fp16 / bf16 activations, got {dtype}")
 
-    def serves(self, ns: int, K: int, blocksize: int, consume: bool, produce: bool = True) -> bool:
+    def serves(self, ns: int, K: int, blocksize: int, consume: bool, produce: bool = True, gated: bool = False) -> bool:
         """The shape preconditions of the fused form - the launcher's OWN check (``peer_geometry`` in csrc/gemv4_stream.hip, launch
         geometry included), asked through ``bnb_mi355x_gemv_4bit_peer_serves``: nothing here can drift from what a launch accepts.
         Shapes only (and the chain's own constants), so every rank answers the same."""
         with torch.cuda.device(self.device):  # (the geometry depends on the device's CU count)
-            return bool(lib.bnb_mi355x_gemv_4bit_peer_serves(self.world, int(ns), int(K), int(blocksize), (1 if consume else 0) | (2 if produce else 0),
+            return bool(lib.bnb_mi355x_gemv_4bit_peer_serves(self.world, int(ns), int(K), int(blocksize),
+                                                             (1 if consume else 0) | (2 if produce else 0) | (8 if gated else 0),
                                                              self.max_values, self.wg_limit))
 
     def gemv(self, x: Optional[torch.Tensor], packed: torch.Tensor, quant_state, bias: Optional[torch.Tensor] = None,
              out_local: Optional[torch.Tensor] = None, consume: bool = False, produce: bool = True,
-             dtype: Optional[torch.dtype] = None) -> bool:
+             dtype: Optional[torch.dtype] = None, gated: bool = False) -> bool:
         """One layer: ``y_shard = x @ dequant(packed)^T (+ bias)``. ``consume``: x is the current exchange (pass ``x=None``);
-        ``produce``: y goes to every rank's exchange buffer (and to ``out_local`` when given). Returns False - nothing launched -
-        when the fused form does not serve the problem."""
+        ``produce``: y goes to every rank's exchange buffer (and to ``out_local`` when given). ``gated`` (with ``consume``): the
+        current exchange was produced by ONE launch over this rank's gate rows followed by its up rows (``K / world`` each), and
+        ``x = silu(gate) * up`` - the down projection of a Llama-style FFN block (``parallel.ShardedFFN4bit``). Returns False -
+        nothing launched - when the fused form does not serve the problem."""
+        if gated and not consume:
+            raise ValueError("gated=True is a form of consume=True")
         if self._broken:
             raise RuntimeError(f"this PeerChain is out of step with its peers and cannot be used any more ({self._broken}); build a new one collectively")
         st = quant_state
@@ -345,7 +350,7 @@ class PeerChain(_PeerBuffers):
             ok = lib.bnb_mi355x_gemv_4bit_peer(self._bufs, ct.c_void_p(self._epoch.data_ptr()), self.world, self.rank, self._dt(dtype), ptr(A), ptr(packed), ptr(absmax),
                                                ptr(absmax8), ptr(code), ptr(offset), ptr(bias), ptr(out_local), ns, K,
                                                int(st.blocksize), 1 if st.quant_type == "fp4" else 2,
-                                               (1 if consume else 0) | (2 if produce else 0), self.max_values, self.wg_limit,
+                                               (1 if consume else 0) | (2 if produce else 0) | (8 if gated else 0), self.max_values, self.wg_limit,
                                                self._pending, ct.c_void_p(stream))
         if ok and produce:
             self._pending += 1

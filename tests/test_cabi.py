@@ -238,43 +238,37 @@ def test_rt_kernel_isa_keeps_its_loads_in_flight():
 
 def test_stream_kernel_isa_waits_for_x_with_an_exact_count_and_never_drains_in_front_of_its_first_barrier():
     """gemv4_stream_kernel keeps its weight ring in flight across the first barrier: the wait for the activation image in front of
-    it is `s_waitcnt vmcnt(NS x 2)` (the x pieces are older than the NS ring stages of two loads each), spelled in asm. Round 5 put a
-    second position of the ring into the program (ring-late prologue, a wavefront-uniform run-time branch): in the instances that
-    hold OTHER compiler-visible loads across that branch (nested statistics: code-2 / offset; grouped; multi-phase; peer chain) hipcc
-    answered with `vmcnt(0)` at the join - the whole ring drained in front of the barrier - which is why those instances compile the
-    second position out (csrc/gemv4_stream.hip, RING_LATE_OK). Pinned on every instance of the built library:
+    it is `s_waitcnt vmcnt(NS x 2)` (the x pieces are older than the NS ring stages of two loads each), spelled in asm. Round 5's
+    ring-late experiment (a second position of the ring under a wavefront-uniform run-time branch) showed how easily that
+    is lost: in every instance that holds OTHER compiler-visible loads across such a branch (nested statistics, grouped, multi-phase,
+    peer chain) hipcc answered with `vmcnt(0)` at the join - the whole ring drained in front of the barrier - invisible in the source
+    and in every test of values. Pinned on every single-phase instance of the built library:
       * the last vector-memory wait in front of the first barrier is the counted one, vmcnt(2 NS);
       * plain instances (no nested statistics, no caller-supplied code table, not the peer chain, not grouped) have NO vmcnt(0)
-        anywhere in front of that barrier; the 16-wavefront ones of them carry both ring positions."""
+        anywhere in front of that barrier, and exactly NS weight requests (one ring position)."""
     import re
 
     kernels = _device_disassembly("gemv4_stream_kernel")
     assert len(kernels) >= 150, len(kernels)
-    plain16_with_two_rings = checked = 0
+    checked = plain = 0
     for name, lines in kernels.items():
         m = re.search(r"stream_kernelI(\w+?)Li(\d)ELi(\d+)ELi(\d)ELi(\d+)E", name)  # <T, MB, WAVES, NS, FLAGS>
         assert m, name
-        waves, ns, flags = int(m.group(3)), int(m.group(4)), int(m.group(5))
+        ns, flags = int(m.group(4)), int(m.group(5))
         if flags & 32:
             continue  # (multi-phase instances: the first barrier in program TEXT is the phase loop's, not the one behind the x wait)
         checked += 1
         ops = [ln.split()[0] for ln in lines]
-        first_barrier = ops.index("s_barrier")
-        head = lines[:first_barrier]
+        head = lines[: ops.index("s_barrier")]
         vm_waits = [int(re.search(r"vmcnt\((\d+)\)", ln).group(1)) for ln in head if ln.startswith("s_waitcnt") and "vmcnt(" in ln]
-        peer = bool(flags & 64)
-        if not peer:  # (the peer-chain instances wait for their granule fetches, tag by tag, between the x wait and the barrier)
+        if not flags & 64:  # (the peer-chain instances wait for their granule fetches, tag by tag, between the x wait and the barrier)
             assert vm_waits and vm_waits[-1] == 2 * ns, f"{name}: waits in front of the first barrier {vm_waits}, expected the last one to be vmcnt({2 * ns})"
-        plain = not (flags & (1 | 2 | 16 | 64))  # nested | caller's code table | grouped | peer
-        if plain:
+        if not (flags & (1 | 2 | 16 | 64)):  # nested | caller's code table | grouped | peer
+            plain += 1
             assert 0 not in vm_waits, f"{name}: vmcnt(0) in front of the first barrier - the weight ring is drained there ({vm_waits})"
             ring_loads = sum(1 for ln in head if ln.startswith("buffer_load_dwordx4"))
-            if waves == 16:
-                assert ring_loads == 2 * ns, f"{name}: {ring_loads} weight requests in front of the barrier, expected both ring positions ({2 * ns})"
-                plain16_with_two_rings += 1
-            else:
-                assert ring_loads == ns, f"{name}: {ring_loads} weight requests in front of the barrier, expected one ring position ({ns})"
-    assert plain16_with_two_rings >= 12 and checked >= 100, (plain16_with_two_rings, checked)
+            assert ring_loads == ns, f"{name}: {ring_loads} weight requests in front of the barrier, expected one ring position ({ns})"
+    assert checked >= 100 and plain >= 24, (checked, plain)
 
 
 def test_launch_plan_workspace_query_is_pure_host_logic():

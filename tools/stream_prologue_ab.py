@@ -1,7 +1,5 @@
 #!/usr/bin/env python3
-"""Round 5 A/B of the streaming kernel (csrc/gemv4_stream.hip): wavefronts per workgroup (16 / 8) and the ring-late prologue (the
-table-building wavefronts request their weight ring BEHIND the table build, so that the activation image is in the CU's memory
-pipeline in front of all weight traffic; a host-chosen run-time bit of the 16-wavefront instances). bf16, one activation row, NF4 bs 64, fp32 absmax (the sweep-only
+"""Round 5 A/B of the streaming kernel (csrc/gemv4_stream.hip): wavefronts per workgroup (16 / 8) and ring depth. bf16, one activation row, NF4 bs 64, fp32 absmax (the sweep-only
 instances); per-launch us over an HBM-resident rotation of distinct layers, hipGraph-replayed (launch-to-launch time in a dependent
 stream).
     python tools/stream_prologue_ab.py [--quick] [--rounds 5]
@@ -24,10 +22,9 @@ from bitsandbytes_amd.backends import hip  # noqa: E402
 from stream_ab import alg_bytes, make_layers  # noqa: E402
 
 SHAPES = [(4096, 4096), (8192, 8192), (11008, 4096), (4096, 11008), (14336, 4096), (28672, 8192), (1376, 4096), (512, 11008)]
-# (label, ring depth knob, nt knob, wavefronts). nt knob: -1 = built-in (non-temporal policy, ring-late by the host's heuristic),
-# 2 / 3 = ring-late forced on / off. (The first runs of this tool - profiles/r5_stream_prologue_ab.txt, first table - also had ring
-# depths 3 and 4 at 16 wavefronts: 2 - 25 % slower on every shape, dropped from the instance set again.)
-CONFIGS = [("built-in", 0, -1, 0), ("16 off", 0, 3, 16), ("16 late", 0, 2, 16), ("8 r4", 0, -1, 8)]
+# (label, ring depth knob, nt knob, wavefronts). (Runs 2 and 3 of profiles/r5_stream_prologue_ab.txt had more columns: the ring-late
+# prologue - dropped, DESIGN 6b - and ring depths 3 / 4 at 16 wavefronts with it.)
+CONFIGS = [("built-in", 0, -1, 0), ("16 r2", 0, -1, 16), ("16 r3", 3, -1, 16), ("8 r4", 0, -1, 8)]
 
 
 def tune(ns=0, nt=-1, waves=0):
