@@ -117,7 +117,7 @@ struct PeerChain {
     uint32_t epoch_offset;  // exchanges produced by earlier launches since the buffer's epoch word was last advanced
     int mode;               // bit 0: x = the current exchange (A is ignored); bit 1: y goes to the exchange (+ to out when non-NULL);
                             // bit 2: rows come in fours (ns and the rows per workgroup are multiples of 4): two granules per store;
-                            // bit 3 (with bit 0): the exchange holds [gate | up] halves per rank, x = silu(gate) * up (kGateRounds)
+                            // bit 3 (with bits 1 and 2): rows are (gate, up) pairs, the exchange gets silu(gate) * up - ns / 2 values
 };
 constexpr size_t kChainDataOffset = 256;
 // The i-th exchange since the last read-out (i = epoch_offset + 1 of the launch that produces it) lives in region i % kChainRegions:
@@ -131,13 +131,14 @@ constexpr size_t kChainDataOffset = 256;
 // exchange n - 1, which every rank produces behind its own read-out.
 constexpr uint32_t kChainRegions = 64;
 constexpr int kChainRounds = 8; // 16-byte fetches per builder lane: K <= 8 * 8 KiB / 4 B = 16384 values
-// "Gated" consumption (mode bit 3; one Llama-style FFN block on the chain, BASELINE.json configs[3]): the exchange holds the outputs
-// of a launch over the rank's gate rows FOLLOWED BY its up rows - rank-major [rank][gate ns_g | up ns_g], ns_g = K / world - and the
-// consumer's x is  x[j] = T(T(silu(gate[j])) * up[j]),  j = rank * ns_g + r  (torch's own arithmetic for `F.silu(g) * u` on 16-bit
-// tensors: each op in fp32, rounded once). A builder lane fetches the 16 bytes = 4 values of gate and the matching 16 bytes of up per
-// round: kGateRounds rounds of 8 wavefronts x 64 lanes x 4 values = 2048 values each, K <= 14336 (Llama-3-8B's F; 11008 for Llama-2).
-constexpr int kGateRounds = 7;
-constexpr int kFetchVecs = 2 * kGateRounds; // fetch registers of a builder lane: 8 in the plain form, 7 + 7 in the gated one
+// "Gated" production (mode bit 3; one Llama-style FFN block on the chain, BASELINE.json configs[3]): the launch runs over a matrix
+// whose rows INTERLEAVE this rank's gate and up rows - row 2 r = gate row r, row 2 r + 1 = up row r - so the thread pair that
+// exchanges its outputs in the epilogue anyway holds g and u of ONE activation, and what goes to the exchange is
+//     a[rank * ns / 2 + r] = T(T(silu(g)) * u)          (torch's arithmetic for `F.silu(g) * u` on 16-bit tensors: each op in fp32,
+// rounded once to T) - half as many values as rows, two of them per granule, one 8-byte store per four rows. The down projection then
+// consumes that exchange in the PLAIN form. (A first build computed the activation in the consumer - 28 exact expf + IEEE divisions
+// per builder lane in front of the first barrier: +1.1 us per block, profiles/r5_peer_ffn.txt; here it is ~ R / 2 activations per
+// workgroup, in an epilogue that waits for nothing.)
 // re-fetches a wait is still worth once a wait on the same buffer has run into its bound (the status word is sticky): the peer
 // is gone - every later round and launch would otherwise spin the full bound again, ~30 s each, before a host-side check() runs
 constexpr uint32_t kPeerPollsAfterTimeout = 16;
@@ -205,8 +206,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     // so a wavefront does not start with a dependent s_load from a cold kernarg buffer
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, int hot_N, int hot_K,
     int hot_packed /* M | bs_shift << 18 | P << 23 */, int hot_geom /* R | SW << 16 | G << 21 */,
-    int hot_inv /* ceil(256 / SW) | (peer chain, gated) ns_g << 12 */, int hot_aux /* (peer chain, gated) ceil(2^32 / (ns_g / 4)) */,
-    const StreamArgs p) {
+    int hot_inv /* ceil(256 / SW) */, const StreamArgs p) {
     constexpr bool NESTED = FLAGS & kNested, CODEPTR = FLAGS & kCodePtr, NT = FLAGS & kNT, GROUPED = FLAGS & kGrouped;
     constexpr bool MULTI = FLAGS & kMulti;
     constexpr bool PEER = (FLAGS & kPeer) != 0;
@@ -240,9 +240,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
     const int nrows = (rows_total - row_begin < R) ? rows_total - row_begin : R;
     const int m0 = blockIdx.y * MB;
     // wave -> (segment column sw, row group g): g = wave / SW by a host-made reciprocal (exact for wave < 16 <= 256 / SW)
-    const int g = (wave * (PEER ? (hot_inv & 0xFFF) : hot_inv)) >> 8;
-    if constexpr (!PEER)
-        (void)hot_aux;
+    const int g = (wave * hot_inv) >> 8;
     const int sw = wave - g * SW;
 #ifdef BNB_PROFILING
     if (p.dbg && lane == 0)
@@ -538,39 +536,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
         // ring, the in-order counter made x wait for every weight byte: +1.2 us per layer, profiles/r4_peer_chain.txt). The epoch
         // they depend on is one scalar load; a lane past the end of x is out of range (zeros, no traffic).
         bool x_from_peer = false;
-        [[maybe_unused]] bool gated = false;
-        u32x4 gx[PEER ? kFetchVecs : 1];
+        u32x4 gx[PEER ? kChainRounds : 1];
         if constexpr (PEER) {
             // (the mode travels in the spare bits of a PRELOADED argument and, when x comes from the exchange, the address of the
             // exchange's region in the slot of the unused activation pointer - the region of an exchange is its POSITION in the chain,
-            // which the host knows, only its tag carries the device-side epoch: the fetch depends on no load at all. The gated form's
-            // two constants - ns_g and the reciprocal of ns_g / 4 - arrive in preloaded dwords too.)
+            // which the host knows, only its tag carries the device-side epoch: the fetch depends on no load at all)
             const int peer_mode = (hot_packed >> 24) & 15;
             x_from_peer = (peer_mode & 1) != 0;
-            gated = (peer_mode & 8) != 0;
             if (x_from_peer && wave < WAVES - BUILDERS) {
-                if (!gated) {
-                    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(hot_A), 0, K * 4, kRsrcFlags);
+                const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(hot_A), 0, K * 4, kRsrcFlags);
 #pragma unroll
-                    for (int r = 0; r < kChainRounds; ++r)
-                        gx[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                              rs_x, static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave) * 64 + lane) * 16u, 0, 17 /* sc0 sc1 */));
-                } else {
-                    // values 4 j4 .. 4 j4 + 3 of x belong to rank q = j4 / (ns_g / 4) - exact by one v_mul_hi (the host's reciprocal;
-                    // tests/checks/peer_gated_division.py sweeps every divisor the form admits) - and sit at value offset
-                    // 4 j4 + q ns_g (gate) / + ns_g more (up) of the exchange, 4 bytes of granule per value; past the end of x: out of range
-                    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(hot_A), 0, K * 8, kRsrcFlags);
-                    const uint32_t nsg = static_cast<uint32_t>(hot_inv) >> 12;
-#pragma unroll
-                    for (int r = 0; r < kGateRounds; ++r) {
-                        const uint32_t j4 = static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave) * 64 + lane);
-                        const uint32_t q = __umulhi(j4, static_cast<uint32_t>(hot_aux));
-                        const uint32_t off = (4u * j4 + q * nsg) * 4u;
-                        const uint32_t oob = 4u * j4 < static_cast<uint32_t>(K) ? 0u : kOob;
-                        gx[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off | oob, 0, 17));
-                        gx[kGateRounds + r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (off + nsg * 4u) | oob, 0, 17));
-                    }
-                }
+                for (int r = 0; r < kChainRounds; ++r)
+                    gx[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                          rs_x, static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave) * 64 + lane) * 16u, 0, 17 /* sc0 sc1 */));
             }
         }
         if (!x_from_peer)
@@ -689,43 +667,12 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
                     const uint32_t sg = c >> 8, cs = c & 255u, lp = cs / CH, q = cs % CH;
                     *reinterpret_cast<u32x2*>(ximg + ((sg * CH * 64 + CH * lp + (q ^ static_cast<uint32_t>(swz(static_cast<int>(lp))))) * 16 + half * 8)) = four;
                 };
-                if (!gated) {
 #pragma unroll
-                    for (int r = 0; r < kChainRounds; ++r) {
-                        const uint32_t off = static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave) * 64 + lane) * 16u;
-                        if (off < static_cast<uint32_t>(K) * 4u) {
-                            const u32x4 gr = settle(gx[r], off);
-                            put4(off >> 4, u32x2{gr[0], gr[2]});
-                        }
-                    }
-                } else {
-                    const uint32_t nsg = static_cast<uint32_t>(hot_inv) >> 12;
-#pragma unroll
-                    for (int r = 0; r < kGateRounds; ++r) {
-                        const uint32_t j4 = static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave) * 64 + lane);
-                        if (4u * j4 < static_cast<uint32_t>(K)) {
-                            const uint32_t q = __umulhi(j4, static_cast<uint32_t>(hot_aux));
-                            const uint32_t off = (4u * j4 + q * nsg) * 4u;
-                            const u32x4 gg = settle(gx[r], off);
-                            const u32x4 gu = settle(gx[kGateRounds + r], off + nsg * 4u);
-                            // x = T(T(silu(g)) * u): silu in fp32 ( g / (1 + exp(-g)) ), rounded to T; the product in fp32, rounded to T
-                            uint32_t outw[2];
-#pragma unroll
-                            for (int w = 0; w < 2; ++w) {
-                                const uint32_t gw = gg[2 * w], uw = gu[2 * w];
-                                unsigned short res[2];
-#pragma unroll
-                                for (int e = 0; e < 2; ++e) {
-                                    const unsigned short gb = static_cast<unsigned short>(gw >> (16 * e)), ub = static_cast<unsigned short>(uw >> (16 * e));
-                                    const float gf = static_cast<float>(__builtin_bit_cast(T, gb)), uf = static_cast<float>(__builtin_bit_cast(T, ub));
-                                    const T st = static_cast<T>(gf / (1.0f + expf(-gf)));
-                                    const T at = static_cast<T>(__fmul_rn(static_cast<float>(st), uf));
-                                    res[e] = __builtin_bit_cast(unsigned short, at);
-                                }
-                                outw[w] = static_cast<uint32_t>(res[0]) | (static_cast<uint32_t>(res[1]) << 16);
-                            }
-                            put4(j4, u32x2{outw[0], outw[1]});
-                        }
+                for (int r = 0; r < kChainRounds; ++r) {
+                    const uint32_t off = static_cast<uint32_t>((r * (WAVES - BUILDERS) + wave) * 64 + lane) * 16u;
+                    if (off < static_cast<uint32_t>(K) * 4u) {
+                        const u32x4 gr = settle(gx[r], off);
+                        put4(off >> 4, u32x2{gr[0], gr[2]});
                     }
                 }
             }
@@ -807,7 +754,31 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
                 const uint32_t pair2 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((lane ^ 2) << 2, static_cast<int>(pair))); // rows r + 2, r + 3
                 const size_t slot = kChainDataOffset + (static_cast<size_t>((p.peer.epoch_offset + 1u) & (kChainRegions - 1u)) * p.peer.max_granules +
                                                         ((static_cast<size_t>(p.peer.rank) * static_cast<size_t>(rows_total) + static_cast<size_t>(row)) >> 1)) * 8u;
-                if (p.peer.mode & 4) {
+                if (p.peer.mode & 8) {
+                    // gated production: this thread's row and its neighbour's are (gate, up) of activation row / 2. silu in fp32
+                    // ( g / (1 + exp(-g)), exact expf and IEEE division: torch's own kernel ), rounded to T; the product in fp32,
+                    // rounded to T - bit for bit what `F.silu(g) * u` gives on the T-valued outputs of the two unsharded layers
+                    // (tests/checks/peer_ranks.py sweeps every finite 16-bit pattern of g). Rows come in fours (host-enforced): the
+                    // thread of row 4 i stores ONE granule = activations 2 i, 2 i + 1 of this rank.
+                    const float gf = static_cast<float>(tv), uf = static_cast<float>(__builtin_bit_cast(T, static_cast<unsigned short>(other)));
+                    const T st = static_cast<T>(gf / (1.0f + expf(-gf)));
+                    const T at = static_cast<T>(__fmul_rn(static_cast<float>(st), uf));
+                    const uint32_t abits = static_cast<uint32_t>(__builtin_bit_cast(unsigned short, at));
+                    const uint32_t anext = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((lane ^ 2) << 2, static_cast<int>(abits)));
+                    if (!(row & 3)) {
+                        using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+                        const u32x2 granule = {abits | (anext << 16), epoch_out};
+                        const size_t aslot = kChainDataOffset + (static_cast<size_t>((p.peer.epoch_offset + 1u) & (kChainRegions - 1u)) * p.peer.max_granules +
+                                                                 ((static_cast<size_t>(p.peer.rank) * static_cast<size_t>(rows_total >> 1) + static_cast<size_t>(row >> 1)) >> 1)) * 8u;
+                        for (int pr = 0; pr < p.peer.world; ++pr) {
+                            unsigned char* const dst = p.peer.base[pr] + aslot;
+                            if (pr == p.peer.rank)
+                                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(granule) : "memory");
+                            else
+                                asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(granule) : "memory");
+                        }
+                    }
+                } else if (p.peer.mode & 4) {
                     // two granules per store: a 16-byte system-scope store costs the fabric what an 8-byte one does (each aligned
                     // 8-byte half carries its own tag, so the two need not land together)
                     if (!(row & 3)) {
@@ -980,7 +951,7 @@ template <typename T, int MB, int WAVES, int NS, int FLAGS> void launch_one(cons
             ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), ge.lds);
             hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), ge.lds, stream, a.A, m0.B, m0.absmax, m0.absmax8, m0.N, a.K,
                                (a.M & 0x3FFFF) | (a.bs_shift << 18) | (ge.P << 23),
-                               ge.R | (ge.SW << 16) | (ge.G << 21), (256 + ge.SW - 1) / ge.SW, 0, a);
+                               ge.R | (ge.SW << 16) | (ge.G << 21), (256 + ge.SW - 1) / ge.SW, a);
             return;
         }
     }
@@ -996,7 +967,7 @@ template <typename T, int MB, int WAVES, int NS, int FLAGS> void launch_one(cons
     ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), ge.lds);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), ge.lds, stream, a.A, m0.B, m0.absmax, m0.absmax8, m0.N, a.K,
                        (a.M & 0x3FFFF) | (a.bs_shift << 18) | (ge.P << 23),
-                       ge.R | (ge.SW << 16) | (ge.G << 21), (256 + ge.SW - 1) / ge.SW, 0, a);
+                       ge.R | (ge.SW << 16) | (ge.G << 21), (256 + ge.SW - 1) / ge.SW, a);
 }
 
 // The sweep-only variants (other ring depths, default cache policy) exist for ONE configuration - bf16, one activation
@@ -1113,16 +1084,9 @@ template <typename T, int FLAGS> void launch_peer(const StreamArgs& a, const Geo
     static LdsLimit lds_limit;
     ensure_dynamic_lds(lds_limit, reinterpret_cast<const void*>(kern), ge.lds);
     const StreamMat& m0 = a.mat[0];
-    // (gated consumption: ns_g = K / world in the spare bits of the reciprocal's dword, ceil(2^32 / (ns_g / 4)) in the last preloaded one)
-    int inv = (256 + ge.SW - 1) / ge.SW, aux = 0;
-    if (a.peer.mode & 8) {
-        const uint32_t nsg = static_cast<uint32_t>(a.K / a.peer.world), d = nsg / 4u;
-        inv |= static_cast<int>(nsg << 12);
-        aux = static_cast<int>(static_cast<uint32_t>(((1ull << 32) + d - 1) / d));
-    }
     hipLaunchKernelGGL(kern, dim3(ge.grid_x, 1), dim3(16 * 64), ge.lds, stream, a.A, m0.B, m0.absmax, m0.absmax8, m0.N, a.K,
                        (1 & 0x3FFFF) | (a.bs_shift << 18) | (1 << 23) | ((a.peer.mode & 15) << 24),
-                       ge.R | (ge.SW << 16) | (ge.G << 21), inv, aux, a);
+                       ge.R | (ge.SW << 16) | (ge.G << 21), (256 + ge.SW - 1) / ge.SW, a);
 }
 template <typename T> void launch_peer_flags(const StreamArgs& a, const Geometry& ge, int quant_type, hipStream_t stream) {
     const int sel = (a.mat[0].absmax8 != nullptr ? 1 : 0) | (quant_type == kFP4 ? 2 : 0);
@@ -1189,18 +1153,12 @@ static bool peer_geometry(int world, int ns, int K, int blocksize, int mode, lon
     if (world < 1 || world > 8 || ns < 2 || (ns & 1) || K < 32 || (K % 32) != 0 || blocksize < 32 || !is_pow2(blocksize) || (mode & 3) == 0 ||
         max_values < 4 || (max_values & 3) || max_values >= (1L << 28))
         return false; // (max_values in fours: max_granules is then even, every region 16-byte aligned - the quad stores and b128 fetches need it)
-    if ((mode & 8) && !(mode & 1))
-        return false; // gated is a form of consumption
-    if (mode & 8) {
-        // x = silu(gate) * up from an exchange of [gate ns_g | up ns_g] per rank: 2 K values in the region, whole fours per rank
-        // (a lane's four values never straddle ranks; ns_g / 4 >= 2 keeps the reciprocal inside a dword), K within the fetch rounds
-        if (K % (4 * world) != 0 || K / world < 8 || K > kGateRounds * 2048 || 2L * K > max_values)
-            return false;
-    } else if ((mode & 1) && (K > kChainRounds * 2048 || K > max_values)) {
+    if ((mode & 1) && (K > kChainRounds * 2048 || K > max_values))
         return false;
-    }
-    if ((mode & 2) && static_cast<long>(world) * ns > max_values)
-        return false;
+    if ((mode & 8) && (!(mode & 2) || (ns & 3)))
+        return false; // gated is a form of production, over (gate, up) row pairs that come in fours
+    if ((mode & 2) && static_cast<long>(world) * ((mode & 8) ? ns / 2 : ns) > max_values)
+        return false; // (a gated launch puts one activation per row PAIR into the exchange)
     // rows per workgroup: even (granules are row pairs), and no more workgroups than the caller allows (ranks that share one
     // device - a test set-up - must be co-resident: a launch that waits for its peers may not fill the device alone)
     int cus = device_cu_count();
@@ -1216,8 +1174,11 @@ static bool peer_geometry(int world, int ns, int K, int blocksize, int mode, lon
         return false;
     if (out_ge)
         *out_ge = ge;
+    const bool quads = (ns & 3) == 0 && (ge.R & 3) == 0;
+    if ((mode & 8) && !quads)
+        return false; // (the partial-sum slots clamped the rows per workgroup off a multiple of four)
     if (out_quads)
-        *out_quads = (ns & 3) == 0 && (ge.R & 3) == 0;
+        *out_quads = quads;
     return true;
 }
 

@@ -292,12 +292,12 @@ class ShardedFFN4bit(nn.Module):
     over the ranks - BASELINE.json ``configs[3]`` as it states it: the Llama FFN matrices sharded across the GPUs of a node. With a
     :class:`bitsandbytes_amd.peer.PeerChain` the block is TWO launches and one small read-out per rank and token:
 
-    1. one launch over this rank's gate rows followed by its up rows (the two shards are concatenated into ONE ``[2 ns, H]`` matrix at
-       construction - they share ``x``, and one matrix needs no grouped form of the peer kernel), whose outputs go straight into
-       every rank's exchange buffer, rank-major ``[rank][gate | up]``;
-    2. the down shard's launch, which takes its input from that exchange and computes ``silu(gate) * up`` on the way into its
-       activation image (``gemv(..., gated=True)``: each op in fp32, rounded once to the 16-bit type - torch's arithmetic for
-       ``F.silu(g) * u``), and whose outputs go to the next exchange;
+    1. one launch over this rank's gate and up rows, INTERLEAVED into one ``[2 ns, H]`` matrix at construction (row ``2 r`` = gate row
+       ``r``, row ``2 r + 1`` = up row ``r``: they share ``x``, and the thread pair that exchanges its outputs in the kernel's epilogue
+       then holds ``g`` and ``u`` of one activation). The epilogue computes ``silu(g) * u`` (``gemv(..., gated=True)``: each op in
+       fp32, rounded once to the 16-bit type - torch's arithmetic for ``F.silu(g) * u``) and stores THAT into every rank's exchange
+       buffer: ``ns`` values per rank instead of ``2 ns``;
+    2. the down shard's launch, which takes its input from that exchange in the chain's plain form, outputs to the next exchange;
     3. ``read``: the gathered ``y``.
 
     Values are bit-identical to the unsharded block (``down(F.silu(gate(x)) * up(x))`` with the three ``Linear4bit`` layers) and to
@@ -317,15 +317,16 @@ class ShardedFFN4bit(nn.Module):
         self.group = ShardedLinear4bitGroup([gate, up])
         self.chain = chain
         ns, H = int(sg.shape[0]), int(sg.shape[1])
-        # ONE matrix [gate rows; up rows]: packed bytes and absmax are row-major over [N, K], so the concatenation of the two shards'
-        # buffers IS the packed form of the stacked matrix. Nested statistics are carried un-nested (the two matrices have their own
-        # offsets and second-level tables; the fp32 values are exactly the ones the nested kernels reconstruct).
+        # ONE matrix with the rows interleaved (g0, u0, g1, u1, ...): packed bytes and absmax are row-major over [N, K] with whole
+        # rows (K % blocksize == 0, K even), so interleaving the two shards' buffers row by row IS the packed form of that matrix.
+        # Nested statistics are carried un-nested (the two matrices have their own offsets and second-level tables; the fp32 values
+        # are exactly the ones the nested kernels reconstruct).
         wg, wu = gate.weight.reshape(-1), up.weight.reshape(-1)
         if wg.dtype != torch.uint8:
             wg, wu = wg.view(torch.uint8), wu.view(torch.uint8)
-        self.register_buffer("gu_weight", torch.cat([wg, wu]).view(-1, 1), persistent=False)
-        self.gu_state = QuantState(absmax=torch.cat([_plain_absmax(sg), _plain_absmax(su)]), shape=torch.Size((2 * ns, H)), code=sg.code,
-                                   blocksize=sg.blocksize, quant_type=sg.quant_type, dtype=sg.dtype)
+        self.register_buffer("gu_weight", torch.stack([wg.view(ns, -1), wu.view(ns, -1)], dim=1).reshape(-1, 1).contiguous(), persistent=False)
+        am = torch.stack([_plain_absmax(sg).view(ns, -1), _plain_absmax(su).view(ns, -1)], dim=1).reshape(-1).contiguous()
+        self.gu_state = QuantState(absmax=am, shape=torch.Size((2 * ns, H)), code=sg.code, blocksize=sg.blocksize, quant_type=sg.quant_type, dtype=sg.dtype)
         self._gu_bias = {}
 
     def _stacked_bias(self, dtype):
@@ -337,7 +338,7 @@ class ShardedFFN4bit(nn.Module):
             ns = int(self.gate.quant_state.shape[0])
             dev = self.gu_weight.device
             parts = [(b.to(dtype) if b is not None else torch.zeros(ns, dtype=dtype, device=dev)) for b in (bg, bu)]
-            self._gu_bias = {"key": key, "bias": torch.cat(parts)}
+            self._gu_bias = {"key": key, "bias": torch.stack(parts, dim=1).reshape(-1).contiguous()}  # interleaved like the rows
         return self._gu_bias["bias"]
 
     def fused(self, x: torch.Tensor) -> bool:
@@ -353,8 +354,8 @@ class ShardedFFN4bit(nn.Module):
         ns, H = int(self.gate.quant_state.shape[0]), int(self.gate.quant_state.shape[1])
         Fdim = int(sd.shape[1])
         return (chain.world * ns == Fdim == self.gate.out_features and chain.world * int(sd.shape[0]) == self.down.out_features
-                and chain.serves(2 * ns, H, int(self.gu_state.blocksize), consume=False)
-                and chain.serves(int(sd.shape[0]), Fdim, int(sd.blocksize), consume=True, gated=True))
+                and chain.serves(2 * ns, H, int(self.gu_state.blocksize), consume=False, gated=True)
+                and chain.serves(int(sd.shape[0]), Fdim, int(sd.blocksize), consume=True))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.fused(x):
@@ -370,10 +371,10 @@ class ShardedFFN4bit(nn.Module):
             db = db.to(x.dtype)
         chain, done = self.chain, 0
         try:
-            if not chain.gemv(x1, self.gu_weight, self.gu_state, bias=gu_bias, consume=False, produce=True):
+            if not chain.gemv(x1, self.gu_weight, self.gu_state, bias=gu_bias, consume=False, produce=True, gated=True):
                 raise RuntimeError("PeerChain refused the gate / up launch although its own shape check accepted it")
             done = 1
-            if not chain.gemv(None, self.down.weight, self.down.quant_state, bias=db, consume=True, produce=True, dtype=x.dtype, gated=True):
+            if not chain.gemv(None, self.down.weight, self.down.quant_state, bias=db, consume=True, produce=True, dtype=x.dtype):
                 raise RuntimeError("PeerChain refused the down launch although its own shape check accepted it")
             done = 2
             return chain.read(self.down.out_features, x.dtype).view(*lead, self.down.out_features)

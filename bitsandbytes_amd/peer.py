@@ -316,12 +316,13 @@ class PeerChain(_PeerBuffers):
              out_local: Optional[torch.Tensor] = None, consume: bool = False, produce: bool = True,
              dtype: Optional[torch.dtype] = None, gated: bool = False) -> bool:
         """One layer: ``y_shard = x @ dequant(packed)^T (+ bias)``. ``consume``: x is the current exchange (pass ``x=None``);
-        ``produce``: y goes to every rank's exchange buffer (and to ``out_local`` when given). ``gated`` (with ``consume``): the
-        current exchange was produced by ONE launch over this rank's gate rows followed by its up rows (``K / world`` each), and
-        ``x = silu(gate) * up`` - the down projection of a Llama-style FFN block (``parallel.ShardedFFN4bit``). Returns False -
-        nothing launched - when the fused form does not serve the problem."""
-        if gated and not consume:
-            raise ValueError("gated=True is a form of consume=True")
+        ``produce``: y goes to every rank's exchange buffer (and to ``out_local`` when given). ``gated`` (with ``produce``): the
+        matrix interleaves this rank's gate and up rows (row ``2 r`` = gate row ``r``, row ``2 r + 1`` = up row ``r``) and the
+        exchange receives ``silu(gate) * up`` - ``ns / 2`` values per rank, computed in the launch's epilogue; the down projection of
+        a Llama-style FFN block then consumes it in the plain form (``parallel.ShardedFFN4bit``). Returns False - nothing launched -
+        when the fused form does not serve the problem."""
+        if gated and not produce:
+            raise ValueError("gated=True is a form of produce=True")
         if self._broken:
             raise RuntimeError(f"this PeerChain is out of step with its peers and cannot be used any more ({self._broken}); build a new one collectively")
         st = quant_state

@@ -181,10 +181,10 @@ int bnb_mi355x_peer_status(const void* local_buffer);
  * yet. No separate collective launch, no flag, no fence (csrc/gemv4_stream.hip, PeerChain).
  *   mode bit 0: x = the current exchange (K values; A is ignored)     bit 1: y (ns values of this rank, rank-major) goes to the
  *   exchange; it is also written to out_local[ns] when that is non-NULL. A launch with bit 1 completes one exchange.
- *   mode bit 3 (with bit 0), "gated": the current exchange was produced by a launch over this rank's GATE rows followed by its UP
- *   rows (one matrix of 2 ns_g rows, ns_g = K / world; rank-major [rank][gate | up]) and x[j] = T(T(silu(gate[j])) * up[j]) - one
- *   Llama-style FFN block = a produce launch over [gate; up], then this launch over the down shard (K = F <= 14336, K % (4 world)
- *   == 0, 2 K <= max_values). Each op in fp32 and rounded once to T: torch's arithmetic for F.silu(g) * u on 16-bit tensors.
+ *   mode bit 3 (with bit 1), "gated": the launch runs over a matrix whose rows INTERLEAVE this rank's gate and up rows (row 2 r =
+ *   gate row r, row 2 r + 1 = up row r; ns % 4 == 0) and what goes to the exchange is a[r] = T(T(silu(g_r)) * u_r) - ns / 2 values
+ *   per rank, each op in fp32 and rounded once to T: torch's arithmetic for F.silu(g) * u on 16-bit tensors. One Llama-style FFN
+ *   block = this launch over [gate; up], then a plain consuming launch over the down shard (K = F = world x ns / 2).
  *   wg_limit: at most that many workgroups (0 = one per CU) - ranks that share ONE device must be co-resident.
  *   epoch_word: 4 bytes of ORDINARY device memory owned by this rank, zeroed once (exchanges completed up to the last read-out;
  *   on the device because a replayed hipGraph re-runs its launches; only the read-out advances it).

@@ -169,6 +169,79 @@ def main():
                 chain.check()
             finally:
                 chain.close()
+        # ---- one gated FFN block on the chain (BASELINE.json configs[3]: the Llama FFN matrices sharded over the ranks):
+        # [gate; up] (rows interleaved) as ONE produce launch whose epilogue computes silu(gate) * up, the down shard's launch
+        # consuming that exchange, the read-out - against the UNSHARDED block down(F.silu(gate(x)) * up(x)) of the three Linear4bit layers, bit for bit.
+        import torch.nn.functional as TF
+
+        chain = PeerChain(max_values=32768)
+        try:
+            for (H, Fd, dt, qt, dq, bias) in ((4096, 11008, torch.bfloat16, "nf4", False, False), (4096, 14336, torch.bfloat16, "nf4", True, False),
+                                              (2048, 4096, torch.float16, "fp4", True, True)):
+                torch.manual_seed(21)  # same weights on every rank
+                gate, up, down = [bnn.Linear4bit(k, n, bias=bias, compute_dtype=dt, quant_type=qt, compress_statistics=dq).to(dev)
+                                  for k, n in ((H, Fd), (H, Fd), (Fd, H))]
+                ffn = bnb.shard_ffn4bit(gate, up, down, rank, world, chain=chain, peer=peer)
+
+                def block(x):
+                    return down(TF.silu(gate(x)) * up(x))
+
+                x = torch.randn(1, H, device=dev, dtype=dt)
+                assert ffn.fused(x), (H, Fd, dt)
+                for it in range(5):
+                    torch.manual_seed(500 + it)
+                    x = torch.randn(1, H, device=dev, dtype=dt) * (1 + it)
+                    y = ffn(x)
+                    torch.cuda.synchronize()
+                    assert torch.equal(y, block(x)), ("ffn", H, Fd, dt, qt, dq, it)
+                graphed = bnb.GraphedBlock(ffn, x, peers=[chain])
+                for it in range(3):
+                    torch.manual_seed(600 + it)
+                    x = torch.randn(1, H, device=dev, dtype=dt)
+                    y = graphed(x).clone()
+                    torch.cuda.synchronize()
+                    assert torch.equal(y, block(x)), ("ffn graph", H, Fd, dt, it)
+                # two rows are outside the fused form: grouped launch, torch's activation, two gathers. (Two, not three: from three rows
+                # on the router picks the kernel FAMILY by matrix size - a shard and the full matrix can then run different arithmetic.)
+                x2 = torch.randn(2, H, device=dev, dtype=dt)
+                assert not ffn.fused(x2) and torch.equal(ffn(x2), block(x2))
+            chain.check()
+            if world == 1:
+                # The activation in the producer's epilogue, EXHAUSTIVELY: gate = identity, up = a permutation, down = identity - NF4 holds
+                # 1.0 and 0.0 exactly, so gate(x) = x, up(x) = x[perm] and down(a) = a bit for bit, and the block's output IS
+                # T(T(silu(g)) * u). Every finite 16-bit pattern is a g once (the upper half of x holds multipliers in [-1, 1]: no
+                # overflow, an inf * 0 in the down layer's sum would turn the whole row into NaN); the unsharded block computes the
+                # same through torch's own silu and multiply.
+                Hh = 4096
+                eye = torch.eye(Hh, device=dev)
+                perm = torch.cat([2048 + (torch.arange(2048, device=dev) * 7 + 3) % 2048, torch.arange(2048, Hh, device=dev)])
+                for dt, ibits in ((torch.bfloat16, torch.int16), (torch.float16, torch.int16)):
+                    def make(W):
+                        layer = bnn.Linear4bit(Hh, Hh, bias=False, compute_dtype=dt, quant_type="nf4")
+                        layer.weight = bnn.Params4bit(W.to(dt), requires_grad=False, quant_type="nf4", module=layer)
+                        return layer.to(dev)
+
+                    gate, up, down = make(eye), make(eye[perm]), make(eye)
+                    ffn = bnb.shard_ffn4bit(gate, up, down, rank, world, chain=chain)
+                    pats = torch.arange(65536, device=dev, dtype=torch.int32).to(torch.int16).view(dt)
+                    pats = pats[torch.isfinite(pats)]
+                    torch.manual_seed(9)
+                    seen = 0
+                    for i in range(0, pats.numel(), 2048):
+                        gpart = pats[i:i + 2048]
+                        x = torch.cat([gpart, gpart.new_zeros(2048 - gpart.numel()), (torch.rand(2048, device=dev) * 2 - 1).to(dt)]).view(1, Hh)
+                        assert ffn.fused(x)
+                        y = ffn(x)
+                        want = down(TF.silu(gate(x)) * up(x))
+                        torch.cuda.synchronize()
+                        assert bool(torch.isfinite(want).all()) and torch.equal(y, want), ("silu sweep", dt, i, int((y != want).sum()))
+                        # (and the block really is the activation: the identity layers add nothing)
+                        assert torch.equal(want[0, :gpart.numel()], TF.silu(gpart) * x[0, perm[:gpart.numel()]])
+                        seen += gpart.numel()
+                    assert seen == pats.numel() >= 63488, seen
+                chain.check()
+        finally:
+            chain.close()
         print(f"PEER_OK {rank}", flush=True)
     finally:
         peer.close()

@@ -613,3 +613,60 @@ def test_peer_chain_counts_in_fours_and_poisoned_chain_raises():
     with pytest.raises(RuntimeError, match="out of step"):
         chain.gemv(None, None, None, consume=True, dtype=torch.bfloat16)
     chain._local = None  # (__del__ of the half-built object)
+
+
+@pytest.mark.parametrize("double_quant", [False, True], ids=["plain", "nested"])
+def test_sharded_ffn_block_host_logic(double_quant):
+    """ShardedFFN4bit off the fused form (CPU, a group of one, the oracle's arithmetic): the row-interleaved [gate; up] matrix it would
+    hand to the peer chain computes exactly what the two members compute (nested statistics carried un-nested: the same fp32 scales),
+    and the block equals down(silu(gate(x)) * up(x)) of the unsharded layers. The fused form's routing rules - one row, 16-bit,
+    no gradients wanted, shapes the chain serves - with a duck-typed chain; a failure after the first launch poisons the chain."""
+    from bitsandbytes_amd.parallel import ShardedFFN4bit, ShardedLinear4bit
+
+    torch.manual_seed(1)
+    H, Fd = 128, 256
+    layers = [Linear4bit(k, n, bias=b, quant_type="nf4", compress_statistics=double_quant, compute_dtype=torch.bfloat16).to("cpu")
+              for k, n, b in ((H, Fd, True), (H, Fd, False), (Fd, H, True))]
+    shards = [ShardedLinear4bit(layer.weight.data.view(-1, 1), layer.weight.quant_state, layer.out_features,
+                                None if layer.bias is None else layer.bias.data) for layer in layers]
+    ffn = ShardedFFN4bit(*shards)
+    gate, up, down = layers
+    for M in (1, 3):
+        x = torch.randn(M, H).bfloat16()
+        with torch.no_grad():
+            want = down(torch.nn.functional.silu(gate(x)) * up(x))
+            assert torch.equal(ffn(x), want)
+            stacked = bnb.matmul_4bit(x, ffn.gu_weight, ffn.gu_state, bias=ffn._stacked_bias(torch.bfloat16))
+            assert torch.equal(stacked, torch.stack([gate(x), up(x)], dim=-1).reshape(M, -1))  # rows interleaved: g0, u0, g1, u1, ...
+    assert not ffn.gu_state.nested and ffn.gu_state.absmax.dtype == torch.float32 and tuple(ffn.gu_state.shape) == (2 * Fd, H)
+
+    class Chain(_FakeChain):
+        def __init__(self, **kw):
+            super().__init__(**kw)
+            self.gated = []
+
+        def serves(self, ns, K, blocksize, consume, produce=True, gated=False):
+            return True
+
+        def gemv(self, x, packed, st, bias=None, consume=False, produce=True, dtype=None, gated=False):
+            ok = super().gemv(x, packed, st, bias, consume, produce, dtype)
+            if ok:
+                self.gated.append(gated)
+            return ok
+
+    x1 = torch.randn(1, H).bfloat16()
+    with torch.no_grad():
+        chain = Chain()
+        fused = ShardedFFN4bit(*shards, chain=chain)
+        assert fused.fused(x1) and not fused.fused(torch.randn(2, H).bfloat16()) and not fused.fused(torch.randn(1, H))
+        y = fused(x1)
+        assert y.shape == (1, H) and chain.launched == [(False, False), (True, True)] and chain.gated == [True, False] and chain.reads == 1
+        broken = Chain(fail_at=1)
+        with pytest.raises(ValueError):
+            ShardedFFN4bit(*shards, chain=broken)(x1)
+        assert broken._broken and "FFN block stopped after 1" in broken._broken
+        first = Chain(fail_at=0)
+        with pytest.raises(ValueError):
+            ShardedFFN4bit(*shards, chain=first)(x1)
+        assert first._broken is None
+    assert not ShardedFFN4bit(*shards, chain=Chain()).fused(x1.clone().requires_grad_())

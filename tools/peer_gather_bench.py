@@ -5,7 +5,9 @@ torch.distributed's all_gather_into_tensor on an RCCL group of ONE rank (the pro
     python tools/peer_gather_bench.py [world ...]          (spawns its own ranks)
     python tools/peer_gather_bench.py chain [world ...]    the FUSED form (peer.PeerChain: the gather inside the gemv launches) against
                                                            kernel + separate gather and against the kernels alone, per layer of an
-                                                           up / down chain whose per-rank shard is 4096^2 weights at every world size"""
+                                                           up / down chain whose per-rank shard is 4096^2 weights at every world size
+    python tools/peer_gather_bench.py ffn [world ...]      one gated FFN block per token on the chain (parallel.ShardedFFN4bit) at the
+                                                           per-rank work of an 8-way sharded Llama FFN, against the member-by-member form"""
 import os
 import socket
 import subprocess
@@ -147,6 +149,56 @@ def chain_main():
         dist.destroy_process_group()
 
 
+def ffn_main():
+    """One gated FFN block per token (BASELINE.json configs[3]). The per-RANK work of an 8-way shard of a Llama FFN is a [2 x F/8, H]
+    gate / up launch and an [H/8, F] down launch whatever the number of ranks present: with WORLD processes on this one GPU the block
+    is built at F_total = WORLD x F/8, H_out = WORLD x H/8 so that every rank does exactly that work (weak scaling, as bench.py's chain).
+    us per block: the fused form (two launches + read-out on the peer chain), the member-by-member form (grouped gate / up launch,
+    one gather, torch's silu * mul, the down shard, one gather), and - world 1 only - the three UNSHARDED matrices of the 8B model."""
+    import torch.distributed as dist
+
+    import bitsandbytes_amd as bnb
+    import bitsandbytes_amd.nn as bnn
+    from bitsandbytes_amd.peer import PeerAllGather, PeerChain
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    peer = PeerAllGather(max_bytes=64 * 1024)
+    chain = PeerChain(max_values=32768)
+    try:
+        for name, H, F8, H8 in (("Llama-3-8B FFN / 8 (H 4096, F 14336)", 4096, 14336 // 8, 512), ("Llama-2-7B FFN / 8 (H 4096, F 11008)", 4096, 11008 // 8, 512)):
+            Fd, Hout = world * F8, world * H8
+            if Fd % 64:
+                continue  # (1 x 1376: the down projection's K must be whole quantization blocks)
+            torch.manual_seed(3)
+            gate, up = [bnn.Linear4bit(H, Fd, bias=False, compute_dtype=torch.bfloat16, quant_type="nf4").to(dev) for _ in range(2)]
+            down = bnn.Linear4bit(Fd, Hout, bias=False, compute_dtype=torch.bfloat16, quant_type="nf4").to(dev)
+            fused = bnb.shard_ffn4bit(gate, up, down, rank, world, chain=chain)
+            plain = bnb.shard_ffn4bit(gate, up, down, rank, world, chain=None, peer=peer)
+            x = torch.randn(1, H, device=dev, dtype=torch.bfloat16)
+            assert fused.fused(x) and torch.equal(fused(x), plain(x))
+            dist.barrier()
+            with torch.no_grad():
+                t_f = min(graph_us(lambda: fused(x), n=100) for _ in range(3))
+                dist.barrier()
+                t_p = min(graph_us(lambda: plain(x), n=100) for _ in range(3))
+            chain.check()
+            line = f"{name}, {world} process(es) on one GPU: fused chain {t_f:6.2f} us per block | member by member {t_p:6.2f}"
+            if world == 1 and rank == 0:
+                full = [bnn.Linear4bit(k, n, bias=False, compute_dtype=torch.bfloat16, quant_type="nf4").to(dev) for k, n in ((H, 8 * F8), (H, 8 * F8), (8 * F8, H))]
+                with torch.no_grad():
+                    t_u = min(graph_us(lambda: full[2](torch.nn.functional.silu(full[0](x)) * full[1](x)), n=50) for _ in range(3))
+                line += f" | the UNSHARDED 8B block on this one GPU {t_u:6.2f}"
+            if rank == 0:
+                print(line, flush=True)
+    finally:
+        chain.close()
+        peer.close()
+        dist.destroy_process_group()
+
+
 def rccl_world_one():
     import torch.distributed as dist
 
@@ -182,9 +234,11 @@ def main():
         return rccl_world_one()
     if os.environ.get("PEER_BENCH_RANK") == "chain":
         return chain_main()
+    if os.environ.get("PEER_BENCH_RANK") == "ffn":
+        return ffn_main()
     mode = "1"
-    if len(sys.argv) > 1 and sys.argv[1] == "chain":
-        mode = "chain"
+    if len(sys.argv) > 1 and sys.argv[1] in ("chain", "ffn"):
+        mode = sys.argv[1]
         del sys.argv[1]
     # (more than ~4 processes on ONE device are time-sliced by the driver - 10 ms per collective at 8: not a property of the kernel)
     worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4]
@@ -197,7 +251,7 @@ def main():
                                            PEER_BENCH_RANK=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(world)]
         for p in procs:
             p.wait(timeout=300)
-    if mode == "chain":
+    if mode in ("chain", "ffn"):
         return
     subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, PEER_BENCH_RANK="rccl"), timeout=300)
 
