@@ -745,6 +745,7 @@ template <typename T> void dispatch_mfma(GemmArgs& p, float* ws, size_t ws_bytes
 // gemm4_mfma_rt.hip (the register-transposed kernel for small batches on small / medium matrices)
 bool gemm_4bit_rt_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize);
 size_t gemm_4bit_rt_workspace_bytes(int M, int N, int K, int force_ks);
+bool gemm_4bit_rt_serves(const float* absmax, const uint8_t* absmax8, int blocksize);
 void gemm_4bit_rt(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int force_waves,
@@ -836,17 +837,20 @@ bool kq_selected(int M, int N, int K, int knob1, int* force_ks) {
 }
 } // namespace
 
-// Preconditions of the MFMA kernel: 16-bit activations, K a multiple of 256, blocksize >= 64
-// (so that a 64-k MFMA pair stays inside one quantization block), 16-byte aligned A, 8-byte aligned B.
-bool gemm_4bit_mfma_supported(int dtype, const void* A, const uint8_t* B, int M, int N, int K, int blocksize) {
-    return dtype != 0 && M >= 1 && N >= 1 && (K % kKC) == 0 && blocksize >= 64 && is_pow2(blocksize) &&
+// Preconditions of the MFMA kernels: 16-bit activations, K a multiple of 256, 16-byte aligned A, 8-byte aligned B, and a blocksize
+// >= 64 (a 64-k MFMA pair stays inside one quantization block) - or, round 5, blocksize 32 with fp32 absmax (`plain_absmax`: the
+// caller knows, the shape-only queries assume it), which the register-transposed kernel's BS32 instances serve at any M.
+bool gemm_4bit_mfma_supported(int dtype, const void* A, const uint8_t* B, int M, int N, int K, int blocksize, bool plain_absmax) {
+    return dtype != 0 && M >= 1 && N >= 1 && (K % kKC) == 0 && is_pow2(blocksize) && (blocksize >= 64 || (blocksize == 32 && plain_absmax && aligned_to(B, 16))) &&
            aligned_to(A, 16) && aligned_to(B, 8);
 }
 
 // Bytes of fp32 slab workspace the launch heuristics would like for this problem (0 = none needed).
-size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K) {
+size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K, int blocksize) {
     if (M < 1 || N < 1 || K < kKC)
         return 0;
+    if (blocksize == 32) // (served by the register-transposed kernel alone, whatever the shape)
+        return gemm_4bit_rt_workspace_bytes(M, N, K, 0);
     int fks, fw;
     const int knob1 = g_mfma_knob1.load(std::memory_order_relaxed);
     int qks;
@@ -872,6 +876,16 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
     int fks, fw;
     const int knob0 = g_mfma_knob0.load(std::memory_order_relaxed), knob1 = g_mfma_knob1.load(std::memory_order_relaxed);
     int qks;
+    if (blocksize == 32) {
+        // blocksize 32: the register-transposed kernel's BS32 instances at any M (row passes over grid.z). The callers
+        // route here only what gemm_4bit_mfma_supported(..., plain_absmax) accepted; anything else is a caller's bug.
+        if (!gemm_4bit_rt_supported(dtype, A, B, code16, M, N, K, blocksize) || !gemm_4bit_rt_serves(absmax, absmax8, blocksize)) {
+            fprintf(stderr, "bitsandbytes_amd: gemm_4bit: internal error, a blocksize-32 call outside the MFMA kernels' preconditions reached them\n");
+            exit(1);
+        }
+        return gemm_4bit_rt(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type, workspace,
+                            workspace_bytes, 0, 0, 0, stream);
+    }
     if (kq_selected(M, N, K, knob1, &qks) && gemm_4bit_kq_supported(dtype, A, B, code16, M, N, K, blocksize) &&
         gemm_4bit_kq_serves(absmax, absmax8, blocksize, K))
         return gemm_4bit_kq(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type,

@@ -78,6 +78,7 @@ template <> struct RtMma<f16> {
 
 constexpr int kRtLut = 32768;            // 256 entries x 32 copies x 4 B, at LDS address 0
 constexpr int kRtScratch = 2 * 1024 + 256; // per wavefront: two transposition tiles + the scale tile (16 x 16 B)
+constexpr int kRtScratch32 = kRtScratch + 256; // blocksize 32: eight scales per row and chunk - two scale tiles
 constexpr int kRtChunk = 256;            // k per wavefront step: four 64-k MFMA pairs
 
 struct RtArgs {
@@ -138,13 +139,26 @@ __device__ __forceinline__ float rt_code_literal(int i, bool fp4) {
 // instead of two bytes. A compile-time choice: as a run-time branch the two paths loaded into the same registers, and at their
 // join the compiler drained the queue (vmcnt(0) between a chunk's weight request and its scale / activation requests: every
 // chunk of a nested call paid an extra memory round trip - 4096^2 M = 3 6.7 us nested against 6.25 plain).
-template <typename T, int MT, int WAVES, bool NESTED, bool DIRECT, bool BL, bool BS64>
+//
+// BS32 (round 5; fp32 absmax only): blocksize 32 - the reference's fused kernels take any power-of-two blocksize
+// (csrc/gemm_4bit_simt.cu:208,225; functional.py:884-969 accepts 32), here such calls ran the streaming kernel in 4-row passes. An
+// MFMA contracts over its 32 k at once, so a 32-k block has to BE one MFMA: after the transposition lane group lg holds block lg of
+// a 128-k half in its four dwords (dword d = k 32 lg + 8 d ...), the MFMA of block j wants k 32 j + 8 g from group g - dword g of
+// group j: a 4 x 4 transposition between lane groups and dwords. Stage one is the regrouping the other instances do anyway
+// (v_permlane32_swap on the dword pairs (0, 2) and (1, 3): 2 x 2 blocks change halves), stage two a v_permlane16_swap on the pairs
+// (0, 1) and (2, 3) (odd 16-lane rows of the first against even rows of the second; semantics probed on the device,
+// tools/ubench/swap16_probe.hip, and the whole algebra replayed lane by lane in tests/checks/emulate_rt_mfma.py). The activation
+// fragment of step s is then the plain one: lane group g fetches A[row][32 s + 8 g ...] - four lanes cover 64 contiguous bytes.
+// Eight scales per row and chunk (two 16-byte loads, two scale tiles), one scale FMA set per MFMA instead of one per pair.
+template <typename T, int MT, int WAVES, bool NESTED, bool DIRECT, bool BL, bool BS64, bool BS32 = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     // hot arguments as separate scalars: preloaded into SGPRs by the command processor (14 dwords)
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, int hot_M, int hot_N,
     int hot_K, int hot_flags /* bs_shift | fp4 << 8 */, int hot_cps /* chunks per K slice */, int hot_kslices,
     const RtArgs p) {
     constexpr int THREADS = WAVES * 64;
+    static_assert(!BS32 || (!NESTED && !BS64 && BL), "blocksize 32: fp32 absmax, branch-free loads");
+    constexpr int SCRATCH = BS32 ? kRtScratch32 : kRtScratch;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -162,12 +176,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     ce = (ce < (K >> 8)) ? ce : (K >> 8);
 
     // LDS map: table | per-wavefront scratch (tile 0, tile 1, scale tile) | nested absmax code (1 KiB) | parked partial tiles
-    unsigned char* const sc = smem + kRtLut + wave * kRtScratch;
+    unsigned char* const sc = smem + kRtLut + wave * SCRATCH;
     u32x4* const tile0 = reinterpret_cast<u32x4*>(sc);
     u32x4* const tile1 = reinterpret_cast<u32x4*>(sc + 1024);
     u32x4* const stile = reinterpret_cast<u32x4*>(sc + 2048);
-    float* const code2 = reinterpret_cast<float*>(smem + kRtLut + WAVES * kRtScratch);
-    unsigned char* const red = smem + kRtLut + WAVES * kRtScratch + 1024; // [WAVES][MT][64 lanes][16 B]
+    float* const code2 = reinterpret_cast<float*>(smem + kRtLut + WAVES * SCRATCH);
+    unsigned char* const red = smem + kRtLut + WAVES * SCRATCH + 1024; // [WAVES][MT][64 lanes][16 B]
 
     // ---- sources. Rows past the end (ragged N or M) re-read the last row: MFMA rows / columns are independent and those
     // results are never stored, so no masking instructions are needed.
@@ -177,19 +191,21 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
     static_assert(!DIRECT || MT == 1, "direct activation fragments: one row tile");
     // (the lane that fetches row x / k group y of a fragment: the load roles (r, pp), or - DIRECT - the MFMA roles (ln, lg))
     const int arow_l = DIRECT ? ln : r, ag_l = DIRECT ? lg : pp;
-    const T* const abase = static_cast<const T*>(hot_A) + (ag_l & 1) * 32 + (ag_l >> 1) * 16;
+    // (k of the lane's 8 elements inside a step: the pair-interleaved order of the 64-k regrouping, or - BS32 - simply 8 ag_l)
+    const int a_lane_k = BS32 ? 8 * ag_l : (ag_l & 1) * 32 + (ag_l >> 1) * 16;
+    const T* const abase = static_cast<const T*>(hot_A) + a_lane_k;
     const long e0 = static_cast<long>(wrow) * K; // flat element index of the row start
     // (BL: byte offsets are 32-bit and stay below the descriptors' 2^31 records - gemm_4bit_rt_supported)
     constexpr uint32_t kOob = 0xFFFFFFF0u; // beyond num_records
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hot_B), 0, 0x7FFFFFFF, 0x00020000);
     const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(hot_A), 0, 0x7FFFFFFF, 0x00020000);
     const uint32_t w_off = static_cast<uint32_t>(wrow) * static_cast<uint32_t>(K >> 1) + static_cast<uint32_t>(pp * 16);
-    const uint32_t a_off = (static_cast<uint32_t>(m_base + arow_l) * static_cast<uint32_t>(K) +
-                            static_cast<uint32_t>((ag_l & 1) * 32 + (ag_l >> 1) * 16)) * static_cast<uint32_t>(sizeof(T));
+    const uint32_t a_off = (static_cast<uint32_t>(m_base + arow_l) * static_cast<uint32_t>(K) + static_cast<uint32_t>(a_lane_k)) * static_cast<uint32_t>(sizeof(T));
 
     struct Raw {
         u32x4 w[2]; // 128 k each: lane (r, pp) holds k [128 h + 32 pp, + 32) of row r
-        u32x4 s;    // the row's scales of the chunk's four 64-k sub-blocks (nested: {4 x uint8, second-level absmax})
+        u32x4 s;    // the row's scales of the chunk's four 64-k sub-blocks (nested: {4 x uint8, second-level absmax}; BS32: blocks 0 - 3)
+        u32x4 s2;   // BS32: the scales of the chunk's 32-k blocks 4 - 7
         u32x4 a[8]; // step (h, j): lane (r, pp) holds A[r][128 h + 64 (j >> 1) + 8 (j & 1) + 32 (pp & 1) + 16 (pp >> 1) + 0..7]
     };
     // Activation rows past the end of the batch are not fetched at all (an out-of-range offset - exec-masked in round 2's form:
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
             const uint32_t inval = (row < M && c < ce) ? 0u : kOob;
             raw.a[s] = __builtin_bit_cast(
                 u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                           rs_a, (a_off + static_cast<uint32_t>((128 * (s >> 2) + 64 * ((s >> 1) & 1) + 8 * (s & 1)) * sizeof(T))) | inval,
+                           rs_a, (a_off + static_cast<uint32_t>((BS32 ? 32 * s : 128 * (s >> 2) + 64 * ((s >> 1) & 1) + 8 * (s & 1)) * sizeof(T))) | inval,
                            // (wavefront-uniform by construction; said explicitly, or the scalar offset arrives in a VGPR and every
                            // load is wrapped in a readfirstlane loop - seen in the ISA of the first build)
                            __builtin_amdgcn_readfirstlane((static_cast<uint32_t>(c) * static_cast<uint32_t>(kRtChunk) +
@@ -215,7 +231,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
         }
         if (row < M)
             raw.a[s] = *reinterpret_cast<const u32x4*>(abase + static_cast<long>(row) * K + static_cast<long>(c) * kRtChunk +
-                                                       128 * (s >> 2) + 64 * ((s >> 1) & 1) + 8 * (s & 1));
+                                                       (BS32 ? 32 * s : 128 * (s >> 2) + 64 * ((s >> 1) & 1) + 8 * (s & 1)));
         else
             raw.a[s] = u32x4{0, 0, 0, 0};
     };
@@ -237,7 +253,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
         // (BL: a wavefront without a chunk issues the same loads - weights and activations out of range, the scales of the last
         // chunk again - so that the start-up has no branch around loads either)
         const long e = e0 + (static_cast<long>(BL && c >= ce ? ce - 1 : c) << 8);
-        if (NESTED ? BS64 : bs_shift == 6) {
+        if constexpr (BS32) {
+            raw.s = *reinterpret_cast<const u32x4*>(hot_absmax + (e >> 5));
+            raw.s2 = *reinterpret_cast<const u32x4*>(hot_absmax + (e >> 5) + 4);
+        } else if (NESTED ? BS64 : bs_shift == 6) {
             if constexpr (NESTED) {
                 raw.s[0] = *reinterpret_cast<const uint32_t*>(hot_absmax8 + (e >> 6));
                 raw.s[1] = __builtin_bit_cast(uint32_t, hot_absmax[e >> 14]);
@@ -335,7 +354,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
         }
         if (pp == 0)
             stile[r] = raw.s;
+        if constexpr (BS32) {
+            if (pp == 1)
+                stile[16 + r] = raw.s2;
+        }
         const u32x4 sraw = stile[ln];
+        [[maybe_unused]] u32x4 sraw2 = sraw;
+        if constexpr (BS32)
+            sraw2 = stile[16 + ln];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const auto s02 = __builtin_amdgcn_permlane32_swap(wt[h][0], wt[h][2], false, false);
@@ -344,10 +370,28 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
             wt[h][2] = s02[1];
             wt[h][1] = s13[0];
             wt[h][3] = s13[1];
+            if constexpr (BS32) {
+                // stage two of the 4 x 4 transposition: dword j of every lane group <- block j's k 8 g ... of the group
+                const auto t01 = __builtin_amdgcn_permlane16_swap(wt[h][0], wt[h][1], false, false);
+                const auto t23 = __builtin_amdgcn_permlane16_swap(wt[h][2], wt[h][3], false, false);
+                wt[h][0] = t01[0];
+                wt[h][1] = t01[1];
+                wt[h][2] = t23[0];
+                wt[h][3] = t23[1];
+            }
         }
-        float scale[4];
+        constexpr int NBLK = BS32 ? 8 : 4, PER = BS32 ? 1 : 2; // scaled blocks of a chunk, MFMAs per block
+        float scale[NBLK];
+        if constexpr (BS32) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t lo = sraw[b], hi = sraw2[b]; // (copies: see below)
+                scale[b] = __builtin_bit_cast(float, lo);
+                scale[4 + b] = __builtin_bit_cast(float, hi);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < (BS32 ? 0 : 4); ++b) {
             // (copies first: __builtin_bit_cast applied to a vector-element lvalue reads element 0 - hipcc 7.2)
             const uint32_t sb = sraw[b], s1 = sraw[1];
             // (nested, blocksize >= 128: the two bytes fetched for sub-blocks 0 and 2 become the four codes here)
@@ -363,11 +407,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int blk = 0; blk < 4; ++blk) {
+            for (int blk = 0; blk < NBLK; ++blk) {
                 f32x4 part = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int h = blk >> 1, j = 2 * (blk & 1) + i, s = 4 * h + j;
+                for (int i = 0; i < PER; ++i) {
+                    const int s = PER * blk + i, h = s >> 2, j = s & 3; // (64-k blocks: steps 2 blk, 2 blk + 1; BS32: step = block)
                     u32x4* const tile = (s & 1) ? tile1 : tile0;
                     u32x4 af;
                     if constexpr (DIRECT) {
@@ -487,8 +531,18 @@ RtPlan rt_plan(int M, int N, int K, int force_ks) {
 template <typename T, int MT, int WAVES, bool DIRECT, bool BL>
 void rt_launch_bl(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, int M, int N, int K, int flags,
                   const RtPlan& pl, const RtArgs& a, hipStream_t stream) {
-    const size_t lds = kRtLut + static_cast<size_t>(WAVES) * kRtScratch + 1024 + static_cast<size_t>(WAVES) * MT * 1024;
+    const bool bs32 = (flags & 31) == 5;
+    const size_t lds = kRtLut + static_cast<size_t>(WAVES) * (bs32 ? kRtScratch32 : kRtScratch) + 1024 + static_cast<size_t>(WAVES) * MT * 1024;
     dim3 grid((N + 15) / 16, pl.ks, (M + 16 * MT - 1) / (16 * MT));
+    if constexpr (BL) {
+        if (bs32) { // (fp32 absmax only: gemm_4bit_rt_supported; the branch-free form only)
+            auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, false, DIRECT, true, false, true>;
+            static LdsLimit lim;
+            ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
+            hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, M, N, K, flags, pl.cps, pl.ks, a);
+            return;
+        }
+    }
     if (absmax8 != nullptr && (flags & 31) == 6) {
         auto kern = gemm4_mfma_rt_kernel<T, MT, WAVES, true, DIRECT, BL, true>;
         static LdsLimit lim;
@@ -540,10 +594,17 @@ template <typename T> void rt_launch_mt(const void* A, const uint8_t* B, const f
 } // namespace
 
 bool gemm_4bit_rt_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize) {
-    return dtype != 0 && code16 == nullptr && M >= 1 && N >= 1 && K >= kRtChunk && (K % kRtChunk) == 0 && blocksize >= 64 && is_pow2(blocksize) &&
+    // (blocksize 32 - the BS32 instances - with fp32 absmax only: gemm_4bit_rt_serves)
+    return dtype != 0 && code16 == nullptr && M >= 1 && N >= 1 && K >= kRtChunk && (K % kRtChunk) == 0 && blocksize >= 32 && is_pow2(blocksize) &&
            aligned_to(A, 16) && aligned_to(B, 16) &&
            // (byte offsets of the buffer loads are 32-bit and must stay below the descriptors' 2^31 records)
            static_cast<long long>(N) * K < (1LL << 32) && static_cast<long long>(M) * K < (1LL << 30);
+}
+
+// statistics the kernel serves at this blocksize: everything from 64 up; at blocksize 32 fp32 absmax on a 16-byte boundary (two
+// 16-byte scale loads per row and chunk)
+bool gemm_4bit_rt_serves(const float* absmax, const uint8_t* absmax8, int blocksize) {
+    return blocksize >= 64 || (absmax8 == nullptr && aligned_to(absmax, 16));
 }
 
 size_t gemm_4bit_rt_workspace_bytes(int M, int N, int K, int force_ks) {

@@ -106,6 +106,92 @@ def emulate(M=13, K=512, seed=0, bank_check=True):
     return err
 
 
+def emulate_bs32(M=13, K=512, seed=0):
+    """The BS32 instances (blocksize 32, round 5): the weight dwords go through a full 4 x 4 transposition between lane groups and
+    dwords (v_permlane32_swap on the pairs (0, 2), (1, 3), then v_permlane16_swap on the pairs (0, 1), (2, 3)) so that MFMA step s
+    of a chunk consumes exactly the 32-k block s; lane group g of the activation fragment fetches k 32 s + 8 g. Replayed per lane
+    against the hardware semantics of both swaps (the 16-lane one: odd 16-lane rows of the first operand against even rows of the
+    second - probed on the device, tools/ubench/swap16_probe.hip)."""
+    rng = np.random.default_rng(seed)
+    N = 16
+    code = rng.standard_normal(16)
+    nib = rng.integers(0, 16, size=(N, K))
+    packed = (nib[:, 0::2] << 4 | nib[:, 1::2]).astype(np.uint8)
+    scale = rng.standard_normal((N, K // 32))           # one scale per 32-k block
+    A = rng.standard_normal((M, K))
+
+    lanes = np.arange(64)
+    r, pp = lanes >> 2, lanes & 3
+    ln, lg = lanes & 15, lanes >> 4
+    wslot = 16 * pp + (r ^ (2 * pp))
+    rslot = 16 * lg + (ln ^ (2 * lg))
+
+    def transpose(vals):
+        tile = {}
+        for l in lanes:
+            tile[wslot[l]] = vals[l]
+        return [tile[rslot[l]] for l in lanes]
+
+    def permlane32_swap(v0, v1):
+        n0, n1 = list(v0), list(v1)
+        for l in range(32):
+            n0[l + 32], n1[l] = v1[l], v0[l + 32]
+        return n0, n1
+
+    def permlane16_swap(v0, v1):
+        """Hardware: lanes 16..31 (48..63) of the first operand are exchanged with lanes 0..15 (32..47) of the second."""
+        n0, n1 = list(v0), list(v1)
+        for base in (0, 32):
+            for l in range(16):
+                n0[base + 16 + l], n1[base + l] = v1[base + l], v0[base + 16 + l]
+        return n0, n1
+
+    acc = np.zeros((16, 16))
+    for c in range(K // 256):
+        wt = []
+        for h in range(2):
+            raw = [[packed[r[l], c * 128 + h * 64 + pp[l] * 16 + 4 * d: c * 128 + h * 64 + pp[l] * 16 + 4 * d + 4] for d in range(4)]
+                   for l in lanes]
+            t = transpose(raw)
+            d = [[t[l][j] for l in lanes] for j in range(4)]
+            d[0], d[2] = permlane32_swap(d[0], d[2])
+            d[1], d[3] = permlane32_swap(d[1], d[3])
+            d[0], d[1] = permlane16_swap(d[0], d[1])
+            d[2], d[3] = permlane16_swap(d[2], d[3])
+            wt.append(d)
+        # scales: lanes (r, pp == 0) / (r, pp == 1) write the row's scales 0-3 / 4-7 to slots r / 16 + r; lane (ln, lg) reads both of row ln
+        sraw = [scale[ln[l], 8 * c: 8 * c + 8] for l in lanes]
+        for blk in range(8):
+            s = blk
+            h, j = s >> 2, s & 3
+            araw = []
+            for l in lanes:
+                m = min(r[l], M - 1)
+                k0 = c * 256 + 32 * s + 8 * pp[l]
+                araw.append((A[m, k0:k0 + 8], k0))
+            af = transpose(araw)
+            for l in lanes:
+                byts = wt[h][j][l]
+                avals, k0 = af[l]
+                kw = c * 256 + 32 * s + 8 * lg[l]
+                assert kw == k0, (kw, k0)
+                assert np.array_equal(byts, packed[ln[l], kw // 2: kw // 2 + 4]), ("weight bytes are not the expected k range", c, s, l)
+                assert kw // 32 == 8 * c + blk, "MFMA step is not one 32-k block"
+            part = np.zeros((16, 16))
+            for g in range(4):
+                Aop = np.stack([af[i + 16 * g][0] for i in range(16)])
+                Bop = np.stack([np.array([code[b >> 4] if e == 0 else code[b & 15] for b in wt[h][j][jc + 16 * g] for e in (0, 1)])
+                                for jc in range(16)])
+                part += Aop @ Bop.T
+            for l in lanes:
+                for q in range(4):
+                    acc[4 * lg[l] + q, ln[l]] += sraw[l][blk] * part[4 * lg[l] + q, ln[l]]
+
+    W = code[nib] * np.repeat(scale, 32, axis=1)
+    ref = A @ W.T
+    return np.abs(acc[:M] - ref).max() / np.abs(ref).max()
+
+
 def final_sum_mapping_ok():
     """thread (col, row) of the epilogue reads float (col + 16 (row >> 2)) * 4 + (row & 3) of a parked f32x4-per-lane tile."""
     ok = True
@@ -121,6 +207,10 @@ if __name__ == "__main__":
     for M in (1, 5, 16):
         e = emulate(M=M, K=768, seed=M)
         print(f"M={M}: max rel err vs plain product {e:.2e}")
+        assert e < 1e-12
+    for M in (1, 7, 16):
+        e = emulate_bs32(M=M, K=768, seed=M)
+        print(f"blocksize 32, M={M}: max rel err vs plain product {e:.2e}")
         assert e < 1e-12
     assert final_sum_mapping_ok()
     print("ok")

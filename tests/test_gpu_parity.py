@@ -1158,6 +1158,64 @@ def test_mfma_kernels_exact_on_representable_inputs():
         assert torch.equal(y.float().cpu(), y_ref.to(torch.bfloat16).float()), knob
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("M", [3, 5, 8, 16, 17, 33, 64, 100, 200])
+def test_gemm_4bit_blocksize_32_runs_the_mfma_kernel(M, dtype):
+    """Round 5: blocksize 32 on the MFMA route (the register-transposed kernel's BS32 instances - a full 4 x 4 transposition of the
+    weight dwords between lane groups so that every MFMA consumes ONE 32-k block; reference capability: any power-of-two blocksize,
+    csrc/gemm_4bit_simt.cu:208,225). Every row-tile geometry (direct fragments, 1 - 4 row tiles, row passes over grid.z), ragged
+    N, NF4 / FP4, with bias - against the oracle, and the family that RAN is asserted. Nested statistics at blocksize 32 keep the
+    streaming kernel (same values, checked too)."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    for (N, K, qt) in ((512, 1024, "nf4"), (1000, 2816, "fp4"), (4096, 4096, "nf4")):
+        if N * K > (4 << 20) and M not in (5, 16, 64):
+            continue
+        g = torch.Generator().manual_seed(M + N)
+        W = (torch.randn(N, K, generator=g) / K**0.5).to(dtype)
+        x = torch.randn(M, K, generator=g).to(dtype)
+        bias = torch.randn(N, generator=g).to(dtype)
+        q, st = F.quantize_4bit(W.to(DEV), blocksize=32, quant_type=qt)
+        y = bnb.matmul_4bit(x.to(DEV), q, st, bias=bias.to(DEV))
+        # (three and four rows go to the MFMA kernels on matrices of >= 12 M weights only: c_api.hip route_to_mfma)
+        want = K_RT if M > 4 or N * K >= (12 << 20) else K_STREAM
+        assert bnb.lib.bnb_mi355x_last_gemm_kernel() == want, (M, N, K, bnb.lib.bnb_mi355x_last_gemm_kernel())
+        y_ref = _oracle_y(x, q, st, bias)
+        assert rel_err(y.cpu(), y_ref) < REL_TOL, (M, N, K, qt)
+        assert torch.equal(y, bnb.matmul_4bit(x.to(DEV), q, st, bias=bias.to(DEV)))  # bit-reproducible
+    # double quantisation at blocksize 32: outside the BS32 instances - the streaming kernel, same tolerance
+    q, st = F.quantize_4bit(W.to(DEV), blocksize=32, quant_type="nf4", compress_statistics=True)
+    y = bnb.matmul_4bit(x.to(DEV), q, st)
+    assert bnb.lib.bnb_mi355x_last_gemm_kernel() == K_STREAM
+    assert rel_err(y.cpu(), _oracle_y(x, q, st)) < REL_TOL
+
+
+def test_mfma_blocksize_32_exact_on_representable_inputs():
+    """The blocksize-32 twin of the test above: with exactly representable codes, power-of-two scales per 32-k block and small
+    integer activations every product and partial sum is exact - a k multiplied with the wrong weight, or a 32-k block scaled with
+    its neighbour's absmax (what a wrong lane-group transposition would do), cannot hide inside 1e-2."""
+    F = _F()
+    import bitsandbytes_amd as bnb
+
+    for M in (4, 16, 48):
+        N, K = 80, 1024
+        g = torch.Generator().manual_seed(7 + M)
+        fp4 = F.get_4bit_type("fp4", device="cpu")
+        allowed = torch.tensor([0, 3, 5, 7, 11, 13, 15])
+        idx = allowed[torch.randint(0, len(allowed), (N, K), generator=g)]
+        idx[:, ::32] = 3  # code 1.0 at the head of every 32-k block: its absmax is the block's scale
+        scale = 2.0 ** torch.randint(-3, 4, (N, K // 32), generator=g)
+        W = (fp4[idx] * scale.repeat_interleave(32, dim=1)).to(torch.bfloat16)
+        x = torch.randint(-4, 5, (M, K), generator=g).to(torch.bfloat16)
+        q, st = F.quantize_4bit(W.to(DEV), blocksize=32, quant_type="fp4")
+        assert torch.equal(st.absmax.cpu().view(N, K // 32), scale.float())
+        y = bnb.matmul_4bit(x.to(DEV), q, st)
+        assert bnb.lib.bnb_mi355x_last_gemm_kernel() == K_RT
+        y_ref = _oracle_y(x, q, st, None)
+        assert torch.equal(y.float().cpu(), y_ref.to(torch.bfloat16).float()), M
+
+
 # ------------------------------------------------------------------------------------------ callers of dequantize_4bit
 @pytest.mark.parametrize("quant_type", ["nf4", "fp4"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32], ids=["fp16", "bf16", "fp32"])

@@ -396,6 +396,7 @@ def test_rt_mfma_lane_algebra_emulation():
     spec.loader.exec_module(mod)
     for M in (1, 7, 16):
         assert mod.emulate(M=M, K=512, seed=M) < 1e-12
+        assert mod.emulate_bs32(M=M, K=512, seed=M) < 1e-12  # blocksize 32: the 4 x 4 lane-group transposition (round 5)
     assert mod.final_sum_mapping_ok()
 
 
