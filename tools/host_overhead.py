@@ -47,3 +47,21 @@ with torch.no_grad():
     print(f"# native dispatch (csrc/torch_dispatch.cpp) loaded: {hip.NATIVE_DISPATCH}")
     for name, fn in rows:
         print(f"{name:40s} {timeit(fn):7.1f} us per call")
+
+
+# ---- load time (round 5): what quantizing one 4096^2 layer costs end to end in eager mode, wall time per call with the queue full
+# (the larger of host dispatch and GPU time): plain statistics, double quantisation (quantize4 + mean + subtract + the 8-bit
+# quantize of 262 144 absmax values: the default of HF NF4 checkpoints' loaders), and the pieces of the latter on their own.
+Wq = (torch.randn(N, K, device="cuda") / 64).bfloat16()
+am = torch.rand(N * K // 64, device="cuda") + 0.5
+with torch.no_grad():
+    rows = [
+        ("quantize_4bit NF4 bs64", lambda: F.quantize_4bit(Wq, blocksize=64, quant_type="nf4")),
+        ("quantize_4bit NF4 bs64 + double quant", lambda: F.quantize_4bit(Wq, blocksize=64, quant_type="nf4", compress_statistics=True)),
+        ("  absmax.mean()", lambda: am.mean()),
+        ("  absmax - offset", lambda: am - 0.25),
+        ("  quantize_blockwise(absmax, 256)", lambda: F.quantize_blockwise(am, blocksize=256)),
+    ]
+    print("# load time, 4096^2 bf16 -> NF4 (wall us per call, eager, queue full)")
+    for name, fn in rows:
+        print(f"{name:40s} {timeit(fn, n=500):7.1f} us per call")
