@@ -303,7 +303,9 @@ class ShardedFFN4bit(nn.Module):
     Values are bit-identical to the unsharded block (``down(F.silu(gate(x)) * up(x))`` with the three ``Linear4bit`` layers) and to
     the member-by-member path, which every call outside the fused form takes (more than one activation row, fp32, gradients, shapes
     ``PeerChain.serves`` refuses): a grouped launch for gate / up, one gather, torch's activation, the down shard, one gather.
-    Decided from shapes, dtypes and the call's autograd mode - the same on every rank. Nothing in the reference to mirror (it has no
+    Decided from shapes, dtypes and the call's autograd mode - the same on every rank. Memory: the interleaved [gate; up] matrix is a
+    second copy of the two shards (the member-by-member path keeps using the members' own buffers) - 2 x F/G x H / 2 bytes per rank and
+    block, 7.3 MB for an 8-way shard of Llama-3-8B's FFN. Nothing in the reference to mirror (it has no
     collective code); the block's arithmetic is the reference's ``Linear4bit`` x 3 (nn/modules.py:609-637)."""
 
     def __init__(self, gate: ShardedLinear4bit, up: ShardedLinear4bit, down: ShardedLinear4bit, chain=None):

@@ -153,15 +153,22 @@ class PeerAllGather(_PeerBuffers):
 def _ranks_on_my_device(group, device) -> int:
     """How many ranks of the group use the device this rank uses (1 on a real node; > 1 where processes share a GPU - the only
     way a 1-GPU box can run the peer paths). Identified by hostname + PCI address where torch reports it, else by hostname +
-    device index + HIP_VISIBLE_DEVICES."""
+    device index + HIP_VISIBLE_DEVICES. Collective: a rank that cannot identify its device says so THROUGH the exchange, and every
+    rank raises - none is left waiting in the all-gather for a peer that raised alone."""
     import socket
 
-    props = torch.cuda.get_device_properties(device)
-    pci = tuple(getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
-    key = (socket.gethostname(), pci) if all(v is not None for v in pci) else \
-        (socket.gethostname(), torch.device(device).index, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"))
+    try:
+        props = torch.cuda.get_device_properties(device)
+        pci = tuple(getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        key = (socket.gethostname(), pci) if all(v is not None for v in pci) else \
+            (socket.gethostname(), torch.device(device).index, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"))
+    except Exception as exc:  # noqa: BLE001  (carried to the exchange below)
+        key = ("cannot identify the device", f"rank {dist.get_rank(group)}: {type(exc).__name__}: {exc}")
     keys = [None] * dist.get_world_size(group)
     dist.all_gather_object(keys, key, group=group)
+    failed = [k[1] for k in keys if k and k[0] == "cannot identify the device"]
+    if failed:
+        raise RuntimeError("a rank could not identify its device: " + "; ".join(failed))
     return sum(1 for k in keys if k == key)
 
 
