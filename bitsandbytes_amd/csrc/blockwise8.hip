@@ -343,7 +343,10 @@ __global__ __launch_bounds__(kQ8LutThreads) void quantize8_lut_kernel(const floa
     }
 }
 
-template <typename T>
+// U = independent 4-element units per lane and loop iteration. The first form (U = 1) had ONE 4-byte load in flight per lane - 8 KB per
+// CU with 8 resident workgroups - and ran at 51 % of the HBM peak where the 4-bit kernel, same output bytes, reaches 76 % (round 5,
+// profiles/r5_stream_kernels_ab.txt): with U units the loads of an iteration are all requested before the first look-up.
+template <typename T, int U>
 __global__ __launch_bounds__(256) void dequantize8_kernel(const float* __restrict__ code,
                                                           const uint8_t* __restrict__ A,
                                                           const float* __restrict__ absmax, T* __restrict__ out,
@@ -351,28 +354,42 @@ __global__ __launch_bounds__(256) void dequantize8_kernel(const float* __restric
     __shared__ float lut[256];
     lut[threadIdx.x] = code[threadIdx.x];
     __syncthreads();
-    const long stride = static_cast<long>(gridDim.x) * 256 * 4;
-    for (long i = (static_cast<long>(blockIdx.x) * 256 + threadIdx.x) * 4; i < n; i += stride) {
-        if (vec_ok && i + 4 <= n) {
-            const uint32_t q4 = stream_load<true>(reinterpret_cast<const uint32_t*>(A + i));
-            const float s = absmax[i >> bs_shift]; // blocksize >= 4 and i % 4 == 0: one block for the four
-            float v[4];
+    const long stride = static_cast<long>(gridDim.x) * 256 * 4 * U;
+    for (long i0 = static_cast<long>(blockIdx.x) * 256 * 4 * U + threadIdx.x * 4; i0 < n; i0 += stride) {
+        // (unit u of the lane: elements i0 + u * 1024 ...: every store instruction of a wavefront stays 1 KiB contiguous)
+        if (vec_ok && i0 + static_cast<long>(U - 1) * 1024 + 4 <= n) {
+            uint32_t q4[U];
+            float s[U];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                v[j] = rounded_f32(lut[(q4 >> (8 * j)) & 0xFFu] * s);
-            if constexpr (sizeof(T) == 4) {
-                stream_store<true>((f32x4_t{v[0], v[1], v[2], v[3]}), reinterpret_cast<f32x4_t*>(out + i));
-            } else {
-                typedef T v4 __attribute__((ext_vector_type(4)));
-                v4 r;
+            for (int u = 0; u < U; ++u) {
+                const long i = i0 + static_cast<long>(u) * 1024;
+                q4[u] = stream_load<true>(reinterpret_cast<const uint32_t*>(A + i));
+                s[u] = absmax[i >> bs_shift]; // blocksize >= 4 and i % 4 == 0: one block for the four
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long i = i0 + static_cast<long>(u) * 1024;
+                float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    r[j] = static_cast<T>(v[j]);
-                stream_store<true>(r, reinterpret_cast<v4*>(out + i));
+                    v[j] = rounded_f32(lut[(q4[u] >> (8 * j)) & 0xFFu] * s[u]);
+                if constexpr (sizeof(T) == 4) {
+                    stream_store<true>((f32x4_t{v[0], v[1], v[2], v[3]}), reinterpret_cast<f32x4_t*>(out + i));
+                } else {
+                    typedef T v4 __attribute__((ext_vector_type(4)));
+                    v4 r;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        r[j] = static_cast<T>(v[j]);
+                    stream_store<true>(r, reinterpret_cast<v4*>(out + i));
+                }
             }
         } else {
-            for (long e = i; e < i + 4 && e < n; ++e)
-                out[e] = static_cast<T>(rounded_f32(lut[A[e]] * absmax[e >> bs_shift]));
+            for (int u = 0; u < U; ++u) {
+                const long i = i0 + static_cast<long>(u) * 1024;
+                for (long e = i; e < i + 4 && e < n; ++e)
+                    out[e] = static_cast<T>(rounded_f32(lut[A[e]] * absmax[e >> bs_shift]));
+            }
         }
     }
 }
@@ -452,11 +469,19 @@ void launch_dequantize8(const float* code, const uint8_t* A, const float* absmax
         exit(1);
     }
     const int vec_ok = aligned_to(A, 4) && aligned_to(out, 16);
-    long grid = (n + 1023) / 1024;
-    if (grid > 8192)
-        grid = 8192;
-    hipLaunchKernelGGL((dequantize8_kernel<T>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, code, A,
-                       absmax, out, ilog2(blocksize), n, vec_ok);
+    // Four units per lane from 2^20 elements on: 16.7 M elements 20.2 -> 17.0 us, 67 M 65.0 -> 58.4 (profiles/r5_stream_kernels_ab.txt);
+    // below that - the absmax vectors of double quantisation: 262 144 elements - a quarter as many workgroups is what costs (2.46 vs
+    // 2.13 us): one unit. (Tuning knob reserved0 = 6 forces the one-unit form, 7 the four-unit form.)
+    const int v8 = g_q8_variant.load(std::memory_order_relaxed);
+    if (v8 == 6 || (v8 != 7 && n < (1L << 20))) {
+        long grid = (n + 1023) / 1024;
+        grid = grid > 8192 ? 8192 : grid;
+        hipLaunchKernelGGL((dequantize8_kernel<T, 1>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, code, A, absmax, out, ilog2(blocksize), n, vec_ok);
+    } else {
+        long grid = (n + 4095) / 4096;
+        grid = grid > 8192 ? 8192 : grid;
+        hipLaunchKernelGGL((dequantize8_kernel<T, 4>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, code, A, absmax, out, ilog2(blocksize), n, vec_ok);
+    }
     BNB_CHECK_LAUNCH();
 }
 

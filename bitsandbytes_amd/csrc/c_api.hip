@@ -56,6 +56,7 @@ bool gemm_4bit_grad_input_supported(int dtype, const void* G, const uint8_t* B, 
 size_t gemm_4bit_grad_input_workspace_bytes(int M, int N, int K);
 void quantize_8bit_set_variant(int variant);
 void quantize_4bit_set_variant(int variant);
+void dequantize_4bit_set_variant(int variant);
 void gemm_4bit_grad_input_set_slices(int ns);
 void gemm_4bit_grad_input(int dtype, const void* G, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                           const float* absmax_code, const float* absmax_offset, void* out, int M, int N, int K, int blocksize,
@@ -383,7 +384,10 @@ int bnb_mi355x_gemm_4bit_grad_input_supported(int dtype, int M, int N, int K, in
 }
 void bnb_mi355x_set_tuning(int reserved0, int reserved1, int mfma_knob0, int mfma_knob1) {
     quantize_8bit_set_variant(reserved0); // 1 / 2: force the cell-table / byte-table 8-bit encoder, anything else: by size
-    quantize_4bit_set_variant(reserved0 == 3 ? 1 : 0); // 3: the one-tile form of the 4-bit quantize kernel everywhere (A/B of the pipelined form)
+    // 3: the one-tile form of the 4-bit quantize kernel everywhere (A/B of the pipelined FP4 form); 4 / 5: round 4's 4 chunks / 8 chunks per
+    // workgroup instead of the shipped 2 on large NF4 inputs (A/B, round 5)
+    quantize_4bit_set_variant(reserved0 == 3 ? 1 : reserved0 == 4 ? 4 : reserved0 == 5 ? 3 : 0);
+    dequantize_4bit_set_variant(reserved0 >= 10 ? reserved0 - 10 : 0); // 10 + v: tile / lane-mapping variants of dequantize4 (dequantize4.hip)
     gemm_4bit_grad_input_set_slices(reserved1); // N slices of the fused backward (sweeps), 0: built-in
     g_mfma_knob0.store(mfma_knob0, std::memory_order_relaxed);
     g_mfma_knob1.store(mfma_knob1, std::memory_order_relaxed);

@@ -18,8 +18,15 @@ namespace bnb {
 namespace {
 
 constexpr int kDqThreads = 256;
-constexpr int kDqUnroll = 4;                              // packed dwords per lane
-constexpr int kDqTile = kDqThreads * kDqUnroll * 8;       // outputs per workgroup (8192)
+// Packed dwords per lane = how many workgroups a tensor is (256 threads x U x 8 outputs each). Round 5, measured round-robin
+// (profiles/r5_stream_kernels_ab.txt): up to ~17 M elements FEWER, larger workgroups win - U = 8: 4096^2 8.91 -> 8.35 us (64 % of the
+// HBM peak; torch's fill of the same output: 7.3), 2048^2 4.47 -> 3.99 - from 33 M elements on U = 4 wins (8192^2 30.3 vs 31.4);
+// U = 2 and 16 lose on one side or the other. (The reverse was expected - more rounds of workgroups to overlap loads and stores.)
+constexpr long kDqBigElements = 1L << 25;
+// sweeps / tests (bnb_mi355x_set_tuning reserved0 = 10 + v): v = 1, 2, 4, 8, 16: packed dwords per lane of the general kernel forced;
+// v = 22 / 24 / 28: the line-contiguous fp32 kernel with 2 / 4 / 8 units per lane; v = 30: the general kernel for fp32 outputs too
+// (round 4's form); 0 = built-in
+thread_local TlsKnob g_dq_variant{0};
 
 // NT: non-temporal stores (the standalone stream; the row gather keeps the default policy - its output is read next)
 template <typename T, bool NT> __device__ __forceinline__ void store8(T* __restrict__ out, long base, const float (&v)[8]) {
@@ -43,11 +50,12 @@ template <typename T, bool NT> __device__ __forceinline__ void store8(T* __restr
     }
 }
 
-template <typename T>
+template <typename T, int kDqUnroll>
 __global__ __launch_bounds__(kDqThreads) void dequantize4_kernel(const uint8_t* __restrict__ A,
                                                                  const float* __restrict__ absmax,
                                                                  T* __restrict__ out, long n, int bs_shift,
                                                                  int quant_type, int vec_ok) {
+    constexpr int kDqTile = kDqThreads * kDqUnroll * 8; // outputs per workgroup
     __shared__ float code[16];
     const int tid = threadIdx.x;
     if (tid < 16)
@@ -98,6 +106,52 @@ __global__ __launch_bounds__(kDqThreads) void dequantize4_kernel(const uint8_t* 
     }
 }
 
+// fp32 outputs with LINE-CONTIGUOUS stores (round 5): in the kernel above a lane owns 8 outputs = two 16-byte stores at a 32-byte
+// stride - every store instruction of a wavefront writes HALF of each 128-byte line it touches (the non-temporal policy measured
+// +33 % there, the default one leaves the halves to the L2: 20.2 us at 4096^2 = 47 % of HBM peak). Here a lane owns 4 outputs per
+// unit - one packed 16-bit piece in, ONE 16-byte store out - so a wavefront's store is 1 KiB contiguous, eight full lines; U units
+// per lane keep the loads in flight. Same arithmetic, same table: bit-identical.
+template <int U>
+__global__ __launch_bounds__(kDqThreads) void dequantize4_f32_lines_kernel(const uint8_t* __restrict__ A, const float* __restrict__ absmax,
+                                                                            float* __restrict__ out, long n, int bs_shift, int quant_type) {
+    constexpr int kTile = kDqThreads * U * 4; // outputs per workgroup
+    __shared__ float code[16];
+    const int tid = threadIdx.x;
+    if (tid < 16)
+        code[tid] = (quant_type == kNF4) ? kNF4Code[tid] : kFP4Code[tid];
+    const long tile_base = static_cast<long>(blockIdx.x) * kTile;
+    unsigned short w[U];
+    float s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long base = tile_base + (static_cast<long>(u) * kDqThreads + tid) * 4;
+        w[u] = stream_load<false>(reinterpret_cast<const unsigned short*>(A + (base >> 1)));
+        s[u] = absmax[base >> bs_shift];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long base = tile_base + (static_cast<long>(u) * kDqThreads + tid) * 4;
+        using V = __attribute__((ext_vector_type(4))) float;
+        V r;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const uint32_t byte = (static_cast<uint32_t>(w[u]) >> (8 * b)) & 0xFFu;
+            r[2 * b] = rounded_f32(code[byte >> 4] * s[u]);
+            r[2 * b + 1] = rounded_f32(code[byte & 0xF] * s[u]);
+        }
+        stream_store<true>(r, reinterpret_cast<V*>(out + base));
+    }
+}
+
+template <typename T, int U>
+void launch_dequantize4_u(const uint8_t* A, const float* absmax, T* out, int blocksize, long n, int quant_type, int vec_ok, hipStream_t stream) {
+    constexpr long tile = static_cast<long>(kDqThreads) * U * 8;
+    const long grid = (n + tile - 1) / tile;
+    hipLaunchKernelGGL((dequantize4_kernel<T, U>), dim3(static_cast<unsigned>(grid)), dim3(kDqThreads), 0, stream, A, absmax, out, n,
+                       ilog2(blocksize), quant_type, vec_ok);
+}
+
 template <typename T>
 void launch_dequantize4(const uint8_t* A, const float* absmax, T* out, int blocksize, long n, int quant_type,
                         hipStream_t stream) {
@@ -108,9 +162,39 @@ void launch_dequantize4(const uint8_t* A, const float* absmax, T* out, int block
         exit(1);
     }
     const int vec_ok = aligned_to(A, 4) && aligned_to(out, 16);
-    const long grid = (n + kDqTile - 1) / kDqTile;
-    hipLaunchKernelGGL((dequantize4_kernel<T>), dim3(static_cast<unsigned>(grid)), dim3(kDqThreads), 0, stream, A,
-                       absmax, out, n, ilog2(blocksize), quant_type, vec_ok);
+    const int variant = g_dq_variant.load(std::memory_order_relaxed);
+    if constexpr (sizeof(T) == 4) {
+        // the line-contiguous form (built-in: 4 units per lane - 12.5 vs 19.3 us at 4096^2, 44.7 vs 72.2 at 8192^2) needs whole tiles
+        // and aligned pointers; everything else (ragged sizes) keeps the general kernel
+        const int u = variant == 0 ? 4 : (variant >= 20 && variant < 30) ? variant - 20 : 0;
+        if (u == 2 || u == 4 || u == 8) {
+            const long tile = static_cast<long>(kDqThreads) * u * 4;
+            if (vec_ok && aligned_to(A, 2) && n % tile == 0 && blocksize >= 4) {
+                if (u == 2)
+                    hipLaunchKernelGGL((dequantize4_f32_lines_kernel<2>), dim3(static_cast<unsigned>(n / tile)), dim3(kDqThreads), 0, stream, A, absmax, out, n, ilog2(blocksize), quant_type);
+                else if (u == 4)
+                    hipLaunchKernelGGL((dequantize4_f32_lines_kernel<4>), dim3(static_cast<unsigned>(n / tile)), dim3(kDqThreads), 0, stream, A, absmax, out, n, ilog2(blocksize), quant_type);
+                else
+                    hipLaunchKernelGGL((dequantize4_f32_lines_kernel<8>), dim3(static_cast<unsigned>(n / tile)), dim3(kDqThreads), 0, stream, A, absmax, out, n, ilog2(blocksize), quant_type);
+                BNB_CHECK_LAUNCH();
+                return;
+            }
+        }
+    }
+    switch (variant) {
+    case 1: launch_dequantize4_u<T, 1>(A, absmax, out, blocksize, n, quant_type, vec_ok, stream); break;
+    case 2: launch_dequantize4_u<T, 2>(A, absmax, out, blocksize, n, quant_type, vec_ok, stream); break;
+    case 8: launch_dequantize4_u<T, 8>(A, absmax, out, blocksize, n, quant_type, vec_ok, stream); break;
+    case 16: launch_dequantize4_u<T, 16>(A, absmax, out, blocksize, n, quant_type, vec_ok, stream); break;
+    case 4:
+    case 30: launch_dequantize4_u<T, 4>(A, absmax, out, blocksize, n, quant_type, vec_ok, stream); break;
+    default:
+        if (n < kDqBigElements)
+            launch_dequantize4_u<T, 8>(A, absmax, out, blocksize, n, quant_type, vec_ok, stream);
+        else
+            launch_dequantize4_u<T, 4>(A, absmax, out, blocksize, n, quant_type, vec_ok, stream);
+        break;
+    }
     BNB_CHECK_LAUNCH();
 }
 
@@ -188,6 +272,8 @@ void launch_dequantize4_rows(const uint8_t* A, const float* absmax, const void* 
 }
 
 } // namespace
+
+void dequantize_4bit_set_variant(int variant) { g_dq_variant.store(variant, std::memory_order_relaxed); }
 
 void dequantize_4bit_f32(const uint8_t* A, const float* absmax, float* out, int blocksize, long n, int qt,
                          hipStream_t s) {

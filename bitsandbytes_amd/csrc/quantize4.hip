@@ -460,8 +460,14 @@ template <typename T, int QT> void launch_quantize4(const T* A, float* absmax, u
     case BS: {                                                                                     \
         constexpr int MINCH = BS > 2048 ? BS / 2048 : 1;                                           \
         constexpr int PCH = BS > 2048 ? BS / 2048 : 2;                                             \
-        if (QT == kFP4 && q4_variant != 1 && vec_ok && (n % (2048L * PCH)) == 0 && n / (2048L * PCH) >= 4 * pipe_grid) \
+        if (q4_variant == 3) /* A/B: 8 chunks per workgroup (round 5: 8 - 13 % slower everywhere) */ \
+            BNB_Q4_LAUNCH(BS, 8)                                                                   \
+        else if (q4_variant == 4 && wide) /* A/B: round 4's 4 chunks per workgroup */             \
+            BNB_Q4_LAUNCH(BS, 4)                                                                   \
+        else if (QT == kFP4 && q4_variant != 1 && vec_ok && (n % (2048L * PCH)) == 0 && n / (2048L * PCH) >= 4 * pipe_grid) \
             BNB_Q4_LAUNCH_PIPE(BS, PCH)                                                            \
+        else if (wide && QT == kNF4 && MINCH <= 2)                                                 \
+            BNB_Q4_LAUNCH(BS, 2) /* round 5 (profiles/r5_stream_kernels_ab.txt): 2 chunks per workgroup, 4096^2 bf16 10.64 -> 9.94 us, fp32 16.6 -> 15.7, 8192^2 30.8 -> 30.1 */ \
         else if (wide)                                                                             \
             BNB_Q4_LAUNCH(BS, 4)                                                                   \
         else                                                                                       \

@@ -205,7 +205,9 @@ void bnb_mi355x_peer_chain_read(void* const* bufs, void* epoch_word, int world, 
 
 /* Tuning overrides for sweeps and tests (0 = built-in heuristic). reserved0: encoder of the 8-bit blockwise quantize - 1 =
  * cell-table kernel, 2 = byte-table kernel, anything else = by input size; 3 = the one-tile form of the 4-bit quantize kernel
- * everywhere (A/B of its pipelined FP4 form); reserved1: N slices of the fused backward (> 0; the
+ * everywhere (A/B of its pipelined FP4 form); 4 / 5 = 4 / 8 chunks per workgroup of the 4-bit quantize kernel instead of the shipped 2
+ * (large NF4 inputs); 6 = one unit in flight per lane in the 8-bit dequantize kernel (its first form); 10 + v = tile / lane-mapping
+ * variants of the 4-bit dequantize kernel (csrc/dequantize4.hip); reserved1: N slices of the fused backward (> 0; the
  * workspace-size query follows it). MFMA kernels: knob0 bit 0 = round 2's form of the register-transposed kernel (measurement build only; ignored by the product library),
  * knob1 = 100 * cfg + K-slice count (cfg 11-14 producer/consumer geometries, 20/21/22
  * register-transposed kernel with built-in / 8 / 16 wavefronts, 40 K-quarter kernel). Every setting

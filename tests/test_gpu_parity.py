@@ -296,6 +296,67 @@ def test_blockwise_8bit_dense_vs_oracle():
     assert torch.equal(q.cpu(), q_o) and torch.equal(am.cpu(), am_o)
 
 
+@pytest.mark.parametrize("quant_type,blocksize", [("nf4", 64), ("fp4", 128), ("nf4", 32), ("nf4", 4096)])
+def test_dequantize_4bit_round5_tile_forms_vs_oracle(quant_type, blocksize):
+    """Round 5 gave dequantize4 size-dependent launch forms (csrc/dequantize4.hip): fp32 outputs of whole 4096-element tiles take the
+    LINE-CONTIGUOUS kernel (one 16-byte store per unit), 16-bit outputs below 2^25 elements 8 packed dwords per lane, from there on 4.
+    Every form against the oracle, the fast paths against the forms they replaced (tuning knob 10 + v) bit for bit, and the sizes that
+    must fall back (a ragged tail, an unaligned output view) too."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    for n in (4096, 4096 * 24, 4096 * 24 + blocksize, 1 << 20, (1 << 25) + 4096 * 3):
+        if n > (1 << 22) and (quant_type, blocksize) != ("nf4", 64):
+            continue  # (the large sizes once: the oracle is scalar C)
+        g = torch.Generator().manual_seed(n % 1000)
+        A = (torch.randn(n, generator=g) * 0.3)
+        A[::13] = 0
+        q_o, am_o = O.quantize_4bit(A, blocksize, quant_type)
+        q, am = q_o.to(DEV), am_o.to(DEV)
+        for dt in (torch.float32, torch.bfloat16, torch.float16):
+            want = O.dequantize_4bit(q_o, am_o, blocksize, quant_type, A.shape, dt)
+            d = torch.ops.bitsandbytes.dequantize_4bit.default(q, am, blocksize, quant_type, (n,), dt)
+            assert same_values_ftz(d.cpu(), want), (n, dt)
+            for knob in (14, 18, 40) if dt != torch.float32 else (40, 32, 38):  # forced general u = 4 / 8, round 4's form; fp32: general, lines u = 2 / 8
+                try:
+                    bnb.lib.bnb_mi355x_set_tuning(knob, 0, 0, 0)
+                    d2 = torch.ops.bitsandbytes.dequantize_4bit.default(q, am, blocksize, quant_type, (n,), dt)
+                finally:
+                    bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+                assert torch.equal(d2.view(torch.int32 if dt == torch.float32 else torch.int16), d.view(torch.int32 if dt == torch.float32 else torch.int16)), (n, dt, knob)
+    # an output view that is only 4-byte aligned: the fp32 fast path must decline (16-byte stores), same values
+    n = 4096 * 8
+    A = torch.randn(n) * 0.3
+    q_o, am_o = O.quantize_4bit(A, blocksize, quant_type)
+    buf = torch.empty(n + 1, device=DEV)
+    out = buf[1:]
+    torch.ops.bitsandbytes.dequantize_4bit.out(q_o.to(DEV), am_o.to(DEV), blocksize, quant_type, (n,), torch.float32, out=out)
+    assert same_values_ftz(out.cpu(), O.dequantize_4bit(q_o, am_o, blocksize, quant_type, A.shape, torch.float32))
+
+
+def test_dequantize_8bit_four_units_per_lane_equals_the_first_form():
+    """dequantize8_kernel keeps four 4-element units in flight per lane since round 5 (one before: 51 % of the HBM peak). Sizes
+    around its 4096-element iteration - whole iterations, a tail that takes the scalar branch unit by unit, fewer elements than
+    one iteration - against the oracle and against the first form (tuning knob 6), every output dtype."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    code = F.create_dynamic_map()
+    for n in (4096 * 5, 4096 * 5 + 1024 + 3, 4096 + 2, 1000, 3, 256 * 1024 + 777):
+        A = torch.randn(n) * 0.2
+        q_o, am_o = O.quantize_blockwise(A, code, 256)
+        q, am = q_o.to(DEV), am_o.to(DEV)
+        for dt in (torch.float32, torch.bfloat16, torch.float16):
+            d = torch.ops.bitsandbytes.dequantize_blockwise.default(q, am, code.to(DEV), 256, dt)
+            assert same_values_ftz(d.cpu(), O.dequantize_blockwise(q_o, am_o, code, 256, dt)), (n, dt)
+            try:
+                bnb.lib.bnb_mi355x_set_tuning(6, 0, 0, 0)
+                d1 = torch.ops.bitsandbytes.dequantize_blockwise.default(q, am, code.to(DEV), 256, dt)
+            finally:
+                bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
+            assert torch.equal(d1.view(torch.int32 if dt == torch.float32 else torch.int16), d.view(torch.int32 if dt == torch.float32 else torch.int16)), (n, dt)
+
+
 @pytest.mark.parametrize("blocksize", [64, 128, 256, 512, 1024, 2048, 4096])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16], ids=["fp32", "fp16", "bf16"])
 def test_blockwise_8bit_general_vs_oracle(blocksize, dtype):
