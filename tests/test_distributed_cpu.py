@@ -81,6 +81,28 @@ def _worker(rank, world, port, results):
             ok = False
         except ValueError:
             pass
+        # one gated FFN block (round 5; BASELINE.json configs[3]) without a PeerChain - the member-by-member path every rank runs off
+        # the fused form: grouped gate / up launch + ONE gather, torch's silu * mul, the down shard + one gather. Equal to the
+        # unsharded block; and the row-interleaved [gate; up] matrix the fused form would launch over computes, on this rank's
+        # rows, exactly the members' outputs (g0, u0, g1, u1, ...), nested statistics carried un-nested.
+        for dq, bias in ((False, False), (True, True)):
+            torch.manual_seed(14 + dq)
+            H, Fd = 128, 512
+            gate, up, down = [Linear4bit(k, n, bias=bias, quant_type="nf4", compress_statistics=dq).to("cpu") for k, n in ((H, Fd), (H, Fd), (Fd, H))]
+            ffn = bnb.shard_ffn4bit(gate, up, down, rank, world)
+            for M in (1, 2):
+                x = torch.randn(M, H)
+                want = down(torch.nn.functional.silu(gate(x)) * up(x))
+                ok &= not ffn.fused(x) and bool(torch.equal(ffn(x), want))
+                ns = Fd // world
+                stacked = bnb.matmul_4bit(x, ffn.gu_weight, ffn.gu_state, bias=ffn._stacked_bias(x.dtype))
+                mine = slice(rank * ns, (rank + 1) * ns)
+                ok &= bool(torch.equal(stacked, torch.stack([gate(x)[:, mine], up(x)[:, mine]], dim=-1).reshape(M, -1)))
+        try:
+            bnb.ShardedFFN4bit(bnb.shard_linear4bit(gate, rank, world), bnb.shard_linear4bit(up, rank, world), bnb.shard_linear4bit(gate, rank, world))
+            ok = False  # (down must take what gate / up produce)
+        except ValueError:
+            pass
         results[rank] = ok
     finally:
         dist.destroy_process_group()
