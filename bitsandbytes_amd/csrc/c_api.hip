@@ -386,7 +386,7 @@ void bnb_mi355x_set_tuning(int reserved0, int reserved1, int mfma_knob0, int mfm
     quantize_8bit_set_variant(reserved0); // 1 / 2: force the cell-table / byte-table 8-bit encoder, anything else: by size
     // 3: the one-tile form of the 4-bit quantize kernel everywhere (A/B of the pipelined FP4 form); 4 / 5: round 4's 4 chunks / 8 chunks per
     // workgroup instead of the shipped 2 on large NF4 inputs (A/B, round 5)
-    quantize_4bit_set_variant(reserved0 == 3 ? 1 : reserved0 == 4 ? 4 : reserved0 == 5 ? 3 : 0);
+    quantize_4bit_set_variant(reserved0 == 3 ? 1 : reserved0 == 4 ? 4 : reserved0 == 5 ? 3 : reserved0 == 8 ? 2 : 0); // (8: 2 chunks forced, FP4 included)
     dequantize_4bit_set_variant(reserved0 >= 10 ? reserved0 - 10 : 0); // 10 + v: tile / lane-mapping variants of dequantize4 (dequantize4.hip)
     gemm_4bit_grad_input_set_slices(reserved1); // N slices of the fused backward (sweeps), 0: built-in
     g_mfma_knob0.store(mfma_knob0, std::memory_order_relaxed);

@@ -22,8 +22,10 @@
 //     common finite case from the special one; lanes of a block combine by xor-shuffles (+ one LDS
 //     hop when a block spans wavefronts);
 //   * finite case: the code of s = x * (1/absmax) comes from a *cell table* in LDS instead of a
-//     compare tree. [-1, 1] is cut into 2*S+1 uniform cells (S = 16 for NF4, 512 for FP4, chosen so that
-//     no cell holds two decision bounds); cell(s) = round(s*S + S) falls out of ONE fma against the
+//     compare tree. [-1, 1] is cut into 2*S+1 uniform cells (S = 16 for NF4, 256 for FP4 - the coarsest powers of two with no
+//     two decision bounds in one cell, static_assert-ed: FP4's tightest bounds are -1/384, 0 (between its two zeros) and
+//     +1/384, which land in cells S - 1, S, S + 1 from S = 256 on; rounds 1 - 4 carried 512, i.e. an 8-KB table per workgroup
+//     where 4 KB do); cell(s) = round(s*S + S) falls out of ONE fma against the
 //     2^23 magic constant (exact, single rounding), the cell stores (bound inside it or +inf, code
 //     below | code above << 16), and the code is `below + (s > bound)`: fma, shift-add, ds_read_b64,
 //     compare, add - 5 VALU ops + 1 LDS read per element, bit-identical to counting the 15 bounds
@@ -70,7 +72,7 @@ struct QCell {
 };
 
 template <int QT> struct CellGrid {
-    static constexpr int S = (QT == kNF4) ? 16 : 512; // cells per unit; power of two => s*S exact
+    static constexpr int S = (QT == kNF4) ? 16 : 256; // cells per unit; power of two => s*S exact
     static constexpr int N = 2 * S + 1;
 };
 
@@ -462,6 +464,8 @@ template <typename T, int QT> void launch_quantize4(const T* A, float* absmax, u
         constexpr int PCH = BS > 2048 ? BS / 2048 : 2;                                             \
         if (q4_variant == 3) /* A/B: 8 chunks per workgroup (round 5: 8 - 13 % slower everywhere) */ \
             BNB_Q4_LAUNCH(BS, 8)                                                                   \
+        else if (q4_variant == 2 && MINCH <= 2) /* A/B: 2 chunks per workgroup whatever the code */ \
+            BNB_Q4_LAUNCH(BS, 2)                                                                   \
         else if (q4_variant == 4 && wide) /* A/B: round 4's 4 chunks per workgroup */             \
             BNB_Q4_LAUNCH(BS, 4)                                                                   \
         else if (QT == kFP4 && q4_variant != 1 && vec_ok && (n % (2048L * PCH)) == 0 && n / (2048L * PCH) >= 4 * pipe_grid) \

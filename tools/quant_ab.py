@@ -59,7 +59,7 @@ def main():
         src = [torch.randn(n, device="cuda", dtype=torch.float32).to(dt) for _ in range(R)]
         packed = [torch.empty(n // 2, device="cuda", dtype=torch.uint8) for _ in range(R)]
         absmax = [torch.empty(n // bs, device="cuda", dtype=torch.float32) for _ in range(R)]
-        variants = [("built-in", 0), ("4 chunks (round 4)", 4), ("8 chunks", 5), ("one tile (FP4 A/B)", 3)]
+        variants = [("built-in", 0), ("2 chunks (forced)", 8), ("4 chunks (round 4)", 4), ("8 chunks", 5), ("one tile (FP4 A/B)", 3)]
 
         def run(knob):
             def fn(s):
