@@ -69,10 +69,11 @@ print(f"# realtime (10 ns ticks): wavefront starts span {(rt[:, 0].max() - r0).i
       f"{(rt[:, 1].max() - r0).item() * 10:.0f} ns after the first start; per-workgroup first start: median "
       f"{(rt[:, 0].view(-1, waves_per_wg).min(1).values - r0).median().item() * 10:.0f} ns")
 t0 = 1.0
-order = [0, 9, 10, 1, 2, 12, 11, 3, 4, 15, 5, 6, 7, 8]
-# (tune[3] == 2, the ring-late form: stamp 1 sits in front of the table build and only means "geometry done"; the ring goes out at 12)
-names = {0: "start", 9: "before x DMA", 10: "x DMA issued", 11: "own x landed", 12: "ring issued (late form)",
-         1: "ring issued" if a.tune[3] != 2 else "geometry done",
+order = [0, 9, 10, 1, 2, 11, 3, 4, 15, 5, 6, 7, 8]
+# CAUTION when reading waits off this table (round 5): stores count in vmcnt on gfx950, and every stamp is a global store -
+# the counted x wait of the measurement build therefore waits for MORE than the product's (the stamps sit in the same in-order queue).
+# Instruction-issue times are right; "own x landed" / "past barrier" are upper bounds.
+names = {0: "start", 9: "before x DMA", 10: "x DMA issued", 11: "own x landed", 1: "ring issued",
          2: "table written", 3: "past barrier", 4: "x slice in regs", 15: "stage-0 weights landed", 5: "item 0 decoded", 6: "items done",
          7: "past final barrier", 8: "end"}
 print(f"# M={M} N={N} K={K} tune={a.tune}: {t.shape[0]} wavefronts; s_memtime ticks relative to the first wavefront start of the SAME workgroup")
