@@ -243,49 +243,66 @@ class PeerChain(_PeerBuffers):
         if H == 0:
             return  # (max_values below one test layer: nothing this chain could carry would fit either)
         ns = H // world
-        try:
-            with torch.no_grad(), torch.cuda.device(dev):
-                gen = torch.Generator(device=dev).manual_seed(20250922)  # the same weights and inputs on every rank
-                layers = []
-                for i in range(3):
-                    W = (torch.randn(H, H, device=dev, generator=gen) / H**0.5).to(torch.bfloat16)
-                    packed, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4" if i != 1 else "fp4", compress_statistics=False)
-                    layers.append(shard_quant_state(packed, st, rank, world))
-                # `launch`: decided from shapes alone, so identical on every rank. A rank whose RESULT is wrong keeps launching like
-                # the others (its peers consume its granules: a rank that stopped would make them spin to their bound);
-                # only a refusal - which every rank sees alike - stops the launches.
-                launch = all(self.serves(ns, H, 64, consume=i > 0) for i in range(3))
-                if not launch:
-                    ok, problem = False, f"the fused form refuses the self-test shapes ({ns} x {H})"
-                nccl = dist.get_backend(self.group) == "nccl"
-                for rep in range(2):  # (the second chain re-uses the regions of the first under a new epoch)
-                    x = torch.randn(H, device=dev, generator=gen).to(torch.bfloat16)
-                    want = x
-                    for q, st in layers:
-                        y_loc = matmul_4bit(want.view(1, H), q, quant_state=st).reshape(-1).contiguous()
-                        if nccl:
-                            buf = torch.empty(H, dtype=y_loc.dtype, device=dev)
-                            dist.all_gather_into_tensor(buf, y_loc, group=self.group)
-                        else:  # (a host-side group - gloo in the shared-GPU test set-up: through the host)
-                            parts = [None] * world
-                            dist.all_gather_object(parts, y_loc.cpu(), group=self.group)
-                            buf = torch.cat(parts).to(dev)
-                        want = buf
-                    if launch:
+        # EVERY host collective below runs on EVERY rank whatever happened locally - a rank that left the sequence on an exception
+        # would meet its peers' all-gathers with the final vote (mismatched collectives: a hang on RCCL). Local failures only set
+        # `ok` / `problem`; the device-side exchange of a rank that cannot launch is simply missing, which its peers' bounded waits
+        # turn into a time-out and a "no" vote.
+
+        def guarded(fn, fallback=None):
+            nonlocal ok, problem
+            try:
+                return fn()
+            except Exception as exc:  # noqa: BLE001
+                if ok:
+                    ok, problem = False, f"{type(exc).__name__}: {exc}"
+                return fallback
+
+        with torch.no_grad(), torch.cuda.device(dev):
+            gen = guarded(lambda: torch.Generator(device=dev).manual_seed(20250922))  # the same weights and inputs on every rank
+
+            def make_layer(i):
+                W = (torch.randn(H, H, device=dev, generator=gen) / H**0.5).to(torch.bfloat16)
+                packed, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4" if i != 1 else "fp4", compress_statistics=False)
+                return shard_quant_state(packed, st, rank, world)
+
+            layers = [guarded(lambda i=i: make_layer(i)) for i in range(3)]
+            # `launch`: decided from shapes alone, so identical on every rank. A rank whose RESULT is wrong keeps launching like
+            # the others (its peers consume its granules: a rank that stopped would make them spin to their bound); only a
+            # refusal - which every rank sees alike - stops the launches.
+            launch = bool(guarded(lambda: all(self.serves(ns, H, 64, consume=i > 0) for i in range(3)), False))
+            if not launch and ok:
+                ok, problem = False, f"the fused form refuses the self-test shapes ({ns} x {H})"
+            nccl = dist.get_backend(self.group) == "nccl"
+            zeros = torch.zeros(ns, dtype=torch.bfloat16, device=dev)
+            for rep in range(2):  # (the second chain re-uses the regions of the first under a new epoch)
+                x = guarded(lambda: torch.randn(H, device=dev, generator=gen).to(torch.bfloat16), torch.zeros(H, dtype=torch.bfloat16, device=dev))
+                want = x
+                for layer in layers:
+                    y_loc = guarded(lambda: matmul_4bit(want.view(1, H), layer[0], quant_state=layer[1]).reshape(-1).contiguous(), zeros) \
+                        if layer is not None else zeros
+                    if nccl:
+                        buf = torch.empty(H, dtype=torch.bfloat16, device=dev)
+                        dist.all_gather_into_tensor(buf, y_loc, group=self.group)
+                    else:  # (a host-side group - gloo in the shared-GPU test set-up: through the host)
+                        parts = [None] * world
+                        dist.all_gather_object(parts, y_loc.cpu(), group=self.group)
+                        buf = torch.cat(parts).to(dev)
+                    want = buf
+                if launch and ok:
+                    def run_chain():
                         for i, (q, st) in enumerate(layers):
                             if not self.gemv(x if i == 0 else None, q, st, consume=i > 0, produce=True, dtype=torch.bfloat16):
-                                # (cannot happen behind serves() + freshly cloned, aligned shards; if it does, every rank is here)
-                                launch, ok, problem = False, False, "a launch of the self-test chain was refused"
-                                break
-                    if launch:
+                                raise RuntimeError("a launch of the self-test chain was refused")  # (cannot happen behind serves() + aligned shards)
                         got = self.read(H, torch.bfloat16)
                         torch.cuda.synchronize(dev)
+                        return got
+
+                    got = guarded(run_chain)
+                    if got is not None and ok:
                         if self.status() != 0:
                             ok, problem = False, "a wait ran into its bound (a peer's granules never became visible)"
                         elif not torch.equal(got, want):
                             ok, problem = False, "its result differs from the layers with the group's all-gather between them"
-        except Exception as exc:  # noqa: BLE001  (carried to the vote below: a rank that raised alone would leave the others waiting)
-            ok, problem = False, f"{type(exc).__name__}: {exc}"
         votes = [None] * world
         dist.all_gather_object(votes, None if ok else f"rank {rank}: {problem}", group=self.group)
         votes = [v for v in votes if v]
