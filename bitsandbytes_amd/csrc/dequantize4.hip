@@ -218,9 +218,42 @@ __global__ __launch_bounds__(kDqThreads) void dequantize4_rows_kernel(const uint
         code[tid] = (quant_type == kNF4) ? kNF4Code[tid] : kFP4Code[tid];
     const long t = blockIdx.y;
     const long row = static_cast<long>(idx[t]);
+    const bool valid = row >= 0 && row < num_rows;
+    if constexpr (sizeof(T) == 4) {
+        // fp32 outputs (round 5): two units of 4 outputs per lane - one packed 16-bit piece in, ONE 16-byte store out, a wavefront's
+        // store 1 KiB contiguous - instead of 8 outputs = two 16-byte stores at a 32-byte stride (half lines per store instruction:
+        // what cost the standalone kernel a third of its bandwidth, see dequantize4_f32_lines_kernel). Same arithmetic, same values.
+        unsigned short w2[2] = {0, 0};
+        float s2[2] = {0.0f, 0.0f};
+        int col2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            col2[u] = static_cast<int>(blockIdx.x) * kDqThreads * 8 + u * kDqThreads * 4 + tid * 4;
+            if (col2[u] < row_len && valid) {
+                const long e = row * row_len + col2[u];
+                w2[u] = *reinterpret_cast<const unsigned short*>(A + (e >> 1));
+                s2[u] = absmax[e >> bs_shift];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (col2[u] >= row_len)
+                continue;
+            using V = __attribute__((ext_vector_type(4))) float;
+            V r;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const uint32_t byte = (static_cast<uint32_t>(w2[u]) >> (8 * b)) & 0xFFu;
+                r[2 * b] = valid ? rounded_f32(code[byte >> 4] * s2[u]) : __builtin_nanf("");
+                r[2 * b + 1] = valid ? rounded_f32(code[byte & 0xF] * s2[u]) : __builtin_nanf("");
+            }
+            *reinterpret_cast<V*>(out + t * row_len + col2[u]) = r;
+        }
+        return;
+    }
     const int col = (static_cast<int>(blockIdx.x) * kDqThreads + tid) * 8;
     const bool live = col < row_len;
-    const bool valid = row >= 0 && row < num_rows;
     uint32_t w = 0;
     float s = 0.0f;
     if (live && valid) {
