@@ -1025,21 +1025,13 @@ template <typename T> void launch_mb(const StreamArgs& a, int quant_type, bool g
     // that is never stored); larger M - only reached for shapes the MFMA kernels do not take - loops passes of 4
     // over grid.y. A caller-supplied code table (legacy op) always runs row by row.
     if (a.M == 1 || a.code16 != nullptr) {
-        // 16 wavefronts (ring of 2) or 8 (ring of 4, decoded two stages at a time). Eight repeat the per-wavefront work
-        // half as often and win once a CU has enough row segments to amortise their longer dependency chains
-        // (measured on MI355X, profiles/r2_stream_ab.txt: 8192^2 9.5 vs 10.7 us, 14336 x 4096 8.8 vs 9.8; but 4096^2 4.44
-        // vs 4.25 and, with 6 or 7 segments per row that leave wavefronts idle, 4096 x 11008 8.8 vs 7.8)
-        const int S = (a.K + kSegK - 1) / kSegK;
-        const long items_per_cu = static_cast<long>((a.rows_total + device_cu_count() - 1) / device_cu_count()) * S;
-        const int tw = g_tune.waves.load(std::memory_order_relaxed);
-        // Round 5: with the round-robin harness (profiles/r5_stream_prologue_ab.txt, two runs on two boxes) 16 wavefronts are level or
-        // ahead on EVERY shape - 8192^2 8.54 / 8.81 vs 8.69 / 8.79 us, 11008 x 4096 6.42 / 6.56 vs 7.21 / 7.22, 14336 x 4096 7.54 / 7.81 vs
-        // 7.93 / 8.11, 28672 x 8192 22.8 / 23.8 vs 23.6 / 24.4, 4096 x 11008 7.44 / 7.41 vs 8.10 / 8.17: round 2's crossover (below) came
-        // from single timings in a fixed order, which that harness showed to carry an 8 % first-measured penalty. The 8-wavefront
-        // instance stays for the tuning knob (A/B runs).
-        (void)S;
-        (void)items_per_cu;
-        const bool eight = tw == 8;
+        // 16 wavefronts (ring of 2) for every call. Round 2 routed long row lists (>= 64 items per CU, 8 % S == 0) to the 8-wavefront
+        // instance (ring of 4, decoded two stages at a time) on single timings in a fixed order - 8192^2 9.5 vs 10.7 us, 14336 x 4096 8.8
+        // vs 9.8. Round 5, round-robin medians on two boxes (profiles/r5_stream_prologue_ab.txt): 16 wavefronts are level or ahead on
+        // EVERY shape - 8192^2 8.54 / 8.81 vs 8.69 / 8.79 us, 11008 x 4096 6.42 / 6.56 vs 7.21 / 7.22, 14336 x 4096 7.54 / 7.81 vs 7.93 /
+        // 8.11, 28672 x 8192 22.8 / 23.8 vs 23.6 / 24.4, 4096 x 11008 7.44 / 7.41 vs 8.10 / 8.17 - and that harness showed what single
+        // timings carry: an 8 % first-measured penalty. The 8-wavefront instance stays for the tuning knob (A/B runs).
+        const bool eight = g_tune.waves.load(std::memory_order_relaxed) == 8;
         if (eight)
             return launch_flags<T, 1, 8>(a, quant_type, grouped, stream);
         return launch_flags<T, 1, 16>(a, quant_type, grouped, stream);
