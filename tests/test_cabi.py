@@ -299,7 +299,16 @@ def test_launch_plan_workspace_query_is_pure_host_logic():
                     assert w == 0, "M <= 2 runs the dot kernel: no workspace"
         assert q(1, BF16, 64, N, K, 64) == 0, "explicit dot kernel never needs a workspace"
         assert q(0, 0, 64, N, K, 64) == 0, "fp32 activations never take the MFMA path"
-        assert q(0, BF16, 64, N, K, 32) == 0, "blocksize 32 is outside the MFMA kernels' preconditions"
+        # blocksize 32 (round 5): on the MFMA route through the register-transposed kernel's BS32 instances from 5 rows on (3 on
+        # >= 12 M weights) wherever K % 256 == 0, whole [M, N] slabs of workspace where that kernel splits K; blocksize 16 stays outside
+        route = ce.lib.bnb_mi355x_gemm_4bit_route
+        for M32 in (1, 2, 3, 4, 5, 16, 64, 200):
+            want = int(K % 256 == 0 and (M32 >= 5 or (M32 >= 3 and N * K >= (12 << 20))))
+            assert route(0, BF16, M32, N, K, 32) == want, (M32, N, K)
+            w32 = q(0, BF16, M32, N, K, 32)
+            assert (w32 == 0 if not want else w32 % (M32 * N * 4) == 0), (M32, N, K, w32)
+        assert route(0, BF16, 64, N, K, 16) == 0 and q(0, BF16, 64, N, K, 16) == 0, "blocksize 16 is outside the MFMA kernels' preconditions"
+        assert route(0, 0, 64, N, K, 32) == 0, "fp32 activations never take the MFMA path"
     # headline shape: single-launch plans (no finalize pass) for every batch up to 48 rows (the register-transposed kernel:
     # 256 column tiles fill the chip without K slices); large matrices with tall tiles split K
     assert q(0, BF16, 16, 4096, 4096, 64) == 0
