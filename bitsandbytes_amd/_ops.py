@@ -284,6 +284,31 @@ def _(A, absmax, indices, row_len: int, blocksize: int, quant_type: str, dtype: 
     return torch.empty((*indices.shape, row_len), dtype=dtype, device=A.device)
 
 
+# ---------------------------------------------------------------------------------------------- quantize_4bit_nested
+# Not a reference op: quantize_4bit(compress_statistics=True) as one operator - the 4-bit encoder, the mean of its fp32 absmax, the
+# subtraction and the 8-bit blockwise encoder (blocksize 256) of the reference's functional.py:925-951, which there are four operator
+# calls. Returns (packed, absmax_8bit, absmax2, offset). code8 is the 256-entry code of the second level (the dynamic map).
+torch.library.define(
+    "bitsandbytes_amd::quantize_4bit_nested",
+    "(Tensor A, Tensor code8, int blocksize, str quant_type, ScalarType quant_storage) -> (Tensor, Tensor, Tensor, Tensor)",
+)
+
+
+@register_fake("bitsandbytes_amd::quantize_4bit_nested")
+def _(A, code8, blocksize: int, quant_type: str, quant_storage: torch.dtype):
+    _check_4bit_common(blocksize, quant_type)
+    torch._check(A.dtype in _FLOAT_DTYPES, lambda: f"Blockwise 4bit quantization only supports 16/32-bit floats, but got {A.dtype}")
+    torch._check(code8.dtype == torch.float32 and code8.numel() == 256, lambda: "code8 must be 256 float32 values")
+    n = A.numel()
+    blocks = -(n // -blocksize)
+    return (
+        torch.empty(((n + 1) // (quant_storage.itemsize * 2), 1), device=A.device, dtype=quant_storage),
+        torch.empty((blocks,), device=A.device, dtype=torch.uint8),
+        torch.empty((-(blocks // -256),), device=A.device, dtype=torch.float32),
+        torch.empty((), device=A.device, dtype=torch.float32),
+    )
+
+
 # ---------------------------------------------------------------------------------------------- gemm_4bit_grad_input
 # Not a reference op: the fused backward of gemm_4bit with respect to its activations,
 #   grad_A[*, K] = grad_out[*, N] @ dequantize_4bit(B)[N, K]

@@ -103,6 +103,37 @@ def _(A: torch.Tensor, blocksize: int, quant_type: str, quant_storage: torch.dty
     return out, absmax
 
 
+@register_kernel("bitsandbytes_amd::quantize_4bit_nested", "cuda")
+def _(A: torch.Tensor, code8: torch.Tensor, blocksize: int, quant_type: str, quant_storage: torch.dtype):
+    """quantize_4bit + the statistics of double quantisation behind ONE native call (three launches: 4-bit encoder, partial sums of
+    the fp32 absmax, shifted 8-bit encoder). Reference bitsandbytes/functional.py:925-951 is four operator calls."""
+    if blocksize not in (32, 64, 128, 256, 512, 1024, 2048, 4096):
+        raise ValueError(f"invalid blocksize {blocksize}")
+    if quant_type not in _QT_CODE:
+        raise ValueError(f"quant_type must be 'nf4' or 'fp4', got {quant_type!r}")
+    if A.dtype not in _DT_CODE:
+        raise ValueError(f"Blockwise 4bit quantization only supports 16/32-bit floats, but got {A.dtype}")
+    if code8.dtype != torch.float32 or code8.numel() != 256 or code8.device != A.device:
+        raise ValueError("code8 must be 256 float32 values on A's device")
+    A = A.contiguous()
+    code8 = code8.contiguous()
+    n = A.numel()
+    if n == 0:
+        raise ValueError("quantize_4bit_nested: empty input")
+    blocks = -(n // -blocksize)
+    out = torch.empty(((n + 1) // (quant_storage.itemsize * 2), 1), device=A.device, dtype=quant_storage)
+    scratch = torch.empty((blocks + 256,), device=A.device, dtype=torch.float32)
+    absmax_8bit = torch.empty((blocks,), device=A.device, dtype=torch.uint8)
+    absmax2 = torch.empty((-(blocks // -256),), device=A.device, dtype=torch.float32)
+    offset = torch.empty((), device=A.device, dtype=torch.float32)
+    with _device_of(A):
+        lib.bnb_mi355x_quantize_4bit_nested(
+            A.data_ptr(), _DT_CODE[A.dtype], n, blocksize, _QT_CODE[quant_type], out.data_ptr(), scratch.data_ptr(),
+            code8.data_ptr(), absmax_8bit.data_ptr(), absmax2.data_ptr(), offset.data_ptr(), _stream(A),
+        )
+    return out, absmax_8bit, absmax2, offset
+
+
 # ------------------------------------------------------------------------------------------ dequantize_4bit
 def _dequantize_4bit_impl(A, absmax, blocksize, quant_type, dtype, out):
     if dtype not in _DT_NAME:

@@ -87,11 +87,67 @@ template <typename T> __device__ __forceinline__ void load4(const T* __restrict_
     }
 }
 
+// Sum of 256 values, one per thread of a 256-thread workgroup, result in every thread. The order is a balanced binary tree over
+// the thread index (wave_sum pairs lanes l and l ^ 1, then pairs of pairs, ...; the four wavefront sums are added as (0 + 1) + (2 + 3)):
+// a fixed function of the inputs, which the tests restate in numpy bit for bit.
+__device__ __forceinline__ float workgroup_sum_256(float v, float* slots /* [4] in LDS */) {
+    v = wave_sum(v);
+    __syncthreads(); // (the slots may still be read from a previous call)
+    if ((threadIdx.x & 63) == 0)
+        slots[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (slots[0] + slots[1]) + (slots[2] + slots[3]);
+}
+
+constexpr int kSumChunk = 1024;   // elements per workgroup step of the partial-sum kernel: 4 per thread
+constexpr int kSumPartials = 256; // at most this many partial sums, whatever the length
+
+// Partial sums for the mean of the fp32 absmax vector of double quantisation (reference bitsandbytes/functional.py:938-951:
+// offset = absmax.mean()). Workgroup c adds elements [c * 1024 * steps, (c + 1) * 1024 * steps): every step of 1024 elements as a
+// balanced binary tree in index order (zeros past the end), the steps one after the other. partial[c] is one float; the consumer
+// (quantize8_kernel<float, 256, true>) adds the <= 256 partials as one more balanced tree and divides by n.
+__global__ __launch_bounds__(256) void absmax_partial_sums_kernel(const float* __restrict__ A, float* __restrict__ partial, long n, int steps) {
+    __shared__ float slots[4];
+    const long begin = static_cast<long>(blockIdx.x) * kSumChunk * steps + threadIdx.x * 4;
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(A) & 15u) == 0;
+    float acc = 0.0f;
+    for (int s = 0; s < steps; ++s) {
+        const long i = begin + static_cast<long>(s) * kSumChunk;
+        float x[4];
+        if (vec_ok && i + 4 <= n) {
+            const f32x4_t r = *reinterpret_cast<const f32x4_t*>(A + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                x[j] = r[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                x[j] = (i + j < n) ? A[i + j] : 0.0f;
+        }
+        const float t = workgroup_sum_256(__fadd_rn(__fadd_rn(x[0], x[1]), __fadd_rn(x[2], x[3])), slots);
+        acc = (s == 0) ? t : __fadd_rn(acc, t);
+    }
+    if (threadIdx.x == 0)
+        partial[blockIdx.x] = acc;
+}
+
 // BS = quantization block size (power of two, 64 .. 4096). One wavefront step = 256 elements.
-template <typename T, int BS>
+// SHIFT (double quantisation, T = float, BS = 256): the input is A - offset with offset = (sum of the partials) / n, computed by every
+// workgroup in the same fixed order, written to offset_out by the first one - the reference's `absmax -= absmax.mean()` folded into
+// the encoder's load (one launch and one pass over the vector instead of three).
+template <typename T, int BS, bool SHIFT = false>
 __global__ __launch_bounds__(256) void quantize8_kernel(const float* __restrict__ code, const T* __restrict__ A,
                                                         float* __restrict__ absmax, uint8_t* __restrict__ out, long n,
-                                                        int vec_ok) {
+                                                        int vec_ok, const float* __restrict__ partial = nullptr, int n_partial = 0,
+                                                        float* __restrict__ offset_out = nullptr) {
+    float shift = 0.0f;
+    if constexpr (SHIFT) {
+        __shared__ float slots[4];
+        const float total = workgroup_sum_256(static_cast<int>(threadIdx.x) < n_partial ? partial[threadIdx.x] : 0.0f, slots);
+        shift = total / static_cast<float>(n); // IEEE division
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            *offset_out = shift;
+    }
     __shared__ float mid[256];
     __shared__ uint32_t thr[256];   // T_i, ascending; thr[255] = 65536
     __shared__ uint32_t cell[1024]; // see the table build below
@@ -135,6 +191,11 @@ __global__ __launch_bounds__(256) void quantize8_kernel(const float* __restrict_
 #pragma unroll
         for (int sp = 0; sp < SPB; ++sp) {
             load4<T>(A, base + sp * 256L, n, vec_ok != 0, x[sp]);
+            if constexpr (SHIFT) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) // (elements past the end stay zero: they must not enter the block's absmax)
+                    x[sp][j] = (base + sp * 256L + j < n) ? __fsub_rn(x[sp][j], shift) : 0.0f;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 m = fmaxf(m, fabsf(x[sp][j]));
@@ -486,6 +547,29 @@ void launch_dequantize8(const float* code, const uint8_t* A, const float* absmax
 }
 
 } // namespace
+
+// Double quantisation's statistics in two launches (reference bitsandbytes/functional.py:938-951 is mean, subtract, quantize_blockwise
+// with blocksize 256: three to five launches and as many host dispatches): partial sums, then the shifted encoder. absmax: the fp32
+// absmax vector of the 4-bit blocks (n values, device); partial: scratch of 256 floats; offset_out: 1 float; out: n codes;
+// absmax2: ceil(n / 256) floats.
+void quantize_absmax_nested(const float* code, const float* absmax, long n, float* partial, float* offset_out, uint8_t* out,
+                            float* absmax2, hipStream_t stream) {
+    if (n <= 0)
+        return;
+    const long per = static_cast<long>(kSumChunk) * kSumPartials;
+    const int steps = static_cast<int>((n + per - 1) / per);
+    const int chunks = static_cast<int>((n + static_cast<long>(kSumChunk) * steps - 1) / (static_cast<long>(kSumChunk) * steps));
+    hipLaunchKernelGGL(absmax_partial_sums_kernel, dim3(static_cast<unsigned>(chunks)), dim3(256), 0, stream, absmax, partial, n, steps);
+    BNB_CHECK_LAUNCH();
+    const int vec_ok = aligned_to(absmax, 16) && aligned_to(out, 4);
+    const long units = (n + 255) / 256;
+    long grid = (units + 3) / 4;
+    if (grid > 2048)
+        grid = 2048;
+    hipLaunchKernelGGL((quantize8_kernel<float, 256, true>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, code, absmax, absmax2,
+                       out, n, vec_ok, partial, chunks, offset_out);
+    BNB_CHECK_LAUNCH();
+}
 
 void quantize_8bit_set_variant(int variant) { g_q8_variant.store(variant, std::memory_order_relaxed); }
 

@@ -55,6 +55,7 @@ extern thread_local TlsKnob g_mfma_knob0, g_mfma_knob1;
 bool gemm_4bit_grad_input_supported(int dtype, const void* G, const uint8_t* B, int M, int N, int K, int blocksize);
 size_t gemm_4bit_grad_input_workspace_bytes(int M, int N, int K);
 void quantize_8bit_set_variant(int variant);
+void quantize_absmax_nested(const float* code, const float* absmax, long n, float* partial, float* offset_out, uint8_t* out, float* absmax2, hipStream_t stream);
 void quantize_4bit_set_variant(int variant);
 void dequantize_4bit_set_variant(int variant);
 void gemm_4bit_grad_input_set_slices(int ns);
@@ -255,6 +256,15 @@ void bnb_mi355x_quantize_8bit(const float* code, const void* A, int dtype, float
         quantize_8bit_f16(code, A, absmax, out, blocksize, n, S(s));
     else
         quantize_8bit_bf16(code, A, absmax, out, blocksize, n, S(s));
+}
+void bnb_mi355x_quantize_4bit_nested(const void* A, int dtype, long n, int blocksize, int quant_type, unsigned char* out,
+                                     float* scratch, const float* code8, unsigned char* absmax_8bit, float* absmax2,
+                                     float* offset, bnb_stream_t s) {
+    // quantize_4bit(compress_statistics=True) of the reference (bitsandbytes/functional.py:925-951) as ONE call: the 4-bit encoder
+    // into scratch[0, blocks), then the statistics (mean, subtract, 8-bit encode in blocks of 256) in two launches
+    bnb_mi355x_quantize_4bit(A, dtype, scratch, out, blocksize, n, quant_type, s);
+    const long blocks = (n + blocksize - 1) / blocksize;
+    quantize_absmax_nested(code8, scratch, blocks, scratch + blocks, offset, absmax_8bit, absmax2, S(s));
 }
 void bnb_mi355x_gemm_4bit(int kernel, int dtype, const void* A, const uint8_t* B, const float* absmax,
                           const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset,

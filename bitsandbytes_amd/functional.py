@@ -159,6 +159,21 @@ _NF4_VALUES = [
 _FP4_VALUES = [0, 0.0625, 8.0, 12.0, 4.0, 6.0, 2.0, 3.0, -0, -0.0625, -8.0, -12.0, -4.0, -6.0, -2.0, -3.0]
 
 
+_DEVICE_CONSTANTS: dict = {}
+
+
+def _per_device_constant(key, device, make) -> Tensor:
+    """A read-only constant tensor, made once on the host by ``make()`` and kept per device. Callers that hand it out copy it."""
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    k = (key, d)
+    t = _DEVICE_CONSTANTS.get(k)
+    if t is None:
+        t = _DEVICE_CONSTANTS[k] = make().to(d)
+    return t
+
+
 def get_4bit_type(typename: str, device=None, blocksize: int = 64) -> Tensor:
     """16-entry fp32 code table of a 4-bit type ('nf4' or 'fp4'); reference functional.py:772-859."""
     if device is None:
@@ -169,9 +184,14 @@ def get_4bit_type(typename: str, device=None, blocksize: int = 64) -> Tensor:
         data = _FP4_VALUES
     else:
         raise NotImplementedError(f"Typename {typename} not supported")
-    t = torch.tensor(data, dtype=torch.float32, device=device)
-    t.div_(t.abs().max())
-    return t
+    # The values are constants of the format: computed once (fp32 IEEE division, as the reference's t / t.abs().max()), kept per device,
+    # and every call gets its own copy - one device-side copy instead of a synchronous host-to-device transfer and three launches
+    # (that was a third of the host time of one quantize_4bit call: profiles/r5_host_overhead.txt)
+    def make():
+        t = torch.tensor(data, dtype=torch.float32)
+        return t.div_(t.abs().max())
+
+    return _per_device_constant(("4bit", typename), device, make).clone()
 
 
 # --------------------------------------------------------------------------------------------------
@@ -313,9 +333,13 @@ class QuantState:
 # 8-bit blockwise (double-quantisation helper)
 # --------------------------------------------------------------------------------------------------
 def _dynamic_map(device) -> Tensor:
-    if "dynamic" not in name2qmap:
-        name2qmap["dynamic"] = create_dynamic_map()
-    return name2qmap["dynamic"].to(device)
+    """The default 8-bit code on ``device``: the SAME tensor on every call (read-only by contract; states get copies)."""
+    def make():
+        if "dynamic" not in name2qmap:
+            name2qmap["dynamic"] = create_dynamic_map()
+        return name2qmap["dynamic"]
+
+    return _per_device_constant("dynamic", device, make)
 
 
 def quantize_blockwise(A: Tensor, code: Optional[Tensor] = None, absmax: Optional[Tensor] = None,
@@ -393,8 +417,23 @@ def quantize_4bit(A: Tensor, absmax: Optional[Tensor] = None, out: Optional[Tens
     if A.dtype not in _FLOAT_DTYPES:
         raise ValueError(f"Blockwise 4bit quantization only supports 16/32-bit floats, but got {A.dtype}")
 
-    packed, am = torch.ops.bitsandbytes.quantize_4bit.default(A, blocksize, quant_type, quant_storage)
     code = get_4bit_type(quant_type, device=A.device)
+    if compress_statistics and A.device.type == "cuda" and A.numel() > 0:
+        # one operator for the encoder and the statistics (three launches behind one native call; the reference's sequence below is
+        # four operator calls, 86 us of host time per 4096 x 4096 layer: profiles/r5_host_overhead.txt). The offset is the mean of the
+        # fp32 absmax in a fixed summation order; the 8-bit codes are what quantize_blockwise gives on absmax - offset, bit for bit.
+        code8 = _dynamic_map(A.device)
+        packed, q_am, am2, offset = torch.ops.bitsandbytes_amd.quantize_4bit_nested.default(A, code8, blocksize, quant_type, quant_storage)
+        state2 = QuantState(absmax=am2, code=code8.clone(), blocksize=256, dtype=torch.float32)
+        state = QuantState(absmax=q_am, shape=A.shape, dtype=A.dtype, blocksize=blocksize, code=code,
+                           quant_type=quant_type, offset=offset, state2=state2)
+        if out is not None:
+            packed = out.copy_(packed)
+        if absmax is not None:
+            state.absmax = absmax.copy_(state.absmax)
+        return packed, state
+
+    packed, am = torch.ops.bitsandbytes.quantize_4bit.default(A, blocksize, quant_type, quant_storage)
 
     if compress_statistics:
         offset = am.mean()

@@ -104,6 +104,15 @@ void* cget_managed_ptr(size_t bytes);
 void bnb_mi355x_quantize_4bit(const void* A, int dtype, float* absmax, unsigned char* out, int blocksize, long n, int quant_type, bnb_stream_t stream);
 void bnb_mi355x_quantize_8bit(const float* code, const void* A, int dtype, float* absmax, unsigned char* out, int blocksize, long n, bnb_stream_t stream);
 
+/* quantize_4bit(compress_statistics=True) as ONE call (reference bitsandbytes/functional.py:925-951: quantize_4bit, absmax.mean(),
+ * absmax - offset, quantize_blockwise(..., blocksize=256) - four to six launches and host dispatches; here three launches behind one).
+ * A: n elements of dtype; out: (n + 1) / 2 packed bytes; scratch: device buffer of ceil(n / blocksize) + 256 floats (the fp32 absmax of
+ * the 4-bit blocks, then 256 partial sums; contents are unspecified afterwards); code8: the 256-entry 8-bit code (fp32, device, ascending:
+ * the dynamic map); absmax_8bit: ceil(n / blocksize) codes; absmax2: ceil(ceil(n / blocksize) / 256) floats; offset: 1 float =
+ * the mean of the fp32 absmax, summed in a FIXED order (a balanced binary tree over 1024-element steps, see csrc/blockwise8.hip:
+ * the same bits on every launch, any device). absmax_8bit / absmax2 are bit for bit what quantize_blockwise gives on absmax - offset. */
+void bnb_mi355x_quantize_4bit_nested(const void* A, int dtype, long n, int blocksize, int quant_type, unsigned char* out, float* scratch, const float* code8, unsigned char* absmax_8bit, float* absmax2, float* offset, bnb_stream_t stream);
+
 /* Row gather + 4-bit dequantize in one launch: out[t, 0:row_len] = dequantize(row indices[t]) for
  * t < rows_out. The fused form of the Embedding4bit lookup (reference bitsandbytes/nn/modules.py:921-951:
  * F.embedding on the packed bytes, F.embedding on absmax, dequantize_4bit). A is the packed

@@ -537,6 +537,66 @@ def test_double_quant_state_vs_oracle(quant_type, blocksize):
     assert err < 0.28
 
 
+def _tree_mean_f32(a: np.ndarray) -> np.float32:
+    """csrc/blockwise8.hip's summation order for the mean of the fp32 absmax, restated: steps of 1024 elements as a balanced binary
+    tree in index order (zeros past the end); the steps of a chunk (ceil(n / (1024 * 256)) of them) one after the other; the <= 256
+    chunk sums as one more balanced tree of 256 leaves; one IEEE division by n."""
+    a = np.asarray(a, dtype=np.float32)
+    n = a.size
+    steps = -(-n // (1024 * 256))
+    chunks = -(-n // (1024 * steps))
+    x = np.zeros(chunks * steps * 1024, dtype=np.float32)
+    x[:n] = a
+    t = x.reshape(chunks * steps, 1024)
+    while t.shape[1] > 1:
+        t = t[:, 0::2] + t[:, 1::2]
+    t = t.reshape(chunks, steps)
+    part = t[:, 0].copy()
+    for s_ in range(1, steps):
+        part = part + t[:, s_]
+    p = np.zeros(256, dtype=np.float32)
+    p[:chunks] = part
+    while p.size > 1:
+        p = p[0::2] + p[1::2]
+    return np.float32(p[0]) / np.float32(n)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("quant_type,blocksize,n", [
+    ("nf4", 64, 512 * 1024), ("fp4", 128, 4096 * 4096), ("nf4", 64, 4096 * 4096), ("nf4", 32, 1000 * 96 + 32), ("fp4", 64, 64 * 255 + 7),
+    ("nf4", 64, 64 * 1025), ("nf4", 4096, 4096 * 3 + 1), ("nf4", 32, 32 * (1024 * 256 + 1029)), ("nf4", 64, 5)])
+def test_quantize_4bit_nested_one_call_equals_the_four_operator_sequence(dtype, quant_type, blocksize, n):
+    """quantize_4bit(compress_statistics=True) runs as ONE operator (three launches). Packed bytes = the plain operator's; the offset
+    = the mean of the fp32 absmax in the documented summation order, bit for bit (numpy restatement above) and within 2 ulp-ish of
+    the float64 mean; 8-bit codes and second-level absmax = quantize_blockwise(absmax - offset, 256), operator AND oracle, bit for bit."""
+    F = _F()
+    torch.manual_seed(n % 9973)
+    W = (torch.randn(n) * 0.03).to(dtype)
+    W[::97] *= 11.0
+    Wd = W.to(DEV)
+    q, st = F.quantize_4bit(Wd, blocksize=blocksize, quant_type=quant_type, compress_statistics=True)
+    q_plain, am_plain = torch.ops.bitsandbytes.quantize_4bit.default(Wd, blocksize, quant_type, torch.uint8)
+    assert torch.equal(q, q_plain)
+    assert st.nested and st.absmax.dtype == torch.uint8 and st.absmax.shape == am_plain.shape and st.state2.blocksize == 256
+    assert st.offset.shape == () and st.offset.dtype == torch.float32 and st.state2.code.dtype == torch.float32
+    am = am_plain.cpu()
+    off = st.offset.cpu()
+    want = _tree_mean_f32(am.numpy())
+    assert off.numpy().view(np.int32) == np.float32(want).view(np.int32), (off.item(), float(want))
+    exact = float(am.double().mean())
+    assert abs(off.item() - exact) <= 3e-7 * abs(exact) + 1e-12
+    code = F.create_dynamic_map()
+    q8, am2 = torch.ops.bitsandbytes.quantize_blockwise.default((am - off).to(DEV), code.to(DEV), 256)
+    assert torch.equal(st.absmax, q8) and torch.equal(st.state2.absmax, am2)
+    if am.numel() <= 1 << 20:
+        q8_o, am2_o = O.quantize_blockwise(am - off, code, 256)
+        assert torch.equal(st.absmax.cpu(), q8_o) and torch.equal(st.state2.absmax.cpu(), am2_o)
+    assert torch.equal(st.state2.code.cpu(), code)
+    # twice the same bits (fixed order, no atomics), also from another launch geometry's neighbourhood: a view at an odd offset
+    q_b, st_b = F.quantize_4bit(Wd, blocksize=blocksize, quant_type=quant_type, compress_statistics=True)
+    assert torch.equal(q_b, q) and torch.equal(st_b.absmax, st.absmax) and torch.equal(st_b.offset.view(torch.int32), st.offset.view(torch.int32))
+
+
 # ------------------------------------------------------------------------------------------ gemm / gemv
 def _oracle_y(x, q, st, bias=None):
     """fp32-dequant + fp32-linear oracle result for a (possibly nested) QuantState living on the GPU."""

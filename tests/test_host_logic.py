@@ -43,6 +43,28 @@ def test_fake_kernels_shapes(storage):
         torch.ops.bitsandbytes.gemm_4bit.default(x, q, (48, 128), am, 64, "int4")
 
 
+def test_nested_quantize_operator_shapes_and_per_device_constants():
+    """The one-call nested quantize (bitsandbytes_amd::quantize_4bit_nested): shapes of its four results on the meta device; and the
+    constants the functional layer hands out (4-bit code table, dynamic map) are per-device singletons whose copies are independent."""
+    A = torch.empty(1000, 96, device="meta", dtype=torch.float16)
+    code8 = torch.empty(256, device="meta", dtype=torch.float32)
+    q, q_am, am2, off = torch.ops.bitsandbytes_amd.quantize_4bit_nested.default(A, code8, 64, "fp4", torch.uint8)
+    assert q.shape == (48000, 1) and q_am.shape == (1500,) and q_am.dtype == torch.uint8
+    assert am2.shape == (6,) and am2.dtype == torch.float32 and off.shape == () and off.dtype == torch.float32
+    with pytest.raises(RuntimeError):
+        torch.ops.bitsandbytes_amd.quantize_4bit_nested.default(A, code8[:16], 64, "fp4", torch.uint8)
+    a = F.get_4bit_type("nf4", device="cpu")
+    a.mul_(2.0)  # a caller's copy: the next call must not see it
+    b = F.get_4bit_type("nf4", device="cpu")
+    assert b.abs().max().item() == 1.0 and b.data_ptr() != a.data_ptr()
+    assert torch.equal(b, from_bits(golden()["code/nf4"], 0))
+    d1, d2 = F._dynamic_map("cpu"), F._dynamic_map(torch.device("cpu"))
+    assert d1.data_ptr() == d2.data_ptr() and torch.equal(d1, F.create_dynamic_map())
+    # states built from it carry copies
+    _, st = F.quantize_blockwise(torch.randn(512), blocksize=256)
+    assert st.code.data_ptr() != d1.data_ptr() and torch.equal(st.code, d1)
+
+
 def test_functional_validation_errors():
     A = torch.randn(64, 64)
     with pytest.raises(ValueError, match="invalid blocksize"):

@@ -58,10 +58,57 @@ with torch.no_grad():
     rows = [
         ("quantize_4bit NF4 bs64", lambda: F.quantize_4bit(Wq, blocksize=64, quant_type="nf4")),
         ("quantize_4bit NF4 bs64 + double quant", lambda: F.quantize_4bit(Wq, blocksize=64, quant_type="nf4", compress_statistics=True)),
-        ("  absmax.mean()", lambda: am.mean()),
-        ("  absmax - offset", lambda: am - 0.25),
-        ("  quantize_blockwise(absmax, 256)", lambda: F.quantize_blockwise(am, blocksize=256)),
+        ("  the raw operator (4-bit encoder)", lambda: torch.ops.bitsandbytes.quantize_4bit.default(Wq, 64, "nf4", torch.uint8)),
+        ("  the nested operator (3 launches)", lambda: torch.ops.bitsandbytes_amd.quantize_4bit_nested.default(Wq, F._dynamic_map(Wq.device), 64, "nf4", torch.uint8)),
+        ("  get_4bit_type (copy of a constant)", lambda: F.get_4bit_type("nf4", device=Wq.device)),
+        ("  (reference sequence) absmax.mean()", lambda: am.mean()),
+        ("  (reference sequence) absmax - offset", lambda: am - 0.25),
+        ("  (reference sequence) quantize_blockwise", lambda: F.quantize_blockwise(am, blocksize=256)),
     ]
     print("# load time, 4096^2 bf16 -> NF4 (wall us per call, eager, queue full)")
     for name, fn in rows:
         print(f"{name:40s} {timeit(fn, n=500):7.1f} us per call")
+
+
+# ---- the same three sequences as GPU time (hipGraph replay, no host in the loop): what the launches themselves cost
+def graph_us(fn, reps=200):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    st_ = torch.cuda.Stream()
+    st_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st_):
+        fn()
+    torch.cuda.current_stream().wait_stream(st_)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(10):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / (reps * 10) * 1e3)
+    return best
+
+
+code8 = F._dynamic_map(Wq.device)
+
+
+def reference_sequence():
+    p_, a_ = torch.ops.bitsandbytes.quantize_4bit.default(Wq, 64, "nf4", torch.uint8)
+    o_ = a_.mean()
+    return p_, torch.ops.bitsandbytes.quantize_blockwise.default(a_ - o_, code8, 256), o_
+
+
+with torch.no_grad():
+    print("# GPU time of the same work (hipGraph replay of 10 calls, us per call; the input is re-read from HBM/MALL every call)")
+    print(f"{'4-bit encoder alone':40s} {graph_us(lambda: torch.ops.bitsandbytes.quantize_4bit.default(Wq, 64, 'nf4', torch.uint8)):7.1f} us")
+    print(f"{'nested operator (3 launches)':40s} {graph_us(lambda: torch.ops.bitsandbytes_amd.quantize_4bit_nested.default(Wq, code8, 64, 'nf4', torch.uint8)):7.1f} us")
+    print(f"{'reference sequence (5 launches)':40s} {graph_us(reference_sequence):7.1f} us")
