@@ -309,6 +309,25 @@ def _(A, code8, blocksize: int, quant_type: str, quant_storage: torch.dtype):
     )
 
 
+# ---------------------------------------------------------------------------------------------- dequantize_4bit_nested
+# Not a reference op: dequantize_4bit for double-quantised statistics as one operator / one launch (the reference reconstructs the
+# fp32 absmax with two more operator calls first, functional.py:1002-1006). absmax2 / code8 / offset are state2.absmax, state2.code
+# and state.offset; second-level blocksize 256.
+torch.library.define(
+    "bitsandbytes_amd::dequantize_4bit_nested",
+    "(Tensor A, Tensor absmax_8bit, Tensor absmax2, Tensor code8, Tensor offset, int blocksize, str quant_type, int[] shape, "
+    "ScalarType dtype) -> Tensor",
+)
+
+
+@register_fake("bitsandbytes_amd::dequantize_4bit_nested")
+def _(A, absmax_8bit, absmax2, code8, offset, blocksize: int, quant_type: str, shape: Sequence[int], dtype: torch.dtype):
+    _check_4bit_common(blocksize, quant_type)
+    torch._check(dtype in _FLOAT_DTYPES, lambda: f"dtype must be a 16/32-bit float, got {dtype}")
+    torch._check(absmax_8bit.dtype == torch.uint8, lambda: f"absmax_8bit must be uint8, got {absmax_8bit.dtype}")
+    return torch.empty(tuple(shape), dtype=dtype, device=A.device)
+
+
 # ---------------------------------------------------------------------------------------------- gemm_4bit_grad_input
 # Not a reference op: the fused backward of gemm_4bit with respect to its activations,
 #   grad_A[*, K] = grad_out[*, N] @ dequantize_4bit(B)[N, K]

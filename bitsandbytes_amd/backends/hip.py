@@ -169,6 +169,40 @@ def _(A, absmax, blocksize: int, quant_type: str, shape: Sequence[int], dtype: t
     _dequantize_4bit_impl(A, absmax, blocksize, quant_type, dtype, out)
 
 
+def _dequantize_4bit_nested_impl(A, absmax_8bit, absmax2, code8, offset, blocksize, quant_type, dtype, out):
+    """One launch: the fp32 absmax of every block is reconstructed inside the dequantize kernel (csrc/dequantize4.hip, NESTED)."""
+    if dtype not in _DT_CODE:
+        raise ValueError(f"Blockwise 4bit dequantization only supports 16/32-bit floats, but got {dtype}")
+    if quant_type not in _QT_CODE:
+        raise ValueError(f"quant_type must be 'nf4' or 'fp4', got {quant_type!r}")
+    if blocksize not in (32, 64, 128, 256, 512, 1024, 2048, 4096):
+        raise ValueError(f"invalid blocksize {blocksize}")
+    n = out.numel()
+    blocks = -(n // -blocksize)
+    if absmax_8bit.dtype != torch.uint8 or absmax_8bit.numel() != blocks:
+        raise ValueError(f"absmax_8bit must hold {blocks} uint8 codes, got {tuple(absmax_8bit.shape)} {absmax_8bit.dtype}")
+    if absmax2.dtype != torch.float32 or absmax2.numel() != -(blocks // -256):
+        raise ValueError(f"absmax2 must hold {-(blocks // -256)} float32 values (second-level blocksize 256)")
+    if code8.dtype != torch.float32 or code8.numel() != 256 or offset.dtype != torch.float32 or offset.numel() != 1:
+        raise ValueError("code8 must be 256 float32 values and offset one float32 value")
+    for t in (absmax_8bit, absmax2, code8, offset):
+        if t.device != A.device:
+            raise ValueError("all statistics must live on A's device")
+    A = A.contiguous()
+    with _device_of(A):
+        lib.bnb_mi355x_dequantize_4bit_nested(
+            _DT_CODE[dtype], A.data_ptr(), absmax_8bit.contiguous().data_ptr(), absmax2.contiguous().data_ptr(),
+            code8.contiguous().data_ptr(), offset.data_ptr(), out.data_ptr(), blocksize, n, _QT_CODE[quant_type], _stream(A),
+        )
+    return out
+
+
+@register_kernel("bitsandbytes_amd::dequantize_4bit_nested", "cuda")
+def _(A, absmax_8bit, absmax2, code8, offset, blocksize: int, quant_type: str, shape: Sequence[int], dtype: torch.dtype):
+    out = torch.empty(tuple(shape), dtype=dtype, device=A.device)
+    return _dequantize_4bit_nested_impl(A, absmax_8bit, absmax2, code8, offset, blocksize, quant_type, dtype, out)
+
+
 @register_kernel("bitsandbytes_amd::dequantize_4bit_rows", "cuda")
 def _(A, absmax, indices, row_len: int, blocksize: int, quant_type: str, dtype: torch.dtype) -> torch.Tensor:
     if dtype not in _DT_CODE:
@@ -481,12 +515,12 @@ def gemm_4bit_grouped(A: torch.Tensor, mats, blocksize: int, quant_type: str, ou
 
 
 def _gemm_4bit_unfused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8bit, absmax_code, absmax_offset):
-    if absmax_8bit is not None:
-        absmax_dq = torch.empty_like(absmax_8bit, dtype=torch.float32)
-        _dequantize_blockwise_impl(absmax_8bit, absmax, absmax_code, 256, torch.float32, absmax_dq)
-        absmax = absmax_dq + absmax_offset
     W = torch.empty(tuple(shapeB), dtype=A.dtype, device=A.device)
-    _dequantize_4bit_impl(B, absmax, blocksize, quant_type, A.dtype, W)
+    if absmax_8bit is not None:
+        # nested statistics: reconstructed inside the dequantize launch (one launch, no fp32 absmax vector; was three)
+        _dequantize_4bit_nested_impl(B, absmax_8bit, absmax, absmax_code, absmax_offset, blocksize, quant_type, A.dtype, W)
+    else:
+        _dequantize_4bit_impl(B, absmax, blocksize, quant_type, A.dtype, W)
     return torch.nn.functional.linear(A, W, bias)
 
 

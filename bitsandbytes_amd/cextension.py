@@ -69,6 +69,7 @@ def _declare(dll: ct.CDLL) -> None:
     sig(["bnb_mi355x_quantize_4bit"], [_VOID_P, _I32, _VOID_P, _VOID_P, _I32, ct.c_long, _I32, _VOID_P])
     sig(["bnb_mi355x_quantize_8bit"], [_VOID_P, _VOID_P, _I32, _VOID_P, _VOID_P, _I32, ct.c_long, _VOID_P])
     sig(["bnb_mi355x_quantize_4bit_nested"], [_VOID_P, _I32, ct.c_long, _I32, _I32] + [_VOID_P] * 7)
+    sig(["bnb_mi355x_dequantize_4bit_nested"], [_I32] + [_VOID_P] * 6 + [_I32, ct.c_long, _I32, _VOID_P])
     sig(["bnb_mi355x_dequantize_4bit_rows"],
         [_I32, _VOID_P, _VOID_P, _VOID_P, _I32, _VOID_P, ct.c_long, ct.c_long, _I32, _I32, _I32, _VOID_P])
     sig(["bnb_mi355x_gemm_4bit"], [_I32, _I32] + [_VOID_P] * 9 + [_I32] * 5 + [_VOID_P, ct.c_size_t, _VOID_P])
@@ -126,7 +127,7 @@ EXPORTED_SYMBOLS = tuple(
     + [f"cdequantize_blockwise_{d}" for d in ("fp32", "bf16", "fp16")]
     + [f"cgemm_4bit_{d}" for d in ("fp32", "bf16", "fp16")]
     + [f"cgemm_4bit_inference_naive_{d}" for d in ("fp32", "bf16", "fp16")]
-    + ["get_context", "cget_managed_ptr", "bnb_mi355x_quantize_4bit", "bnb_mi355x_quantize_8bit", "bnb_mi355x_quantize_4bit_nested", "bnb_mi355x_dequantize_4bit_rows",
+    + ["get_context", "cget_managed_ptr", "bnb_mi355x_quantize_4bit", "bnb_mi355x_quantize_8bit", "bnb_mi355x_quantize_4bit_nested", "bnb_mi355x_dequantize_4bit_nested", "bnb_mi355x_dequantize_4bit_rows",
        "bnb_mi355x_gemm_4bit", "bnb_mi355x_gemm_4bit_workspace_bytes", "bnb_mi355x_gemm_4bit_route", "bnb_mi355x_last_gemm_kernel",
        "bnb_mi355x_gemm_4bit_grouped",
        "bnb_mi355x_gemm_4bit_grad_input", "bnb_mi355x_gemm_4bit_grad_input_workspace_bytes", "bnb_mi355x_gemm_4bit_grad_input_supported",

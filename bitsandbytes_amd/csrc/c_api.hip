@@ -58,6 +58,7 @@ void quantize_8bit_set_variant(int variant);
 void quantize_absmax_nested(const float* code, const float* absmax, long n, float* partial, float* offset_out, uint8_t* out, float* absmax2, hipStream_t stream);
 void quantize_4bit_set_variant(int variant);
 void dequantize_4bit_set_variant(int variant);
+void dequantize_4bit_nested(int, const uint8_t*, const uint8_t*, const float*, const float*, const float*, void*, int, long, int, hipStream_t);
 void gemm_4bit_grad_input_set_slices(int ns);
 void gemm_4bit_grad_input(int dtype, const void* G, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                           const float* absmax_code, const float* absmax_offset, void* out, int M, int N, int K, int blocksize,
@@ -247,6 +248,15 @@ void bnb_mi355x_dequantize_4bit_rows(int dtype, const unsigned char* A, const fl
                                      int blocksize, int quant_type, bnb_stream_t s) {
     dequantize_4bit_rows(dtype, A, absmax, indices, index_bytes, out, rows_out, num_rows, row_len, blocksize,
                          quant_type, S(s));
+}
+void bnb_mi355x_dequantize_4bit_nested(int dtype, const unsigned char* A, const unsigned char* absmax_8bit, const float* absmax2,
+                                       const float* absmax_code, const float* absmax_offset, void* out, int blocksize, long n,
+                                       int quant_type, bnb_stream_t s) {
+    if (quant_type != kFP4 && quant_type != kNF4) {
+        fprintf(stderr, "bitsandbytes_amd: dequantize_4bit_nested: quant_type must be 1 (FP4) or 2 (NF4)\n");
+        exit(1);
+    }
+    dequantize_4bit_nested(dtype, A, absmax_8bit, absmax2, absmax_code, absmax_offset, out, blocksize, n, quant_type, S(s));
 }
 void bnb_mi355x_quantize_8bit(const float* code, const void* A, int dtype, float* absmax, unsigned char* out,
                               int blocksize, long n, bnb_stream_t s) {

@@ -50,30 +50,66 @@ template <typename T, bool NT> __device__ __forceinline__ void store8(T* __restr
     }
 }
 
-template <typename T, int kDqUnroll>
+// Double-quantised statistics (NESTED; round 5): the scale of block b is reconstructed in the kernel,
+//     absmax[b] = code2[absmax8[b]] * absmax2[b >> 8] + offset        (fp32 product, rounded, then fp32 sum - NOT one fma:
+// the product passes through rounded_f32; the first build, written with __fmul_rn / __fadd_rn, compiled to v_fma_f32 and differed
+// from the sequence in the last bit of rare fp16 outputs)
+// which is, bit for bit, what the reference's two extra operator calls produce (dequantize_blockwise with blocksize 256, then
+// `absmax += offset`: bitsandbytes/functional.py:1002-1006) - one launch instead of three and no fp32 absmax vector in HBM.
+struct NestedStats {
+    const uint8_t* absmax8; // one code per 4-bit block
+    const float* code2;     // 256 entries (device)
+    const float* offset;    // 1 float (device)
+};
+
+template <typename T, int kDqUnroll, bool NESTED = false>
 __global__ __launch_bounds__(kDqThreads) void dequantize4_kernel(const uint8_t* __restrict__ A,
                                                                  const float* __restrict__ absmax,
                                                                  T* __restrict__ out, long n, int bs_shift,
-                                                                 int quant_type, int vec_ok) {
+                                                                 int quant_type, int vec_ok, NestedStats nested = {}) {
     constexpr int kDqTile = kDqThreads * kDqUnroll * 8; // outputs per workgroup
     __shared__ float code[16];
+    __shared__ float code2[NESTED ? 256 : 1];
     const int tid = threadIdx.x;
     if (tid < 16)
         code[tid] = (quant_type == kNF4) ? kNF4Code[tid] : kFP4Code[tid];
+    float offset = 0.0f;
+    if constexpr (NESTED) {
+        code2[tid] = nested.code2[tid];
+        offset = *nested.offset;
+    }
+    // scale of block b; NESTED: `absmax` is the second-level vector (one float per 256 blocks)
+    auto scale_of = [&](long b, uint32_t q8) -> float {
+        if constexpr (NESTED)
+            return rounded_f32(code2[q8] * absmax[b >> 8]) + offset; // (rounded_f32: hipcc contracts __fadd_rn(__fmul_rn()) into ONE v_fma_f32)
+        else
+            return absmax[b];
+    };
 
     const long tile_base = static_cast<long>(blockIdx.x) * kDqTile;
     const bool full = (tile_base + kDqTile <= n) && vec_ok;
 
     uint32_t w[kDqUnroll];
     float s[kDqUnroll];
+    [[maybe_unused]] uint32_t q8[kDqUnroll];
     if (full) {
 #pragma unroll
         for (int u = 0; u < kDqUnroll; ++u) {
             const long base = tile_base + (static_cast<long>(u) * kDqThreads + tid) * 8;
             w[u] = stream_load<sizeof(T) == 2>(reinterpret_cast<const uint32_t*>(A + (base >> 1)));
-            s[u] = absmax[base >> bs_shift];
+            if constexpr (NESTED) {
+                q8[u] = nested.absmax8[base >> bs_shift];
+                s[u] = absmax[(base >> bs_shift) >> 8];
+            } else {
+                s[u] = absmax[base >> bs_shift];
+            }
         }
         __syncthreads();
+        if constexpr (NESTED) {
+#pragma unroll
+            for (int u = 0; u < kDqUnroll; ++u)
+                s[u] = rounded_f32(code2[q8[u]] * s[u]) + offset;
+        }
 #pragma unroll
         for (int u = 0; u < kDqUnroll; ++u) {
             const long base = tile_base + (static_cast<long>(u) * kDqThreads + tid) * 8;
@@ -98,9 +134,12 @@ __global__ __launch_bounds__(kDqThreads) void dequantize4_kernel(const uint8_t* 
                 if (e >= n)
                     break;
                 const uint32_t byte = A[e >> 1];
-                out[e] = static_cast<T>(rounded_f32(code[byte >> 4] * absmax[e >> bs_shift]));
-                if (e + 1 < n)
-                    out[e + 1] = static_cast<T>(rounded_f32(code[byte & 0xF] * absmax[(e + 1) >> bs_shift]));
+                const long b0 = e >> bs_shift;
+                out[e] = static_cast<T>(rounded_f32(code[byte >> 4] * scale_of(b0, NESTED ? nested.absmax8[b0] : 0u)));
+                if (e + 1 < n) {
+                    const long b1 = (e + 1) >> bs_shift;
+                    out[e + 1] = static_cast<T>(rounded_f32(code[byte & 0xF] * scale_of(b1, NESTED ? nested.absmax8[b1] : 0u)));
+                }
             }
         }
     }
@@ -306,6 +345,30 @@ void launch_dequantize4_rows(const uint8_t* A, const float* absmax, const void* 
 
 } // namespace
 
+template <typename T>
+void launch_dequantize4_nested(const uint8_t* A, const uint8_t* absmax8, const float* absmax2, const float* code2, const float* offset,
+                               T* out, int blocksize, long n, int quant_type, hipStream_t stream) {
+    if (n <= 0)
+        return;
+    if (!is_pow2(blocksize) || blocksize < 8) {
+        fprintf(stderr, "bitsandbytes_amd: dequantize_4bit (nested): unsupported blocksize %d\n", blocksize);
+        exit(1);
+    }
+    const int vec_ok = aligned_to(A, 4) && aligned_to(out, 16);
+    const NestedStats ns{absmax8, code2, offset};
+    // the general kernel's two tile sizes, chosen as for plain statistics (launch_dequantize4)
+    if (n < kDqBigElements) {
+        constexpr long tile = static_cast<long>(kDqThreads) * 8 * 8;
+        hipLaunchKernelGGL((dequantize4_kernel<T, 8, true>), dim3(static_cast<unsigned>((n + tile - 1) / tile)), dim3(kDqThreads), 0, stream, A,
+                           absmax2, out, n, ilog2(blocksize), quant_type, vec_ok, ns);
+    } else {
+        constexpr long tile = static_cast<long>(kDqThreads) * 4 * 8;
+        hipLaunchKernelGGL((dequantize4_kernel<T, 4, true>), dim3(static_cast<unsigned>((n + tile - 1) / tile)), dim3(kDqThreads), 0, stream, A,
+                           absmax2, out, n, ilog2(blocksize), quant_type, vec_ok, ns);
+    }
+    BNB_CHECK_LAUNCH();
+}
+
 void dequantize_4bit_set_variant(int variant) { g_dq_variant.store(variant, std::memory_order_relaxed); }
 
 void dequantize_4bit_f32(const uint8_t* A, const float* absmax, float* out, int blocksize, long n, int qt,
@@ -319,6 +382,16 @@ void dequantize_4bit_f16(const uint8_t* A, const float* absmax, void* out, int b
 void dequantize_4bit_bf16(const uint8_t* A, const float* absmax, void* out, int blocksize, long n, int qt,
                           hipStream_t s) {
     launch_dequantize4<bf16>(A, absmax, static_cast<bf16*>(out), blocksize, n, qt, s);
+}
+
+void dequantize_4bit_nested(int dtype, const uint8_t* A, const uint8_t* absmax8, const float* absmax2, const float* code2,
+                            const float* offset, void* out, int blocksize, long n, int qt, hipStream_t stream) {
+    if (dtype == 0)
+        launch_dequantize4_nested<float>(A, absmax8, absmax2, code2, offset, static_cast<float*>(out), blocksize, n, qt, stream);
+    else if (dtype == 1)
+        launch_dequantize4_nested<f16>(A, absmax8, absmax2, code2, offset, static_cast<f16*>(out), blocksize, n, qt, stream);
+    else
+        launch_dequantize4_nested<bf16>(A, absmax8, absmax2, code2, offset, static_cast<bf16*>(out), blocksize, n, qt, stream);
 }
 
 void dequantize_4bit_rows(int dtype, const uint8_t* A, const float* absmax, const void* idx, int index_bytes, void* out,

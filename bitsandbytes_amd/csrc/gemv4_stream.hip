@@ -24,6 +24,9 @@
 //  * The per-block scale multiplies the fp32 sum of a lane's 32-nibble run (never straddles a quantization block:
 //    blocksize >= 32, K % 32 == 0). Nested (double-quantised) absmax is reconstructed in-kernel:
 //    scale = absmax_code[absmax_8bit[b]] * absmax[b >> 8] + offset   (reference autograd/_functions.py:471-485).
+//    (hipcc contracts the product and the sum into ONE v_fma_f32 - as nvcc does in the reference's CUDA kernel; the host-side
+//    sequence rounds twice. The difference is at most one ulp of an fp32 scale, far inside the tolerance of a bf16 / fp16 matmul;
+//    dequantize_4bit, which is compared bit for bit, rounds twice: csrc/dequantize4.hip, NESTED.)
 //  * Segment partials of a row are combined in FIXED order (LDS slots, no atomics): results are bit-reproducible and
 //    independent of the launch geometry (the reference's test_matmul_4bit_weight_orientation demands exact equality).
 //

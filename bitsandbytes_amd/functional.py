@@ -481,6 +481,16 @@ def dequantize_4bit(A: Tensor, quant_state: Optional[QuantState] = None, absmax:
         raise ValueError(f"Blockwise 4bit dequantization only supports 16/32-bit floats, but got {quant_state.dtype}")
 
     if quant_state.nested:
+        s2 = quant_state.state2
+        if (A.device.type == "cuda" and out is None and s2.blocksize == 256 and not s2.nested and s2.absmax.dtype == torch.float32
+                and s2.code.dtype == torch.float32 and quant_state.absmax.dtype == torch.uint8
+                and quant_state.offset.dtype == torch.float32 and A.numel() > 0):
+            # one operator / one launch: the fp32 absmax is reconstructed inside the dequantize kernel with the same two roundings
+            # (code2[q] * absmax2, + offset) the sequence below performs
+            res = torch.ops.bitsandbytes_amd.dequantize_4bit_nested.default(
+                A, quant_state.absmax, s2.absmax, s2.code, quant_state.offset, quant_state.blocksize, quant_state.quant_type,
+                quant_state.shape, quant_state.dtype)
+            return res.t() if A.shape[0] == 1 else res
         absmax = dequantize_blockwise(quant_state.absmax, quant_state.state2)
         absmax += quant_state.offset
         if absmax.dtype != torch.float32:

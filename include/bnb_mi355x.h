@@ -113,6 +113,12 @@ void bnb_mi355x_quantize_8bit(const float* code, const void* A, int dtype, float
  * the same bits on every launch, any device). absmax_8bit / absmax2 are bit for bit what quantize_blockwise gives on absmax - offset. */
 void bnb_mi355x_quantize_4bit_nested(const void* A, int dtype, long n, int blocksize, int quant_type, unsigned char* out, float* scratch, const float* code8, unsigned char* absmax_8bit, float* absmax2, float* offset, bnb_stream_t stream);
 
+/* dequantize_4bit for double-quantised statistics in ONE launch (reference bitsandbytes/functional.py:1002-1006 is three operator
+ * calls: dequantize_blockwise(absmax, state2), `+= offset`, dequantize_4bit): the scale of 4-bit block b is reconstructed in the kernel as
+ * absmax_code[absmax_8bit[b]] * absmax2[b >> 8] + *absmax_offset (fp32 product, then fp32 sum: the same two roundings). Second-level
+ * blocksize 256. n = number of OUTPUT elements; dtype: 0 = fp32, 1 = fp16, 2 = bf16. */
+void bnb_mi355x_dequantize_4bit_nested(int dtype, const unsigned char* A, const unsigned char* absmax_8bit, const float* absmax2, const float* absmax_code, const float* absmax_offset, void* out, int blocksize, long n, int quant_type, bnb_stream_t stream);
+
 /* Row gather + 4-bit dequantize in one launch: out[t, 0:row_len] = dequantize(row indices[t]) for
  * t < rows_out. The fused form of the Embedding4bit lookup (reference bitsandbytes/nn/modules.py:921-951:
  * F.embedding on the packed bytes, F.embedding on absmax, dequantize_4bit). A is the packed

@@ -597,6 +597,55 @@ def test_quantize_4bit_nested_one_call_equals_the_four_operator_sequence(dtype, 
     assert torch.equal(q_b, q) and torch.equal(st_b.absmax, st.absmax) and torch.equal(st_b.offset.view(torch.int32), st.offset.view(torch.int32))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("quant_type,blocksize,shape", [
+    ("nf4", 64, (4096, 4096)), ("fp4", 128, (1024, 1024)), ("nf4", 32, (1000, 96)), ("nf4", 64, (64 * 255 + 7,)), ("fp4", 4096, (3, 4096 + 512)),
+    ("nf4", 64, (5,)), ("nf4", 64, (8192, 4096 + 64))])
+def test_dequantize_4bit_nested_one_launch_equals_the_three_operator_sequence(dtype, quant_type, blocksize, shape):
+    """dequantize_4bit of a double-quantised state runs as ONE operator / launch (the scale of every block reconstructed in the kernel:
+    code2[q] * absmax2 + offset, two roundings). Bit for bit the reference's sequence dequantize_blockwise -> += offset ->
+    dequantize_4bit through the plain operators (each checked against the oracle elsewhere), and against the oracle itself where the
+    size allows. Both tile sizes of the kernel (below / from 2^25 elements), ragged ends, every dtype."""
+    F = _F()
+    torch.manual_seed(blocksize + len(shape))
+    W = (torch.randn(*shape) * 0.05).to(dtype).to(DEV)
+    q, st = F.quantize_4bit(W, blocksize=blocksize, quant_type=quant_type, compress_statistics=True)
+    got = F.dequantize_4bit(q, st)
+    assert got.shape == W.shape and got.dtype == dtype
+    am = torch.ops.bitsandbytes.dequantize_blockwise.default(st.absmax, st.state2.absmax, st.state2.code, 256, torch.float32)
+    am = am + st.offset
+    want = torch.ops.bitsandbytes.dequantize_4bit.default(q, am, blocksize, quant_type, list(W.shape), dtype)
+    assert torch.equal(got.view(torch.int16 if dtype != torch.float32 else torch.int32), want.view(torch.int16 if dtype != torch.float32 else torch.int32))
+    if W.numel() <= 1 << 21:
+        code = st.state2.code.cpu()
+        am_o = O.dequantize_blockwise(st.absmax.cpu(), st.state2.absmax.cpu(), code, 256, torch.float32) + st.offset.cpu()
+        assert torch.equal(am_o, am.cpu())
+        assert same_values_ftz(got.cpu(), O.dequantize_4bit(q.cpu(), am_o, blocksize, quant_type, W.shape, dtype))
+    # the out= form keeps the three-operator sequence: same bits
+    out = torch.empty_like(W)
+    F.dequantize_4bit(q, st, out=out)
+    assert torch.equal(out.view(got.dtype), got)
+
+
+def test_unfused_gemm_with_nested_statistics_equals_the_plain_statistics_call():
+    """M above the fused range with double-quantised statistics: one dequantize launch (statistics reconstructed in it) + the library
+    GEMM. The same call with the reconstructed fp32 absmax handed over must give the same bits (same weights, same GEMM)."""
+    F = _F()
+    from bitsandbytes_amd.backends import hip
+
+    torch.manual_seed(5)
+    W = (torch.randn(1024, 2048) * 0.03).bfloat16().to(DEV)
+    q, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4", compress_statistics=True)
+    x = torch.randn(640, 2048, device=DEV).bfloat16()
+    am = torch.ops.bitsandbytes.dequantize_blockwise.default(st.absmax, st.state2.absmax, st.state2.code, 256, torch.float32) + st.offset
+    a = hip._gemm_4bit_unfused(x, q, st.shape, st.state2.absmax, 64, "nf4", None, st.absmax, st.state2.code, st.offset)
+    b = hip._gemm_4bit_unfused(x, q, st.shape, am, 64, "nf4", None, None, None, None)
+    assert torch.equal(a, b)
+    y = torch.ops.bitsandbytes.gemm_4bit.default(x, q, st.shape, st.state2.absmax, 64, "nf4", absmax_8bit=st.absmax,
+                                                 absmax_code=st.state2.code, absmax_offset=st.offset)
+    assert rel_err(y, x.float() @ F.dequantize_4bit(q, st).float().t()) < REL_TOL
+
+
 # ------------------------------------------------------------------------------------------ gemm / gemv
 def _oracle_y(x, q, st, bias=None):
     """fp32-dequant + fp32-linear oracle result for a (possibly nested) QuantState living on the GPU."""

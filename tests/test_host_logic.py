@@ -53,6 +53,10 @@ def test_nested_quantize_operator_shapes_and_per_device_constants():
     assert am2.shape == (6,) and am2.dtype == torch.float32 and off.shape == () and off.dtype == torch.float32
     with pytest.raises(RuntimeError):
         torch.ops.bitsandbytes_amd.quantize_4bit_nested.default(A, code8[:16], 64, "fp4", torch.uint8)
+    d = torch.ops.bitsandbytes_amd.dequantize_4bit_nested.default(q, q_am, am2, code8, off, 64, "fp4", [1000, 96], torch.float16)
+    assert d.shape == (1000, 96) and d.dtype == torch.float16
+    with pytest.raises(RuntimeError):
+        torch.ops.bitsandbytes_amd.dequantize_4bit_nested.default(q, am2, am2, code8, off, 64, "fp4", [1000, 96], torch.float16)
     a = F.get_4bit_type("nf4", device="cpu")
     a.mul_(2.0)  # a caller's copy: the next call must not see it
     b = F.get_4bit_type("nf4", device="cpu")

@@ -112,3 +112,18 @@ with torch.no_grad():
     print(f"{'4-bit encoder alone':40s} {graph_us(lambda: torch.ops.bitsandbytes.quantize_4bit.default(Wq, 64, 'nf4', torch.uint8)):7.1f} us")
     print(f"{'nested operator (3 launches)':40s} {graph_us(lambda: torch.ops.bitsandbytes_amd.quantize_4bit_nested.default(Wq, code8, 64, 'nf4', torch.uint8)):7.1f} us")
     print(f"{'reference sequence (5 launches)':40s} {graph_us(reference_sequence):7.1f} us")
+
+
+# ---- dequantize_4bit of a double-quantised state (the unfused route above 512 rows and the unfused backward call it once per layer)
+with torch.no_grad():
+    qn, stn = F.quantize_4bit(Wq, blocksize=64, quant_type="nf4", compress_statistics=True)
+
+    def three_ops():
+        a_ = torch.ops.bitsandbytes.dequantize_blockwise.default(stn.absmax, stn.state2.absmax, stn.state2.code, 256, torch.float32)
+        a_ += stn.offset
+        return torch.ops.bitsandbytes.dequantize_4bit.default(qn, a_, 64, "nf4", [N, K], torch.bfloat16)
+
+    print("# dequantize_4bit, nested statistics, 4096^2 -> bf16: wall us per call (eager, queue full) | GPU us (hipGraph replay)")
+    print(f"{'one operator / one launch':40s} {timeit(lambda: F.dequantize_4bit(qn, stn), n=500):7.1f} | {graph_us(lambda: F.dequantize_4bit(qn, stn)):6.1f}")
+    print(f"{'reference sequence (three operators)':40s} {timeit(three_ops, n=500):7.1f} | {graph_us(three_ops):6.1f}")
+    print(f"{'plain statistics (one operator)':40s} {timeit(lambda: F.dequantize_4bit(q, st), n=500):7.1f} | {graph_us(lambda: F.dequantize_4bit(q, st)):6.1f}")
