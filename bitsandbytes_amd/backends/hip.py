@@ -411,6 +411,11 @@ def _(grad_out, B, shapeB: Sequence[int], absmax, blocksize: int, quant_type: st
     G = grad_out.contiguous()
     if M == 0 or not grad_input_fused_ok(G.dtype, M, N, K, blocksize) or G.data_ptr() % 16 or B.data_ptr() % 16:
         # unfused, like the reference: dequantize the weight, dense matmul (also the path for fp32 gradients and odd shapes)
+        if absmax_8bit is not None and absmax_offset.dtype == torch.float32 and absmax_code.dtype == torch.float32:
+            # nested statistics: reconstructed inside the dequantize launch (the batches of QLoRA training land here: M in the thousands)
+            W = torch.empty((N, K), dtype=G.dtype, device=G.device)
+            _dequantize_4bit_nested_impl(B, absmax_8bit, absmax, absmax_code, absmax_offset, blocksize, quant_type, G.dtype, W)
+            return torch.matmul(G, W)
         scales = absmax
         if absmax_8bit is not None:
             scales = torch.ops.bitsandbytes.dequantize_blockwise.default(absmax_8bit, absmax, absmax_code, 256, torch.float32)

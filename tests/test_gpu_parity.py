@@ -1149,6 +1149,27 @@ def test_backward_through_matmul_4bit_gpu(M, N, K):
     assert rel_err(x.grad.detach().cpu(), _oracle_grad_input(g, q, st)) < 4e-3
 
 
+def test_backward_above_the_fused_range_with_nested_statistics():
+    """QLoRA-shaped backward (double quantisation, M in the hundreds): dequantize - statistics reconstructed inside that ONE launch -
+    + library matmul. Same bits as the same operator handed the reconstructed fp32 absmax; and end to end against the oracle."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    torch.manual_seed(11)
+    N, K, M = 768, 1024, 384
+    W = (torch.randn(N, K, device=DEV) / K**0.5).bfloat16()
+    q, st = F.quantize_4bit(W, quant_type="nf4", blocksize=64, compress_statistics=True)
+    g = torch.randn(M, N, device=DEV, dtype=torch.bfloat16)
+    op = torch.ops.bitsandbytes_amd.gemm_4bit_grad_input.default
+    am = torch.ops.bitsandbytes.dequantize_blockwise.default(st.absmax, st.state2.absmax, st.state2.code, 256, torch.float32) + st.offset
+    a = op(g, q, st.shape, st.state2.absmax, 64, "nf4", absmax_8bit=st.absmax, absmax_code=st.state2.code, absmax_offset=st.offset)
+    b = op(g, q, st.shape, am, 64, "nf4")
+    assert torch.equal(a, b)
+    x = torch.randn(M, K, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    bnb.matmul_4bit(x, q, st).backward(g)
+    assert rel_err(x.grad.detach().cpu(), _oracle_grad_input(g, q, st)) < 4e-3
+
+
 # kernel families as bnb_mi355x_last_gemm_kernel() reports them (include/bnb_mi355x.h)
 K_STREAM, K_GENERIC, K_RT, K_PC, K_KQ = 1, 2, 3, 4, 6
 
