@@ -151,6 +151,18 @@ __device__ __forceinline__ float rounded_f32(float v) {
     return v;
 }
 
+// The fp32 scale of a double-quantised block, absmax[b] = code2[q] * absmax2 + offset, with the TWO roundings of the host-side
+// sequence (dequantize_blockwise, then `+= offset`: reference bitsandbytes/functional.py:1002-1006). Written as
+// __fadd_rn(__fmul_rn(c, a), offset) hipcc 7.2 emits ONE v_fma_f32 (the intrinsics are plain * and + by the time the contraction pass
+// runs): one rounding, a last-bit difference in ~1/5 of the scales - enough to flip a bf16 output of a 14336-row layer every few
+// calls, which is how it was found (the sharded FFN block carries un-nested statistics and is compared bit for bit with the unsharded
+// block). The empty asm (not volatile: it may be scheduled freely) makes the product opaque.
+__device__ __forceinline__ float nested_scale(float c, float a, float offset) {
+    float prod = c * a;
+    asm("" : "+v"(prod));
+    return prod + offset;
+}
+
 // A zero the compiler cannot see through, materialised at the point of the call. Adding it to the
 // shift amounts of the nibble/byte extraction ties the whole decode to program order *after* this
 // point: without it LLVM hoists the first v_bfe_u32 of the decode above the workgroup barrier and

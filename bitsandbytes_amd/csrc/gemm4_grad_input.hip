@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kGiWaves * 64) void gemm4_grad_input_kernel(
             float scale;
             if constexpr (NESTED) {
                 const uint32_t q = ws.s, a2 = ws.s2;
-                scale = __fadd_rn(__fmul_rn(code2[q & 0xFFu], __builtin_bit_cast(float, a2)), offset);
+                scale = nested_scale(code2[q & 0xFFu], __builtin_bit_cast(float, a2), offset);
             } else {
                 const uint32_t sv = ws.s;
                 scale = __builtin_bit_cast(float, sv);

@@ -373,7 +373,7 @@ __global__ __launch_bounds__((CW + kPcProducers) * 64) void gemm4_mfma_pc_kernel
                     const f32x4 a2 = *reinterpret_cast<const f32x4*>(wb + NTW * 2048 + NTW * 256 + t * 256 + ln * 16);
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
-                        sc4[t][b] = __fadd_rn(__fmul_rn(code2[q8[b] & 0xFFu], a2[b]), offset);
+                        sc4[t][b] = nested_scale(code2[q8[b] & 0xFFu], a2[b], offset);
                 } else {
                     sc4[t] = *reinterpret_cast<const f32x4*>(wb + NTW * 2048 + t * 256 + ln * 16);
                 }

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(kKqWaves * 64) void gemm4_mfma_kq_kernel(
             if (BNB_KQ_ON(16)) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
-                    sc[nt] = __fadd_rn(__fmul_rn(c2[nt], a2[nt]), offset);
+                    sc[nt] = nested_scale(c2[nt], a2[nt], offset);
             }
         }
         if constexpr ((ABL & 1024) != 0)

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_rt_kernel(
             // (nested, blocksize >= 128: the two bytes fetched for sub-blocks 0 and 2 become the four codes here)
             const uint32_t s0 = BS64 ? sraw[0] : sraw[0] * 0x0101u + sraw[2] * 0x01010000u;
             if constexpr (NESTED)
-                scale[b] = __fadd_rn(__fmul_rn(code2[(s0 >> (8 * b)) & 0xFFu], __builtin_bit_cast(float, s1)), offset);
+                scale[b] = nested_scale(code2[(s0 >> (8 * b)) & 0xFFu], __builtin_bit_cast(float, s1), offset);
             else
                 scale[b] = __builtin_bit_cast(float, sb);
         }

@@ -24,9 +24,8 @@
 //  * The per-block scale multiplies the fp32 sum of a lane's 32-nibble run (never straddles a quantization block:
 //    blocksize >= 32, K % 32 == 0). Nested (double-quantised) absmax is reconstructed in-kernel:
 //    scale = absmax_code[absmax_8bit[b]] * absmax[b >> 8] + offset   (reference autograd/_functions.py:471-485).
-//    (hipcc contracts the product and the sum into ONE v_fma_f32 - as nvcc does in the reference's CUDA kernel; the host-side
-//    sequence rounds twice. The difference is at most one ulp of an fp32 scale, far inside the tolerance of a bf16 / fp16 matmul;
-//    dequantize_4bit, which is compared bit for bit, rounds twice: csrc/dequantize4.hip, NESTED.)
+//    Two roundings, as the host-side sequence (bnb_common.h nested_scale: written with __fmul_rn / __fadd_rn hipcc emitted ONE
+//    v_fma_f32 until round 5 - a last-bit difference in the scale that the un-nested statistics of the sharded layers did not have).
 //  * Segment partials of a row are combined in FIXED order (LDS slots, no atomics): results are bit-reproducible and
 //    independent of the launch geometry (the reference's test_matmul_4bit_weight_orientation demands exact equality).
 //
@@ -476,9 +475,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVE
                 const uint32_t lane_grp = ((static_cast<uint32_t>(rowl) * static_cast<uint32_t>(K) + k0) >> bs_shift) >> 8;
                 const float s2 = lane_grp == s.grp ? s.s2a : s.s2b;
                 if constexpr (GROUPED)
-                    scale = __fadd_rn(__fmul_rn(c2v[u], s2), offs[mi]);
+                    scale = nested_scale(c2v[u], s2, offs[mi]);
                 else
-                    scale = __fadd_rn(__fmul_rn(c2v[u], s2), offset);
+                    scale = nested_scale(c2v[u], s2, offset);
             } else {
                 scale = s.s;
             }
@@ -857,7 +856,7 @@ template <typename T, bool NESTED> __global__ __launch_bounds__(256) void gemv4_
     long run_blk = -1;
     auto block_scale = [&](long blk) -> float {
         if constexpr (NESTED)
-            return __fadd_rn(__fmul_rn(code2[p.absmax8[blk]], p.absmax[blk >> 8]), p.absmax_offset[0]);
+            return nested_scale(code2[p.absmax8[blk]], p.absmax[blk >> 8], p.absmax_offset[0]);
         else
             return p.absmax[blk];
     };
