@@ -1,0 +1,23 @@
+"""GPU (-m gpu): the path's bit-for-bit identities on MANY random inputs (tests/checks/identity_stress.py, its own process: it opens
+a one-rank process group for the peer chain). The other tests check each identity on a handful of inputs; a one-fma / two-roundings
+difference in the double-quantised scale survived two rounds of those by luck."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import gpu_ready
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_identities_hold_on_many_random_inputs():
+    if not gpu_ready() and not os.path.exists("/dev/kfd") and os.environ.get("BNB_REQUIRE_GPU") != "1":
+        pytest.skip("no GPU device on this host")
+    assert gpu_ready(), "GPU tests selected but torch.cuda.is_available() is False"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "identity_stress.py"), "--iters", "36"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "IDENTITY_STRESS OK" in p.stdout, p.stdout[-3000:]
