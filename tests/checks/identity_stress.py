@@ -79,7 +79,12 @@ def main():
     from bitsandbytes_amd.peer import PeerChain
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29733")
+    if "MASTER_PORT" not in os.environ:
+        import socket
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
     dist.init_process_group("gloo", rank=0, world_size=1)
     n = bad = 0
     chain = PeerChain(max_values=32768)

@@ -2,6 +2,7 @@
 a one-rank process group for the peer chain). The other tests check each identity on a handful of inputs; a one-fma / two-roundings
 difference in the double-quantised scale survived two rounds of those by luck."""
 import os
+import socket
 import subprocess
 import sys
 
@@ -17,7 +18,10 @@ def test_identities_hold_on_many_random_inputs():
     if not gpu_ready() and not os.path.exists("/dev/kfd") and os.environ.get("BNB_REQUIRE_GPU") != "1":
         pytest.skip("no GPU device on this host")
     assert gpu_ready(), "GPU tests selected but torch.cuda.is_available() is False"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "identity_stress.py"), "--iters", "36"], cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0 and "IDENTITY_STRESS OK" in p.stdout, p.stdout[-3000:]
