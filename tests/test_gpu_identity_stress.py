@@ -25,3 +25,14 @@ def test_identities_hold_on_many_random_inputs():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "identity_stress.py"), "--iters", "36"], cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0 and "IDENTITY_STRESS OK" in p.stdout, p.stdout[-3000:]
+
+
+def test_every_kernel_is_deterministic_run_to_run_under_a_busy_memory_system():
+    """tests/checks/determinism_stress.py: ~200 cases (routed and forced geometries of every kernel family, forward and backward, the
+    standalone kernels), each repeated while a second stream keeps copying: every result equals the first, bit for bit."""
+    if not gpu_ready() and not os.path.exists("/dev/kfd") and os.environ.get("BNB_REQUIRE_GPU") != "1":
+        pytest.skip("no GPU device on this host")
+    assert gpu_ready(), "GPU tests selected but torch.cuda.is_available() is False"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "determinism_stress.py"), "--runs", "60"], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "DETERMINISM_STRESS OK" in p.stdout, p.stdout[-3000:]
