@@ -36,3 +36,14 @@ def test_every_kernel_is_deterministic_run_to_run_under_a_busy_memory_system():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "determinism_stress.py"), "--runs", "60"], cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0 and "DETERMINISM_STRESS OK" in p.stdout, p.stdout[-3000:]
+
+
+def test_random_shapes_through_the_public_operators_against_the_oracle():
+    """tests/checks/fuzz_vs_oracle.py (imports the oracle: test infrastructure): 120 random draws of shape / blocksize / type / dtype /
+    statistics kind / bias - quantize bit-exact, dequantize equal, gemm_4bit within tolerance of fp32 dequantize + fp32 linear."""
+    if not gpu_ready() and not os.path.exists("/dev/kfd") and os.environ.get("BNB_REQUIRE_GPU") != "1":
+        pytest.skip("no GPU device on this host")
+    assert gpu_ready(), "GPU tests selected but torch.cuda.is_available() is False"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "fuzz_vs_oracle.py"), "--draws", "120", "--seed", "7"], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0 and "FUZZ OK" in p.stdout, p.stdout[-3000:]
