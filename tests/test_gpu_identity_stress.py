@@ -47,3 +47,14 @@ def test_random_shapes_through_the_public_operators_against_the_oracle():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "fuzz_vs_oracle.py"), "--draws", "120", "--seed", "7"], cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert p.returncode == 0 and "FUZZ OK" in p.stdout, p.stdout[-3000:]
+
+
+def test_no_entry_point_writes_outside_its_outputs_or_needs_more_than_element_alignment():
+    """tests/checks/guard_stress.py: every operand of every C-ABI entry point carved out of a larger buffer at a random element
+    offset, outputs and scratch between guard bands: bands untouched, results equal to the public operator on aligned tensors."""
+    if not gpu_ready() and not os.path.exists("/dev/kfd") and os.environ.get("BNB_REQUIRE_GPU") != "1":
+        pytest.skip("no GPU device on this host")
+    assert gpu_ready(), "GPU tests selected but torch.cuda.is_available() is False"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "guard_stress.py"), "--draws", "60", "--seed", "5"], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0 and "GUARD_STRESS OK" in p.stdout, p.stdout[-3000:]
