@@ -183,8 +183,12 @@ def _dequantize_4bit_nested_impl(A, absmax_8bit, absmax2, code8, offset, blocksi
         raise ValueError(f"absmax_8bit must hold {blocks} uint8 codes, got {tuple(absmax_8bit.shape)} {absmax_8bit.dtype}")
     if absmax2.dtype != torch.float32 or absmax2.numel() != -(blocks // -256):
         raise ValueError(f"absmax2 must hold {-(blocks // -256)} float32 values (second-level blocksize 256)")
-    if code8.dtype != torch.float32 or code8.numel() != 256 or offset.dtype != torch.float32 or offset.numel() != 1:
-        raise ValueError("code8 must be 256 float32 values and offset one float32 value")
+    if code8.numel() != 256 or offset.numel() != 1:
+        raise ValueError("code8 must hold 256 values and offset one value")
+    # (a state rebuilt by QuantState.from_dict under another default dtype - model loaders set fp16 / bf16 - carries its offset in that
+    # dtype; the host-side sequence promotes it in `absmax + offset`: the same value)
+    code8 = code8.to(torch.float32)
+    offset = offset.to(torch.float32)
     for t in (absmax_8bit, absmax2, code8, offset):
         if t.device != A.device:
             raise ValueError("all statistics must live on A's device")

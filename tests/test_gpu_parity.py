@@ -641,6 +641,13 @@ def test_unfused_gemm_with_nested_statistics_equals_the_plain_statistics_call():
     a = hip._gemm_4bit_unfused(x, q, st.shape, st.state2.absmax, 64, "nf4", None, st.absmax, st.state2.code, st.offset)
     b = hip._gemm_4bit_unfused(x, q, st.shape, am, 64, "nf4", None, None, None, None)
     assert torch.equal(a, b)
+    # a state rebuilt by QuantState.from_dict under a 16-bit default dtype (model loaders set one) carries a 16-bit offset: the host
+    # sequence promotes it in `absmax + offset`; the one-launch form must take the same value
+    off16 = st.offset.to(torch.float16)
+    am16 = torch.ops.bitsandbytes.dequantize_blockwise.default(st.absmax, st.state2.absmax, st.state2.code, 256, torch.float32) + off16
+    a16 = hip._gemm_4bit_unfused(x, q, st.shape, st.state2.absmax, 64, "nf4", None, st.absmax, st.state2.code, off16)
+    b16 = hip._gemm_4bit_unfused(x, q, st.shape, am16, 64, "nf4", None, None, None, None)
+    assert am16.dtype == torch.float32 and torch.equal(a16, b16)
     y = torch.ops.bitsandbytes.gemm_4bit.default(x, q, st.shape, st.state2.absmax, 64, "nf4", absmax_8bit=st.absmax,
                                                  absmax_code=st.state2.code, absmax_offset=st.offset)
     assert rel_err(y, x.float() @ F.dequantize_4bit(q, st).float().t()) < REL_TOL
