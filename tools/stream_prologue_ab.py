@@ -22,13 +22,14 @@ from bitsandbytes_amd.backends import hip  # noqa: E402
 from stream_ab import alg_bytes, make_layers  # noqa: E402
 
 SHAPES = [(4096, 4096), (8192, 8192), (11008, 4096), (4096, 11008), (14336, 4096), (28672, 8192), (1376, 4096), (512, 11008)]
-# (label, ring depth knob, nt knob, wavefronts). (Runs 2 and 3 of profiles/r5_stream_prologue_ab.txt had more columns: the ring-late
-# prologue - dropped, DESIGN 6b - and ring depths 3 / 4 at 16 wavefronts with it.)
-CONFIGS = [("built-in", 0, -1, 0), ("16 r2", 0, -1, 16), ("16 r3", 3, -1, 16), ("8 r4", 0, -1, 8)]
+# (label, ring depth knob, nt knob, wavefronts[, 2048-k segments side by side]). (Runs 2 and 3 of profiles/r5_stream_prologue_ab.txt had
+# more columns: the ring-late prologue - dropped, DESIGN 6b - and ring depths 3 / 4 at 16 wavefronts with it. Run 5: "16 sw1" = ONE segment
+# column, i.e. a wavefront walks a whole row of K in K / 2048 phases and no other wavefront holds a partial sum of its rows.)
+CONFIGS = [("built-in", 0, -1, 0), ("16 r2", 0, -1, 16), ("16 sw1", 0, -1, 16, 1), ("8 r4", 0, -1, 8)]
 
 
-def tune(ns=0, nt=-1, waves=0):
-    bnb.lib.bnb_mi355x_set_stream_tuning(ns, 0, 0, nt, waves)
+def tune(ns=0, nt=-1, waves=0, sw=0):
+    bnb.lib.bnb_mi355x_set_stream_tuning(ns, sw, 0, nt, waves)
 
 
 def one(q, st, x, out=None):
@@ -81,10 +82,10 @@ def main():
         for waves in (16, 8):
             tune(waves=waves)
             ref = [one(q, st, x).clone() for q, st in layers]
-            for label, ns, nt, w in CONFIGS:
+            for label, ns, nt, w, *sw in CONFIGS:
                 if w != waves:
                     continue
-                tune(ns, nt, w)
+                tune(ns, nt, w, *sw)
                 got = [one(q, st, x).clone() for q, st in layers]
                 torch.cuda.synchronize()
                 if not all(torch.equal(a, b) for a, b in zip(ref, got)):
@@ -100,8 +101,8 @@ def main():
         x = torch.randn(1, K, device="cuda").bfloat16()
         outs = [torch.empty(1, N, device="cuda", dtype=torch.bfloat16) for _ in layers]
         graphs = []
-        for label, ns, nt, w in CONFIGS:  # the tuning is read at launch time, i.e. at capture: one graph per configuration
-            tune(ns, nt, w)
+        for label, ns, nt, w, *sw in CONFIGS:  # the tuning is read at launch time, i.e. at capture: one graph per configuration
+            tune(ns, nt, w, *sw)
             graphs.append(capture(layers, x, outs))
         tune()
         t0 = timed(graphs[0], L, 20)
