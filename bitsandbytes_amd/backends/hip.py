@@ -27,14 +27,22 @@ _DT_NAME = {torch.float32: "fp32", torch.float16: "fp16", torch.bfloat16: "bf16"
 _DT_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 _QT_CODE = {"fp4": 1, "nf4": 2}
 
-# Largest M routed to the fused kernels; above it one dequantize + hipBLASLt GEMM moves fewer bytes
-# per FLOP than re-streaming the packed weight per 64-row slab. Calibrated on MI355X (profiles/r4_route_ab.txt, us per launch,
-# fused (K-quarter kernel) vs dequantize + hipBLASLt at M = 512: 4096^2 24 vs 41, 8192^2 89 vs 111, 11008 x 4096 70 vs 78,
-# 4096 x 11008 59 vs 94; at M = 1024 (profiles/r3_tall_batch_ab.txt: 49 / 144 / 105 / 116 unfused) twice the fused M = 512 time is
-# level at best. So: 512 rows everywhere (the two constants are kept apart: they are calibrated separately).
+# Largest M routed to the fused kernels; above it one dequantize + hipBLASLt GEMM moves fewer bytes per FLOP than re-streaming the
+# packed weight per 64-row pass. Calibrated on MI355X, us per call, fused vs dequantize + hipBLASLt:
+#  * M = 512 (profiles/r4_route_ab.txt): 4096^2 24 vs 41, 8192^2 89 vs 111, 11008 x 4096 70 vs 78, 4096 x 11008 59 vs 94 - 512 rows everywhere;
+#  * 513 ... 1024 rows (round 5, profiles/r5_tall_small_ab.txt): the row passes of a call run side by side over grid.z, so on matrices
+#    with LONG rows (K >= 2 N: 2048 x 8192, 1376 x 4096, 4096 x 11008) the fused call stays 8 - 30 % ahead up to 1024 rows, on square-ish
+#    ones (K >= 0.7 N: 4096^2, 3072^2, 5120^2, 5120 x 3584) up to 640 rows, and on wide ones (8192 x 2048, 11008 x 4096) it loses from
+#    576 on. Measured up to 45 M weights: the extended ranges apply up to FUSED_TALL_WEIGHTS, larger matrices keep 512 (8192^2 at
+#    M = 1024: 178 vs 144).
 FUSED_MAX_M = 512
-FUSED_MAX_M_SMALL = 512
-FUSED_SMALL_WEIGHTS = 20 << 20
+FUSED_MAX_M_LONG_ROWS = 1024   # K >= 2 N
+FUSED_MAX_M_SQUARE = 640       # 10 K >= 7 N
+FUSED_TALL_WEIGHTS = 48 << 20
+# Calls the MFMA kernels do not serve (K not a multiple of 256 - e.g. K = 2752, a 4-way shard of an 11008-wide projection -, or
+# blocksize 32 with double-quantised statistics) run the streaming kernel in 4-row passes: ahead of dequantize + GEMM up to 12 rows,
+# level at 16, 3 - 4 x behind at 64 (profiles/r5_tall_small_ab.txt, second table; until round 5 they were sent there up to 512 rows).
+STREAM_ONLY_MAX_M = 16
 _REFERENCE_CUSTOM_MAX_M = 256  # reference backends/cuda/ops.py:816 (_gemm_4bit_custom_max_m on ROCm)
 
 
@@ -320,7 +328,7 @@ def _(A, B, shapeB: Sequence[int], absmax, code, blocksize: int, out: torch.Tens
 
 
 # ------------------------------------------------------------------------------------------ gemm_4bit
-def _gemm_4bit_route(dtype: torch.dtype, M: int, N: int, K: int, blocksize: int) -> str:
+def _gemm_4bit_route(dtype: torch.dtype, M: int, N: int, K: int, blocksize: int, nested: bool = False) -> str:
     """MI355X routing: 'fused' (HIP dot / MFMA kernels, chosen inside the library by M) or 'unfused'
     (dequantize + hipBLASLt). Replaces reference backends/cuda/ops.py:814-843,921-962."""
     if K % blocksize != 0:
@@ -337,12 +345,19 @@ def _gemm_4bit_route(dtype: torch.dtype, M: int, N: int, K: int, blocksize: int)
         # fp32 activations: the streaming kernel (fp32 FMA decode, same code path as bf16/fp16) for decode-sized batches;
         # no fp32 MFMA path worth having above that (1/16 of the bf16 matrix rate)
         return "fused" if M <= 4 else "unfused"
-    return "fused" if M <= fused_max_m(N, K) else "unfused"
+    return "fused" if M <= fused_max_m(N, K, blocksize, nested) else "unfused"
 
 
-def fused_max_m(N: int, K: int) -> int:
-    """Largest batch (rows of A) the fused 16-bit kernels serve for an N x K weight."""
-    return FUSED_MAX_M_SMALL if N * K <= FUSED_SMALL_WEIGHTS else FUSED_MAX_M
+def fused_max_m(N: int, K: int, blocksize: int = 64, nested: bool = False) -> int:
+    """Largest batch (rows of A) the fused 16-bit kernels are used for on an N x K weight (csrc/torch_dispatch.cpp: fused_max_m)."""
+    if K % 256 != 0 or blocksize < 32 or (blocksize == 32 and nested):
+        return STREAM_ONLY_MAX_M  # (the MFMA kernels' preconditions, csrc/gemm4_mfma.hip: gemm_4bit_mfma_supported)
+    if N * K <= FUSED_TALL_WEIGHTS:
+        if K >= 2 * N:
+            return FUSED_MAX_M_LONG_ROWS
+        if 10 * K >= 7 * N:
+            return FUSED_MAX_M_SQUARE
+    return FUSED_MAX_M
 
 
 def _gemm_4bit_fused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8bit, absmax_code, absmax_offset,
@@ -547,7 +562,7 @@ def _gemm_4bit_python_kernel(
 ) -> torch.Tensor:
     K = A.shape[-1]
     M = A.numel() // K if K else 0
-    route = _gemm_4bit_route(A.dtype, M, int(shapeB[0]), K, blocksize)
+    route = _gemm_4bit_route(A.dtype, M, int(shapeB[0]), K, blocksize, absmax_8bit is not None)
     args = (A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8bit, absmax_code, absmax_offset)
     if route == "fused":
         return _gemm_4bit_fused(*args)

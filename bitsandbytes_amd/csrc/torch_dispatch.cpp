@@ -29,14 +29,30 @@
 
 namespace {
 
-// keep in step with bitsandbytes_amd/backends/hip.py (FUSED_MAX_M, FUSED_MAX_M_SMALL, FUSED_SMALL_WEIGHTS,
-// _REFERENCE_CUSTOM_MAX_M, _gemm_4bit_route); the GPU test tests/test_gpu_parity.py::test_native_dispatch_matches_python_kernel
-// runs both over fused and unfused shapes, tests/test_cabi.py pins the constants
+// keep in step with bitsandbytes_amd/backends/hip.py (FUSED_MAX_M, FUSED_MAX_M_LONG_ROWS, FUSED_MAX_M_SQUARE, FUSED_TALL_WEIGHTS,
+// STREAM_ONLY_MAX_M, _REFERENCE_CUSTOM_MAX_M, fused_max_m, _gemm_4bit_route - the measurements behind the numbers are quoted there);
+// the GPU test tests/test_gpu_parity.py::test_native_dispatch_matches_python_kernel runs both over fused and unfused shapes,
+// tests/test_cabi.py pins the constants and the function against the Python twin
 constexpr int64_t kFusedMaxM = 512;
-constexpr int64_t kFusedMaxMSmall = 512;
-constexpr int64_t kFusedSmallWeights = 20971520; // 20 << 20
+constexpr int64_t kFusedMaxMLongRows = 1024; // K >= 2 N
+constexpr int64_t kFusedMaxMSquare = 640;    // 10 K >= 7 N
+constexpr int64_t kFusedTallWeights = 50331648; // 48 << 20
+constexpr int64_t kStreamOnlyMaxM = 16;
 constexpr int64_t kFusedMaxMFp32 = 4;
 constexpr int64_t kReferenceCustomMaxM = 256; // reference backends/cuda/ops.py:816
+
+// Largest batch the fused 16-bit kernels are used for on an N x K weight (backends/hip.py: fused_max_m)
+int64_t fused_max_m(int64_t N, int64_t K, int64_t blocksize, bool nested) {
+    if (K % 256 != 0 || blocksize < 32 || (blocksize == 32 && nested))
+        return kStreamOnlyMaxM; // the MFMA kernels do not serve the call: the streaming kernel's 4-row passes
+    if (N * K <= kFusedTallWeights) {
+        if (K >= 2 * N)
+            return kFusedMaxMLongRows;
+        if (10 * K >= 7 * N)
+            return kFusedMaxMSquare;
+    }
+    return kFusedMaxM;
+}
 
 int dtype_code(at::ScalarType t) {
     switch (t) {
@@ -134,26 +150,31 @@ at::Tensor gemm_4bit_hip(const at::Tensor& A_in, const at::Tensor& B_in, at::Int
                                ", falling back to slower implementation."));
         fused = false;
     } else {
-        fused = M <= (dt == 0 ? kFusedMaxMFp32 : (N * K <= kFusedSmallWeights ? kFusedMaxMSmall : kFusedMaxM));
+        fused = M <= (dt == 0 ? kFusedMaxMFp32 : fused_max_m(N, K, blocksize, absmax_8bit_in.has_value()));
     }
 
     if (!fused) {
         // dequantize once + library GEMM: the reference's own strategy for these batches (backends/cuda/ops.py:904-916)
-        at::Tensor am = absmax;
+        at::Tensor W = at::empty(shapeB, A.options());
         if (absmax_8bit_in.has_value()) {
+            // nested statistics: reconstructed inside the ONE dequantize launch (csrc/dequantize4.hip, NESTED) with the two roundings of
+            // the host-side sequence dequantize_blockwise, += offset (which this branch ran as three launches until round 5)
             TORCH_CHECK(absmax_code_in.has_value() && absmax_offset_in.has_value(), "nested absmax needs absmax_code and absmax_offset");
             const at::Tensor a8 = absmax_8bit_in->contiguous();
-            const at::Tensor code = absmax_code_in->contiguous();
+            const at::Tensor code = absmax_code_in->to(at::kFloat).contiguous();
+            const at::Tensor offset = absmax_offset_in->to(at::kFloat);
             TORCH_CHECK(a8.scalar_type() == at::kByte, "A must be uint8, got ", a8.scalar_type());
-            check_c_int(a8.numel(), "dequantize_blockwise");
-            at::Tensor dq = at::empty(a8.sizes(), a8.options().dtype(at::kFloat));
-            cdequantize_blockwise_fp32(static_cast<float*>(code.data_ptr()), static_cast<unsigned char*>(a8.data_ptr()),
-                                       static_cast<float*>(absmax.data_ptr()), static_cast<float*>(dq.data_ptr()), 256,
-                                       static_cast<int>(a8.numel()), stream);
-            am = dq + *absmax_offset_in;
+            TORCH_CHECK(absmax.scalar_type() == at::kFloat, "absmax must be float32, got ", absmax.scalar_type());
+            const int64_t n = W.numel();
+            const int64_t blocks = (n + blocksize - 1) / blocksize;
+            TORCH_CHECK(a8.numel() == blocks && absmax.numel() == (blocks + 255) / 256 && code.numel() == 256 && offset.numel() == 1,
+                        "nested statistics do not match the weight: ", a8.numel(), " codes, ", absmax.numel(), " second-level values for ", blocks, " blocks");
+            bnb_mi355x_dequantize_4bit_nested(dt, static_cast<const unsigned char*>(B.const_data_ptr()), static_cast<const unsigned char*>(a8.const_data_ptr()),
+                                              static_cast<const float*>(absmax.const_data_ptr()), static_cast<const float*>(code.const_data_ptr()),
+                                              static_cast<const float*>(offset.const_data_ptr()), W.data_ptr(), static_cast<int>(blocksize), n, qt, stream);
+        } else {
+            dequantize_4bit_into(B, absmax, blocksize, qt, W, stream);
         }
-        at::Tensor W = at::empty(shapeB, A.options());
-        dequantize_4bit_into(B, am, blocksize, qt, W, stream);
         return at::linear(A, W, bias);
     }
 

@@ -78,7 +78,12 @@ def main():
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 y = torch.ops.bitsandbytes.gemm_4bit.default(x.to(DEV), q, st.shape, am_dev, bs, qt, bias=None if b is None else b.to(DEV), **kw)
-            fam = FAMILY.get(bnb.lib.bnb_mi355x_last_gemm_kernel() if M <= 512 and (dt != torch.float32 or M <= 4) else 0, "?")
+            from bitsandbytes_amd.backends import hip
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                routed = hip._gemm_4bit_route(dt, M, N, K, bs, dq)
+            fam = FAMILY.get(bnb.lib.bnb_mi355x_last_gemm_kernel() if routed == "fused" else 0, "?")
             y_o = O.gemm_4bit(x, q_o, (N, K), am_rec, bs, qt, b)[1]
             e = rel_err(y.float().cpu(), y_o)
             tol = 1e-5 if dt == torch.float32 else 1e-2

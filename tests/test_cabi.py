@@ -369,15 +369,43 @@ def test_native_dispatch_routing_constants_match_python():
         return int(m.group(1))
 
     assert const("kFusedMaxM") == hip.FUSED_MAX_M
-    assert const("kFusedMaxMSmall") == hip.FUSED_MAX_M_SMALL
-    assert const("kFusedSmallWeights") == hip.FUSED_SMALL_WEIGHTS
+    assert const("kFusedMaxMLongRows") == hip.FUSED_MAX_M_LONG_ROWS
+    assert const("kFusedMaxMSquare") == hip.FUSED_MAX_M_SQUARE
+    assert const("kFusedTallWeights") == hip.FUSED_TALL_WEIGHTS
+    assert const("kStreamOnlyMaxM") == hip.STREAM_ONLY_MAX_M
     assert const("kReferenceCustomMaxM") == hip._REFERENCE_CUSTOM_MAX_M
     # fp32 activations: fused up to 4 rows in both
     assert const("kFusedMaxMFp32") == 4
     import torch
 
     assert hip._gemm_4bit_route(torch.float32, 4, 64, 64, 64) == "fused" and hip._gemm_4bit_route(torch.float32, 5, 64, 64, 64) == "unfused"
-    assert hip._gemm_4bit_route(torch.bfloat16, hip.FUSED_MAX_M_SMALL, 64, 64, 64) == "fused"
-    assert hip._gemm_4bit_route(torch.bfloat16, hip.FUSED_MAX_M_SMALL + 1, 64, 64, 64) == "unfused"
+    # K = 64 is not a multiple of 256: the MFMA kernels do not serve it, the streaming kernel's passes stop at STREAM_ONLY_MAX_M
+    assert hip._gemm_4bit_route(torch.bfloat16, hip.STREAM_ONLY_MAX_M, 64, 64, 64) == "fused"
+    assert hip._gemm_4bit_route(torch.bfloat16, hip.STREAM_ONLY_MAX_M + 1, 64, 64, 64) == "unfused"
+    assert hip._gemm_4bit_route(torch.bfloat16, 64, 4096, 2752, 64) == "unfused" and hip._gemm_4bit_route(torch.bfloat16, 12, 4096, 2752, 64) == "fused"
+    assert hip._gemm_4bit_route(torch.bfloat16, 64, 4096, 4096, 32, True) == "unfused" and hip._gemm_4bit_route(torch.bfloat16, 64, 4096, 4096, 32) == "fused"
     assert hip._gemm_4bit_route(torch.bfloat16, hip.FUSED_MAX_M, 8192, 8192, 64) == "fused"
     assert hip._gemm_4bit_route(torch.bfloat16, hip.FUSED_MAX_M + 1, 8192, 8192, 64) == "unfused"
+    assert hip.fused_max_m(4096, 11008) == 1024 and hip.fused_max_m(4096, 4096) == 640 and hip.fused_max_m(11008, 4096) == 512
+    assert hip.fused_max_m(8192, 28672) == 512  # (long rows, but beyond the measured 48 M weights)
+    # the C++ function itself, compiled out of the source, against the Python twin on a grid of shapes
+    m = re.search(r"int64_t fused_max_m\(int64_t N, int64_t K, int64_t blocksize, bool nested\) \{.*?\n\}\n", src, re.S)
+    assert m, "fused_max_m not found in torch_dispatch.cpp"
+    consts = "\n".join(re.findall(r"constexpr\s+int64_t\s+k\w+\s*=\s*\d+\s*;", src))
+    prog = ("#include <cstdint>\n#include <cstdio>\n#include <initializer_list>\n" + consts + "\n" + m.group(0) +
+            "int main() { const long Ns[] = {64, 1376, 2048, 3072, 4096, 5120, 8192, 11008, 14336, 28672};\n"
+            "const long Ks[] = {64, 1088, 2048, 2752, 3072, 3584, 4096, 5120, 8192, 11008, 14336, 28672};\n"
+            "for (long n : Ns) for (long k : Ks) for (long bs : {32L, 64L, 128L}) for (int ne = 0; ne < 2; ++ne)\n"
+            "  std::printf(\"%ld %ld %ld %d %ld\\n\", n, k, bs, ne, (long)fused_max_m(n, k, bs, ne != 0));\nreturn 0; }\n")
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        cpp, exe = os.path.join(td, "f.cpp"), os.path.join(td, "f")
+        open(cpp, "w").write(prog)
+        subprocess.run(["g++", "-std=c++17", "-O0", cpp, "-o", exe], check=True)
+        out = subprocess.run([exe], check=True, stdout=subprocess.PIPE, text=True).stdout
+    rows = [tuple(int(v) for v in line.split()) for line in out.strip().splitlines()]
+    assert len(rows) == 10 * 12 * 3 * 2
+    for n, k, bs, ne, got in rows:
+        assert got == hip.fused_max_m(n, k, bs, bool(ne)), (n, k, bs, ne, got)

@@ -1426,10 +1426,17 @@ def test_gemm_4bit_blocksize_32_runs_the_mfma_kernel(M, dtype):
         y_ref = _oracle_y(x, q, st, bias)
         assert rel_err(y.cpu(), y_ref) < REL_TOL, (M, N, K, qt)
         assert torch.equal(y, bnb.matmul_4bit(x.to(DEV), q, st, bias=bias.to(DEV)))  # bit-reproducible
-    # double quantisation at blocksize 32: outside the BS32 instances - the streaming kernel, same tolerance
+    # double quantisation at blocksize 32: outside the BS32 instances - the streaming kernel (4-row passes) up to STREAM_ONLY_MAX_M rows,
+    # dequantize + library GEMM above (3 - 4 x cheaper than the passes at 64 rows: profiles/r5_tall_small_ab.txt); same tolerance
+    from bitsandbytes_amd.backends import hip
+
     q, st = F.quantize_4bit(W.to(DEV), blocksize=32, quant_type="nf4", compress_statistics=True)
     y = bnb.matmul_4bit(x.to(DEV), q, st)
-    assert bnb.lib.bnb_mi355x_last_gemm_kernel() == K_STREAM
+    if M <= hip.STREAM_ONLY_MAX_M:
+        assert bnb.lib.bnb_mi355x_last_gemm_kernel() == K_STREAM
+    else:
+        assert hip._gemm_4bit_route(dtype, M, st.shape[0], st.shape[1], 32, True) == "unfused"
+        assert bnb.lib.bnb_mi355x_last_gemm_kernel() == K_RT  # (the plain-statistics call above: this one launched no fused kernel)
     assert rel_err(y.cpu(), _oracle_y(x, q, st)) < REL_TOL
 
 
@@ -1599,7 +1606,12 @@ def test_native_dispatch_matches_python_kernel():
         ((3,), 256, 1024, 64, "nf4", False, torch.float32, True),
         ((8,), 256, 1024, 64, "fp4", False, torch.float32, False),       # fp32 above 4 rows: unfused
         ((200,), 256, 1024, 64, "nf4", True, torch.bfloat16, True),      # tall batch on the fused kernels (several row passes)
-        ((600,), 256, 1024, 64, "nf4", True, torch.bfloat16, True),      # above FUSED_MAX_M_SMALL: unfused
+        ((600,), 256, 1024, 64, "nf4", True, torch.bfloat16, True),      # long rows (K >= 2 N): fused up to 1024 rows
+        ((1100,), 256, 1024, 64, "nf4", True, torch.bfloat16, True),     # ... and unfused above (nested: ONE dequantize launch)
+        ((700,), 1024, 1024, 64, "nf4", False, torch.float16, True),     # square: fused up to 640 rows, this one unfused
+        ((12,), 512, 2752, 64, "nf4", True, torch.bfloat16, False),      # K % 256 != 0: the streaming kernel's passes up to 16 rows
+        ((48,), 512, 2752, 64, "nf4", True, torch.bfloat16, True),       # ... above that dequantize + GEMM (round 5: was fused to 512)
+        ((48,), 512, 2048, 32, "nf4", True, torch.bfloat16, False),      # blocksize 32 with nested statistics: likewise
         ((5,), 64, 96, 64, "nf4", False, torch.bfloat16, True),          # K % blocksize != 0: warning + unfused
     ]:
         W = (torch.randn(N, K, device=DEV) / K**0.5).to(dtype)
