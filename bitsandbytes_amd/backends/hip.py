@@ -43,6 +43,9 @@ FUSED_TALL_WEIGHTS = 48 << 20
 # blocksize 32 with double-quantised statistics) run the streaming kernel in 4-row passes: ahead of dequantize + GEMM up to 12 rows,
 # level at 16, 3 - 4 x behind at 64 (profiles/r5_tall_small_ab.txt, second table; until round 5 they were sent there up to 512 rows).
 STREAM_ONLY_MAX_M = 16
+# Blocksize 32 (plain statistics) runs the register-transposed kernel's BS32 instances, 64-row passes one after the other: 4096^2
+# fused vs unfused 11.5 vs 28.9 us at 64 rows, 21.0 vs 37.5 at 128, 39.1 vs 33.1 at 256, 75 vs 40 at 512 (profiles/r5_tall_small_ab.txt, table 3).
+FUSED_MAX_M_BS32 = 128
 _REFERENCE_CUSTOM_MAX_M = 256  # reference backends/cuda/ops.py:816 (_gemm_4bit_custom_max_m on ROCm)
 
 
@@ -352,7 +355,11 @@ def fused_max_m(N: int, K: int, blocksize: int = 64, nested: bool = False) -> in
     """Largest batch (rows of A) the fused 16-bit kernels are used for on an N x K weight (csrc/torch_dispatch.cpp: fused_max_m)."""
     if K % 256 != 0 or blocksize < 32 or (blocksize == 32 and nested):
         return STREAM_ONLY_MAX_M  # (the MFMA kernels' preconditions, csrc/gemm4_mfma.hip: gemm_4bit_mfma_supported)
-    if N * K <= FUSED_TALL_WEIGHTS:
+    if blocksize == 32:
+        return FUSED_MAX_M_BS32
+    # (the extended ranges were measured on the K-quarter kernel: plain statistics at any blocksize >= 64, nested ones at blocksize 64
+    # and K <= 16384 - csrc/gemm4_mfma_kq.hip: gemm_4bit_kq_serves; other nested calls run the producer/consumer kernel and keep 512)
+    if N * K <= FUSED_TALL_WEIGHTS and blocksize >= 64 and (not nested or (blocksize == 64 and K <= 16384)):
         if K >= 2 * N:
             return FUSED_MAX_M_LONG_ROWS
         if 10 * K >= 7 * N:

@@ -38,6 +38,7 @@ constexpr int64_t kFusedMaxMLongRows = 1024; // K >= 2 N
 constexpr int64_t kFusedMaxMSquare = 640;    // 10 K >= 7 N
 constexpr int64_t kFusedTallWeights = 50331648; // 48 << 20
 constexpr int64_t kStreamOnlyMaxM = 16;
+constexpr int64_t kFusedMaxMBs32 = 128; // blocksize 32, plain statistics: the register-transposed kernel's row passes
 constexpr int64_t kFusedMaxMFp32 = 4;
 constexpr int64_t kReferenceCustomMaxM = 256; // reference backends/cuda/ops.py:816
 
@@ -45,7 +46,10 @@ constexpr int64_t kReferenceCustomMaxM = 256; // reference backends/cuda/ops.py:
 int64_t fused_max_m(int64_t N, int64_t K, int64_t blocksize, bool nested) {
     if (K % 256 != 0 || blocksize < 32 || (blocksize == 32 && nested))
         return kStreamOnlyMaxM; // the MFMA kernels do not serve the call: the streaming kernel's 4-row passes
-    if (N * K <= kFusedTallWeights) {
+    if (blocksize == 32)
+        return kFusedMaxMBs32;
+    // (the extended ranges were measured on the K-quarter kernel: nested statistics only at blocksize 64 and K <= 16384)
+    if (N * K <= kFusedTallWeights && blocksize >= 64 && (!nested || (blocksize == 64 && K <= 16384))) {
         if (K >= 2 * N)
             return kFusedMaxMLongRows;
         if (10 * K >= 7 * N)

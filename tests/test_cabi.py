@@ -373,6 +373,7 @@ def test_native_dispatch_routing_constants_match_python():
     assert const("kFusedMaxMSquare") == hip.FUSED_MAX_M_SQUARE
     assert const("kFusedTallWeights") == hip.FUSED_TALL_WEIGHTS
     assert const("kStreamOnlyMaxM") == hip.STREAM_ONLY_MAX_M
+    assert const("kFusedMaxMBs32") == hip.FUSED_MAX_M_BS32
     assert const("kReferenceCustomMaxM") == hip._REFERENCE_CUSTOM_MAX_M
     # fp32 activations: fused up to 4 rows in both
     assert const("kFusedMaxMFp32") == 4

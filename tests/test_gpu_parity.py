@@ -1419,13 +1419,24 @@ def test_gemm_4bit_blocksize_32_runs_the_mfma_kernel(M, dtype):
         x = torch.randn(M, K, generator=g).to(dtype)
         bias = torch.randn(N, generator=g).to(dtype)
         q, st = F.quantize_4bit(W.to(DEV), blocksize=32, quant_type=qt)
-        y = bnb.matmul_4bit(x.to(DEV), q, st, bias=bias.to(DEV))
+        from bitsandbytes_amd.backends import hip
+
+        if hip._gemm_4bit_route(dtype, M, N, K, 32, False) == "fused":
+            call = lambda: bnb.matmul_4bit(x.to(DEV), q, st, bias=bias.to(DEV))  # noqa: E731
+        else:
+            # above FUSED_MAX_M_BS32 rows the public route is dequantize + GEMM (cheaper from ~200 rows on: the BS32 instances' row
+            # passes run one after the other); the kernel's row-pass geometry is still exercised here, through the library call
+            assert M > hip.FUSED_MAX_M_BS32
+            y_pub = bnb.matmul_4bit(x.to(DEV), q, st, bias=bias.to(DEV))
+            assert rel_err(y_pub.cpu(), _oracle_y(x, q, st, bias)) < REL_TOL
+            call = lambda: _run_kernel(0, x.to(DEV), q, st, bias.to(DEV))  # noqa: E731
+        y = call()
         # (three and four rows go to the MFMA kernels on matrices of >= 12 M weights only: c_api.hip route_to_mfma)
         want = K_RT if M > 4 or N * K >= (12 << 20) else K_STREAM
         assert bnb.lib.bnb_mi355x_last_gemm_kernel() == want, (M, N, K, bnb.lib.bnb_mi355x_last_gemm_kernel())
         y_ref = _oracle_y(x, q, st, bias)
         assert rel_err(y.cpu(), y_ref) < REL_TOL, (M, N, K, qt)
-        assert torch.equal(y, bnb.matmul_4bit(x.to(DEV), q, st, bias=bias.to(DEV)))  # bit-reproducible
+        assert torch.equal(y, call())  # bit-reproducible
     # double quantisation at blocksize 32: outside the BS32 instances - the streaming kernel (4-row passes) up to STREAM_ONLY_MAX_M rows,
     # dequantize + library GEMM above (3 - 4 x cheaper than the passes at 64 rows: profiles/r5_tall_small_ab.txt); same tolerance
     from bitsandbytes_amd.backends import hip

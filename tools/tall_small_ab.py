@@ -55,6 +55,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default=None, help="e.g. 4096x2752,11008x2752 (N x K)")
     ap.add_argument("--ms", default=None, help="e.g. 8,16,32")
+    ap.add_argument("--bs", type=int, default=64, help="blocksize (32: plain statistics only are served by the MFMA route)")
+    ap.add_argument("--plain-only", action="store_true")
     a = ap.parse_args()
     if a.shapes:
         SHAPES = [tuple(int(v) for v in t.split("x")) for t in a.shapes.split(",")]
@@ -63,8 +65,8 @@ def main():
     print(torch.cuda.get_device_name(0))
     print(f"{'N x K (M weights)':>22s} {'nested':>6s} | " + " | ".join(f"M={m:<4d} fused unfus" for m in MS))
     for (N, K) in SHAPES:
-        for nested in (False, True):
-            layers = make_layers(N, K, 64, "nf4", nested, cap=8)
+        for nested in ((False,) if a.plain_only else (False, True)):
+            layers = make_layers(N, K, a.bs, "nf4", nested, cap=8)
             cells = []
             for M in MS:
                 x = torch.randn(M, K, device="cuda").bfloat16()
@@ -90,8 +92,8 @@ def main():
                 for r in range(3):
                     for i in ((0, 1) if r % 2 == 0 else (1, 0)):
                         samples[i].append(timed(gs[i], len(layers), reps))
-                a, b = (statistics.median(s) for s in samples)
-                cells.append(f"{a:10.1f} {b:5.1f}" + ("*" if a < 0.97 * b else " "))
+                t_f, t_u = (statistics.median(s) for s in samples)
+                cells.append(f"{t_f:10.1f} {t_u:5.1f}" + ("*" if t_f < 0.97 * t_u else " "))
                 del gs
             print(f"{N:>7d}x{K:<6d} ({N * K / 1e6:5.1f}) {int(nested):>6d} | " + " | ".join(cells), flush=True)
             del layers
