@@ -759,6 +759,13 @@ void gemm_4bit_kq(int dtype, const void* A, const uint8_t* B, const float* absma
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int ablate, hipStream_t stream);
 
+// gemm4_mfma_sm.hip (the streaming MFMA kernel: one persistent workgroup per CU, activations once per CU; 2 ... 16 rows)
+bool gemm_4bit_sm_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize);
+bool gemm_4bit_sm_serves(const float* absmax, const uint8_t* absmax8, int blocksize);
+void gemm_4bit_sm(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
+                  const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
+                  int blocksize, int quant_type, hipStream_t stream);
+
 // shared with gemm4_mfma_rt.hip: the slab finalize launch and the library-owned workspace
 void gemm_4bit_finalize(int dtype, const float* ws, const void* bias, void* out, int M, int N, int kslices, hipStream_t stream) {
     const long total = static_cast<long>(M) * N;
@@ -804,6 +811,17 @@ bool rt_selected(int M, int N, int K, int knob1, int* force_ks, int* force_waves
     if (M <= 64)
         return weights <= (17L << 19);
     return false;
+}
+// Which problems go to the streaming MFMA kernel (tuning knob cfg 50 forces it, cfg 51 keeps it out of the built-in route).
+bool sm_selected(int M, int N, int K, int knob0, int knob1) {
+    const int cfg = knob1 / 100;
+    if (cfg == 50)
+        return true;
+    if (cfg != 0 || (knob0 & 2)) // (knob0 bit 1: the routing as it was before this kernel - A/B runs)
+        return false;
+    (void)K;
+    // one persistent workgroup per CU needs >= ~3/4 of the chip's CUs in 16-row tiles
+    return M >= 2 && M <= 16 && N >= 12 * device_cu_count_or_default();
 }
 // Which problems go to the K-quarter kernel (tuning knob cfg 40 forces it; knob % 100 = K slices).
 bool kq_selected(int M, int N, int K, int knob1, int* force_ks) {
@@ -886,6 +904,8 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
         return gemm_4bit_rt(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type, workspace,
                             workspace_bytes, 0, 0, 0, stream);
     }
+    if (sm_selected(M, N, K, knob0, knob1) && gemm_4bit_sm_supported(dtype, A, B, code16, M, N, K, blocksize) && gemm_4bit_sm_serves(absmax, absmax8, blocksize))
+        return gemm_4bit_sm(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type, stream);
     if (kq_selected(M, N, K, knob1, &qks) && gemm_4bit_kq_supported(dtype, A, B, code16, M, N, K, blocksize) &&
         gemm_4bit_kq_serves(absmax, absmax8, blocksize, K))
         return gemm_4bit_kq(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type,

@@ -1,0 +1,570 @@
+// gemm4_mfma_sm.hip — "streaming MFMA" kernel for small decode batches (2 <= M <= 16, bf16 / fp16, K % 256 == 0):
+//   out[m, n] = sum_k A[m, k] * code[B[n, k]] * scale[n, k / bs]  (+ bias[n])
+//
+// Replaces, on MI355X, the small-M window of the reference's fused kernels (csrc/gemm_4bit_simt.cu:109-533, selected by
+// bitsandbytes/backends/cuda/ops.py:823-835 for M <= 4, and the first row tile of csrc/gemm_4bit_sm80.cu:127-457 above).
+// Round 6: the batched-decode range M = 2 ... 16 cost 21 - 53 % more than M = 1 on the headline shape for < 2 % more bytes
+// (4096^2: 4.13 us at M = 1, 5.0 / 5.5 / 5.9 / 6.3 at M = 2 / 4 / 8 / 16; 8192^2 M = 16: 15.4 against 8.6). Two causes,
+// both visible in the designs it ran on: the streaming kernel (gemv4_stream.hip) multiplies on the VALU, so every extra
+// row is another 16 packed FMAs per weight item of a VALU-bound decode; the register-transposed kernel
+// (gemm4_mfma_rt.hip) gives ONE workgroup per 16 output columns, so every workgroup - two per CU on large matrices -
+// pulls ALL of A through its L1 (8192^2, M = 16: 2 x 256 KB per CU, 3.4 us at 64 B / clk) behind a prologue of 11 vector
+// loads per wavefront. This kernel keeps the streaming kernel's skeleton and lets the matrix pipe do the rows:
+//
+//  * ONE persistent workgroup per CU owns R = ceil(N / CUs) consecutive output columns (weight rows) in tiles of 16, for the
+//    whole of K. Wavefront w owns the 256-k chunks w, w + WAVES, ... of K for ALL of the workgroup's tiles and keeps that
+//    chunk's activation fragments in REGISTERS (8 MFMA operands, 32 VGPRs) while it walks the tiles: every byte of A enters
+//    the CU exactly once per launch, whatever R is.
+//  * A travels by LDS-DMA (buffer_load ... lds) in full lines - instruction i of a chunk covers rows 2 i, 2 i + 1 x 512
+//    contiguous bytes - into a staging area private to the wavefront, XOR-swizzled on the SOURCE side so that the
+//    fragment reads (ds_read_b128 in MFMA shape: lane (m, kg)) are bank-conflict-free under gfx950's 16-lane read groups:
+//    ROWS / 2 vector-memory instructions per chunk (M <= 4: two) instead of eight fragment-shaped loads. The DMAs are
+//    spelled in asm and issued FIRST, i.e. they are the oldest entries of the wavefront's in-order queue: the fragments
+//    are in registers (and the next chunk's DMA requested) long before the first weight bytes arrive from HBM. The next
+//    chunk's fragments wait in the staging area until the wavefront gets there; the hand-off is one counted s_waitcnt.
+//  * Weights stream through a two-stage REGISTER ring of branch-free buffer loads exactly as in the register-transposed
+//    kernel (lane 4 r + p = 16-byte piece p of row r: a lane quad covers 64 contiguous bytes of one row), are transposed
+//    to MFMA shape through a 1-KiB tile private to the wavefront, regrouped by v_permlane32_swap so that every MFMA
+//    consumes k from ONE quantization block, decoded by one LDS look-up per packed byte (byte -> two 16-bit code values,
+//    table built from literals while the loads fly) and multiplied by v_mfma_f32_16x16x32: one decode serves all rows.
+//    An item past the end of a wavefront's list is an out-of-range offset (zeros, nothing fetched): the number of loads in
+//    flight is the same on every path, which is what makes the counted waits - the compiler's and the two written here - exact.
+//  * The exact fp32 absmax multiplies the fp32 partial tile of each 64-k block (4 v_fma per block and tile), nested
+//    statistics are reconstructed in-kernel with the two roundings of the host-side sequence (bnb_common.h nested_scale).
+//  * The wavefronts' partial tiles are combined once, through LDS, in FIXED order ((w0 + w1 + w2 + w3) + ... by four
+//    threads per output, then two DPP adds): bit-reproducible, no atomics, no second launch, no workspace.
+#include "bnb_common.h"
+
+namespace bnb {
+
+#ifdef BNB_PROFILING
+extern unsigned long long* g_dbg_buf; // c_api.hip (profiling builds only)
+#endif
+
+namespace {
+
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+
+template <typename T> struct SmMma;
+template <> struct SmMma<bf16> {
+    using frag = __attribute__((ext_vector_type(8))) bf16;
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(frag, a), __builtin_bit_cast(frag, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t pack(float first, float second) {
+        using V = __attribute__((ext_vector_type(2))) bf16;
+        V v;
+        v[0] = static_cast<bf16>(first);
+        v[1] = static_cast<bf16>(second);
+        return __builtin_bit_cast(uint32_t, v);
+    }
+};
+template <> struct SmMma<f16> {
+    using frag = __attribute__((ext_vector_type(8))) f16;
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(frag, a), __builtin_bit_cast(frag, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t pack(float first, float second) {
+        using V = __attribute__((ext_vector_type(2))) f16;
+        V v;
+        v[0] = static_cast<f16>(first);
+        v[1] = static_cast<f16>(second);
+        return __builtin_bit_cast(uint32_t, v);
+    }
+};
+
+constexpr int kSmLut = 32768;    // 256 entries x 32 copies x 4 B, at LDS address 0
+constexpr int kSmCode2 = 1024;   // nested absmax code (256 floats)
+constexpr int kSmScratch = 2560; // per wavefront: two transposition tiles + the scale tile (16 x 16 B), padded to 512 B
+constexpr int kSmChunk = 256;    // k per item: four 64-k MFMA pairs
+constexpr int kSmMaxTiles = 4;   // 16-row tiles of weight rows per workgroup
+
+struct SmArgs {
+#ifdef BNB_PROFILING
+    unsigned long long* dbg;
+#endif
+    const float* absmax_offset;
+    void* out;
+    const void* bias;
+};
+
+// Time stamps (measurement build): s_memtime values collect in scalar registers and are stored ONCE, at the end of the kernel
+// (a store at the point of the stamp sits in the same in-order queue as the counted waits it is meant to observe).
+#ifdef BNB_PROFILING
+#define BNB_SM_STAMP(i) { ts[i] = __builtin_amdgcn_s_memtime(); }
+#else
+#define BNB_SM_STAMP(i) {}
+#endif
+
+__device__ __forceinline__ float sm_code_literal(int i, bool fp4) {
+    // compare/select over literals: no memory access in front of the table
+    constexpr float nf4[16] = {BNB_NF4_VALUES};
+    constexpr float fp4v[16] = {BNB_FP4_VALUES};
+    float v = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        v = (i == j) ? (fp4 ? fp4v[j] : nf4[j]) : v;
+    return v;
+}
+
+__device__ __forceinline__ i32x4 sm_rsrc(const void* base) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    return i32x4{static_cast<int>(a), static_cast<int>((a >> 32) & 0xFFFFu), 0x7FFFFFFF, 0x00020000};
+}
+// LDS-DMA, spelled out: the compiler does not know that this is a vector-memory operation, so its own counted waits for the
+// weight ring stay counted (with the builtin it treats the counter as out of order: every register wait becomes vmcnt(0)).
+// An unseen DMA that is YOUNGER than a load the compiler waits for only makes that wait stricter; the waits for the DMAs
+// themselves are written by hand (sm_wait_vm) at the two places that read the staging area.
+__device__ __forceinline__ void sm_dma16(i32x4 rs, uint32_t lds, uint32_t voff, uint32_t soff) {
+    lds = __builtin_amdgcn_readfirstlane(lds);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+template <int N> __device__ __forceinline__ void sm_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void sm_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// swizzle of the activation staging area: piece P (16 B = 8 k) of staged row m lives at piece P ^ swz(m) of the row's 512 B.
+// It uses bits 0, 1, 3 of the piece index only: bit 2 is the one that tells lane groups kg and kg ^ 1 - which share a
+// ds_read_b128 service group - apart (see the fragment addresses in the kernel).
+__device__ __forceinline__ int sm_swz(int m) { return (m & 3) | ((m & 4) << 1); }
+
+// T in {bf16, f16}; ROWS in {4, 8, 16} = activation rows staged per chunk (>= M; rows past M repeat row M - 1 and are never
+// stored); WAVES wavefronts per workgroup (16; 8 at ROWS = 16, whose staging area is 8 KiB per wavefront); TT = 16-row tiles
+// of weight rows per workgroup (compile time: the accumulators of a wavefront's TT tiles live in registers and the ring
+// stage of an item must be a compile-time index); NESTED / BS64 as in gemm4_mfma_rt.hip, except that BS64 is a
+// compile-time property of the plain instances too (the loads per ring stage - LPS - enter the hand-written waits).
+// grid = (ceil(N / R), ceil(M / 16)); hot_geom = R | fp4 << 16 | bs_shift << 20.
+template <typename T, int ROWS, int WAVES, int TT, bool NESTED, bool BS64>
+__global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
+    // hot arguments as separate scalars: preloaded into SGPRs by the command processor (14 dwords)
+    const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, const float* hot_code2, int hot_M,
+    int hot_N, int hot_K, int hot_geom, const SmArgs p) {
+    constexpr int THREADS = WAVES * 64;
+    constexpr int NA = ROWS / 2;         // DMA instructions per chunk (1 KiB each)
+    constexpr int STAGE = ROWS * 512;    // bytes of a wavefront's staging area
+    constexpr int REGION = STAGE + kSmScratch;
+    // vector-memory loads per ring stage: two weight loads + the scales (fp32 absmax: one 16-byte load at blocksize 64, else
+    // four dwords; nested: a dword of four codes + the second-level absmax at blocksize 64, else two bytes + that)
+    constexpr int LPS = 2 + (NESTED ? (BS64 ? 2 : 3) : (BS64 ? 1 : 4));
+    static_assert(ROWS == 4 || ROWS == 8 || ROWS == 16, "staged activation rows");
+    static_assert(TT >= 1 && TT <= kSmMaxTiles, "tiles per workgroup");
+    static_assert(TT * 1024 <= REGION - 256, "the partial tiles of a wavefront are parked in its own region");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef BNB_PROFILING
+    unsigned long long ts[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+        ts[i] = 0;
+#endif
+    BNB_SM_STAMP(0)
+    const int r = lane >> 2, pp = lane & 3;   // weight-load roles: row r of the 16-row tile, 16-byte piece pp of its 64 bytes
+    const int ln = lane & 15, lg = lane >> 4; // MFMA roles: row / column ln, k group lg
+    const int M = hot_M, N = hot_N, K = hot_K;
+    const int R = hot_geom & 0xFFFF;
+    const bool fp4 = (hot_geom >> 16) & 1;
+    const int bs_shift = (hot_geom >> 20) & 31;
+    const int row0 = blockIdx.x * R;
+    int row_end = row0 + R;
+    row_end = row_end < N ? row_end : N;
+    const int m_base = blockIdx.y * 16;
+    const int C = K >> 8; // chunks of a row
+    // chunks of this wavefront: wave, wave + WAVES, ... < C
+    const int nchunks = (C - wave + WAVES - 1) / WAVES > 0 ? (C - wave + WAVES - 1) / WAVES : 0;
+    const int nitems = nchunks * TT;
+
+    // LDS map: table | nested code | per wavefront: staging (512-byte aligned: fragment addresses are formed with XOR) |
+    // transposition tile 0 | tile 1 | scale tile. A wavefront that is done parks its partial tiles in its OWN region.
+    constexpr int kRegions = kSmLut + kSmCode2;
+    static_assert(kRegions % 512 == 0 && REGION % 512 == 0, "staging areas are 512-byte aligned");
+    float* const code2 = reinterpret_cast<float*>(smem + kSmLut);
+    unsigned char* const region = smem + kRegions + wave * REGION;
+    u32x4* const tile0 = reinterpret_cast<u32x4*>(region + STAGE);
+    u32x4* const tile1 = reinterpret_cast<u32x4*>(region + STAGE + 1024);
+    u32x4* const stile = reinterpret_cast<u32x4*>(region + STAGE + 2048);
+    const uint32_t stage_lds = static_cast<uint32_t>(kRegions + wave * REGION);
+
+    // ---- activation DMA: instruction i, lane L fills slot 64 i + L of the staging area = piece P' = L & 31 of staged row
+    // m = 2 i + (L >> 5), and fetches piece P' ^ swz(m) of batch row m_base + m (rows past the batch: the last row again)
+    const i32x4 rs_a = sm_rsrc(hot_A);
+    uint32_t a_voff[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = 2 * i + (lane >> 5);
+        int mr = m_base + m;
+        mr = mr < M ? mr : M - 1;
+        a_voff[i] = static_cast<uint32_t>(mr) * static_cast<uint32_t>(K) * 2u + static_cast<uint32_t>(((lane & 31) ^ sm_swz(m)) << 4);
+    }
+    auto issue_a = [&](int ci) {
+        // chunk ci of this wavefront (a wavefront without chunks stages the row's last chunk: nobody reads it)
+        int c = wave + ci * WAVES;
+        c = c < C ? c : C - 1;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            sm_dma16(rs_a, stage_lds + static_cast<uint32_t>(i * 1024), a_voff[i], static_cast<uint32_t>(c) * 512u);
+    };
+    if constexpr (NESTED) {
+        // the second-level code table (256 floats): ONE 1-KiB DMA by wavefront 0, the oldest entry of its queue - the table's
+        // address arrives in a preloaded argument, so nothing waits for the kernarg segment here. Landed behind the wait for the
+        // first fragments, published by the table barrier.
+        if (wave == 0)
+            sm_dma16(sm_rsrc(hot_code2), static_cast<uint32_t>(kSmLut), static_cast<uint32_t>(lane) * 16u, 0u);
+    }
+    issue_a(0);
+
+    // ---- weight ring
+    struct Stage {
+        u32x4 w[2]; // 128 k each: lane (r, pp) holds k [128 h + 32 pp, + 32) of row r of the tile
+        u32x4 s;    // the row's scales of the chunk's four 64-k sub-blocks (nested: {codes, second-level absmax, codes', -})
+    };
+    constexpr uint32_t kOob = 0xFFFFFFF0u; // beyond num_records
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hot_B), 0, 0x7FFFFFFF, 0x00020000);
+    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hot_absmax), 0, 0x7FFFFFFF, 0x00020000);
+    const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hot_absmax8), 0, 0x7FFFFFFF, 0x00020000);
+    // item q of this wavefront = (chunk q / TT of its list, tile q % TT). Every load is branch-free: an item past the end of
+    // the list, and a tile row past the end of the workgroup's rows, is an out-of-range offset (zeros, nothing fetched).
+    auto issue = [&](Stage& st, int q) {
+        const int ci = q / TT, t = q - ci * TT;
+        const int c = wave + ci * WAVES;
+        const int wrow = row0 + 16 * t + r;
+        const uint32_t inval = (q < nitems && wrow < row_end) ? 0u : kOob;
+        const uint32_t w_off = static_cast<uint32_t>(wrow) * static_cast<uint32_t>(K >> 1) + static_cast<uint32_t>(pp * 16);
+        const uint32_t soff_w = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(c) * 128u);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            st.w[h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off | inval, soff_w + static_cast<uint32_t>(h * 64), 0));
+        // flat element index of the row's first element of the chunk (N K < 2^32: gemm_4bit_sm_supported)
+        const uint32_t e = static_cast<uint32_t>(wrow) * static_cast<uint32_t>(K) + (static_cast<uint32_t>(c) << 8);
+        if constexpr (NESTED) {
+            if constexpr (BS64) {
+                st.s[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(rs_q, ((e >> 6) & ~3u) | inval, 0, 0));
+                st.s[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(rs_s, ((e >> 14) << 2) | inval, 0, 0));
+                st.s[2] = st.s[3] = 0;
+            } else {
+                // (a chunk's four 64-k sub-blocks lie in two blocks at blocksize 128 and in one above: sub-blocks 0 and 2 are
+                // fetched, 1 = 0 and 3 = 2; the bytes stay apart until the item is consumed)
+                st.s[0] = static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b8(rs_q, (e >> bs_shift) | inval, 0, 0));
+                st.s[2] = static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b8(rs_q, ((e + 128u) >> bs_shift) | inval, 0, 0));
+                st.s[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(rs_s, (((e >> bs_shift) >> 8) << 2) | inval, 0, 0));
+                st.s[3] = 0;
+            }
+        } else if constexpr (BS64) {
+            st.s = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_s, ((e >> 6) << 2) | inval, 0, 0));
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                st.s[b] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(rs_s, (((e + static_cast<uint32_t>(b * 64)) >> bs_shift) << 2) | inval, 0, 0));
+        }
+    };
+    Stage st[2];
+    issue(st[0], 0);
+    __builtin_amdgcn_sched_barrier(0); // keep the queue in stage order
+    issue(st[1], 1);
+    __builtin_amdgcn_sched_barrier(0); // nothing that is not needed for the loads runs before them
+    BNB_SM_STAMP(1)
+
+    // ---- decode table, built while the loads fly: entry e (a packed byte) = 32 copies of (T(code[e >> 4]), T(code[e & 15])),
+    // 128 B per entry (as in gemm4_mfma_rt.hip: the eight lanes one ds_write_b128 services together land in eight bank quads)
+    {
+        const float cv = sm_code_literal((lane & 15) + opaque_zero(), fp4);
+        const int cvb = __builtin_bit_cast(int, cv);
+        u32x4* const lut = reinterpret_cast<u32x4*>(smem);
+        // (the wavefronts of a 16-wavefront workgroup start ~90 cycles apart: the early half builds the table)
+        constexpr int BUILD_THREADS = (WAVES >= 16) ? THREADS / 2 : THREADS;
+#pragma unroll
+        for (int idx = tid; idx < 1024 && tid < BUILD_THREADS; idx += BUILD_THREADS) {
+            const int e = idx >> 2, sub = idx & 3;
+            const float hi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e >> 4) * 4, cvb));
+            const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e & 15) * 4, cvb));
+            const uint32_t pr = SmMma<T>::pack(hi, lo);
+            const u32x4 v = {pr, pr, pr, pr};
+            lut[e * 8 + ((2 * sub) ^ (e & 1))] = v;
+            lut[e * 8 + ((2 * sub + 1) ^ (e & 1))] = v;
+        }
+    }
+    BNB_SM_STAMP(2)
+    float offset = 0.0f;
+    if constexpr (NESTED) {
+        // a scalar load (constant address space): a vector load here would sit in the counted queue behind the ring
+        typedef const __attribute__((address_space(4))) float* cfloat_ptr;
+        int ob = __builtin_bit_cast(int, *(cfloat_ptr)(reinterpret_cast<uintptr_t>(p.absmax_offset)));
+        asm volatile("" : "+s"(ob));
+        offset = __builtin_bit_cast(float, ob);
+    }
+
+    // ---- the first chunk's fragments: its DMAs are older than the two ring stages
+    // fragment of step s = 4 h + 2 a + b, lane (m = ln, kg = lg): 8 k from 128 h + 64 a + 8 b + 32 (kg & 1) + 16 (kg >> 1) of row m,
+    // i.e. piece 16 h + 8 a + b + 4 (kg & 1) + 2 (kg >> 1) - the k order the weight regrouping below produces. Lanes of rows past
+    // ROWS read a staged row again (their MFMA rows are never stored).
+    const int mrow = ln & (ROWS - 1);
+    const uint32_t frag_base = stage_lds + static_cast<uint32_t>(mrow * 512) +
+                               static_cast<uint32_t>(((4 * (lg & 1) + 2 * (lg >> 1)) ^ sm_swz(mrow)) << 4);
+    u32x4 af[8];
+    auto read_frags = [&]() {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const uint32_t sbits = static_cast<uint32_t>(256 * (s >> 2) + 128 * ((s >> 1) & 1) + 16 * (s & 1));
+            af[s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(frag_base ^ sbits);
+        }
+    };
+    sm_wait_vm<2 * LPS>();
+    BNB_SM_STAMP(3)
+    read_frags();
+    if (nchunks > 1) {
+        sm_wait_lgkm0(); // the fragment reads have returned before the staging area is overwritten
+        issue_a(1);
+    }
+    BNB_SM_STAMP(4)
+    __syncthreads();
+    BNB_SM_STAMP(5)
+#ifdef BNB_PROFILING
+    sm_wait_vm<LPS>(); // (measurement build: when the first ring stage has landed)
+    BNB_SM_STAMP(6)
+#endif
+
+    // Where lane (r, pp) puts its 16 bytes, and where lane (ln, lg) finds those of lane (r = ln, pp = lg): conflict-free both
+    // ways under the hardware's lane grouping (gemm4_mfma_rt.hip).
+    const int wslot = 16 * pp + (r ^ (2 * pp));
+    const int rslot = 16 * lg + (ln ^ (2 * lg));
+    const uint32_t lane_off = static_cast<uint32_t>(lane & 31) * 4u + static_cast<uint32_t>(opaque_zero());
+
+    f32x4 acc[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](const Stage& s, int t) {
+        // weights: transpose, then regroup so that dwords 0/1 (2/3) of every lane group belong to block 2h (2h + 1)
+        u32x4 wt[2];
+        tile0[wslot] = s.w[0];
+        wt[0] = tile0[rslot];
+        tile1[wslot] = s.w[1];
+        wt[1] = tile1[rslot];
+        if (pp == 0)
+            stile[r] = s.s;
+        const u32x4 sraw = stile[ln];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const auto s02 = __builtin_amdgcn_permlane32_swap(wt[h][0], wt[h][2], false, false);
+            const auto s13 = __builtin_amdgcn_permlane32_swap(wt[h][1], wt[h][3], false, false);
+            wt[h][0] = s02[0];
+            wt[h][2] = s02[1];
+            wt[h][1] = s13[0];
+            wt[h][3] = s13[1];
+        }
+        float scale[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            // (copies first: __builtin_bit_cast applied to a vector-element lvalue reads element 0 - hipcc 7.2)
+            const uint32_t sb = sraw[b], s1 = sraw[1];
+            const uint32_t s0 = BS64 ? sraw[0] : sraw[0] * 0x0101u + sraw[2] * 0x01010000u;
+            if constexpr (NESTED)
+                scale[b] = nested_scale(code2[(s0 >> (8 * b)) & 0xFFu], __builtin_bit_cast(float, s1), offset);
+            else
+                scale[b] = __builtin_bit_cast(float, sb);
+        }
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            f32x4 part = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int sidx = 2 * blk + i, h = sidx >> 2, j = sidx & 3;
+                const uint32_t w = wt[h][j];
+                u32x4 bf;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const uint32_t byte = __builtin_amdgcn_ubfe(w, 8u * qq, 8u);
+                    bf[qq] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((byte << 7) + lane_off);
+                }
+                part = SmMma<T>::run(af[sidx], bf, part);
+            }
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                acc[t][qq] = fmaf(scale[blk], part[qq], acc[t][qq]);
+        }
+    };
+
+    // ---- items, UNROLL at a time: the ring stage (q & 1) and the tile (q % TT) of an item are compile-time values. Every item
+    // is followed by the request of item q + 2 into the stage just emptied - valid or not (see issue): LPS loads are in flight
+    // behind the stage about to be consumed at every point of the loop.
+    constexpr int UNROLL = (TT % 2) ? 2 * TT : TT;
+    for (int q0 = 0; q0 < nitems; q0 += UNROLL) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int q = q0 + u;
+            const int t = u % TT;
+            if (t == 0 && q > 0 && q < nitems) {
+                // first item of the wavefront's next chunk: its fragments were requested when the previous chunk's were read,
+                // behind at most the ring stage about to be consumed and in front of the other one
+                sm_wait_vm<LPS>();
+                read_frags();
+                if (q / TT + 1 < nchunks) {
+                    sm_wait_lgkm0();
+                    issue_a(q / TT + 1);
+                }
+            }
+            if (q < nitems)
+                compute(st[u & 1], t);
+            if (q == 0)
+                BNB_SM_STAMP(7)
+            issue(st[u & 1], q + 2);
+        }
+    }
+    // The table is addressed with raw LDS offsets: it must sit at LDS address 0 (no static LDS in this kernel).
+    if (reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem) != 0)
+        __builtin_trap();
+
+    // ---- combine the wavefronts' partial tiles in a fixed order. A wavefront parks its tiles in its own region (its last
+    // DMA was waited for at its last chunk switch; the ring's dummy requests do not write LDS).
+    BNB_SM_STAMP(8)
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+        *reinterpret_cast<f32x4*>(region + t * 1024 + lane * 16) = acc[t];
+    __syncthreads();
+    BNB_SM_STAMP(9)
+    constexpr int PARTS = 4, WPP = WAVES / PARTS;
+    const int nout = TT * 16 * ROWS;
+    for (int idx = tid; idx < nout * PARTS; idx += THREADS) {
+        const int o = idx >> 2, part = idx & 3;
+        const int col = o & 15, m = (o >> 4) & (ROWS - 1), t = o / (16 * ROWS);
+        const int src = (col + 16 * (m >> 2)) * 4 + (m & 3);
+        float pv[WPP];
+#pragma unroll
+        for (int w = 0; w < WPP; ++w)
+            pv[w] = reinterpret_cast<const float*>(smem + kRegions + (part * WPP + w) * REGION + t * 1024)[src];
+        float v = pv[0];
+#pragma unroll
+        for (int w = 1; w < WPP; ++w)
+            v += pv[w];
+        // (a + b is the same value in both lanes of a pair: the four partial sums combine as (p0 + p1) + (p2 + p3) everywhere)
+        v = dpp_add<0xB1>(v);
+        v = dpp_add<0x4E>(v);
+        const int mm = m_base + m, n = row0 + 16 * t + col;
+        if (part == 0 && mm < M && n < row_end) {
+            const T* bias = static_cast<const T*>(p.bias);
+            const float b = bias ? static_cast<float>(bias[n]) : 0.0f;
+            static_cast<T*>(p.out)[static_cast<long>(mm) * N + n] = static_cast<T>(v + b);
+        }
+    }
+#ifdef BNB_PROFILING
+    BNB_SM_STAMP(10)
+    if (p.dbg && lane == 0) {
+        unsigned long long* const d = p.dbg + ((static_cast<long>(blockIdx.y) * gridDim.x + blockIdx.x) * WAVES + wave) * 16;
+#pragma unroll
+        for (int i = 0; i < 11; ++i)
+            d[i] = ts[i];
+    }
+#endif
+}
+
+int sm_cu_count() { return device_cu_count_or_default(); }
+
+struct SmPlan {
+    int R, tt, grid_x, rows;
+};
+
+// rows per workgroup: one workgroup per CU when 64 rows are enough, else whole rounds of workgroups
+SmPlan sm_plan(int M, int N) {
+    SmPlan pl;
+    const int cus = sm_cu_count();
+    const long per_round = static_cast<long>(cus) * 16 * kSmMaxTiles;
+    const int rounds = static_cast<int>((N + per_round - 1) / per_round);
+    int R = (N + cus * rounds - 1) / (cus * rounds);
+    R = R < 16 ? 16 : R;
+    pl.R = R;
+    pl.tt = (R + 15) / 16;
+    pl.grid_x = (N + R - 1) / R;
+    pl.rows = M <= 4 ? 4 : M <= 8 ? 8 : 16;
+    return pl;
+}
+
+template <typename T, int ROWS, int WAVES, int TT, bool NESTED, bool BS64>
+void sm_launch_one(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, const float* code2, int M, int N, int K, int geom,
+                   const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
+    constexpr size_t lds = kSmLut + kSmCode2 + static_cast<size_t>(WAVES) * (ROWS * 512 + kSmScratch);
+    auto kern = gemm4_mfma_sm_kernel<T, ROWS, WAVES, TT, NESTED, BS64>;
+    static LdsLimit lim;
+    ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
+    hipLaunchKernelGGL(kern, dim3(pl.grid_x, (M + 15) / 16), dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, code2, M, N, K, geom, a);
+}
+
+template <typename T, int ROWS, int WAVES, int TT>
+void sm_launch_kind(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, const float* code2, int M, int N, int K, int geom,
+                    int blocksize, const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
+    const bool nested = absmax8 != nullptr, bs64 = blocksize == 64;
+    if (nested && bs64)
+        return sm_launch_one<T, ROWS, WAVES, TT, true, true>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+    if (nested)
+        return sm_launch_one<T, ROWS, WAVES, TT, true, false>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+    if (bs64)
+        return sm_launch_one<T, ROWS, WAVES, TT, false, true>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+    return sm_launch_one<T, ROWS, WAVES, TT, false, false>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+}
+
+// 16 wavefronts per workgroup, 8 where 128 registers (four tiles' accumulators beside the fragments and the ring) or the LDS
+// (8-KiB staging areas at ROWS = 16) do not allow them
+template <typename T, int ROWS>
+void sm_launch_tt(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, const float* code2, int M, int N, int K, int geom,
+                  int blocksize, const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
+    constexpr int W = ROWS == 16 ? 8 : 16;
+    switch (pl.tt) {
+    case 1: return sm_launch_kind<T, ROWS, W, 1>(A, B, absmax, absmax8, code2, M, N, K, geom, blocksize, pl, a, stream);
+    case 2: return sm_launch_kind<T, ROWS, W, 2>(A, B, absmax, absmax8, code2, M, N, K, geom, blocksize, pl, a, stream);
+    case 3: return sm_launch_kind<T, ROWS, W, 3>(A, B, absmax, absmax8, code2, M, N, K, geom, blocksize, pl, a, stream);
+    default: return sm_launch_kind<T, ROWS, 8, 4>(A, B, absmax, absmax8, code2, M, N, K, geom, blocksize, pl, a, stream);
+    }
+}
+
+template <typename T>
+void sm_launch_rows(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, const float* code2, int M, int N, int K, int geom,
+                    int blocksize, const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
+    switch (pl.rows) {
+    case 4: return sm_launch_tt<T, 4>(A, B, absmax, absmax8, code2, M, N, K, geom, blocksize, pl, a, stream);
+    case 8: return sm_launch_tt<T, 8>(A, B, absmax, absmax8, code2, M, N, K, geom, blocksize, pl, a, stream);
+    default: return sm_launch_tt<T, 16>(A, B, absmax, absmax8, code2, M, N, K, geom, blocksize, pl, a, stream);
+    }
+}
+
+} // namespace
+
+// Preconditions of the kernel (the statistics' alignment is checked by gemm_4bit_sm_serves): 16-bit activations, literal code
+// table, K a multiple of 256, blocksize >= 64, 16-byte aligned A and B, 32-bit byte offsets below the descriptors' records.
+bool gemm_4bit_sm_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize) {
+    return dtype != 0 && code16 == nullptr && M >= 1 && N >= 1 && K >= kSmChunk && (K % kSmChunk) == 0 && blocksize >= 64 && is_pow2(blocksize) &&
+           aligned_to(A, 16) && aligned_to(B, 16) && static_cast<long long>(N) * K < (1LL << 32) && static_cast<long long>(M) * K < (1LL << 30);
+}
+
+// fp32 absmax at blocksize 64 travels as one 16-byte load per row and chunk; nested statistics at blocksize 64 as one dword of
+// four codes
+bool gemm_4bit_sm_serves(const float* absmax, const uint8_t* absmax8, int blocksize) {
+    if (blocksize != 64)
+        return true;
+    return absmax8 != nullptr ? aligned_to(absmax8, 4) : aligned_to(absmax, 16);
+}
+
+// dtype: 1 = f16, 2 = bf16. Any M (row passes of 16 over grid.y); meant for M <= 16.
+void gemm_4bit_sm(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
+                  const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
+                  int blocksize, int quant_type, hipStream_t stream) {
+    g_last_gemm_kernel = kKernelSm;
+    const SmPlan pl = sm_plan(M, N);
+    SmArgs a;
+#ifdef BNB_PROFILING
+    a.dbg = g_dbg_buf;
+#endif
+    a.absmax_offset = absmax_offset;
+    a.out = out;
+    a.bias = bias;
+    const int geom = pl.R | ((quant_type == kFP4) ? (1 << 16) : 0) | (ilog2(blocksize) << 20);
+    if (dtype == 2)
+        sm_launch_rows<bf16>(A, B, absmax, absmax8, absmax_code, M, N, K, geom, blocksize, pl, a, stream);
+    else
+        sm_launch_rows<f16>(A, B, absmax, absmax8, absmax_code, M, N, K, geom, blocksize, pl, a, stream);
+    BNB_CHECK_LAUNCH();
+}
+
+} // namespace bnb
