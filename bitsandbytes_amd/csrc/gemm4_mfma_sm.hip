@@ -75,9 +75,9 @@ template <> struct SmMma<f16> {
     }
 };
 
-constexpr int kSmLut = 32768;    // 256 entries x 32 copies x 4 B, at LDS address 0
+constexpr int kSmLut = 65536;    // 256 entries x 64 lane-private copies x 4 B, at LDS address 0: a table address is ONE v_perm_b32
 constexpr int kSmCode2 = 1024;   // nested absmax code (256 floats)
-constexpr int kSmScratch = 2560; // per wavefront: two transposition tiles + the scale tile (16 x 16 B), padded to 512 B
+constexpr int kSmScratch = 1536; // per wavefront: one transposition tile (1 KiB) + the scale tile (256 B), padded to 512 B
 constexpr int kSmChunk = 256;    // k per item: four 64-k MFMA pairs
 constexpr int kSmMaxTiles = 4;   // 16-row tiles of weight rows per workgroup
 
@@ -131,12 +131,12 @@ __device__ __forceinline__ void sm_wait_lgkm0() { asm volatile("s_waitcnt lgkmcn
 __device__ __forceinline__ int sm_swz(int m) { return (m & 3) | ((m & 4) << 1); }
 
 // T in {bf16, f16}; ROWS in {4, 8, 16} = activation rows staged per chunk (>= M; rows past M repeat row M - 1 and are never
-// stored); WAVES wavefronts per workgroup (16; 8 at ROWS = 16, whose staging area is 8 KiB per wavefront); TT = 16-row tiles
-// of weight rows per workgroup (compile time: the accumulators of a wavefront's TT tiles live in registers and the ring
-// stage of an item must be a compile-time index); NESTED / BS64 as in gemm4_mfma_rt.hip, except that BS64 is a
-// compile-time property of the plain instances too (the loads per ring stage - LPS - enter the hand-written waits).
+// stored); WAVES wavefronts per workgroup (16; 8 at ROWS = 16, whose staging area is 8 KiB per wavefront, and at four tiles);
+// TT = 16-row tiles of weight rows per workgroup (compile time: the accumulators of a wavefront's TT tiles live in registers and
+// the ring stage of an item must be a compile-time index); NESTED: double-quantised statistics; SINGLE: no wavefront has more
+// than ONE item (K <= 256 WAVES and one tile - the headline shape): no ring, no refill requests.
 // grid = (ceil(N / R), ceil(M / 16)); hot_geom = R | fp4 << 16 | bs_shift << 20.
-template <typename T, int ROWS, int WAVES, int TT, bool NESTED, bool BS64>
+template <typename T, int ROWS, int WAVES, int TT, bool NESTED, bool SINGLE>
 __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     // hot arguments as separate scalars: preloaded into SGPRs by the command processor (14 dwords)
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, const float* hot_code2, int hot_M,
@@ -144,13 +144,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     constexpr int THREADS = WAVES * 64;
     constexpr int NA = ROWS / 2;         // DMA instructions per chunk (1 KiB each)
     constexpr int STAGE = ROWS * 512;    // bytes of a wavefront's staging area
-    constexpr int REGION = STAGE + kSmScratch;
-    // vector-memory loads per ring stage: two weight loads + the scales (fp32 absmax: one 16-byte load at blocksize 64, else
-    // four dwords; nested: a dword of four codes + the second-level absmax at blocksize 64, else two bytes + that)
-    constexpr int LPS = 2 + (NESTED ? (BS64 ? 2 : 3) : (BS64 ? 1 : 4));
+    constexpr int REGION = (STAGE + kSmScratch) > TT * 1024 ? (STAGE + kSmScratch) : TT * 1024;
+    // vector-memory loads per ring stage: two weight loads + the lane's scale (fp32 absmax: one dword; nested: its 8-bit code and
+    // the second-level absmax)
+    constexpr int LPS = 2 + (NESTED ? 2 : 1);
+    constexpr int NS = SINGLE ? 1 : 2;   // ring stages
     static_assert(ROWS == 4 || ROWS == 8 || ROWS == 16, "staged activation rows");
-    static_assert(TT >= 1 && TT <= kSmMaxTiles, "tiles per workgroup");
-    static_assert(TT * 1024 <= REGION - 256, "the partial tiles of a wavefront are parked in its own region");
+    static_assert(TT >= 1 && TT <= kSmMaxTiles && (!SINGLE || TT == 1), "tiles per workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -178,15 +178,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     const int nitems = nchunks * TT;
 
     // LDS map: table | nested code | per wavefront: staging (512-byte aligned: fragment addresses are formed with XOR) |
-    // transposition tile 0 | tile 1 | scale tile. A wavefront that is done parks its partial tiles in its OWN region.
+    // transposition tile | scale tile. A wavefront that is done parks its partial tiles in its OWN region.
     constexpr int kRegions = kSmLut + kSmCode2;
     static_assert(kRegions % 512 == 0 && REGION % 512 == 0, "staging areas are 512-byte aligned");
-    float* const code2 = reinterpret_cast<float*>(smem + kSmLut);
     unsigned char* const region = smem + kRegions + wave * REGION;
-    u32x4* const tile0 = reinterpret_cast<u32x4*>(region + STAGE);
-    u32x4* const tile1 = reinterpret_cast<u32x4*>(region + STAGE + 1024);
-    u32x4* const stile = reinterpret_cast<u32x4*>(region + STAGE + 2048);
+    u32x4* const tile = reinterpret_cast<u32x4*>(region + STAGE);
     const uint32_t stage_lds = static_cast<uint32_t>(kRegions + wave * REGION);
+    const uint32_t stile_lds = stage_lds + static_cast<uint32_t>(STAGE + 1024);
 
     // ---- activation DMA: instruction i, lane L fills slot 64 i + L of the staging area = piece P' = L & 31 of staged row
     // m = 2 i + (L >> 5), and fetches piece P' ^ swz(m) of batch row m_base + m (rows past the batch: the last row again)
@@ -210,7 +208,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     if constexpr (NESTED) {
         // the second-level code table (256 floats): ONE 1-KiB DMA by wavefront 0, the oldest entry of its queue - the table's
         // address arrives in a preloaded argument, so nothing waits for the kernarg segment here. Landed behind the wait for the
-        // first fragments, published by the table barrier.
+        // first fragments, published by the barrier behind it.
         if (wave == 0)
             sm_dma16(sm_rsrc(hot_code2), static_cast<uint32_t>(kSmLut), static_cast<uint32_t>(lane) * 16u, 0u);
     }
@@ -218,13 +216,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
 
     // ---- weight ring
     struct Stage {
-        u32x4 w[2]; // 128 k each: lane (r, pp) holds k [128 h + 32 pp, + 32) of row r of the tile
-        u32x4 s;    // the row's scales of the chunk's four 64-k sub-blocks (nested: {codes, second-level absmax, codes', -})
+        u32x4 w[2];  // 128 k each: lane (r, pp) holds k [128 h + 32 pp, + 32) of row r of the tile
+        uint32_t s;  // lane (r, pp): the fp32 absmax of 64-k sub-block pp of row r's chunk (nested: its 8-bit code)
+        uint32_t s2; // nested: the second-level absmax of that block
     };
     constexpr uint32_t kOob = 0xFFFFFFF0u; // beyond num_records
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hot_B), 0, 0x7FFFFFFF, 0x00020000);
     const auto rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hot_absmax), 0, 0x7FFFFFFF, 0x00020000);
-    const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hot_absmax8), 0, 0x7FFFFFFF, 0x00020000);
+    [[maybe_unused]] const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hot_absmax8), 0, 0x7FFFFFFF, 0x00020000);
     // item q of this wavefront = (chunk q / TT of its list, tile q % TT). Every load is branch-free: an item past the end of
     // the list, and a tile row past the end of the workgroup's rows, is an out-of-range offset (zeros, nothing fetched).
     auto issue = [&](Stage& st, int q) {
@@ -237,53 +236,44 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
 #pragma unroll
         for (int h = 0; h < 2; ++h)
             st.w[h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off | inval, soff_w + static_cast<uint32_t>(h * 64), 0));
-        // flat element index of the row's first element of the chunk (N K < 2^32: gemm_4bit_sm_supported)
-        const uint32_t e = static_cast<uint32_t>(wrow) * static_cast<uint32_t>(K) + (static_cast<uint32_t>(c) << 8);
+        // quantization block of the lane's 64-k sub-block (N K < 2^32: gemm_4bit_sm_supported)
+        const uint32_t blk = (static_cast<uint32_t>(wrow) * static_cast<uint32_t>(K) + (static_cast<uint32_t>(c) << 8) + static_cast<uint32_t>(pp * 64)) >> bs_shift;
         if constexpr (NESTED) {
-            if constexpr (BS64) {
-                st.s[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(rs_q, ((e >> 6) & ~3u) | inval, 0, 0));
-                st.s[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(rs_s, ((e >> 14) << 2) | inval, 0, 0));
-                st.s[2] = st.s[3] = 0;
-            } else {
-                // (a chunk's four 64-k sub-blocks lie in two blocks at blocksize 128 and in one above: sub-blocks 0 and 2 are
-                // fetched, 1 = 0 and 3 = 2; the bytes stay apart until the item is consumed)
-                st.s[0] = static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b8(rs_q, (e >> bs_shift) | inval, 0, 0));
-                st.s[2] = static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b8(rs_q, ((e + 128u) >> bs_shift) | inval, 0, 0));
-                st.s[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(rs_s, (((e >> bs_shift) >> 8) << 2) | inval, 0, 0));
-                st.s[3] = 0;
-            }
-        } else if constexpr (BS64) {
-            st.s = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_s, ((e >> 6) << 2) | inval, 0, 0));
+            st.s = static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b8(rs_q, blk | inval, 0, 0));
+            st.s2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(rs_s, ((blk >> 8) << 2) | inval, 0, 0));
         } else {
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                st.s[b] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(rs_s, (((e + static_cast<uint32_t>(b * 64)) >> bs_shift) << 2) | inval, 0, 0));
+            st.s = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(rs_s, (blk << 2) | inval, 0, 0));
+            st.s2 = 0;
         }
     };
-    Stage st[2];
+    Stage st[NS];
     issue(st[0], 0);
-    __builtin_amdgcn_sched_barrier(0); // keep the queue in stage order
-    issue(st[1], 1);
+    if constexpr (!SINGLE) {
+        __builtin_amdgcn_sched_barrier(0); // keep the queue in stage order
+        issue(st[1], 1);
+    }
     __builtin_amdgcn_sched_barrier(0); // nothing that is not needed for the loads runs before them
     BNB_SM_STAMP(1)
 
-    // ---- decode table, built while the loads fly: entry e (a packed byte) = 32 copies of (T(code[e >> 4]), T(code[e & 15])),
-    // 128 B per entry (as in gemm4_mfma_rt.hip: the eight lanes one ds_write_b128 services together land in eight bank quads)
+    // ---- decode table, built while the loads fly: entry e (a packed byte) = 64 copies of (T(code[e >> 4]), T(code[e & 15])),
+    // 256 B per entry; the two halves of the builders write 8 of its 16 16-byte chunks each, in an order rotated by e (the eight
+    // lanes one ds_write_b128 services together land in eight bank quads)
     {
-        const float cv = sm_code_literal((lane & 15) + opaque_zero(), fp4);
-        const int cvb = __builtin_bit_cast(int, cv);
-        u32x4* const lut = reinterpret_cast<u32x4*>(smem);
         // (the wavefronts of a 16-wavefront workgroup start ~90 cycles apart: the early half builds the table)
-        constexpr int BUILD_THREADS = (WAVES >= 16) ? THREADS / 2 : THREADS;
-#pragma unroll
-        for (int idx = tid; idx < 1024 && tid < BUILD_THREADS; idx += BUILD_THREADS) {
-            const int e = idx >> 2, sub = idx & 3;
-            const float hi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e >> 4) * 4, cvb));
-            const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e & 15) * 4, cvb));
-            const uint32_t pr = SmMma<T>::pack(hi, lo);
+        constexpr int BUILD_THREADS = 512;
+        if (tid < BUILD_THREADS) {
+            const float cv = sm_code_literal((lane & 15) + opaque_zero(), fp4);
+            const int cvb = __builtin_bit_cast(int, cv);
+            const int e = tid & 255;
+            const float hi = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((e >> 4) & 15) * 4, cvb));
+            const float lov = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((e & 15) * 4, cvb));
+            const uint32_t pr = SmMma<T>::pack(hi, lov);
             const u32x4 v = {pr, pr, pr, pr};
-            lut[e * 8 + ((2 * sub) ^ (e & 1))] = v;
-            lut[e * 8 + ((2 * sub + 1) ^ (e & 1))] = v;
+            u32x4* const dst = reinterpret_cast<u32x4*>(smem + e * 256);
+            const int half = tid >> 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                dst[(8 * half + j + e) & 15] = v;
         }
     }
     BNB_SM_STAMP(2)
@@ -296,7 +286,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
         offset = __builtin_bit_cast(float, ob);
     }
 
-    // ---- the first chunk's fragments: its DMAs are older than the two ring stages
+    // ---- the first chunk's fragments: its DMAs are older than the ring stages
     // fragment of step s = 4 h + 2 a + b, lane (m = ln, kg = lg): 8 k from 128 h + 64 a + 8 b + 32 (kg & 1) + 16 (kg >> 1) of row m,
     // i.e. piece 16 h + 8 a + b + 4 (kg & 1) + 2 (kg >> 1) - the k order the weight regrouping below produces. Lanes of rows past
     // ROWS read a staged row again (their MFMA rows are never stored).
@@ -311,18 +301,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
             af[s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(frag_base ^ sbits);
         }
     };
-    sm_wait_vm<2 * LPS>();
+    sm_wait_vm<NS * LPS>();
     BNB_SM_STAMP(3)
     read_frags();
-    if (nchunks > 1) {
-        sm_wait_lgkm0(); // the fragment reads have returned before the staging area is overwritten
-        issue_a(1);
+    if constexpr (!SINGLE) {
+        if (nchunks > 1) {
+            sm_wait_lgkm0(); // the fragment reads have returned before the staging area is overwritten
+            issue_a(1);
+        }
     }
     BNB_SM_STAMP(4)
     __syncthreads();
     BNB_SM_STAMP(5)
 #ifdef BNB_PROFILING
-    sm_wait_vm<LPS>(); // (measurement build: when the first ring stage has landed)
+    sm_wait_vm<(NS - 1) * LPS>(); // (measurement build: when the first ring stage has landed)
     BNB_SM_STAMP(6)
 #endif
 
@@ -330,7 +322,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     // ways under the hardware's lane grouping (gemm4_mfma_rt.hip).
     const int wslot = 16 * pp + (r ^ (2 * pp));
     const int rslot = 16 * lg + (ln ^ (2 * lg));
-    const uint32_t lane_off = static_cast<uint32_t>(lane & 31) * 4u + static_cast<uint32_t>(opaque_zero());
+    const uint32_t lane4 = static_cast<uint32_t>(lane) * 4u;
+    const uint32_t perm_sel = 0x0C0C0400u + static_cast<uint32_t>(opaque_zero()); // {lane offset, weight byte, 0, 0}
 
     f32x4 acc[TT];
 #pragma unroll
@@ -338,15 +331,22 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
         acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](const Stage& s, int t) {
-        // weights: transpose, then regroup so that dwords 0/1 (2/3) of every lane group belong to block 2h (2h + 1)
+        // the lane's scale: lane (r, pp) = 4 r + pp writes dword pp of row r's 16 bytes, lane (ln, lg) reads row ln's four
+        float sc;
+        if constexpr (NESTED)
+            sc = nested_scale(*reinterpret_cast<const __attribute__((address_space(3))) float*>(static_cast<uint32_t>(kSmLut) + s.s * 4u),
+                              __builtin_bit_cast(float, s.s2), offset);
+        else
+            sc = __builtin_bit_cast(float, s.s);
+        *reinterpret_cast<__attribute__((address_space(3))) float*>(stile_lds + lane4) = sc;
+        // weights: transpose (one tile, the two halves in turn: same wavefront, in-order LDS), then regroup so that dwords 0/1
+        // (2/3) of every lane group belong to block 2h (2h + 1)
         u32x4 wt[2];
-        tile0[wslot] = s.w[0];
-        wt[0] = tile0[rslot];
-        tile1[wslot] = s.w[1];
-        wt[1] = tile1[rslot];
-        if (pp == 0)
-            stile[r] = s.s;
-        const u32x4 sraw = stile[ln];
+        tile[wslot] = s.w[0];
+        wt[0] = tile[rslot];
+        tile[wslot] = s.w[1];
+        wt[1] = tile[rslot];
+        const f32x4 scale = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(stile_lds + static_cast<uint32_t>(ln * 16));
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const auto s02 = __builtin_amdgcn_permlane32_swap(wt[h][0], wt[h][2], false, false);
@@ -356,62 +356,66 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
             wt[h][1] = s13[0];
             wt[h][3] = s13[1];
         }
-        float scale[4];
+        // all look-ups first (one v_perm_b32 + one ds_read_b32 per packed byte), then the MFMAs: written look-up by look-up, every
+        // MFMA waited for its own four LDS round trips (2100 cycles per item with four wavefronts per SIMD). With several tiles'
+        // accumulators in 128 registers: half a chunk (16 look-ups, four MFMAs) at a time.
+        constexpr int GROUP = (TT == 1 || WAVES == 8) ? 8 : 4; // MFMA steps decoded together
+        u32x4 bf[GROUP];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            // (copies first: __builtin_bit_cast applied to a vector-element lvalue reads element 0 - hipcc 7.2)
-            const uint32_t sb = sraw[b], s1 = sraw[1];
-            const uint32_t s0 = BS64 ? sraw[0] : sraw[0] * 0x0101u + sraw[2] * 0x01010000u;
-            if constexpr (NESTED)
-                scale[b] = nested_scale(code2[(s0 >> (8 * b)) & 0xFFu], __builtin_bit_cast(float, s1), offset);
-            else
-                scale[b] = __builtin_bit_cast(float, sb);
-        }
+        for (int g0 = 0; g0 < 8; g0 += GROUP) {
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
-            f32x4 part = {0.f, 0.f, 0.f, 0.f};
+            for (int sidx = g0; sidx < g0 + GROUP; ++sidx) {
+                const uint32_t w = wt[sidx >> 2][sidx & 3];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int sidx = 2 * blk + i, h = sidx >> 2, j = sidx & 3;
-                const uint32_t w = wt[h][j];
-                u32x4 bf;
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const uint32_t byte = __builtin_amdgcn_ubfe(w, 8u * qq, 8u);
-                    bf[qq] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((byte << 7) + lane_off);
-                }
-                part = SmMma<T>::run(af[sidx], bf, part);
+                for (int qq = 0; qq < 4; ++qq)
+                    bf[sidx - g0][qq] = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(__builtin_amdgcn_perm(w, lane4, perm_sel + (qq << 8)));
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq)
-                acc[t][qq] = fmaf(scale[blk], part[qq], acc[t][qq]);
+            for (int blk = g0 / 2; blk < (g0 + GROUP) / 2; ++blk) {
+                f32x4 part = {0.f, 0.f, 0.f, 0.f};
+                part = SmMma<T>::run(af[2 * blk], bf[2 * blk - g0], part);
+                part = SmMma<T>::run(af[2 * blk + 1], bf[2 * blk + 1 - g0], part);
+                const float sb = scale[blk];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                    acc[t][qq] = fmaf(sb, part[qq], acc[t][qq]);
+            }
+            if (g0 + GROUP < 8)
+                __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    // ---- items, UNROLL at a time: the ring stage (q & 1) and the tile (q % TT) of an item are compile-time values. Every item
-    // is followed by the request of item q + 2 into the stage just emptied - valid or not (see issue): LPS loads are in flight
-    // behind the stage about to be consumed at every point of the loop.
-    constexpr int UNROLL = (TT % 2) ? 2 * TT : TT;
-    for (int q0 = 0; q0 < nitems; q0 += UNROLL) {
+    if constexpr (SINGLE) {
+        if (nitems > 0)
+            compute(st[0], 0);
+        BNB_SM_STAMP(7)
+    } else {
+        // ---- items, UNROLL at a time: the ring stage (q & 1) and the tile (q % TT) of an item are compile-time values. Every item
+        // is followed by the request of item q + 2 into the stage just emptied - valid or not (see issue): LPS loads are in flight
+        // behind the stage about to be consumed at every point of the loop.
+        constexpr int UNROLL = (TT % 2) ? 2 * TT : TT;
+        for (int q0 = 0; q0 < nitems; q0 += UNROLL) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int q = q0 + u;
-            const int t = u % TT;
-            if (t == 0 && q > 0 && q < nitems) {
-                // first item of the wavefront's next chunk: its fragments were requested when the previous chunk's were read,
-                // behind at most the ring stage about to be consumed and in front of the other one
-                sm_wait_vm<LPS>();
-                read_frags();
-                if (q / TT + 1 < nchunks) {
-                    sm_wait_lgkm0();
-                    issue_a(q / TT + 1);
+            for (int u = 0; u < UNROLL; ++u) {
+                const int q = q0 + u;
+                const int t = u % TT;
+                if (t == 0 && q > 0 && q < nitems) {
+                    // first item of the wavefront's next chunk: its fragments were requested when the previous chunk's were read,
+                    // behind at most the ring stage about to be consumed and in front of the other one
+                    sm_wait_vm<LPS>();
+                    read_frags();
+                    if (q / TT + 1 < nchunks) {
+                        sm_wait_lgkm0();
+                        issue_a(q / TT + 1);
+                    }
                 }
+                if (q < nitems)
+                    compute(st[u & 1], t);
+                if (q == 0)
+                    BNB_SM_STAMP(7)
+                issue(st[u & 1], q + 2);
             }
-            if (q < nitems)
-                compute(st[u & 1], t);
-            if (q == 0)
-                BNB_SM_STAMP(7)
-            issue(st[u & 1], q + 2);
         }
     }
     // The table is addressed with raw LDS offsets: it must sit at LDS address 0 (no static LDS in this kernel).
@@ -482,11 +486,12 @@ SmPlan sm_plan(int M, int N) {
     return pl;
 }
 
-template <typename T, int ROWS, int WAVES, int TT, bool NESTED, bool BS64>
+template <typename T, int ROWS, int WAVES, int TT, bool NESTED, bool SINGLE>
 void sm_launch_one(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, const float* code2, int M, int N, int K, int geom,
                    const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
-    constexpr size_t lds = kSmLut + kSmCode2 + static_cast<size_t>(WAVES) * (ROWS * 512 + kSmScratch);
-    auto kern = gemm4_mfma_sm_kernel<T, ROWS, WAVES, TT, NESTED, BS64>;
+    constexpr size_t region = (ROWS * 512 + kSmScratch) > TT * 1024 ? (ROWS * 512 + kSmScratch) : TT * 1024;
+    constexpr size_t lds = kSmLut + kSmCode2 + static_cast<size_t>(WAVES) * region;
+    auto kern = gemm4_mfma_sm_kernel<T, ROWS, WAVES, TT, NESTED, SINGLE>;
     static LdsLimit lim;
     ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(pl.grid_x, (M + 15) / 16), dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, code2, M, N, K, geom, a);
@@ -494,38 +499,41 @@ void sm_launch_one(const void* A, const uint8_t* B, const float* absmax, const u
 
 template <typename T, int ROWS, int WAVES, int TT>
 void sm_launch_kind(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, const float* code2, int M, int N, int K, int geom,
-                    int blocksize, const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
-    const bool nested = absmax8 != nullptr, bs64 = blocksize == 64;
-    if (nested && bs64)
-        return sm_launch_one<T, ROWS, WAVES, TT, true, true>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+                    const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
+    const bool nested = absmax8 != nullptr;
+    if constexpr (TT == 1) {
+        if (K <= kSmChunk * WAVES) { // one item per wavefront at most: no ring
+            if (nested)
+                return sm_launch_one<T, ROWS, WAVES, 1, true, true>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+            return sm_launch_one<T, ROWS, WAVES, 1, false, true>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+        }
+    }
     if (nested)
         return sm_launch_one<T, ROWS, WAVES, TT, true, false>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
-    if (bs64)
-        return sm_launch_one<T, ROWS, WAVES, TT, false, true>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
     return sm_launch_one<T, ROWS, WAVES, TT, false, false>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
 }
 
-// 16 wavefronts per workgroup, 8 where 128 registers (four tiles' accumulators beside the fragments and the ring) or the LDS
+// 16 wavefronts per workgroup, 8 where 128 registers (three or four tiles' accumulators and item bodies beside the fragments and the ring) or the LDS
 // (8-KiB staging areas at ROWS = 16) do not allow them
 template <typename T, int ROWS>
 void sm_launch_tt(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, const float* code2, int M, int N, int K, int geom,
-                  int blocksize, const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
+                  const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
     constexpr int W = ROWS == 16 ? 8 : 16;
     switch (pl.tt) {
-    case 1: return sm_launch_kind<T, ROWS, W, 1>(A, B, absmax, absmax8, code2, M, N, K, geom, blocksize, pl, a, stream);
-    case 2: return sm_launch_kind<T, ROWS, W, 2>(A, B, absmax, absmax8, code2, M, N, K, geom, blocksize, pl, a, stream);
-    case 3: return sm_launch_kind<T, ROWS, W, 3>(A, B, absmax, absmax8, code2, M, N, K, geom, blocksize, pl, a, stream);
-    default: return sm_launch_kind<T, ROWS, 8, 4>(A, B, absmax, absmax8, code2, M, N, K, geom, blocksize, pl, a, stream);
+    case 1: return sm_launch_kind<T, ROWS, W, 1>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+    case 2: return sm_launch_kind<T, ROWS, W, 2>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+    case 3: return sm_launch_kind<T, ROWS, 8, 3>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+    default: return sm_launch_kind<T, ROWS, 8, 4>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
     }
 }
 
 template <typename T>
 void sm_launch_rows(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, const float* code2, int M, int N, int K, int geom,
-                    int blocksize, const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
+                    const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
     switch (pl.rows) {
-    case 4: return sm_launch_tt<T, 4>(A, B, absmax, absmax8, code2, M, N, K, geom, blocksize, pl, a, stream);
-    case 8: return sm_launch_tt<T, 8>(A, B, absmax, absmax8, code2, M, N, K, geom, blocksize, pl, a, stream);
-    default: return sm_launch_tt<T, 16>(A, B, absmax, absmax8, code2, M, N, K, geom, blocksize, pl, a, stream);
+    case 4: return sm_launch_tt<T, 4>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+    case 8: return sm_launch_tt<T, 8>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+    default: return sm_launch_tt<T, 16>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
     }
 }
 
@@ -538,12 +546,11 @@ bool gemm_4bit_sm_supported(int dtype, const void* A, const uint8_t* B, const fl
            aligned_to(A, 16) && aligned_to(B, 16) && static_cast<long long>(N) * K < (1LL << 32) && static_cast<long long>(M) * K < (1LL << 30);
 }
 
-// fp32 absmax at blocksize 64 travels as one 16-byte load per row and chunk; nested statistics at blocksize 64 as one dword of
-// four codes
+// (statistics travel as one dword / one byte per lane: no alignment beyond the element's)
 bool gemm_4bit_sm_serves(const float* absmax, const uint8_t* absmax8, int blocksize) {
-    if (blocksize != 64)
-        return true;
-    return absmax8 != nullptr ? aligned_to(absmax8, 4) : aligned_to(absmax, 16);
+    (void)absmax8;
+    (void)blocksize;
+    return aligned_to(absmax, 4);
 }
 
 // dtype: 1 = f16, 2 = bf16. Any M (row passes of 16 over grid.y); meant for M <= 16.
@@ -561,9 +568,9 @@ void gemm_4bit_sm(int dtype, const void* A, const uint8_t* B, const float* absma
     a.bias = bias;
     const int geom = pl.R | ((quant_type == kFP4) ? (1 << 16) : 0) | (ilog2(blocksize) << 20);
     if (dtype == 2)
-        sm_launch_rows<bf16>(A, B, absmax, absmax8, absmax_code, M, N, K, geom, blocksize, pl, a, stream);
+        sm_launch_rows<bf16>(A, B, absmax, absmax8, absmax_code, M, N, K, geom, pl, a, stream);
     else
-        sm_launch_rows<f16>(A, B, absmax, absmax8, absmax_code, M, N, K, geom, blocksize, pl, a, stream);
+        sm_launch_rows<f16>(A, B, absmax, absmax8, absmax_code, M, N, K, geom, pl, a, stream);
     BNB_CHECK_LAUNCH();
 }
 
