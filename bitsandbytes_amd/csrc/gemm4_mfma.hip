@@ -764,7 +764,7 @@ bool gemm_4bit_sm_supported(int dtype, const void* A, const uint8_t* B, const fl
 bool gemm_4bit_sm_serves(const float* absmax, const uint8_t* absmax8, int blocksize);
 void gemm_4bit_sm(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
-                  int blocksize, int quant_type, hipStream_t stream);
+                  int blocksize, int quant_type, int variant, hipStream_t stream);
 
 // shared with gemm4_mfma_rt.hip: the slab finalize launch and the library-owned workspace
 void gemm_4bit_finalize(int dtype, const float* ws, const void* bias, void* out, int M, int N, int kslices, hipStream_t stream) {
@@ -905,7 +905,7 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
                             workspace_bytes, 0, 0, 0, stream);
     }
     if (sm_selected(M, N, K, knob0, knob1) && gemm_4bit_sm_supported(dtype, A, B, code16, M, N, K, blocksize) && gemm_4bit_sm_serves(absmax, absmax8, blocksize))
-        return gemm_4bit_sm(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type, stream);
+        return gemm_4bit_sm(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type, knob0, stream);
     if (kq_selected(M, N, K, knob1, &qks) && gemm_4bit_kq_supported(dtype, A, B, code16, M, N, K, blocksize) &&
         gemm_4bit_kq_serves(absmax, absmax8, blocksize, K))
         return gemm_4bit_kq(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type,

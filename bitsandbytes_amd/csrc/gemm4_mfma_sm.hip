@@ -136,7 +136,7 @@ __device__ __forceinline__ int sm_swz(int m) { return (m & 3) | ((m & 4) << 1); 
 // the ring stage of an item must be a compile-time index); NESTED: double-quantised statistics; SINGLE: no wavefront has more
 // than ONE item (K <= 256 WAVES and one tile - the headline shape): no ring, no refill requests.
 // grid = (ceil(N / R), ceil(M / 16)); hot_geom = R | fp4 << 16 | bs_shift << 20.
-template <typename T, int ROWS, int WAVES, int TT, bool NESTED, bool SINGLE>
+template <typename T, int ROWS, int WAVES, int TT, bool NESTED, bool SINGLE, int ORDER = 0>
 __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     // hot arguments as separate scalars: preloaded into SGPRs by the command processor (14 dwords)
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, const float* hot_code2, int hot_M,
@@ -212,7 +212,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
         if (wave == 0)
             sm_dma16(sm_rsrc(hot_code2), static_cast<uint32_t>(kSmLut), static_cast<uint32_t>(lane) * 16u, 0u);
     }
-    issue_a(0);
+    // ORDER (experiment, single-item instances): 0 = activations first (the DMAs are the oldest entries: fragments in registers
+    // before the weights land), 1 = weights first (every wavefront's weight requests go out before anybody's activation requests;
+    // the fragments are read behind the weights' arrival)
+    static_assert(ORDER == 0 || SINGLE, "weights-first: single-item instances");
+    if constexpr (ORDER == 0)
+        issue_a(0);
 
     // ---- weight ring
     struct Stage {
@@ -248,11 +253,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     };
     Stage st[NS];
     issue(st[0], 0);
-    if constexpr (!SINGLE) {
-        __builtin_amdgcn_sched_barrier(0); // keep the queue in stage order
-        issue(st[1], 1);
-    }
     __builtin_amdgcn_sched_barrier(0); // nothing that is not needed for the loads runs before them
+    if constexpr (ORDER == 1)
+        issue_a(0);
     BNB_SM_STAMP(1)
 
     // ---- decode table, built while the loads fly: entry e (a packed byte) = 64 copies of (T(code[e >> 4]), T(code[e & 15])),
@@ -301,7 +304,21 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
             af[s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(frag_base ^ sbits);
         }
     };
-    sm_wait_vm<NS * LPS>();
+    // The table barrier waits for nobody's memory: a wavefront whose activation DMA sits behind other wavefronts' weight requests
+    // in the CU's in-order address pipeline (8192^2: the last wavefront's requests went out 7000 cycles into the kernel, and the
+    // barrier - then behind the wait for the fragments - held every wavefront until then) delays only itself. The ring's second
+    // stage is requested behind the barrier: 32 KiB of weight requests per CU up front fill the memory pipeline, 64 KiB only
+    // congest the address pipeline in front of the late wavefronts' first requests.
+    __syncthreads();
+    BNB_SM_STAMP(5)
+    if constexpr (!SINGLE) {
+        issue(st[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (ORDER == 1)
+        sm_wait_vm<0>();
+    else
+        sm_wait_vm<NS * LPS>();
     BNB_SM_STAMP(3)
     read_frags();
     if constexpr (!SINGLE) {
@@ -311,10 +328,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
         }
     }
     BNB_SM_STAMP(4)
-    __syncthreads();
-    BNB_SM_STAMP(5)
 #ifdef BNB_PROFILING
-    sm_wait_vm<(NS - 1) * LPS>(); // (measurement build: when the first ring stage has landed)
+    sm_wait_vm<(NS - 1) * LPS + (SINGLE ? 0 : NA)>(); // (measurement build: when the first ring stage has landed; exact with >= 2 chunks)
     BNB_SM_STAMP(6)
 #endif
 
@@ -469,6 +484,7 @@ int sm_cu_count() { return device_cu_count_or_default(); }
 
 struct SmPlan {
     int R, tt, grid_x, rows;
+    int variant = 0; // experiment bits (bnb_mi355x_set_tuning knob0)
 };
 
 // rows per workgroup: one workgroup per CU when 64 rows are enough, else whole rounds of workgroups
@@ -486,12 +502,12 @@ SmPlan sm_plan(int M, int N) {
     return pl;
 }
 
-template <typename T, int ROWS, int WAVES, int TT, bool NESTED, bool SINGLE>
+template <typename T, int ROWS, int WAVES, int TT, bool NESTED, bool SINGLE, int ORDER = 0>
 void sm_launch_one(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, const float* code2, int M, int N, int K, int geom,
                    const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
     constexpr size_t region = (ROWS * 512 + kSmScratch) > TT * 1024 ? (ROWS * 512 + kSmScratch) : TT * 1024;
     constexpr size_t lds = kSmLut + kSmCode2 + static_cast<size_t>(WAVES) * region;
-    auto kern = gemm4_mfma_sm_kernel<T, ROWS, WAVES, TT, NESTED, SINGLE>;
+    auto kern = gemm4_mfma_sm_kernel<T, ROWS, WAVES, TT, NESTED, SINGLE, ORDER>;
     static LdsLimit lim;
     ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(pl.grid_x, (M + 15) / 16), dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, code2, M, N, K, geom, a);
@@ -505,6 +521,8 @@ void sm_launch_kind(const void* A, const uint8_t* B, const float* absmax, const 
         if (K <= kSmChunk * WAVES) { // one item per wavefront at most: no ring
             if (nested)
                 return sm_launch_one<T, ROWS, WAVES, 1, true, true>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+            if (pl.variant & 4)
+                return sm_launch_one<T, ROWS, WAVES, 1, false, true, 1>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
             return sm_launch_one<T, ROWS, WAVES, 1, false, true>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
         }
     }
@@ -556,9 +574,10 @@ bool gemm_4bit_sm_serves(const float* absmax, const uint8_t* absmax8, int blocks
 // dtype: 1 = f16, 2 = bf16. Any M (row passes of 16 over grid.y); meant for M <= 16.
 void gemm_4bit_sm(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
-                  int blocksize, int quant_type, hipStream_t stream) {
+                  int blocksize, int quant_type, int variant, hipStream_t stream) {
     g_last_gemm_kernel = kKernelSm;
-    const SmPlan pl = sm_plan(M, N);
+    SmPlan pl = sm_plan(M, N);
+    pl.variant = variant;
     SmArgs a;
 #ifdef BNB_PROFILING
     a.dbg = g_dbg_buf;

@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--m", default="2,3,4,6,8,12,16")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--variants", default="", help="comma-separated knob0 values: A/B of experiment variants of the sm kernel instead of the routing table")
+    ap.add_argument("--skip-odd", action="store_true")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     print(torch.cuda.get_device_name(0), bnb.lib.bnb_mi355x_version().decode())
@@ -73,7 +75,7 @@ def main():
     ms = tuple(int(v) for v in args.m.split(","))
     print("# forced sm kernel on odd shapes: relative error against fp32 dequantize + fp64 matmul (bias included)")
     bad = 0
-    for (N, K, bs, qt, dq, dtc) in [(4100, 512, 64, "nf4", False, torch.bfloat16), (5000, 1024, 128, "fp4", True, torch.float16), (12345, 768, 64, "nf4", True, torch.bfloat16),
+    for (N, K, bs, qt, dq, dtc) in [] if args.skip_odd else [(4100, 512, 64, "nf4", False, torch.bfloat16), (5000, 1024, 128, "fp4", True, torch.float16), (12345, 768, 64, "nf4", True, torch.bfloat16),
                                     (16, 256, 64, "nf4", False, torch.bfloat16), (4096, 4352, 256, "nf4", False, torch.float16), (20000, 256, 64, "fp4", False, torch.bfloat16),
                                     (70000, 512, 64, "nf4", False, torch.bfloat16), (4097, 8192, 512, "nf4", True, torch.bfloat16)]:
         W = (torch.randn(N, K, device="cuda") / K**0.5).to(dtc)
@@ -99,6 +101,8 @@ def main():
     print(f"   {bad} failures")
     # configurations: (label, kernel argument, knob0, knob1)
     configs = [("before", 0, 2, 0), ("sm", 2, 0, 5000), ("routed", 0, 0, 0)]
+    if args.variants:
+        configs = [("before", 0, 2, 0)] + [(f"sm v{v}", 2, int(v), 5000) for v in args.variants.split(",")]
     print(f"{'N x K':>14s} {'bs':>4s} {'qt':>3s} {'dq':>2s} {'M':>3s} " + " ".join(f"{c[0]:>12s}" for c in configs) + "   err before / sm    GB/s sm (%HBM)")
     for (N, K, bs, qt, dq) in cases:
         layers = make_layers(N, K, bs, qt, dq, dtype=dt)

@@ -52,12 +52,12 @@ if (t[:, :, 0] > 0).sum() == 0:
     print("no stamps: not a profiling build?")
     sys.exit(0)
 t0 = t[:, :, 0].min(dim=1, keepdim=True).values
-names = ["start", "loads issued", "table written", "A landed", "frags read, next A requested", "past table barrier", "stage 0 landed",
+names = ["start", "loads issued", "table written", "A landed (behind the barrier)", "frags read, next A requested", "past table barrier", "stage 0 landed",
          "item 0 done", "items done", "partials parked, past barrier", "end"]
 print(f"# sm kernel M={a.m}, N={N}, K={K}: {waves} wavefronts per workgroup; s_memtime ticks relative to the first wavefront start of the SAME workgroup")
 print(f"{'stamp':30s} {'min':>7s} {'median':>7s} {'p90':>7s} {'max':>7s}   median delta to previous stamp")
 prev = None
-for i in range(11):
+for i in (0, 1, 2, 5, 3, 4, 6, 7, 8, 9, 10):
     ok = t[:, :, i] > 0
     if ok.sum() == 0:
         continue
