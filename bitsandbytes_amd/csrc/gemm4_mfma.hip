@@ -812,16 +812,23 @@ bool rt_selected(int M, int N, int K, int knob1, int* force_ks, int* force_waves
         return weights <= (17L << 19);
     return false;
 }
-// Which problems go to the streaming MFMA kernel (tuning knob cfg 50 forces it, cfg 51 keeps it out of the built-in route).
+// Which problems go to the streaming MFMA kernel (tuning knob cfg 50 forces it; knob0 bit 1 keeps it out of the built-in route).
+// Measured on MI355X (profiles/r6_sm_v3_ab_full.txt), us per launch, streaming MFMA kernel vs what ran before (streaming kernel at
+// 2 rows, register-transposed kernel above), M = 2 / 4 / 8 / 16: 4096^2 4.44 / 4.56 / 5.15 / 6.18 vs 4.95 / 5.72 / 6.05 / 6.62; 8192^2
+// 10.8 / 10.9 / 12.0 / 14.0 vs 11.2 / 14.1 / 15.0 / 16.0; 11008 x 4096 8.2 / 8.1 / 8.7 / 9.7 vs 8.6 / 11.1 / 11.9 / 13.1; 14336 x 4096
+// 9.7 / 10.0 / 10.6 / 11.9 vs 10.3 / 13.6 / 14.6 / 15.6; 5120^2 (blocksize 128) 6.5 / 6.7 / 7.4 / 8.9 vs 6.8 / 8.7 / 9.3 / 10.9; nested
+// statistics level with plain ones. Behind only on long rows with more than 8 batch rows (4096 x 11008, M = 9 / 16: 11.9 / 12.2 vs
+// 10.7 / 11.9: eight wavefronts there, one chunk switch per item) and at one row (the streaming kernel: 4.20 vs 4.43).
 bool sm_selected(int M, int N, int K, int knob0, int knob1) {
     const int cfg = knob1 / 100;
     if (cfg == 50)
         return true;
     if (cfg != 0 || (knob0 & 2)) // (knob0 bit 1: the routing as it was before this kernel - A/B runs)
         return false;
-    (void)K;
     // one persistent workgroup per CU needs >= ~3/4 of the chip's CUs in 16-row tiles
-    return M >= 2 && M <= 16 && N >= 12 * device_cu_count_or_default();
+    if (M < 2 || M > 16 || N < 12 * device_cu_count_or_default())
+        return false;
+    return !(M > 8 && K > 2 * N);
 }
 // Which problems go to the K-quarter kernel (tuning knob cfg 40 forces it; knob % 100 = K slices).
 bool kq_selected(int M, int N, int K, int knob1, int* force_ks) {
@@ -855,6 +862,13 @@ bool kq_selected(int M, int N, int K, int knob1, int* force_ks) {
 }
 } // namespace
 
+// Whether the built-in route hands this problem to the streaming MFMA kernel (c_api.hip: such calls take the MFMA route from two
+// rows on; pointer alignment is gemm_4bit_mfma_supported's business)
+bool gemm_4bit_sm_routes(int dtype, int M, int N, int K, int blocksize) {
+    return dtype != 0 && blocksize >= 64 && (K % kKC) == 0 &&
+           sm_selected(M, N, K, g_mfma_knob0.load(std::memory_order_relaxed), g_mfma_knob1.load(std::memory_order_relaxed));
+}
+
 // Preconditions of the MFMA kernels: 16-bit activations, K a multiple of 256, 16-byte aligned A, 8-byte aligned B, and a blocksize
 // >= 64 (a 64-k MFMA pair stays inside one quantization block) - or, round 5, blocksize 32 with fp32 absmax (`plain_absmax`: the
 // caller knows, the shape-only queries assume it), which the register-transposed kernel's BS32 instances serve at any M.
@@ -871,6 +885,10 @@ size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K, int blocksize) {
         return gemm_4bit_rt_workspace_bytes(M, N, K, 0);
     int fks, fw;
     const int knob1 = g_mfma_knob1.load(std::memory_order_relaxed);
+    // (the streaming MFMA kernel needs none; a call it turns down at launch time - a caller-supplied code table, misaligned
+    // statistics - runs the kernels below with the library's own buffer or fewer K slices)
+    if (blocksize >= 64 && sm_selected(M, N, K, g_mfma_knob0.load(std::memory_order_relaxed), knob1))
+        return 0;
     int qks;
     size_t kq_bytes = 0;
     if (kq_selected(M, N, K, knob1, &qks)) {

@@ -72,11 +72,13 @@ void cdequantize_blockwise_bf16(float* code, unsigned char* A, float* absmax, vo
  *   scale of block b = absmax[b]                                            (absmax_8bit == NULL)
  *                    = absmax_code[absmax_8bit[b]] * absmax[b >> 8] + *absmax_offset   (nested)
  * K % blocksize == 0 is guaranteed by the caller (reference backends/cuda/ops.py:956-962);
- * absmax_offset is fp32; bias has A's dtype. M is any positive value: M <= 2 (and M = 3, 4 on matrices below 12 M weights)
- * runs the streaming kernel (gemv4_stream.hip: persistent workgroups, weights through a register ring, any M in row
- * passes of up to four), larger M the MFMA kernels (gemm4_mfma_rt.hip / gemm4_mfma.hip: bf16 / fp16, K % 256 == 0,
- * blocksize >= 64, aligned pointers; any M in row tiles); shapes the MFMA kernels do not take (fp32, odd K, small blocks) run
- * the streaming kernel at any M. */
+ * absmax_offset is fp32; bias has A's dtype. M is any positive value: M = 1 (and M <= 4 on matrices with fewer than 12 CUs
+ * x 16 rows, M = 3, 4 below 12 M weights) runs the streaming kernel (gemv4_stream.hip: persistent workgroups, weights through a
+ * register ring, any M in row passes of up to four); 2 ... 16 rows on matrices of >= 3072 rows the streaming MFMA kernel
+ * (gemm4_mfma_sm.hip: one persistent workgroup per CU, one decode for all rows, activations once per CU); larger M and smaller
+ * matrices the other MFMA kernels (gemm4_mfma_rt.hip / gemm4_mfma.hip / gemm4_mfma_kq.hip: bf16 / fp16, K % 256 == 0, blocksize
+ * >= 64, aligned pointers; any M in row tiles); shapes the MFMA kernels do not take (fp32, odd K, small blocks) run the
+ * streaming kernel at any M. */
 void cgemm_4bit_bf16(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K, int blocksize, int quant_type, bnb_stream_t stream);
 void cgemm_4bit_fp16(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K, int blocksize, int quant_type, bnb_stream_t stream);
 void cgemm_4bit_fp32(const float* A, const uint8_t* B, const float* absmax, const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, float* out, const float* bias, int M, int N, int K, int blocksize, int quant_type, bnb_stream_t stream);
@@ -139,7 +141,8 @@ size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N,
 int bnb_mi355x_gemm_4bit_route(int kernel, int dtype, int M, int N, int K, int blocksize);
 /* Which kernel family the calling thread's LAST gemm_4bit / gemv_4bit call (any entry point) launched: 0 none yet, 1 streaming
  * kernel (gemv4_stream_kernel), 2 generic scalar kernel (odd shapes), 3 register-transposed MFMA kernel (gemm4_mfma_rt_kernel),
- * 4 producer/consumer MFMA kernel (gemm4_mfma_pc_kernel), 6 K-quarter MFMA kernel (gemm4_mfma_kq_kernel). Debug / test query:
+ * 4 producer/consumer MFMA kernel (gemm4_mfma_pc_kernel), 6 K-quarter MFMA kernel (gemm4_mfma_kq_kernel),
+ * 7 streaming MFMA kernel (gemm4_mfma_sm_kernel: 2 ... 16 rows, one persistent workgroup per CU). Debug / test query:
  * a test that forces a kernel with bnb_mi355x_set_tuning asserts here that it ran (a geometry the forced kernel does not
  * serve falls back to another family by design). */
 int bnb_mi355x_last_gemm_kernel(void);
@@ -224,8 +227,9 @@ void bnb_mi355x_peer_chain_read(void* const* bufs, void* epoch_word, int world, 
  * (large NF4 inputs); 6 = one unit in flight per lane in the 8-bit dequantize kernel (its first form); 10 + v = tile / lane-mapping
  * variants of the 4-bit dequantize kernel (csrc/dequantize4.hip); reserved1: N slices of the fused backward (> 0; the
  * workspace-size query follows it). MFMA kernels: knob0 bit 0 = round 2's form of the register-transposed kernel (measurement build only; ignored by the product library),
+ * knob0 bit 1 = the built-in route without the streaming MFMA kernel (round 5's routing: A/B runs), bit 2 = its weights-first experiment,
  * knob1 = 100 * cfg + K-slice count (cfg 11-14 producer/consumer geometries, 20/21/22
- * register-transposed kernel with built-in / 8 / 16 wavefronts, 40 K-quarter kernel). Every setting
+ * register-transposed kernel with built-in / 8 / 16 wavefronts, 40 K-quarter kernel, 50 streaming MFMA kernel). Every setting
  * computes correct results - the knobs only choose a launch geometry. THREAD-LOCAL: a setting applies to the calls the
  * SAME host thread makes afterwards and to nothing else in the process. */
 void bnb_mi355x_set_tuning(int reserved0, int reserved1, int mfma_knob0, int mfma_knob1);

@@ -52,11 +52,20 @@ def main():
                 for M in (1, 2):
                     x = (torch.randn(M, K, device=DEV) * (1 + it % 3)).to(dt)
                     y = layer(x)
+                    fam_full = bnb.lib.bnb_mi355x_last_gemm_kernel()
                     for r, sh in enumerate(shards):
                         ns = N // world
                         n += 1
-                        bad += 0 if torch.equal(sh.local_forward(x), y[:, r * ns:(r + 1) * ns]) else 1
-    report("row shards (world 2/4/8) == rows of the unsharded layer, M = 1, 2", n, bad)
+                        ys = sh.local_forward(x)
+                        if bnb.lib.bnb_mi355x_last_gemm_kernel() == fam_full == 1:
+                            bad += 0 if torch.equal(ys, y[:, r * ns:(r + 1) * ns]) else 1
+                        else:
+                            # (round 6: two rows on a layer of >= 3072 rows run the streaming MFMA kernel, narrower shards the streaming
+                            # kernel - another summation order and 16-bit code values: the matmul tolerance, not the bits)
+                            assert M == 2, (M, fam_full)
+                            ref = y[:, r * ns:(r + 1) * ns].float()
+                            bad += 0 if float((ys.float() - ref).norm() / ref.norm()) < 1e-2 else 1
+    report("row shards (world 2/4/8) == rows of the unsharded layer, M = 1 (bits), 2 (bits where both ran the streaming kernel)", n, bad)
 
     # 2. grouped launch
     n = bad = 0

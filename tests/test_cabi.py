@@ -296,7 +296,7 @@ def test_launch_plan_workspace_query_is_pure_host_logic():
                 ks = w // slab if w % slab == 0 else w // slab_kq
                 assert ks == 0 or 2 <= ks <= max(2, K // 512), (M, N, K, ks)
                 if kernel == 0 and M <= 2:
-                    assert w == 0, "M <= 2 runs the dot kernel: no workspace"
+                    assert w == 0, "M <= 2 runs the dot kernel or the streaming MFMA kernel: no workspace"
         assert q(1, BF16, 64, N, K, 64) == 0, "explicit dot kernel never needs a workspace"
         assert q(0, 0, 64, N, K, 64) == 0, "fp32 activations never take the MFMA path"
         # blocksize 32 (round 5): on the MFMA route through the register-transposed kernel's BS32 instances from 5 rows on (3 on

@@ -1178,7 +1178,7 @@ def test_backward_above_the_fused_range_with_nested_statistics():
 
 
 # kernel families as bnb_mi355x_last_gemm_kernel() reports them (include/bnb_mi355x.h)
-K_STREAM, K_GENERIC, K_RT, K_PC, K_KQ = 1, 2, 3, 4, 6
+K_STREAM, K_GENERIC, K_RT, K_PC, K_KQ, K_SM = 1, 2, 3, 4, 6, 7
 
 
 class _forced:
@@ -1394,7 +1394,7 @@ def test_mfma_kernels_exact_on_representable_inputs():
     y_ref = _oracle_y(x, q, st, None)
     import bitsandbytes_amd as bnb
     # register-transposed kernel (one / two K slices), producer/consumer kernel, K-quarter kernel (one / two K slices)
-    for knob, fam in ((2000, K_RT), (2002, K_RT), (1100, K_PC), (4000, K_KQ), (4002, K_KQ)):
+    for knob, fam in ((2000, K_RT), (2002, K_RT), (1100, K_PC), (4000, K_KQ), (4002, K_KQ), (5000, K_SM)):
         with _forced(knob, fam):
             y = _run_kernel(2, x.to(DEV), q, st, None)
         assert torch.equal(y.float().cpu(), y_ref.to(torch.bfloat16).float()), knob
@@ -1474,6 +1474,98 @@ def test_mfma_blocksize_32_exact_on_representable_inputs():
         assert bnb.lib.bnb_mi355x_last_gemm_kernel() == K_RT
         y_ref = _oracle_y(x, q, st, None)
         assert torch.equal(y.float().cpu(), y_ref.to(torch.bfloat16).float()), M
+
+
+# ------------------------------------------------------------------------------------------ streaming MFMA kernel (round 6)
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 7, 8, 9, 13, 16, 17, 33])
+@pytest.mark.parametrize("N,K", [(16, 256), (200, 512), (4100, 512), (5000, 1024), (12345, 768), (20000, 256), (70000, 512), (4097, 8192),
+                                 (600, 11008 - 11008 % 256)])
+def test_mfma_sm_kernel_geometries(M, N, K):
+    """The streaming MFMA kernel (csrc/gemm4_mfma_sm.hip), forced, in every launch geometry: 4 / 8 / 16 staged activation rows
+    (16 / 8 wavefronts), row passes above 16 rows, one to four tiles per workgroup and several rounds of workgroups (N = 70000),
+    single-item and ring instances, wavefronts with no / one / several chunks (K = 256 ... 10752), ragged N and tile rows past the
+    workgroup's share - against the oracle, for fp32 and nested absmax, NF4 and FP4, blocksize 64 ... 512, bf16 and fp16, with and
+    without bias; bit-reproducible run to run; the family that ran is asserted."""
+    F = _F()
+    if N * K > (8 << 20) and M not in (2, 8, 16):
+        pytest.skip("large shapes: three batch sizes")
+    for dtype, qt, bs, dq in ((torch.bfloat16, "nf4", 64, False), (torch.bfloat16, "nf4", 64, True), (torch.float16, "fp4", 128, True),
+                              (torch.float16, "nf4", 256, False), (torch.bfloat16, "fp4", 512, True)):
+        if (N * K) % bs or K % bs:
+            continue
+        g = torch.Generator().manual_seed(M + N + K)
+        W = (torch.randn(N, K, generator=g) / K**0.5).to(dtype)
+        x = torch.randn(M, K, generator=g).to(dtype)
+        bias = torch.randn(N, generator=g).to(dtype)
+        q, st = F.quantize_4bit(W.to(DEV), blocksize=bs, quant_type=qt, compress_statistics=dq)
+        y_ref = _oracle_y(x, q, st, bias)
+        with _forced(5000, K_SM):
+            y1 = _run_kernel(2, x.to(DEV), q, st, bias.to(DEV))
+            y2 = _run_kernel(2, x.to(DEV), q, st, bias.to(DEV))
+            y3 = _run_kernel(2, x.to(DEV), q, st, None)
+        assert rel_err(y1.cpu(), y_ref) < REL_TOL, (dtype, qt, bs, dq)
+        assert torch.equal(y1, y2)
+        assert rel_err(y3.cpu(), _oracle_y(x, q, st, None)) < REL_TOL
+        # every row on its own: a row of the batch mixed with another row's activations cannot hide in the batch's norm
+        worst = ((y1.double().cpu() - y_ref.double()).norm(dim=1) / y_ref.double().norm(dim=1)).max()
+        assert worst < 2 * REL_TOL, (dtype, qt, bs, dq, float(worst))
+
+
+def test_mfma_sm_kernel_exact_on_representable_inputs():
+    """Small-integer activations, exactly representable FP4 codes and a different power-of-two scale per 64-k block: every product
+    and partial sum is exact in fp32, so the streaming MFMA kernel equals the oracle bit for bit - for every staged-row count, for
+    single-item and ring instances, several tiles per workgroup and several chunks per wavefront. A fragment piece read from the wrong
+    slot of the swizzled staging area, a k paired with the wrong weight or a block scaled with its neighbour's absmax cannot hide."""
+    F = _F()
+    fp4 = F.get_4bit_type("fp4", device="cpu")
+    allowed = torch.tensor([0, 3, 5, 7, 11, 13, 15])
+    for (N, K) in ((80, 1024), (4096 + 48, 4096), (8192, 8192), (2048, 11008 - 11008 % 256)):
+        g = torch.Generator().manual_seed(N + K)
+        idx = allowed[torch.randint(0, len(allowed), (N, K), generator=g)]
+        idx[:, ::64] = 3  # code 1.0 at the head of every block: its absmax is the block's scale
+        scale = 2.0 ** torch.randint(-2, 3, (N, K // 64), generator=g)
+        W = (fp4[idx] * scale.repeat_interleave(64, dim=1)).to(torch.bfloat16)
+        q, st = F.quantize_4bit(W.to(DEV), blocksize=64, quant_type="fp4")
+        assert torch.equal(st.absmax.cpu().view(N, K // 64), scale.float())
+        Wd = F.dequantize_4bit(q, st).double().cpu()
+        for M in (2, 3, 4, 7, 8, 11, 16, 20):
+            # (distinct rows: row m carries a pattern no other row has)
+            x = torch.randint(-4, 5, (M, K), generator=g).to(torch.bfloat16)
+            with _forced(5000, K_SM):
+                y = _run_kernel(2, x.to(DEV), q, st, None)
+            y_ref = (x.double() @ Wd.t()).to(torch.bfloat16)
+            assert torch.equal(y.float().cpu(), y_ref.float()), (N, K, M)
+
+
+@pytest.mark.parametrize("N,K,dq", [(4096, 4096, False), (4096, 4096, True), (8192, 8192, False), (11008, 4096, True), (14336, 4096, False),
+                                    (4096, 11008 - 11008 % 256, True), (5120, 5120, False)])
+def test_mfma_sm_kernel_is_routed_and_deterministic(N, K, dq):
+    """The BUILT-IN route takes the streaming MFMA kernel for 2 ... 16 rows on matrices of >= 3072 rows (one row: the streaming
+    kernel; long rows with more than 8 batch rows: the register-transposed kernel). 30 launches each with other work in between, all
+    bit-identical; the first within tolerance of fp32 dequantize + matmul on the device."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    g = torch.Generator(device=DEV).manual_seed(N + K)
+    W = (torch.randn(N, K, device=DEV, generator=g) / K**0.5).bfloat16()
+    q, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4", compress_statistics=dq)
+    Wd = F.dequantize_4bit(q, st).float()
+    junk = torch.randn(1 << 20, device=DEV)
+    for M in (1, 2, 4, 8, 9, 16, 17):
+        x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+        y0 = bnb.matmul_4bit(x, q, st).clone()
+        fam = bnb.lib.bnb_mi355x_last_gemm_kernel()
+        want = K_STREAM if M == 1 else K_SM if M <= 8 or (M <= 16 and K <= 2 * N) else None
+        if want is not None:
+            assert fam == want, (M, fam)
+        else:
+            assert fam != K_SM
+        assert rel_err(y0.float().cpu(), (x.float() @ Wd.t()).cpu()) < REL_TOL
+        for i in range(30):
+            if i % 3 == 0:
+                junk = junk * 1.0001
+            assert torch.equal(bnb.matmul_4bit(x, q, st), y0), (M, i)
+
 
 
 # ------------------------------------------------------------------------------------------ callers of dequantize_4bit
@@ -2023,8 +2115,9 @@ def test_config5_fp4_nested_bs128_full():
 def test_config4_eight_row_shards_equal_the_full_layer(N, K, M):
     """BASELINE.json configs[3] as the sharded path computes it: the 8 row shards parallel.shard_linear4bit hands to the 8
     ranks (1376 x 4096, 512 x 11008; nested absmax, so the second-level slicing is exercised), each run on this GPU,
-    concatenated = the un-sharded layer. Bit for bit at M <= 2 (the streaming kernel's result does not depend on the launch
-    geometry), within the matmul tolerance of the oracle above (the MFMA geometry follows N)."""
+    concatenated = the un-sharded layer. Bit for bit at M = 1 (the streaming kernel's result does not depend on the launch
+    geometry; round 6: from two rows on the full layer takes the streaming MFMA kernel, its narrow shards do not), within the
+    matmul tolerance of the oracle above (the MFMA geometry follows N)."""
     import bitsandbytes_amd.nn as bnn
     from bitsandbytes_amd.parallel import shard_linear4bit
 
@@ -2035,7 +2128,7 @@ def test_config4_eight_row_shards_equal_the_full_layer(N, K, M):
     parts = [shard_linear4bit(layer, rank=r, world_size=8, gather_output=False)(x) for r in range(8)]
     y_cat = torch.cat(parts, dim=-1)
     assert y_cat.shape == y_full.shape
-    if M <= 2:
+    if M == 1:
         assert torch.equal(y_cat, y_full)
     else:
         assert rel_err(y_cat.cpu(), y_full.cpu()) < 3e-3
@@ -2129,7 +2222,7 @@ def test_sharded_linear4bit_over_rccl_two_ranks():
                 x = torch.randn(M, K, generator=torch.Generator().manual_seed(M)).to(dev, torch.bfloat16)
                 y, y0 = sh(x), layer(x)
                 assert y.shape == y0.shape
-                if M <= 2:
+                if M == 1:
                     assert torch.equal(y, y0), (N, K, M)
                 else:
                     assert ((y.float() - y0.float()).abs().max() / y0.float().abs().max()).item() < 1e-2
