@@ -26,10 +26,12 @@ layer) when it reproduces the separate form bit for bit at start-up on every ran
 kernels alone are timed beside it ("sharded_chain"). N > 1 was never run on real links by the builder.
 
 Extra objects on the JSON line:
-  "roofline"      dominant kernel; achieved = algorithmic bytes / kernel_us, frac = achieved / 8 TB/s. THREE clocks are
-                  taken and all three stay on the line:
-                    frac_wall    (= frac, the figure of record since round 5) kernel_us = HIP events around the timed region /
-                                 launches: the product binary, the driver's own clock (kernel + launch boundary);
+  "roofline"      dominant kernel; achieved = algorithmic bytes / kernel_us, frac = achieved / 8 TB/s. FOUR clocks are
+                  taken and all stay on the line:
+                    frac         (the figure of record) kernel_us = HIP events - recorded on the stream the kernels are launched
+                                 on - around the timed region / launches: the product binary, kernel + launch boundary;
+                    frac_wall    the same region on the host's wall clock (perf_counter around synchronize: what `value` and
+                                 ms_per_step use and the driver can check from outside);
                     frac_span    the kernel's own span, first wavefront in to last wavefront out, from in-kernel
                                  s_memrealtime stamps over hipGraph replays of the same step (child process, MEASUREMENT
                                  build of the library - a different binary, hence not the figure of record): the only
@@ -37,11 +39,14 @@ Extra objects on the JSON line:
                     frac_rocprof average duration from `rocprofv3 --kernel-trace --stats` over the same workload (the
                                  profiler serialises dispatches: 128 x this figure exceeds the step - kept as the
                                  cross-check the rules name; the CSV is copied to --profile-out when given);
-                  "method" says which clock frac uses; the HIP-event launch-to-launch time of a separate 10-replay region is
+                  "method" says which clock each key uses; the HIP-event launch-to-launch time of a separate 10-replay region is
                   kept as a secondary key; "traffic" from two rocprofv3 PMC passes.
   "cpu_baseline"  (N = 1, rank 0) the reference's own AVX512-BF16 fused CPU gemv from oracle/_ref when the host
                   supports it, else the scalar port from oracle/.
-  "headline_sweep_N4096_K4096"  M = 1..64 (the other half of BASELINE.json's metric; --no-sweep skips it).
+  "headline_sweep_N4096_K4096"  M = 1..64 (the other half of BASELINE.json's metric; --no-sweep skips it): every entry carries the
+                  kernel family that ran, GB/s, TFLOP/s and both roofline fractions.
+  "config3"       BASELINE.json configs[2] (gemm_4bit M = 64, N = K = 8192) through the public op: kernel, us, frac_hbm, frac_mfma and the
+                  HBM traffic per call from the PMC counters (--no-config3 skips it).
   "grouped"       the same 128 layers launched as 32 groups of 4 through matmul_4bit_grouped (one launch per group):
                   what the boundary costs, reported beside the headline, never instead of it.
 """
@@ -63,7 +68,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 
 LAYERS = 128
 KERNEL_SUBSTR = "gemv4_stream_kernel"  # the headline (M = 1) kernel; other --m: dominant_kernel() asks the library which family ran
 # bnb_mi355x_last_gemm_kernel() (csrc/bnb_common.h, GemmKernelId) -> the kernel's name as the profiler prints it
-KERNEL_FAMILIES = {1: "gemv4_stream_kernel", 2: "gemv4_generic_kernel", 3: "gemm4_mfma_rt_kernel", 4: "gemm4_mfma_pc_kernel", 6: "gemm4_mfma_kq_kernel"}
+KERNEL_FAMILIES = {1: "gemv4_stream_kernel", 2: "gemv4_generic_kernel", 3: "gemm4_mfma_rt_kernel", 4: "gemm4_mfma_pc_kernel", 6: "gemm4_mfma_kq_kernel",
+                   7: "gemm4_mfma_sm_kernel"}
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak (MI355X_MICROARCH.md)
 
 
 def dominant_kernel(M, N, K, bs, qt):
@@ -78,7 +85,7 @@ def dominant_kernel(M, N, K, bs, qt):
     torch.cuda.synchronize()
     fam = KERNEL_FAMILIES.get(int(bnb.lib.bnb_mi355x_last_gemm_kernel()), KERNEL_SUBSTR)
     rows = f"{M} row" + ("" if M == 1 else "s")
-    return fam, f"{fam}<bf16, {rows}>" + (" (+ its split-K finalize launch where the plan has K slices)" if fam.startswith("gemm4_mfma") and fam != "gemm4_mfma_rt_kernel" else "")
+    return fam, f"{fam}<bf16, {rows}>" + (" (+ its split-K finalize launch where the plan has K slices)" if fam in ("gemm4_mfma_pc_kernel", "gemm4_mfma_kq_kernel") else "")
 
 
 def algorithmic_bytes(M, N, K, bs, elt=2):
@@ -319,13 +326,15 @@ def kernel_span(extra_args, span_out=None, timeout_s=240):
     return None, {"error": "no span line", "stderr": r.stderr[-400:]}
 
 
-def pmc_traffic(extra_args, timeout_s=180):
+def pmc_traffic(extra_args, timeout_s=180, substrings=None, calls_per_sweep=None):
     """HBM bytes per launch of the dominant kernel from rocprofv3 PMC counters, collected the way
     /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE
     passes (they do not fit one TCC pass), no tracing domains besides the kernel trace; both counters are
     reported in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes,
     so it is doubled. WRITE_SIZE is uncalibrated on gfx950 (guide) and is only ~0.1 % of this kernel's
-    traffic. Returns (bytes_per_launch or None, detail dict)."""
+    traffic. Returns (bytes_per_launch or None, detail dict). With `substrings` (several kernels per call of the op: a split-K
+    kernel and its finalize launch) the counters of every matching dispatch of the second sweep are summed and divided by
+    `calls_per_sweep`: bytes per CALL of the op."""
     import csv
     import glob
 
@@ -342,16 +351,24 @@ def pmc_traffic(extra_args, timeout_s=180):
         try:
             subprocess.run(cmd, cwd="/tmp", env=_child_env(), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            timeout=timeout_s, check=True)
-            rows = []
+            rows, by_kernel = [], {}
             for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
                 with open(f, newline="") as fh:
-                    for r in csv.DictReader(fh):
-                        if KERNEL_SUBSTR in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
-                            rows.append(float(r["Counter_Value"]))
+                    recs = list(csv.DictReader(fh))
+                recs.sort(key=lambda r: int(float(r.get("Dispatch_Id", 0) or 0)))
+                for r in recs:
+                    if any(sub in r.get("Kernel_Name", "") for sub in (substrings or (KERNEL_SUBSTR,))) and r.get("Counter_Name") == counter:
+                        rows.append(float(r["Counter_Value"]))
+                        by_kernel.setdefault(r["Kernel_Name"].split("<")[0].split("(")[0], []).append(float(r["Counter_Value"]))
             if not rows:
                 raise RuntimeError("no counter rows for the kernel")
-            rows = rows[len(rows) // 2:]  # second sweep over the rotation
-            vals[counter] = sum(rows) / len(rows)
+            if calls_per_sweep:
+                # several kernels per call of the op: every kernel's last `calls_per_sweep` dispatches = the second sweep over the rotation
+                vals[counter] = sum(sum(v[-calls_per_sweep:]) / len(v[-calls_per_sweep:]) for v in by_kernel.values())
+                detail[counter + "_kernels"] = {k: round(sum(v[-calls_per_sweep:]) / len(v[-calls_per_sweep:]), 1) for k, v in by_kernel.items()}
+            else:
+                rows = rows[len(rows) // 2:]  # second sweep over the rotation
+                vals[counter] = sum(rows) / len(rows)
             detail[counter + "_KiB_per_launch_raw"] = round(vals[counter], 1)
             detail[counter + "_dispatches"] = len(rows)
         except Exception as exc:
@@ -362,6 +379,49 @@ def pmc_traffic(extra_args, timeout_s=180):
     traffic = 2.0 * vals["FETCH_SIZE"] * 1024.0 + vals["WRITE_SIZE"] * 1024.0
     detail["correction"] = "bytes = 2 x FETCH_SIZE[KiB] x 1024 (gfx950 64-B tally of 128-B requests) + WRITE_SIZE[KiB] x 1024"
     return traffic, detail
+
+
+def config3_leg(device, with_pmc):
+    """BASELINE.json configs[2] - gemm_4bit NF4 bf16 M = 64, N = K = 8192, the one compute-side configuration - through the public op:
+    a hipGraph over 8 distinct layers (302 MB of packed weights + scales: beyond the 256-MiB Infinity Cache), HIP events around a
+    >= 20 ms region; the kernel family the library reports; HBM traffic per call from two PMC child passes (kernel + finalize)."""
+    import bitsandbytes_amd as bnb
+
+    M3, N3, K3, L3 = 64, 8192, 8192, 8
+    layers3, x3 = build_layers(device, L3, N3, K3, M3, 64, "nf4", seed=77)
+
+    def fn():
+        for q, st in layers3:
+            bnb.matmul_4bit(x3, q, st)
+
+    g = capture(fn)
+    fam = KERNEL_FAMILIES.get(int(bnb.lib.bnb_mi355x_last_gemm_kernel()), "?")
+    for _ in range(20):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 150
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / (reps * L3) * 1e3
+    nbytes, flops = algorithmic_bytes(M3, N3, K3, 64), 2 * M3 * N3 * K3
+    out = {"workload": "gemm_4bit NF4 bf16 M=64 N=K=8192 blocksize=64 fp32-absmax (BASELINE.json configs[2]) through bitsandbytes_amd.matmul_4bit; "
+                       f"hipGraph of {L3} distinct layers ({L3 * nbytes / 1e6:.0f} MB: HBM-resident), HIP events around {reps} replays",
+           "kernel": fam + (" + its split-K finalize launch" if fam in ("gemm4_mfma_pc_kernel", "gemm4_mfma_kq_kernel") else ""),
+           "us": round(us, 2), "bytes_per_call": nbytes, "flops_per_call": flops,
+           "GBps": round(nbytes / us / 1e3, 1), "TFLOPs": round(flops / us / 1e6, 1),
+           "frac_hbm": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4), "frac_mfma": round(flops / us / 1e6 / MFMA_PEAK_TFLOPS, 4),
+           "bound": "hbm (arithmetic intensity 216 FLOP/B, below the ~300 FLOP/B machine balance)", "traffic": None}
+    del layers3
+    if with_pmc:
+        traffic, detail = pmc_traffic(["--m", str(M3), "--n", str(N3), "--k", str(K3), "--blocksize", "64", "--quant-type", "nf4", "--layers", str(L3)],
+                                      substrings=("gemm4_",), calls_per_sweep=L3)
+        out["traffic"] = None if traffic is None else round(traffic)
+        out["traffic_detail"] = detail
+    return out
 
 
 def main():
@@ -384,11 +444,13 @@ def main():
     ap.add_argument("--sharded-path", action="store_true",
                     help="run the multi-GPU code path (ShardedLinear4bit shards, bucketed RCCL all-gather, per-layer "
                          "gather) even at world size 1: how that path is exercised on a 1-GPU box")
+    ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE.json configs[2] leg (M = 64, N = K = 8192)")
     ap.add_argument("--no-span", action="store_true", help="skip the kernel-span leg (roofline then falls back to the rocprofv3 average)")
     ap.add_argument("--span-out", default=None, help="write the kernel-span measurement here (e.g. profiles/r3_bench_kernel_span.json)")
     ap.add_argument("--span-child", action="store_true", help=argparse.SUPPRESS)  # span measurement under the measurement build
     ap.add_argument("--prof-child", action="store_true", help=argparse.SUPPRESS)  # workload run under rocprofv3
     ap.add_argument("--prof-eager", action="store_true", help=argparse.SUPPRESS)  # ... enqueued eagerly (PMC passes serialise dispatches)
+    ap.add_argument("--layers", type=int, default=LAYERS, help=argparse.SUPPRESS)  # child passes of the config3 leg: a shorter rotation
     args = ap.parse_args()
     if args.span_child:
         kernel_span_child(args.m, args.n, args.k, args.blocksize, args.quant_type)
@@ -428,7 +490,7 @@ def main():
     peer = chain = None
     chain_info = None
     if not multi:
-        layers, x = build_layers(device, LAYERS, N, K, M, bs, qt, seed=1234 + rank)
+        layers, x = build_layers(device, args.layers if args.prof_child else LAYERS, N, K, M, bs, qt, seed=1234 + rank)
         nbytes_layer = algorithmic_bytes(M, N, K, bs)
         nbytes_step = LAYERS * nbytes_layer
         flops_step = LAYERS * 2 * M * N * K
@@ -597,17 +659,24 @@ def main():
     torch.cuda.synchronize()
 
     # ---- timed region: exactly args.steps steps
+    # Two clocks on the same region: HIP events recorded on the stream the kernels are launched on (torch's current stream; the
+    # clock the contract names for roofline.achieved) and the host's wall clock around synchronize (the clock `value` uses and the
+    # driver can check from outside; it can only be the slower of the two).
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev0.record()
     run_steps(args.steps)
+    ev1.record()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_events = ev0.elapsed_time(ev1) * 1e-3
     if multi:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed, elapsed_events], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, elapsed_events = float(t[0].item()), float(t[1].item())
 
     # ---- secondary timings (outside the timed region)
     def graph_us_per_launch(fn, launches, reps=10):
@@ -662,9 +731,10 @@ def main():
         sweep = []
         for m_rows in (1, 2, 4, 8, 16, 32, 64):
             t_us = per_launch_us(m_rows, reps=5)
-            sweep.append({"M": m_rows, "us_per_launch": round(t_us, 2),
-                          "GBps": round(algorithmic_bytes(m_rows, N, K, bs) / t_us / 1e3, 1),
-                          "TFLOPs": round(2 * m_rows * N * K / t_us / 1e6, 2)})
+            fam = KERNEL_FAMILIES.get(int(bnb.lib.bnb_mi355x_last_gemm_kernel()), "?")  # (the family the capture's last call launched)
+            gbps, tfl = algorithmic_bytes(m_rows, N, K, bs) / t_us / 1e3, 2 * m_rows * N * K / t_us / 1e6
+            sweep.append({"M": m_rows, "us_per_launch": round(t_us, 2), "kernel": fam, "GBps": round(gbps, 1), "TFLOPs": round(tfl, 2),
+                          "frac_hbm": round(gbps / HBM_PEAK_GBS, 4), "frac_mfma": round(tfl / MFMA_PEAK_TFLOPS, 4)})
         gsz = 4
 
         def grouped_fn():
@@ -676,6 +746,13 @@ def main():
                    "frac_of_hbm_peak": round(nbytes_layer / t_grp / 1e3 / HBM_PEAK_GBS, 4),
                    "what": "the same 128 layers as 32 launches of matmul_4bit_grouped (4 matrices sharing x per launch: Q/K/V/O- or "
                            "gate/up-style); informational - the headline keeps one launch per layer"}
+
+    config3 = None
+    if not multi and not args.no_config3 and rank == 0 and (M, N, K) == (1, 4096, 4096):
+        try:
+            config3 = config3_leg(device, with_pmc=not args.no_pmc)
+        except Exception as exc:  # informational: never lose the headline over it
+            config3 = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     if rank == 0:
         total_steps = args.steps * world
@@ -691,11 +768,13 @@ def main():
         # the launches in it (kernel + the boundary to the next dependent launch): what the contract prescribes and what the driver's
         # clock can check. The in-kernel span (measurement build of the library: a different binary) and the rocprofv3 average (the
         # profiler serialises dispatches: 128 x its figure exceeds the step) stay on the line as frac_span / frac_rocprof.
-        kernel_us = elapsed / args.steps / LAYERS * 1e6
-        method = (f"HIP events around the timed region ({args.steps} hipGraph replays of the {LAYERS}-layer step on torch's current stream, the "
-                  "stream the kernels are launched on) divided by the launches in it: the dominant kernel + its boundary to the next dependent "
-                  "launch, product library. frac_span = the kernel's own span from in-kernel s_memrealtime stamps (measurement build, child "
-                  "process); frac_rocprof = average duration from `rocprofv3 --kernel-trace --stats` over the same workload (serialised dispatches)")
+        kernel_us = elapsed_events / args.steps / LAYERS * 1e6
+        method = (f"frac: HIP events (recorded on torch's current stream, the stream the kernels are launched on) around the timed region - {args.steps} "
+                  f"hipGraph replays of the {LAYERS}-layer step - divided by the launches in it: the dominant kernel + its boundary to the next "
+                  "dependent launch, product library. frac_wall: the same region on the host's wall clock (time.perf_counter around "
+                  "torch.cuda.synchronize: the clock `value` and ms_per_step use). frac_span: the kernel's own span from in-kernel s_memrealtime "
+                  "stamps (measurement build, child process). frac_rocprof: average duration from `rocprofv3 --kernel-trace --stats` over the "
+                  "same workload (serialised dispatches)")
         achieved = nbytes_layer / (kernel_us * 1e-6) / 1e9
         line = {
             "metric": "NF4 gemv_4bit / Linear4bit decode forward GB/s (M=1, N=K=4096; algorithmic bytes / time)",
@@ -731,7 +810,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": kernel_label + (", 16 wavefronts" if M == 1 and KERNEL_SUBSTR == "gemv4_stream_kernel" and N * K <= (20 << 20) else ""),
+                "kernel": kernel_label + (", 16 wavefronts" if M == 1 and KERNEL_SUBSTR == "gemv4_stream_kernel" else ""),
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -745,7 +824,8 @@ def main():
                 "kernel_us_rocprof_stats": None if avg_ns is None else round(avg_ns / 1e3, 3),
                 "kernel_span": span_detail,
                 "kernel_us_span": None if span_us is None else round(span_us, 3),
-                "fits_in_step": True if span_us is None else bool(span_us * LAYERS <= elapsed / args.steps * 1e6),
+                "fits_in_step": None if span_us is None else bool(span_us * LAYERS <= elapsed / args.steps * 1e6),
+                "timed_region_events_s": round(elapsed_events, 6),
                 "method": method,
                 "kernel_trace": kt_detail,
             },
@@ -760,6 +840,8 @@ def main():
             line["headline_sweep_N4096_K4096"] = sweep
         if grouped is not None:
             line["grouped"] = grouped
+        if config3 is not None:
+            line["config3"] = config3
         if not multi and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(M, N, K, bs, qt)

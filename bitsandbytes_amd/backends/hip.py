@@ -212,6 +212,32 @@ def _dequantize_4bit_nested_impl(A, absmax_8bit, absmax2, code8, offset, blocksi
     return out
 
 
+def _nested_one_launch_ok(A, absmax_8bit, absmax2, code8, offset, blocksize, n) -> bool:
+    """Whether the one-launch nested dequantize serves these statistics - what the three-operator sequence tolerates and that kernel
+    does not: tensors on another device, a code array that is not one uint8 per block, missing code / offset."""
+    if absmax_8bit is None or code8 is None or offset is None:
+        return False
+    blocks = -(n // -blocksize)
+    return (absmax_8bit.dtype == torch.uint8 and absmax_8bit.numel() == blocks and absmax2.dtype == torch.float32
+            and absmax2.numel() == -(blocks // -256) and code8.numel() == 256 and offset.numel() == 1
+            and all(t.device == A.device for t in (absmax_8bit, absmax2, code8, offset)))
+
+
+def _dequantize_4bit_any(A, absmax, blocksize, quant_type, dtype, out, absmax_8bit=None, absmax_code=None, absmax_offset=None):
+    """Dequantize into ``out`` with plain or nested statistics: the one-launch nested kernel where it serves the call, else the
+    host-side sequence of the reference (bitsandbytes/functional.py:1002-1006)."""
+    if absmax_8bit is None:
+        return _dequantize_4bit_impl(A, absmax, blocksize, quant_type, dtype, out)
+    if _nested_one_launch_ok(A, absmax_8bit, absmax, absmax_code, absmax_offset, blocksize, out.numel()):
+        return _dequantize_4bit_nested_impl(A, absmax_8bit, absmax, absmax_code, absmax_offset, blocksize, quant_type, dtype, out)
+    if absmax_code is None or absmax_offset is None:
+        raise RuntimeError("nested statistics need absmax_code and absmax_offset")
+    scales = torch.ops.bitsandbytes.dequantize_blockwise.default(absmax_8bit.to(A.device), absmax.to(A.device), absmax_code.to(A.device), 256,
+                                                                  torch.float32)
+    scales = (scales + absmax_offset.to(A.device)).float()
+    return _dequantize_4bit_impl(A, scales, blocksize, quant_type, dtype, out)
+
+
 @register_kernel("bitsandbytes_amd::dequantize_4bit_nested", "cuda")
 def _(A, absmax_8bit, absmax2, code8, offset, blocksize: int, quant_type: str, shape: Sequence[int], dtype: torch.dtype):
     out = torch.empty(tuple(shape), dtype=dtype, device=A.device)
@@ -437,16 +463,10 @@ def _(grad_out, B, shapeB: Sequence[int], absmax, blocksize: int, quant_type: st
     G = grad_out.contiguous()
     if M == 0 or not grad_input_fused_ok(G.dtype, M, N, K, blocksize) or G.data_ptr() % 16 or B.data_ptr() % 16:
         # unfused, like the reference: dequantize the weight, dense matmul (also the path for fp32 gradients and odd shapes)
-        if absmax_8bit is not None and absmax_offset.dtype == torch.float32 and absmax_code.dtype == torch.float32:
-            # nested statistics: reconstructed inside the dequantize launch (the batches of QLoRA training land here: M in the thousands)
-            W = torch.empty((N, K), dtype=G.dtype, device=G.device)
-            _dequantize_4bit_nested_impl(B, absmax_8bit, absmax, absmax_code, absmax_offset, blocksize, quant_type, G.dtype, W)
-            return torch.matmul(G, W)
-        scales = absmax
-        if absmax_8bit is not None:
-            scales = torch.ops.bitsandbytes.dequantize_blockwise.default(absmax_8bit, absmax, absmax_code, 256, torch.float32)
-            scales = scales + absmax_offset
-        W = torch.ops.bitsandbytes.dequantize_4bit.default(B, scales.float(), blocksize, quant_type, (N, K), G.dtype)
+        # (nested statistics: reconstructed inside the dequantize launch where that kernel serves them - the batches of QLoRA training
+        # land here, M in the thousands - else the reference's host-side sequence)
+        W = torch.empty((N, K), dtype=G.dtype, device=G.device)
+        _dequantize_4bit_any(B, absmax, blocksize, quant_type, G.dtype, W, absmax_8bit, absmax_code, absmax_offset)
         return torch.matmul(G, W)
     out = torch.empty((*G.shape[:-1], K), dtype=G.dtype, device=G.device)
     B = B.contiguous()
@@ -547,11 +567,8 @@ def gemm_4bit_grouped(A: torch.Tensor, mats, blocksize: int, quant_type: str, ou
 
 def _gemm_4bit_unfused(A, B, shapeB, absmax, blocksize, quant_type, bias, absmax_8bit, absmax_code, absmax_offset):
     W = torch.empty(tuple(shapeB), dtype=A.dtype, device=A.device)
-    if absmax_8bit is not None:
-        # nested statistics: reconstructed inside the dequantize launch (one launch, no fp32 absmax vector; was three)
-        _dequantize_4bit_nested_impl(B, absmax_8bit, absmax, absmax_code, absmax_offset, blocksize, quant_type, A.dtype, W)
-    else:
-        _dequantize_4bit_impl(B, absmax, blocksize, quant_type, A.dtype, W)
+    # (nested statistics: reconstructed inside the dequantize launch - one launch, no fp32 absmax vector; was three)
+    _dequantize_4bit_any(B, absmax, blocksize, quant_type, A.dtype, W, absmax_8bit, absmax_code, absmax_offset)
     return torch.nn.functional.linear(A, W, bias)
 
 

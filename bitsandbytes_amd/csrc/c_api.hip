@@ -44,7 +44,7 @@ thread_local int g_last_gemm_kernel = kKernelNone;
 unsigned long long* g_dbg_buf = nullptr; // profiling builds only: device buffer for the kernels' s_memtime stamps
 #endif
 // gemm4_mfma.hip
-bool gemm_4bit_mfma_supported(int dtype, const void* A, const uint8_t* B, int M, int N, int K, int blocksize, bool plain_absmax);
+bool gemm_4bit_mfma_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize, bool plain_absmax);
 void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
                     const float* absmax_code, const float* absmax_offset, const float* code16, void* out,
                     const void* bias, int M, int N, int K, int blocksize, int quant_type, void* workspace,
@@ -74,11 +74,11 @@ constexpr int kStreamMaxM = 4;
 
 // plain_absmax: the call carries fp32 absmax (not the double-quantised form) - what the MFMA route needs to know at blocksize 32,
 // where only the register-transposed kernel's BS32 instances (fp32 absmax) exist; the shape-only queries pass true.
-bool route_to_mfma(int kernel, int dtype, const void* A, const uint8_t* B, int M, int N, int K, int blocksize, bool plain_absmax) {
+bool route_to_mfma(int kernel, int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize, bool plain_absmax) {
     if (kernel == 1 || kernel == 3)
         return false;
     if (kernel == 2)
-        return gemm_4bit_mfma_supported(dtype, A, B, M, N, K, blocksize, plain_absmax);
+        return gemm_4bit_mfma_supported(dtype, A, B, code16, M, N, K, blocksize, plain_absmax);
     // three or four rows: the streaming kernel's FMA count grows with M while the MFMA kernel's does not - on matrices that
     // fill the chip with 16-column workgroups the MFMA kernel is ahead from M = 3 (4096^2 6.5 vs 6.9 us, 4096 x 11008 10.8 vs
     // 26.7), on small ones the streaming kernel's cheaper launch still wins (1376 x 4096 4.9 vs 5.3)
@@ -86,7 +86,7 @@ bool route_to_mfma(int kernel, int dtype, const void* A, const uint8_t* B, int M
     // activations once per CU (4096^2 M = 2: 4.44 vs 4.95 us; profiles/r6_sm_v3_ab_full.txt)
     const bool big = static_cast<long>(N) * K >= (12L << 20);
     return (M > kStreamMaxM || (M >= 3 && big) || (M >= 2 && gemm_4bit_sm_routes(dtype, M, N, K, blocksize))) &&
-           gemm_4bit_mfma_supported(dtype, A, B, M, N, K, blocksize, plain_absmax);
+           gemm_4bit_mfma_supported(dtype, A, B, code16, M, N, K, blocksize, plain_absmax);
 }
 
 void gemm_4bit_dispatch(int kernel, int dtype, const void* A, const uint8_t* B, const float* absmax,
@@ -99,7 +99,7 @@ void gemm_4bit_dispatch(int kernel, int dtype, const void* A, const uint8_t* B, 
         fprintf(stderr, "bitsandbytes_amd: gemm_4bit: quant_type must be 1 (FP4) or 2 (NF4), got %d\n", quant_type);
         exit(1);
     }
-    if (route_to_mfma(kernel, dtype, A, B, M, N, K, blocksize, absmax8 == nullptr && aligned_to(absmax, 16)))
+    if (route_to_mfma(kernel, dtype, A, B, code16, M, N, K, blocksize, absmax8 == nullptr && aligned_to(absmax, 16)))
         gemm_4bit_mfma(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, code16, out, bias, M, N, K, blocksize,
                        quant_type, workspace, workspace_bytes, stream);
     else
@@ -115,6 +115,8 @@ using namespace bnb;
 static inline hipStream_t S(bnb_stream_t s) { return static_cast<hipStream_t>(s); }
 
 extern "C" {
+// the library is built with -fvisibility=hidden: the C ABI declared in include/bnb_mi355x.h is ALL it exports
+#pragma GCC visibility push(default)
 
 // ------------------------------------------------------------------ 4-bit quantize (NULL stream, like the reference)
 void cquantize_blockwise_fp32_nf4(float*, float* A, float* absmax, unsigned char* out, int bs, const int n) {
@@ -301,7 +303,7 @@ void bnb_mi355x_gemm_4bit_grouped(int dtype, const void* A, int count, const uin
     // four rows on a big matrix) must not run the streaming kernel's arithmetic here - then the whole group goes matrix by matrix
     bool any_mfma = false;
     for (int i = 0; i < count; ++i)
-        any_mfma = any_mfma || route_to_mfma(0, dtype, A, B[i], M, N[i], K, blocksize,
+        any_mfma = any_mfma || route_to_mfma(0, dtype, A, B[i], nullptr, M, N[i], K, blocksize,
                                              (absmax_8bit == nullptr || absmax_8bit[i] == nullptr) && aligned_to(absmax[i], 16));
     if (!any_mfma && gemv_4bit_grouped(dtype, A, count, B, absmax, absmax_8bit, absmax_code, absmax_offset, out, bias, N, M, K,
                                        blocksize, quant_type, S(s)))
@@ -316,7 +318,7 @@ size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N,
     // alignment of A/B is unknown here; assume the aligned (fast) case, an unused workspace is harmless
     static const int dummy_aligned[4] __attribute__((aligned(16))) = {0, 0, 0, 0};
     const void* a = dummy_aligned;
-    if (!route_to_mfma(kernel, dtype, a, reinterpret_cast<const uint8_t*>(a), M, N, K, blocksize, true))
+    if (!route_to_mfma(kernel, dtype, a, reinterpret_cast<const uint8_t*>(a), nullptr, M, N, K, blocksize, true))
         return 0;
     return gemm_4bit_mfma_workspace_bytes(M, N, K, blocksize);
 }
@@ -388,7 +390,7 @@ void bnb_mi355x_peer_chain_read(void* const* bufs, void* epoch_word, int world, 
 int bnb_mi355x_gemm_4bit_route(int kernel, int dtype, int M, int N, int K, int blocksize) {
     // (alignment of A / B is unknown here; the aligned - fast - case is assumed, as in the workspace query)
     static const int dummy_aligned[4] __attribute__((aligned(16))) = {0, 0, 0, 0};
-    return route_to_mfma(kernel, dtype, dummy_aligned, reinterpret_cast<const uint8_t*>(dummy_aligned), M, N, K, blocksize, true) ? 1 : 0;
+    return route_to_mfma(kernel, dtype, dummy_aligned, reinterpret_cast<const uint8_t*>(dummy_aligned), nullptr, M, N, K, blocksize, true) ? 1 : 0;
 }
 void bnb_mi355x_gemm_4bit_grad_input(int dtype, const void* grad_out, const uint8_t* B, const float* absmax,
                                      const uint8_t* absmax_8bit, const float* absmax_code, const float* absmax_offset, void* grad_A,
@@ -428,4 +430,5 @@ void bnb_mi355x_set_stamp_buffer(void* device_u64_buffer) {
 }
 const char* bnb_mi355x_version(void) { return "bitsandbytes_amd 0.1.0 gfx950"; }
 
+#pragma GCC visibility pop
 } // extern "C"

@@ -759,6 +759,11 @@ void gemm_4bit_kq(int dtype, const void* A, const uint8_t* B, const float* absma
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
                   int blocksize, int quant_type, void* workspace, size_t workspace_bytes, int force_ks, int ablate, hipStream_t stream);
 
+// gemv4_stream.hip (what a call outside every MFMA kernel's preconditions runs)
+void gemv_4bit_stream(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8,
+                      const float* absmax_code, const float* absmax_offset, const float* code16, void* out,
+                      const void* bias, int M, int N, int K, int blocksize, int quant_type, hipStream_t stream);
+
 // gemm4_mfma_sm.hip (the streaming MFMA kernel: one persistent workgroup per CU, activations once per CU; 2 ... 16 rows)
 bool gemm_4bit_sm_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize);
 bool gemm_4bit_sm_serves(const float* absmax, const uint8_t* absmax8, int blocksize);
@@ -872,9 +877,11 @@ bool gemm_4bit_sm_routes(int dtype, int M, int N, int K, int blocksize) {
 // Preconditions of the MFMA kernels: 16-bit activations, K a multiple of 256, 16-byte aligned A, 8-byte aligned B, and a blocksize
 // >= 64 (a 64-k MFMA pair stays inside one quantization block) - or, round 5, blocksize 32 with fp32 absmax (`plain_absmax`: the
 // caller knows, the shape-only queries assume it), which the register-transposed kernel's BS32 instances serve at any M.
-bool gemm_4bit_mfma_supported(int dtype, const void* A, const uint8_t* B, int M, int N, int K, int blocksize, bool plain_absmax) {
-    return dtype != 0 && M >= 1 && N >= 1 && (K % kKC) == 0 && is_pow2(blocksize) && (blocksize >= 64 || (blocksize == 32 && plain_absmax && aligned_to(B, 16))) &&
-           aligned_to(A, 16) && aligned_to(B, 8);
+bool gemm_4bit_mfma_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize, bool plain_absmax) {
+    if (blocksize == 32) // (the BS32 instances' own preconditions: literal code table, 32-bit byte offsets - ADVICE round 5: a call that
+                         // passed this test and failed those used to end the process)
+        return plain_absmax && gemm_4bit_rt_supported(dtype, A, B, code16, M, N, K, blocksize);
+    return dtype != 0 && M >= 1 && N >= 1 && (K % kKC) == 0 && is_pow2(blocksize) && blocksize >= 64 && aligned_to(A, 16) && aligned_to(B, 8);
 }
 
 // Bytes of fp32 slab workspace the launch heuristics would like for this problem (0 = none needed).
@@ -915,10 +922,9 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
     if (blocksize == 32) {
         // blocksize 32: the register-transposed kernel's BS32 instances at any M (row passes over grid.z). The callers
         // route here only what gemm_4bit_mfma_supported(..., plain_absmax) accepted; anything else is a caller's bug.
-        if (!gemm_4bit_rt_supported(dtype, A, B, code16, M, N, K, blocksize) || !gemm_4bit_rt_serves(absmax, absmax8, blocksize)) {
-            fprintf(stderr, "bitsandbytes_amd: gemm_4bit: internal error, a blocksize-32 call outside the MFMA kernels' preconditions reached them\n");
-            exit(1);
-        }
+        if (!gemm_4bit_rt_supported(dtype, A, B, code16, M, N, K, blocksize) || !gemm_4bit_rt_serves(absmax, absmax8, blocksize))
+            // (not reachable through route_to_mfma, which asks the same questions; a direct caller gets the streaming kernel, not exit(1))
+            return gemv_4bit_stream(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, code16, out, bias, M, N, K, blocksize, quant_type, stream);
         return gemm_4bit_rt(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type, workspace,
                             workspace_bytes, 0, 0, 0, stream);
     }

@@ -118,6 +118,8 @@ __global__ __launch_bounds__(kPeerThreads) void peer_allgather_kernel(PeerBufs b
 using namespace bnb;
 
 extern "C" {
+// the library is built with -fvisibility=hidden: the C ABI declared in include/bnb_mi355x.h is ALL it exports
+#pragma GCC visibility push(default)
 
 // Bytes a rank's buffer needs for shards of up to `max_bytes` (rounded up to 256) in a group of `world` ranks.
 size_t bnb_mi355x_peer_buffer_bytes(int world, size_t max_bytes) {
@@ -206,4 +208,5 @@ int bnb_mi355x_peer_status(const void* local_buffer) {
     return static_cast<int>(v[1]);
 }
 
+#pragma GCC visibility pop
 } // extern "C"

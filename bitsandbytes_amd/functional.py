@@ -170,7 +170,12 @@ def _per_device_constant(key, device, make) -> Tensor:
     k = (key, d)
     t = _DEVICE_CONSTANTS.get(k)
     if t is None:
-        t = _DEVICE_CONSTANTS[k] = make().to(d)
+        t = make().to(d)
+        # (only a real tensor is kept: under FakeTensorMode / tracing `.to` hands back a fake or traced tensor, which every later
+        # real call would otherwise receive from the cache)
+        if type(t) is not torch.Tensor or torch.compiler.is_compiling():
+            return t
+        _DEVICE_CONSTANTS[k] = t
     return t
 
 
@@ -482,9 +487,14 @@ def dequantize_4bit(A: Tensor, quant_state: Optional[QuantState] = None, absmax:
 
     if quant_state.nested:
         s2 = quant_state.state2
+        n_blocks = -(-int(torch.Size(quant_state.shape).numel()) // quant_state.blocksize)
         if (A.device.type == "cuda" and out is None and s2.blocksize == 256 and not s2.nested and s2.absmax.dtype == torch.float32
                 and s2.code.dtype == torch.float32 and quant_state.absmax.dtype == torch.uint8
-                and quant_state.offset.dtype == torch.float32 and A.numel() > 0):
+                and quant_state.offset.dtype == torch.float32 and A.numel() > 0
+                # (what the sequence below tolerates and the one-launch kernel does not: statistics on another device, a code
+                # array that is not exactly one byte per block)
+                and quant_state.absmax.device == A.device and s2.absmax.device == A.device and s2.code.device == A.device
+                and quant_state.offset.device == A.device and quant_state.absmax.numel() == n_blocks):
             # one operator / one launch: the fp32 absmax is reconstructed inside the dequantize kernel with the same two roundings
             # (code2[q] * absmax2, + offset) the sequence below performs
             res = torch.ops.bitsandbytes_amd.dequantize_4bit_nested.default(

@@ -204,7 +204,11 @@ def main():
                 # two rows are outside the fused form: grouped launch, torch's activation, two gathers. (Two, not three: from three rows
                 # on the router picks the kernel FAMILY by matrix size - a shard and the full matrix can then run different arithmetic.)
                 x2 = torch.randn(2, H, device=dev, dtype=dt)
-                assert not ffn.fused(x2) and torch.equal(ffn(x2), block(x2))
+                # (round 6: two rows on an unsharded projection of >= 3072 rows run the streaming MFMA kernel, its narrower shards the
+                # streaming kernel: the matmul tolerance through the block, not the bits - one row, above: bits)
+                y2, want2 = ffn(x2), block(x2)
+                assert not ffn.fused(x2) and y2.shape == want2.shape
+                assert float((y2.float() - want2.float()).norm() / want2.float().norm()) < 2e-2, ("ffn 2 rows", H, Fd, dt)
             chain.check()
             if world == 1:
                 # The activation in the producer's epilogue, EXHAUSTIVELY: gate = identity, up = a permutation, down = identity - NF4 holds

@@ -36,6 +36,28 @@ def test_library_exports_every_declared_symbol():
     assert ce.lib.bnb_mi355x_version().decode().endswith("gfx950")
 
 
+def test_library_exports_nothing_but_the_declared_c_abi():
+    """Round-5 review: a drop-in .so exposes the reference's ABI + the documented extensions and nothing else. The library is built
+    with -fvisibility=hidden and a linker version script (csrc/exports.map): its dynamic symbol table holds exactly the names
+    include/bnb_mi355x.h declares - no bnb:: C++ symbol, no compiler-generated marker."""
+    import shutil
+    import subprocess
+
+    from bitsandbytes_amd import cextension as ce
+
+    nm = shutil.which("nm")
+    if nm is None:
+        import pytest
+
+        pytest.skip("binutils nm not available")
+    out = subprocess.run([nm, "-D", "--defined-only", str(ce.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    declared = set(_header_symbols())
+    assert exported, "empty dynamic symbol table?"
+    assert not (exported - declared), f"exported but not declared in include/bnb_mi355x.h: {sorted(exported - declared)[:10]}"
+    assert not (declared - exported), f"declared but not exported: {sorted(declared - exported)[:10]}"
+
+
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     """The product path must raise, never fall back, when the HIP library is absent."""
     import importlib

@@ -117,6 +117,56 @@ def test_sharded_linear4bit_two_ranks():
         assert dict(results) == {0: True, 1: True}
 
 
+def _worker_c4(rank, world, port, results):
+    """BASELINE.json configs[3] with its REAL shard geometry: the Llama FFN projections 11008 x 4096 (gate, up) and 4096 x 11008
+    (down) N-sharded over `world` ranks - 8 ranks: 1376 / 512 rows per rank, 4 ranks: 2752 / 1024 - i.e. the shapes bench.py --gpus 8
+    and a real tensor-parallel decode run, end to end over gloo."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(1)
+    import _oracle_cpu_backend
+
+    _oracle_cpu_backend.register()
+    import bitsandbytes_amd as bnb
+    from bitsandbytes_amd.nn import Linear4bit
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        H, Fd = 4096, 11008
+        torch.manual_seed(21)  # the same block on every rank
+        gate, up, down = [Linear4bit(k, n, bias=b, quant_type="nf4", compress_statistics=True, compute_dtype=torch.bfloat16).to("cpu")
+                          for k, n, b in ((H, Fd, False), (H, Fd, False), (Fd, H, True))]
+        ffn = bnb.shard_ffn4bit(gate, up, down, rank, world)
+        ok &= tuple(ffn.gate.quant_state.shape) == (Fd // world, H) and tuple(ffn.down.quant_state.shape) == (H // world, Fd)
+        chain = bnb.ShardedLinear4bitChain([bnb.shard_linear4bit(up, rank, world), bnb.shard_linear4bit(down, rank, world)], None)
+        for M in (1, 2):
+            x = torch.randn(M, H, generator=torch.Generator().manual_seed(5 + M)).bfloat16()
+            want = down(torch.nn.functional.silu(gate(x)) * up(x))
+            got = ffn(x)
+            ok &= got.shape == (M, H) and bool(torch.equal(got, want))
+            ok &= bool(torch.equal(chain(x), down(up(x))))
+            # this rank's part of the gathered activation is its row block of the unsharded projections
+            ns = Fd // world
+            ok &= bool(torch.equal(ffn.up.local_forward(x), up(x)[:, rank * ns:(rank + 1) * ns]))
+        results[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_sharded_ffn_block_with_config4_shard_geometry(world):
+    """Round-5 review item 8: the sharded FFN block and the sharded chain at world 4 and 8 with BASELINE.json configs[3]'s real
+    shapes (1376 / 512 and 2752 / 1024 rows per rank) - what `bench.py --gpus 8` and the peer chain's member-by-member path
+    compute - equal the unsharded block bit for bit on every rank (CPU, gloo, the oracle's arithmetic)."""
+    port = 29500 + ((os.getpid() + 7 * world) % 2000)
+    with mp.Manager() as mgr:
+        results = mgr.dict()
+        mp.spawn(_worker_c4, args=(world, port, results), nprocs=world, join=True)
+        assert dict(results) == {r: True for r in range(world)}
+
+
 def test_shard_validation():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle_cpu_backend
