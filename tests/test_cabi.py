@@ -293,6 +293,35 @@ def test_stream_kernel_isa_waits_for_x_with_an_exact_count_and_never_drains_in_f
     assert checked >= 100 and plain >= 24, (checked, plain)
 
 
+def test_sm_kernel_isa_counts_its_waits_and_keeps_the_ring_in_flight():
+    """gemm4_mfma_sm_kernel mixes LDS-DMA spelled in asm (the activation staging) with compiler-visible buffer loads (the weight
+    ring): the hand-written wait for the first fragments must leave EXACTLY the ring in flight - vmcnt(NS x LPS), LPS = two weight
+    loads + the lane's scale (nested: + the second-level absmax), NS = 1 for the single-item instances, else 2 - and in the ring
+    instances nothing between the table barrier and the first MFMA may drain the queue (the second stage stays in flight while the
+    first item is decoded). Every instance stages its first chunk with ROWS / 2 DMA instructions in front of the barrier (+ one for
+    the nested code table)."""
+    import re
+
+    kernels = _device_disassembly("gemm4_mfma_sm_kernel")
+    assert len(kernels) >= 40, len(kernels)
+    for name, lines in kernels.items():
+        m = re.search(r"sm_kernelI(\w+?)Li(\d+)ELi(\d+)ELi(\d)ELb([01])ELb([01])ELi(\d)E", name)  # <T, ROWS, WAVES, TT, NESTED, SINGLE, ORDER>
+        assert m, name
+        rows, nested, single, order = int(m.group(2)), m.group(5) == "1", m.group(6) == "1", int(m.group(7))
+        ns, lps = (1 if single else 2), (4 if nested else 3)
+        ops = [ln.split()[0] for ln in lines]
+        bar = ops.index("s_barrier")
+        dmas = sum(1 for ln in lines[:bar] if ln.startswith("buffer_load_dwordx4") and " lds" in ln)
+        assert dmas == rows // 2 + (1 if nested else 0), f"{name}: {dmas} DMA instructions in front of the table barrier"
+        first_mfma = next(i for i, op in enumerate(ops) if op.startswith("v_mfma"))
+        waits = [int(re.search(r"vmcnt\((\d+)\)", ln).group(1)) for ln in lines[bar:first_mfma] if ln.startswith("s_waitcnt") and "vmcnt(" in ln]
+        assert waits, name
+        if order == 0:
+            assert waits[0] == ns * lps, f"{name}: the wait for the first fragments is vmcnt({waits[0]}), expected vmcnt({ns * lps})"
+        if not single:
+            assert 0 not in waits, f"{name}: vmcnt(0) between the table barrier and the first MFMA - the ring is drained there ({waits})"
+
+
 def test_launch_plan_workspace_query_is_pure_host_logic():
     """bnb_mi355x_gemm_4bit_workspace_bytes runs the launch plans on the host (no GPU needed): for every BASELINE
     shape the split-K workspace is a whole number of fp32 slabs - [M, N] ones, or the K-quarter kernel's (whole 128-column x
