@@ -51,6 +51,7 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
                     size_t workspace_bytes, hipStream_t stream);
 size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K, int blocksize);
 bool gemm_4bit_sm_routes(int dtype, int M, int N, int K, int blocksize);
+bool gemm_4bit_sm_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize);
 extern thread_local TlsKnob g_mfma_knob0, g_mfma_knob1;
 // gemm4_grad_input.hip
 bool gemm_4bit_grad_input_supported(int dtype, const void* G, const uint8_t* B, int M, int N, int K, int blocksize);
@@ -77,16 +78,18 @@ constexpr int kStreamMaxM = 4;
 bool route_to_mfma(int kernel, int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize, bool plain_absmax) {
     if (kernel == 1 || kernel == 3)
         return false;
+    // the streaming MFMA kernel's own reach: 2 ... 16 rows on matrices of >= 3072 rows, any K % 64 == 0 (the other MFMA kernels
+    // need whole 256-k chunks) - round 6
+    const bool sm = gemm_4bit_sm_routes(dtype, M, N, K, blocksize) && gemm_4bit_sm_supported(dtype, A, B, code16, M, N, K, blocksize);
     if (kernel == 2)
-        return gemm_4bit_mfma_supported(dtype, A, B, code16, M, N, K, blocksize, plain_absmax);
+        return sm || gemm_4bit_mfma_supported(dtype, A, B, code16, M, N, K, blocksize, plain_absmax);
     // three or four rows: the streaming kernel's FMA count grows with M while the MFMA kernel's does not - on matrices that
     // fill the chip with 16-column workgroups the MFMA kernel is ahead from M = 3 (4096^2 6.5 vs 6.9 us, 4096 x 11008 10.8 vs
     // 26.7), on small ones the streaming kernel's cheaper launch still wins (1376 x 4096 4.9 vs 5.3)
     // round 6: from TWO rows on wherever the streaming MFMA kernel (gemm4_mfma_sm.hip) serves the shape - one decode for all rows,
     // activations once per CU (4096^2 M = 2: 4.44 vs 4.95 us; profiles/r6_sm_v3_ab_full.txt)
     const bool big = static_cast<long>(N) * K >= (12L << 20);
-    return (M > kStreamMaxM || (M >= 3 && big) || (M >= 2 && gemm_4bit_sm_routes(dtype, M, N, K, blocksize))) &&
-           gemm_4bit_mfma_supported(dtype, A, B, code16, M, N, K, blocksize, plain_absmax);
+    return sm || ((M > kStreamMaxM || (M >= 3 && big)) && gemm_4bit_mfma_supported(dtype, A, B, code16, M, N, K, blocksize, plain_absmax));
 }
 
 void gemm_4bit_dispatch(int kernel, int dtype, const void* A, const uint8_t* B, const float* absmax,

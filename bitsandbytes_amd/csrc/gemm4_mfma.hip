@@ -870,7 +870,7 @@ bool kq_selected(int M, int N, int K, int knob1, int* force_ks) {
 // Whether the built-in route hands this problem to the streaming MFMA kernel (c_api.hip: such calls take the MFMA route from two
 // rows on; pointer alignment is gemm_4bit_mfma_supported's business)
 bool gemm_4bit_sm_routes(int dtype, int M, int N, int K, int blocksize) {
-    return dtype != 0 && blocksize >= 64 && (K % kKC) == 0 &&
+    return dtype != 0 && blocksize >= 64 && (K % 64) == 0 &&
            sm_selected(M, N, K, g_mfma_knob0.load(std::memory_order_relaxed), g_mfma_knob1.load(std::memory_order_relaxed));
 }
 
@@ -896,6 +896,8 @@ size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K, int blocksize) {
     // statistics - runs the kernels below with the library's own buffer or fewer K slices)
     if (blocksize >= 64 && sm_selected(M, N, K, g_mfma_knob0.load(std::memory_order_relaxed), knob1))
         return 0;
+    if (K % kKC)
+        return 0; // (only the streaming MFMA kernel takes rows that are not whole 256-k chunks)
     int qks;
     size_t kq_bytes = 0;
     if (kq_selected(M, N, K, knob1, &qks)) {
@@ -930,6 +932,8 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
     }
     if (sm_selected(M, N, K, knob0, knob1) && gemm_4bit_sm_supported(dtype, A, B, code16, M, N, K, blocksize) && gemm_4bit_sm_serves(absmax, absmax8, blocksize))
         return gemm_4bit_sm(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type, knob0, stream);
+    if (K % kKC) // (rows that are not whole 256-k chunks are the streaming MFMA kernel's alone: a call it turned down runs the streaming kernel)
+        return gemv_4bit_stream(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, code16, out, bias, M, N, K, blocksize, quant_type, stream);
     if (kq_selected(M, N, K, knob1, &qks) && gemm_4bit_kq_supported(dtype, A, B, code16, M, N, K, blocksize) &&
         gemm_4bit_kq_serves(absmax, absmax8, blocksize, K))
         return gemm_4bit_kq(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type,

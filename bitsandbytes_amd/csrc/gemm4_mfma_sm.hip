@@ -172,7 +172,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     int row_end = row0 + R;
     row_end = row_end < N ? row_end : N;
     const int m_base = blockIdx.y * 16;
-    const int C = K >> 8; // chunks of a row
+    const int C = (K + 255) >> 8; // chunks of a row (K % 64 == 0: the last one may hold one to three 64-k blocks only)
     // chunks of this wavefront: wave, wave + WAVES, ... < C
     const int nchunks = (C - wave + WAVES - 1) / WAVES > 0 ? (C - wave + WAVES - 1) / WAVES : 0;
     const int nitems = nchunks * TT;
@@ -190,20 +190,27 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     // m = 2 i + (L >> 5), and fetches piece P' ^ swz(m) of batch row m_base + m (rows past the batch: the last row again)
     const i32x4 rs_a = sm_rsrc(hot_A);
     uint32_t a_voff[NA];
+    int a_k[NA]; // k of the lane's piece inside the chunk
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = 2 * i + (lane >> 5);
         int mr = m_base + m;
         mr = mr < M ? mr : M - 1;
-        a_voff[i] = static_cast<uint32_t>(mr) * static_cast<uint32_t>(K) * 2u + static_cast<uint32_t>(((lane & 31) ^ sm_swz(m)) << 4);
+        const int piece = (lane & 31) ^ sm_swz(m);
+        a_k[i] = 8 * piece;
+        a_voff[i] = static_cast<uint32_t>(mr) * static_cast<uint32_t>(K) * 2u + static_cast<uint32_t>(piece << 4);
     }
+    constexpr uint32_t kOob = 0xFFFFFFF0u; // beyond num_records
     auto issue_a = [&](int ci) {
-        // chunk ci of this wavefront (a wavefront without chunks stages the row's last chunk: nobody reads it)
+        // chunk ci of this wavefront (a wavefront without chunks stages the row's last chunk: nobody reads it). Pieces past the end of
+        // a row - the last chunk of a K that is not a multiple of 256 - are out-of-range offsets: nothing is fetched (the MFMA steps
+        // that would consume them are skipped, see compute: no value of those slots is ever used).
         int c = wave + ci * WAVES;
         c = c < C ? c : C - 1;
+        const int tail = K - (c << 8);
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            sm_dma16(rs_a, stage_lds + static_cast<uint32_t>(i * 1024), a_voff[i], static_cast<uint32_t>(c) * 512u);
+            sm_dma16(rs_a, stage_lds + static_cast<uint32_t>(i * 1024), a_voff[i] | (a_k[i] < tail ? 0u : kOob), static_cast<uint32_t>(c) * 512u);
     };
     if constexpr (NESTED) {
         // the second-level code table (256 floats): ONE 1-KiB DMA by wavefront 0, the oldest entry of its queue - the table's
@@ -225,7 +232,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
         uint32_t s;  // lane (r, pp): the fp32 absmax of 64-k sub-block pp of row r's chunk (nested: its 8-bit code)
         uint32_t s2; // nested: the second-level absmax of that block
     };
-    constexpr uint32_t kOob = 0xFFFFFFF0u; // beyond num_records
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hot_B), 0, 0x7FFFFFFF, 0x00020000);
     const auto rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hot_absmax), 0, 0x7FFFFFFF, 0x00020000);
     [[maybe_unused]] const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hot_absmax8), 0, 0x7FFFFFFF, 0x00020000);
@@ -238,16 +244,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
         const uint32_t inval = (q < nitems && wrow < row_end) ? 0u : kOob;
         const uint32_t w_off = static_cast<uint32_t>(wrow) * static_cast<uint32_t>(K >> 1) + static_cast<uint32_t>(pp * 16);
         const uint32_t soff_w = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(c) * 128u);
+        const int tail = K - (c << 8); // k left in the row from this chunk on (>= 256 except in the last chunk of a K % 256 != 0 row)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-            st.w[h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off | inval, soff_w + static_cast<uint32_t>(h * 64), 0));
+            st.w[h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off | inval | (128 * h + 32 * pp < tail ? 0u : kOob),
+                                                                                       soff_w + static_cast<uint32_t>(h * 64), 0));
         // quantization block of the lane's 64-k sub-block (N K < 2^32: gemm_4bit_sm_supported)
         const uint32_t blk = (static_cast<uint32_t>(wrow) * static_cast<uint32_t>(K) + (static_cast<uint32_t>(c) << 8) + static_cast<uint32_t>(pp * 64)) >> bs_shift;
+        const uint32_t inval_s = inval | (64 * pp < tail ? 0u : kOob);
         if constexpr (NESTED) {
-            st.s = static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b8(rs_q, blk | inval, 0, 0));
-            st.s2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(rs_s, ((blk >> 8) << 2) | inval, 0, 0));
+            st.s = static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b8(rs_q, blk | inval_s, 0, 0));
+            st.s2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(rs_s, ((blk >> 8) << 2) | inval_s, 0, 0));
         } else {
-            st.s = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(rs_s, (blk << 2) | inval, 0, 0));
+            st.s = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(rs_s, (blk << 2) | inval_s, 0, 0));
             st.s2 = 0;
         }
     };
@@ -345,7 +354,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     for (int t = 0; t < TT; ++t)
         acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](const Stage& s, int t) {
+    // nb = 64-k blocks of the item's chunk (4; fewer in the last chunk of a K % 256 != 0 row: the MFMA pairs of the missing blocks are
+    // skipped - wave-uniform - so neither the staging slots nor the weight registers behind the end of the row are ever multiplied)
+    auto compute = [&](const Stage& s, int t, int nb) {
         // the lane's scale: lane (r, pp) = 4 r + pp writes dword pp of row r's 16 bytes, lane (ln, lg) reads row ln's four
         float sc;
         if constexpr (NESTED)
@@ -388,6 +399,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int blk = g0 / 2; blk < (g0 + GROUP) / 2; ++blk) {
+                if (blk >= nb)
+                    continue;
                 f32x4 part = {0.f, 0.f, 0.f, 0.f};
                 part = SmMma<T>::run(af[2 * blk], bf[2 * blk - g0], part);
                 part = SmMma<T>::run(af[2 * blk + 1], bf[2 * blk + 1 - g0], part);
@@ -402,8 +415,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     };
 
     if constexpr (SINGLE) {
-        if (nitems > 0)
-            compute(st[0], 0);
+        if (nitems > 0) {
+            const int left = (K >> 6) - 4 * wave;
+            compute(st[0], 0, left < 4 ? left : 4);
+        }
         BNB_SM_STAMP(7)
     } else {
         // ---- items, UNROLL at a time: the ring stage (q & 1) and the tile (q % TT) of an item are compile-time values. Every item
@@ -425,8 +440,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
                         issue_a(q / TT + 1);
                     }
                 }
-                if (q < nitems)
-                    compute(st[u & 1], t);
+                if (q < nitems) {
+                    const int left = (K >> 6) - 4 * (wave + (q / TT) * WAVES);
+                    compute(st[u & 1], t, left < 4 ? left : 4);
+                }
                 if (q == 0)
                     BNB_SM_STAMP(7)
                 issue(st[u & 1], q + 2);
@@ -518,7 +535,7 @@ void sm_launch_kind(const void* A, const uint8_t* B, const float* absmax, const 
                     const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
     const bool nested = absmax8 != nullptr;
     if constexpr (TT == 1) {
-        if (K <= kSmChunk * WAVES) { // one item per wavefront at most: no ring
+        if ((K + kSmChunk - 1) / kSmChunk <= WAVES) { // one item per wavefront at most: no ring
             if (nested)
                 return sm_launch_one<T, ROWS, WAVES, 1, true, true>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
             if (pl.variant & 4)
@@ -558,9 +575,10 @@ void sm_launch_rows(const void* A, const uint8_t* B, const float* absmax, const 
 } // namespace
 
 // Preconditions of the kernel (the statistics' alignment is checked by gemm_4bit_sm_serves): 16-bit activations, literal code
-// table, K a multiple of 256, blocksize >= 64, 16-byte aligned A and B, 32-bit byte offsets below the descriptors' records.
+// table, K a multiple of 64 (the last 256-k chunk of a row may be partial; the reference's fused kernels take any K % blocksize
+// == 0, csrc/gemm_4bit_simt.cu:208,225), blocksize >= 64, 16-byte aligned A and B, 32-bit byte offsets below the descriptors' records.
 bool gemm_4bit_sm_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize) {
-    return dtype != 0 && code16 == nullptr && M >= 1 && N >= 1 && K >= kSmChunk && (K % kSmChunk) == 0 && blocksize >= 64 && is_pow2(blocksize) &&
+    return dtype != 0 && code16 == nullptr && M >= 1 && N >= 1 && K >= 64 && (K % 64) == 0 && blocksize >= 64 && is_pow2(blocksize) &&
            aligned_to(A, 16) && aligned_to(B, 16) && static_cast<long long>(N) * K < (1LL << 32) && static_cast<long long>(M) * K < (1LL << 30);
 }
 
