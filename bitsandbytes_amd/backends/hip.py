@@ -43,6 +43,12 @@ FUSED_TALL_WEIGHTS = 48 << 20
 # blocksize 32 with double-quantised statistics) run the streaming kernel in 4-row passes: ahead of dequantize + GEMM up to 12 rows,
 # level at 16, 3 - 4 x behind at 64 (profiles/r5_tall_small_ab.txt, second table; until round 5 they were sent there up to 512 rows).
 STREAM_ONLY_MAX_M = 16
+# Round 6: rows that are not whole 256-k chunks (K % 64 == 0: K = 2752, 1344, 1088 ...) on matrices of >= SM_MIN_ROWS rows run the
+# streaming MFMA kernel (csrc/gemm4_mfma_sm.hip), above 16 rows in row passes of 16 over grid.y. Fused vs dequantize + GEMM, us
+# (profiles/r6_sm_ktail_ab.txt): 4096 x 2752 M = 32 / 64 / 96 / 128 8.9 / 15.6 / 22.2 / 28.9 vs 25.5 / 29.4 / 36.2 / 36.5; 11008 x 1344 10.8 /
+# 20.2 / 29.4 / 38.6 vs 29.4 / 30.5 / 29.8 / 29.3; 8192 x 2752 12.0 / 21.7 / 31.3 / 41.0 vs 37.9 / 44.0 / 44.5 / 44.2: ahead up to 64 rows.
+SM_TAIL_MAX_M = 64
+SM_MIN_ROWS = 3072  # 12 x 256 CUs (csrc/gemm4_mfma.hip: sm_selected)
 # Blocksize 32 (plain statistics) runs the register-transposed kernel's BS32 instances, 64-row passes one after the other: 4096^2
 # fused vs unfused 11.5 vs 28.9 us at 64 rows, 21.0 vs 37.5 at 128, 39.1 vs 33.1 at 256, 75 vs 40 at 512 (profiles/r5_tall_small_ab.txt, table 3).
 FUSED_MAX_M_BS32 = 128
@@ -379,6 +385,8 @@ def _gemm_4bit_route(dtype: torch.dtype, M: int, N: int, K: int, blocksize: int,
 
 def fused_max_m(N: int, K: int, blocksize: int = 64, nested: bool = False) -> int:
     """Largest batch (rows of A) the fused 16-bit kernels are used for on an N x K weight (csrc/torch_dispatch.cpp: fused_max_m)."""
+    if K % 256 != 0 and K % 64 == 0 and blocksize >= 64 and N >= SM_MIN_ROWS:
+        return SM_TAIL_MAX_M  # (the streaming MFMA kernel's row passes)
     if K % 256 != 0 or blocksize < 32 or (blocksize == 32 and nested):
         return STREAM_ONLY_MAX_M  # (the MFMA kernels' preconditions, csrc/gemm4_mfma.hip: gemm_4bit_mfma_supported)
     if blocksize == 32:

@@ -30,7 +30,7 @@
 namespace {
 
 // keep in step with bitsandbytes_amd/backends/hip.py (FUSED_MAX_M, FUSED_MAX_M_LONG_ROWS, FUSED_MAX_M_SQUARE, FUSED_TALL_WEIGHTS,
-// STREAM_ONLY_MAX_M, _REFERENCE_CUSTOM_MAX_M, fused_max_m, _gemm_4bit_route - the measurements behind the numbers are quoted there);
+// STREAM_ONLY_MAX_M, SM_TAIL_MAX_M, SM_MIN_ROWS, _REFERENCE_CUSTOM_MAX_M, fused_max_m, _gemm_4bit_route - the measurements behind the numbers are quoted there);
 // the GPU test tests/test_gpu_parity.py::test_native_dispatch_matches_python_kernel runs both over fused and unfused shapes,
 // tests/test_cabi.py pins the constants and the function against the Python twin
 constexpr int64_t kFusedMaxM = 512;
@@ -38,12 +38,16 @@ constexpr int64_t kFusedMaxMLongRows = 1024; // K >= 2 N
 constexpr int64_t kFusedMaxMSquare = 640;    // 10 K >= 7 N
 constexpr int64_t kFusedTallWeights = 50331648; // 48 << 20
 constexpr int64_t kStreamOnlyMaxM = 16;
+constexpr int64_t kSmTailMaxM = 64;   // rows that are not whole 256-k chunks: the streaming MFMA kernel's row passes (>= kSmMinRows rows)
+constexpr int64_t kSmMinRows = 3072;
 constexpr int64_t kFusedMaxMBs32 = 128; // blocksize 32, plain statistics: the register-transposed kernel's row passes
 constexpr int64_t kFusedMaxMFp32 = 4;
 constexpr int64_t kReferenceCustomMaxM = 256; // reference backends/cuda/ops.py:816
 
 // Largest batch the fused 16-bit kernels are used for on an N x K weight (backends/hip.py: fused_max_m)
 int64_t fused_max_m(int64_t N, int64_t K, int64_t blocksize, bool nested) {
+    if (K % 256 != 0 && K % 64 == 0 && blocksize >= 64 && N >= kSmMinRows)
+        return kSmTailMaxM; // the streaming MFMA kernel's row passes
     if (K % 256 != 0 || blocksize < 32 || (blocksize == 32 && nested))
         return kStreamOnlyMaxM; // the MFMA kernels do not serve the call: the streaming kernel's 4-row passes
     if (blocksize == 32)

@@ -424,6 +424,7 @@ def test_native_dispatch_routing_constants_match_python():
     assert const("kFusedMaxMSquare") == hip.FUSED_MAX_M_SQUARE
     assert const("kFusedTallWeights") == hip.FUSED_TALL_WEIGHTS
     assert const("kStreamOnlyMaxM") == hip.STREAM_ONLY_MAX_M
+    assert const("kSmTailMaxM") == hip.SM_TAIL_MAX_M and const("kSmMinRows") == hip.SM_MIN_ROWS
     assert const("kFusedMaxMBs32") == hip.FUSED_MAX_M_BS32
     assert const("kReferenceCustomMaxM") == hip._REFERENCE_CUSTOM_MAX_M
     # fp32 activations: fused up to 4 rows in both
@@ -434,7 +435,10 @@ def test_native_dispatch_routing_constants_match_python():
     # K = 64 is not a multiple of 256: the MFMA kernels do not serve it, the streaming kernel's passes stop at STREAM_ONLY_MAX_M
     assert hip._gemm_4bit_route(torch.bfloat16, hip.STREAM_ONLY_MAX_M, 64, 64, 64) == "fused"
     assert hip._gemm_4bit_route(torch.bfloat16, hip.STREAM_ONLY_MAX_M + 1, 64, 64, 64) == "unfused"
-    assert hip._gemm_4bit_route(torch.bfloat16, 64, 4096, 2752, 64) == "unfused" and hip._gemm_4bit_route(torch.bfloat16, 12, 4096, 2752, 64) == "fused"
+    # (round 6: K % 64 == 0 rows on >= 3072-row matrices take the streaming MFMA kernel's row passes up to SM_TAIL_MAX_M rows)
+    assert hip._gemm_4bit_route(torch.bfloat16, 64, 4096, 2752, 64) == "fused" and hip._gemm_4bit_route(torch.bfloat16, 65, 4096, 2752, 64) == "unfused"
+    assert hip._gemm_4bit_route(torch.bfloat16, 64, 1376, 2752, 64) == "unfused" and hip._gemm_4bit_route(torch.bfloat16, 12, 1376, 2752, 64) == "fused"
+    assert hip._gemm_4bit_route(torch.bfloat16, 17, 4096, 2752 + 32, 64) == "unfused"
     assert hip._gemm_4bit_route(torch.bfloat16, 64, 4096, 4096, 32, True) == "unfused" and hip._gemm_4bit_route(torch.bfloat16, 64, 4096, 4096, 32) == "fused"
     assert hip._gemm_4bit_route(torch.bfloat16, hip.FUSED_MAX_M, 8192, 8192, 64) == "fused"
     assert hip._gemm_4bit_route(torch.bfloat16, hip.FUSED_MAX_M + 1, 8192, 8192, 64) == "unfused"

@@ -1552,11 +1552,14 @@ def test_mfma_sm_kernel_is_routed_and_deterministic(N, K, dq):
     q, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4", compress_statistics=dq)
     Wd = F.dequantize_4bit(q, st).float()
     junk = torch.randn(1 << 20, device=DEV)
-    for M in (1, 2, 4, 8, 9, 16, 17):
+    for M in (1, 2, 4, 8, 9, 16, 17, 40, 64):
         x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
         y0 = bnb.matmul_4bit(x, q, st).clone()
         fam = bnb.lib.bnb_mi355x_last_gemm_kernel()
-        want = K_STREAM if M == 1 else K_SM if M <= 8 or (M <= 16 and K <= 2 * N) else None
+        if K % 256:  # (rows that are not whole 256-k chunks: the streaming MFMA kernel's row passes up to 64 rows)
+            want = K_STREAM if M == 1 else K_SM
+        else:
+            want = K_STREAM if M == 1 else K_SM if M <= 8 or (M <= 16 and K <= 2 * N) else None
         from bitsandbytes_amd.backends import hip
 
         if want is not None:
@@ -1717,6 +1720,8 @@ def test_native_dispatch_matches_python_kernel():
         ((700,), 1024, 1024, 64, "nf4", False, torch.float16, True),     # square: fused up to 640 rows, this one unfused
         ((12,), 512, 2752, 64, "nf4", True, torch.bfloat16, False),      # K % 256 != 0: the streaming kernel's passes up to 16 rows
         ((48,), 512, 2752, 64, "nf4", True, torch.bfloat16, True),       # ... above that dequantize + GEMM (round 5: was fused to 512)
+        ((48,), 3200, 1344, 64, "nf4", True, torch.bfloat16, True),      # ... but >= 3072 rows: the streaming MFMA kernel's row passes up to 64 rows (round 6)
+        ((70,), 3200, 1344, 64, "nf4", False, torch.bfloat16, False),    # ... and dequantize + GEMM above
         ((48,), 512, 2048, 32, "nf4", True, torch.bfloat16, False),      # blocksize 32 with nested statistics: likewise
         ((5,), 64, 96, 64, "nf4", False, torch.bfloat16, True),          # K % blocksize != 0: warning + unfused
     ]:

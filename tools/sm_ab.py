@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--variants", default="", help="comma-separated knob0 values: A/B of experiment variants of the sm kernel instead of the routing table")
     ap.add_argument("--skip-odd", action="store_true")
+    ap.add_argument("--shapes", default="", help="NxK[,NxK...]: these shapes (NF4, blocksize 64, plain statistics) instead of the built-in list")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     print(torch.cuda.get_device_name(0), bnb.lib.bnb_mi355x_version().decode())
@@ -72,6 +73,8 @@ def main():
              (8192, 8192, 64, "nf4", True), (5120, 5120, 128, "nf4", False)]
     if args.quick:
         cases = cases[:3]
+    if args.shapes:
+        cases = [(int(v.split("x")[0]), int(v.split("x")[1]), 64, "nf4", False) for v in args.shapes.split(",")]
     ms = tuple(int(v) for v in args.m.split(","))
     print("# forced sm kernel on odd shapes: relative error against fp32 dequantize + fp64 matmul (bias included)")
     bad = 0
