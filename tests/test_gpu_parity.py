@@ -1476,6 +1476,28 @@ def test_mfma_blocksize_32_exact_on_representable_inputs():
         assert torch.equal(y.float().cpu(), y_ref.to(torch.bfloat16).float()), M
 
 
+def test_blocksize_32_call_with_a_caller_supplied_code_table_runs_the_streaming_kernel():
+    """the blocksize-32 MFMA route accepted calls its BS32 instances then refused - a public C-ABI call
+    with a caller-supplied code table (`code16`) at blocksize 32 printed 'internal error' and ended the process. The route now asks the
+    instances' own preconditions (gemm_4bit_rt_supported) and such a call runs the streaming kernel: any M, kernel = 0 and the forced
+    MFMA request alike, values against the oracle."""
+    import bitsandbytes_amd as bnb
+    from bitsandbytes_amd.backends import hip
+
+    F = _F()
+    N, K = 512, 1024
+    g = torch.Generator().manual_seed(3)
+    W = (torch.randn(N, K, generator=g) / K**0.5).bfloat16()
+    q, st = F.quantize_4bit(W.to(DEV), blocksize=32, quant_type="nf4")
+    code16 = F.get_4bit_type("nf4", device=DEV)
+    for M in (1, 8, 40):
+        x = torch.randn(M, K, generator=g).bfloat16()
+        for kernel in (0, 2):
+            y = hip._gemm_4bit_fused(x.to(DEV), q, st.shape, st.absmax, 32, "nf4", None, None, None, None, kernel=kernel, code16=code16)
+            assert bnb.lib.bnb_mi355x_last_gemm_kernel() == K_STREAM, (M, kernel)
+            assert rel_err(y.cpu(), _oracle_y(x, q, st, None)) < REL_TOL, (M, kernel)
+
+
 # ------------------------------------------------------------------------------------------ streaming MFMA kernel (round 6)
 @pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 7, 8, 9, 13, 16, 17, 33])
 @pytest.mark.parametrize("N,K", [(16, 256), (200, 512), (4100, 512), (5000, 1024), (12345, 768), (20000, 256), (70000, 512), (4097, 8192),
