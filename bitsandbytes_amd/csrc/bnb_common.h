@@ -93,7 +93,7 @@ struct TlsKnob {
 // Which kernel family the calling thread's last gemm_4bit / gemv_4bit call launched (bnb_mi355x_last_gemm_kernel: tests assert
 // that the kernel they name is the kernel that ran - a forced geometry that silently falls back to another family is not
 // coverage). Written by the launchers themselves, at the point of the launch.
-enum GemmKernelId { kKernelNone = 0, kKernelStream = 1, kKernelGeneric = 2, kKernelRt = 3, kKernelPc = 4, kKernelPs = 5, kKernelKq = 6, kKernelSm = 7 };
+enum GemmKernelId { kKernelNone = 0, kKernelStream = 1, kKernelGeneric = 2, kKernelRt = 3, kKernelPc = 4, kKernelPs = 5, kKernelKq = 6, kKernelSm = 7, kKernelTall = 8 };
 extern thread_local int g_last_gemm_kernel;
 
 // ---------------------------------------------------------------------------------------------

@@ -771,6 +771,12 @@ void gemm_4bit_sm(int dtype, const void* A, const uint8_t* B, const float* absma
                   const float* absmax_code, const float* absmax_offset, void* out, const void* bias, int M, int N, int K,
                   int blocksize, int quant_type, int variant, hipStream_t stream);
 
+// gemm4_mfma_tall.hip (128 x 128 tiles, pre-scaled operand decoded once per 128 rows: tall batches)
+bool gemm_4bit_tall_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize);
+void gemm_4bit_tall(int dtype, const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, const float* absmax_code,
+                    const float* absmax_offset, void* out, const void* bias, int M, int N, int K, int blocksize, int quant_type,
+                    int ablate, hipStream_t stream);
+
 // shared with gemm4_mfma_rt.hip: the slab finalize launch and the library-owned workspace
 void gemm_4bit_finalize(int dtype, const float* ws, const void* bias, void* out, int M, int N, int kslices, hipStream_t stream) {
     const long total = static_cast<long>(M) * N;
@@ -934,6 +940,8 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
         return gemm_4bit_rt(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type, workspace,
                             workspace_bytes, 0, 0, 0, stream);
     }
+    if (knob1 / 100 == 60 && gemm_4bit_tall_supported(dtype, A, B, code16, M, N, K, blocksize)) // (tuning knob cfg 60: the tall-tile kernel)
+        return gemm_4bit_tall(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type, knob1 % 100, stream);
     if (sm_selected(M, N, K, knob0, knob1) && gemm_4bit_sm_supported(dtype, A, B, code16, M, N, K, blocksize) && gemm_4bit_sm_serves(absmax, absmax8, blocksize))
         return gemm_4bit_sm(dtype, A, B, absmax, absmax8, absmax_code, absmax_offset, out, bias, M, N, K, blocksize, quant_type, knob0, stream);
     if (K % kKC) // (rows that are not whole 256-k chunks are the streaming MFMA kernel's alone: a call it turned down runs the streaming kernel)

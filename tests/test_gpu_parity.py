@@ -1596,6 +1596,48 @@ def test_mfma_sm_kernel_is_routed_and_deterministic(N, K, dq):
 
 
 
+def test_mfma_tall_tile_experiment_is_correct_and_deterministic():
+    """csrc/gemm4_mfma_tall.hip (round 6, review item 2; reachable with knob cfg 60, NOT routed: 27.6 % of the dense peak against a bar of 40,
+    profiles/r6_tall_tile_experiment.txt): 128 x 128 tiles, the pre-scaled operand T(code * scale) decoded once per 128 rows, LDS-DMA
+    activation ring, hand-counted waits. Kept in the library as the measured starting point of that work - and therefore tested: against
+    the oracle over ragged M / N, several step counts (incl. fewer steps than the ring is deep), nested statistics, FP4, blocksize 64 ... 256,
+    both dtypes, with bias; bit-exact on exactly-representable inputs; bit-reproducible run to run. (K in whole 256-k chunks: the forced MFMA
+    request - kernel = 2 - is only honoured where the MFMA family's own precondition holds.)"""
+    F = _F()
+    K_TALL = 8
+    for (M, N, K, dtype, qt, bs, dq) in ((128, 256, 512, torch.bfloat16, "nf4", 64, False), (300, 200, 1024, torch.float16, "fp4", 128, True),
+                                         (130, 1000, 256, torch.bfloat16, "nf4", 64, True), (1024, 4096, 4096, torch.bfloat16, "nf4", 64, False),
+                                         (257, 384, 768, torch.bfloat16, "fp4", 64, False), (512, 512, 2816, torch.float16, "nf4", 256, False)):
+        g = torch.Generator().manual_seed(M + N + K)
+        W = (torch.randn(N, K, generator=g) / K**0.5).to(dtype)
+        x = torch.randn(M, K, generator=g).to(dtype)
+        bias = torch.randn(N, generator=g).to(dtype)
+        q, st = F.quantize_4bit(W.to(DEV), blocksize=bs, quant_type=qt, compress_statistics=dq)
+        with _forced(6000, K_TALL):
+            y1 = _run_kernel(2, x.to(DEV), q, st, bias.to(DEV))
+            y2 = _run_kernel(2, x.to(DEV), q, st, bias.to(DEV))
+        ref = (x.double().to(DEV) @ F.dequantize_4bit(q, st).double().t() + bias.double().to(DEV))
+        assert float((y1.double() - ref).norm() / ref.norm()) < REL_TOL, (M, N, K)
+        worst = ((y1.double() - ref).norm(dim=1) / ref.norm(dim=1)).max()
+        assert worst < 2 * REL_TOL, (M, N, K, float(worst))
+        assert torch.equal(y1, y2)
+    # exact inputs: small-integer activations, exactly representable FP4 codes, a power-of-two scale per block
+    fp4 = F.get_4bit_type("fp4", device="cpu")
+    allowed = torch.tensor([0, 3, 5, 7, 11, 13, 15])
+    M, N, K = 200, 300, 1024
+    g = torch.Generator().manual_seed(9)
+    idx = allowed[torch.randint(0, len(allowed), (N, K), generator=g)]
+    idx[:, ::64] = 3
+    scale = 2.0 ** torch.randint(-2, 3, (N, K // 64), generator=g)
+    W = (fp4[idx] * scale.repeat_interleave(64, dim=1)).to(torch.bfloat16)
+    x = torch.randint(-4, 5, (M, K), generator=g).to(torch.bfloat16)
+    q, st = F.quantize_4bit(W.to(DEV), blocksize=64, quant_type="fp4")
+    with _forced(6000, K_TALL):
+        y = _run_kernel(2, x.to(DEV), q, st, None)
+    y_ref = (x.double() @ F.dequantize_4bit(q, st).double().cpu().t()).to(torch.bfloat16)
+    assert torch.equal(y.float().cpu(), y_ref.float())
+
+
 # ------------------------------------------------------------------------------------------ callers of dequantize_4bit
 @pytest.mark.parametrize("quant_type", ["nf4", "fp4"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32], ids=["fp16", "bf16", "fp32"])
