@@ -18,7 +18,7 @@ import bitsandbytes_amd.functional as F  # noqa: E402
 from bitsandbytes_amd.backends import hip  # noqa: E402
 
 DEV = "cuda"
-FAMILY = {1: "stream", 2: "generic", 3: "rt", 4: "pc", 6: "kq"}
+FAMILY = {1: "stream", 2: "generic", 3: "rt", 4: "pc", 6: "kq", 7: "sm", 8: "tall"}
 
 
 def main():
@@ -90,7 +90,7 @@ def main():
                 args = (st.shape, st.state2.absmax, 64, "nf4", None, st.absmax, st.state2.code, st.offset)
             else:
                 args = (st.shape, st.absmax, 64, "nf4", None, None, None, None)
-            for knob in (1101, 1202, 1304, 1401, 2000, 2100, 2202, 4000, 4002, 4003):
+            for knob in (1101, 1202, 1304, 1401, 2000, 2100, 2202, 4000, 4002, 4003, 5000, 6000):  # (50: streaming MFMA kernel, row passes above 16 rows; 60: the tall-tile experiment)
                 bnb.lib.bnb_mi355x_set_tuning(0, 0, 0, knob)
                 try:
                     d = repeat(lambda: [hip._gemm_4bit_fused(x, q, *args, kernel=2)], f"forced {knob} {N} x {K} M = {M} nested {int(dq)}")

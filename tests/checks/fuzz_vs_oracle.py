@@ -23,7 +23,7 @@ from conftest import rel_err, same_values_ftz  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 DEV = "cuda"
-FAMILY = {1: "stream", 2: "generic", 3: "rt", 4: "pc", 6: "kq", 0: "unfused"}
+FAMILY = {1: "stream", 2: "generic", 3: "rt", 4: "pc", 6: "kq", 7: "sm", 0: "unfused"}
 
 
 def main():
@@ -52,6 +52,12 @@ def main():
         N = min(rng.choice([1, 7, 16, 96, 130, 200, 256, 384, 1000, 1376, 2048, 4096, rng.randint(1, 3000)]), n_cap)
         if rng.random() < 0.04 and K % 256 == 0:  # a few draws large enough for the K-quarter kernel's range (>= 16 M weights, M >= 17)
             M, N, K = rng.choice([17, 33, 64, 100]), 4096 + 16 * rng.randint(0, 8), max(4096 // bs * bs, bs)
+        if rng.random() < 0.08 and bs >= 64 and dt != torch.float32:
+            # a few draws in the streaming MFMA kernel's range (round 6): 2 ... 16 rows (to 64 where K is not a multiple of 256) on a
+            # matrix of >= 3072 rows, any K % 64 == 0 that the blocksize divides
+            N = 3072 + rng.randint(0, 1200)
+            K = max(bs, 64) * rng.randint(1, max(1, 3072 // max(bs, 64)))
+            M = rng.choice([2, 3, 4, 5, 8, 9, 13, 16]) if K % 256 == 0 else rng.choice([2, 7, 16, 17, 40, 64])
         bias = rng.random() < 0.4
         label = f"draw {d}: M {M} N {N} K {K} bs {bs} {qt} {str(dt)[6:]} nested {int(dq)} bias {int(bias)}"
         try:

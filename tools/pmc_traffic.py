@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     for fam in ("gemm4_finalize_kq_kernel", "gemm4_finalize_kernel", "gemm4_mfma_kq_kernel", "gemm4_mfma_pc_kernel", "gemm4_mfma_rt_kernel",
+                "gemm4_mfma_sm_kernel", "gemm4_mfma_tall_kernel",
                 "gemv4_stream_kernel", "dequantize4_kernel", "quantize4_kernel"):
         if fam in name:
             return fam
