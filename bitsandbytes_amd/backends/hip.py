@@ -139,7 +139,7 @@ def _(A: torch.Tensor, code8: torch.Tensor, blocksize: int, quant_type: str, qua
         raise ValueError("quantize_4bit_nested: empty input")
     blocks = -(n // -blocksize)
     out = torch.empty(((n + 1) // (quant_storage.itemsize * 2), 1), device=A.device, dtype=quant_storage)
-    scratch = torch.empty((blocks + 256,), device=A.device, dtype=torch.float32)
+    scratch = torch.empty((blocks + 1536,), device=A.device, dtype=torch.float32)  # include/bnb_mi355x.h: absmax, partial sums, encoder tables
     absmax_8bit = torch.empty((blocks,), device=A.device, dtype=torch.uint8)
     absmax2 = torch.empty((-(blocks // -256),), device=A.device, dtype=torch.float32)
     offset = torch.empty((), device=A.device, dtype=torch.float32)

@@ -99,6 +99,39 @@ __device__ __forceinline__ float workgroup_sum_256(float v, float* slots /* [4] 
     return (slots[0] + slots[1]) + (slots[2] + slots[3]);
 }
 
+// The encoder's two tables from the 256-entry code (256-thread workgroup; ends with a barrier). thr[i] = T_i = the first 16-bit bin
+// whose value lies above the mid-point of code[i] and code[i + 1] (thr[255] = 65536); cell[c], c = bin >> 6: bits 0-7 thresholds
+// below the cell, bits 8-15 thresholds inside it, bits 16-21 offset of the first one inside (what the common single-threshold case
+// compares against).
+__device__ __forceinline__ void build_cell_tables(const float* __restrict__ code, uint32_t* thr /* [256] LDS */, uint32_t* cell /* [1024] LDS */) {
+    __shared__ float mid[256];
+    __shared__ uint8_t below_s[1025];
+    const int tid = threadIdx.x;
+    mid[tid] = (tid < 255) ? 0.5f * (code[tid] + code[tid + 1]) : __builtin_inff();
+    __syncthreads();
+    thr[tid] = first_bin_above(mid[tid]);
+    __syncthreads();
+    for (int c = tid; c < 1025; c += 256) {
+        // thresholds below bin 64c, by binary search over the ascending thr[0..254]
+        const unsigned first = static_cast<unsigned>(c) * 64u;
+        int below = 0;
+#pragma unroll
+        for (int step = 128; step >= 1; step >>= 1)
+            below += (below + step - 1 < 255 && thr[below + step - 1] < first) ? step : 0;
+        below_s[c] = static_cast<uint8_t>(below);
+    }
+    __syncthreads();
+    for (int c = tid; c < 1024; c += 256) {
+        const int below = below_s[c];
+        const int inside = static_cast<int>(below_s[c + 1]) - below;
+        const unsigned off = (inside > 0) ? (thr[below] - static_cast<unsigned>(c) * 64u) : 0u;
+        cell[c] = static_cast<uint32_t>(below) | (static_cast<uint32_t>(inside) << 8) | (off << 16);
+    }
+    __syncthreads();
+}
+
+constexpr int kQ8TableWords = 256 + 1024; // thr[256] then cell[1024]: what the partial-sum launch leaves for the nested encoder
+
 constexpr int kSumChunk = 1024;   // elements per workgroup step of the partial-sum kernel: 4 per thread
 constexpr int kSumPartials = 256; // at most this many partial sums, whatever the length
 
@@ -106,7 +139,21 @@ constexpr int kSumPartials = 256; // at most this many partial sums, whatever th
 // offset = absmax.mean()). Workgroup c adds elements [c * 1024 * steps, (c + 1) * 1024 * steps): every step of 1024 elements as a
 // balanced binary tree in index order (zeros past the end), the steps one after the other. partial[c] is one float; the consumer
 // (quantize8_kernel<float, 256, true>) adds the <= 256 partials as one more balanced tree and divides by n.
-__global__ __launch_bounds__(256) void absmax_partial_sums_kernel(const float* __restrict__ A, float* __restrict__ partial, long n, int steps) {
+//
+// One workgroup more than there are chunks: the last one builds the 8-bit encoder's threshold / cell tables from the code and leaves
+// them in `tables` (kQ8TableWords dwords) - once per call instead of once per encoder workgroup, and beside the sums, not after them.
+__global__ __launch_bounds__(256) void absmax_partial_sums_kernel(const float* __restrict__ A, float* __restrict__ partial, long n, int steps,
+                                                                  const float* __restrict__ code, uint32_t* __restrict__ tables) {
+    if (blockIdx.x == gridDim.x - 1) {
+        __shared__ uint32_t thr[256];
+        __shared__ uint32_t cell[1024];
+        build_cell_tables(code, thr, cell);
+        tables[threadIdx.x] = thr[threadIdx.x];
+#pragma unroll
+        for (int c = threadIdx.x; c < 1024; c += 256)
+            tables[256 + c] = cell[c];
+        return;
+    }
     __shared__ float slots[4];
     const long begin = static_cast<long>(blockIdx.x) * kSumChunk * steps + threadIdx.x * 4;
     const bool vec_ok = (reinterpret_cast<uintptr_t>(A) & 15u) == 0;
@@ -139,43 +186,34 @@ template <typename T, int BS, bool SHIFT = false>
 __global__ __launch_bounds__(256) void quantize8_kernel(const float* __restrict__ code, const T* __restrict__ A,
                                                         float* __restrict__ absmax, uint8_t* __restrict__ out, long n,
                                                         int vec_ok, const float* __restrict__ partial = nullptr, int n_partial = 0,
-                                                        float* __restrict__ offset_out = nullptr) {
+                                                        float* __restrict__ offset_out = nullptr, const uint32_t* __restrict__ tables = nullptr) {
     float shift = 0.0f;
+    [[maybe_unused]] uint32_t t_thr = 0, t_cell[4] = {0, 0, 0, 0};
     if constexpr (SHIFT) {
+        // (requested before the sum of the partials, used after it)
+        t_thr = tables[threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            t_cell[j] = tables[256 + j * 256 + threadIdx.x];
         __shared__ float slots[4];
         const float total = workgroup_sum_256(static_cast<int>(threadIdx.x) < n_partial ? partial[threadIdx.x] : 0.0f, slots);
         shift = total / static_cast<float>(n); // IEEE division
         if (blockIdx.x == 0 && threadIdx.x == 0)
             *offset_out = shift;
     }
-    __shared__ float mid[256];
     __shared__ uint32_t thr[256];   // T_i, ascending; thr[255] = 65536
-    __shared__ uint32_t cell[1024]; // see the table build below
+    __shared__ uint32_t cell[1024]; // see build_cell_tables
     const int tid = threadIdx.x;
-    mid[tid] = (tid < 255) ? 0.5f * (code[tid] + code[tid + 1]) : __builtin_inff();
-    __syncthreads();
-    thr[tid] = first_bin_above(mid[tid]);
-    __syncthreads();
-    __shared__ uint8_t below_s[1025];
-    for (int c = tid; c < 1025; c += 256) {
-        // thresholds below bin 64c, by binary search over the ascending thr[0..254]
-        const unsigned first = static_cast<unsigned>(c) * 64u;
-        int below = 0;
+    if constexpr (SHIFT) {
+        // double quantisation: the tables were built once, by the extra workgroup of the partial-sum launch
+        thr[tid] = t_thr;
 #pragma unroll
-        for (int step = 128; step >= 1; step >>= 1)
-            below += (below + step - 1 < 255 && thr[below + step - 1] < first) ? step : 0;
-        below_s[c] = static_cast<uint8_t>(below);
+        for (int j = 0; j < 4; ++j)
+            cell[j * 256 + tid] = t_cell[j];
+        __syncthreads();
+    } else {
+        build_cell_tables(code, thr, cell);
     }
-    __syncthreads();
-    for (int c = tid; c < 1024; c += 256) {
-        // bits 0-7: thresholds below the cell; bits 8-15: thresholds inside the cell; bits 16-21: offset of the
-        // first one inside the cell (what the common single-threshold case compares against)
-        const int below = below_s[c];
-        const int inside = static_cast<int>(below_s[c + 1]) - below;
-        const unsigned off = (inside > 0) ? (thr[below] - static_cast<unsigned>(c) * 64u) : 0u;
-        cell[c] = static_cast<uint32_t>(below) | (static_cast<uint32_t>(inside) << 8) | (off << 16);
-    }
-    __syncthreads();
 
     const int lane = tid & 63;
     const long wave_global = static_cast<long>(blockIdx.x) * 4 + (tid >> 6);
@@ -550,7 +588,8 @@ void launch_dequantize8(const float* code, const uint8_t* A, const float* absmax
 
 // Double quantisation's statistics in two launches (reference bitsandbytes/functional.py:938-951 is mean, subtract, quantize_blockwise
 // with blocksize 256: three to five launches and as many host dispatches): partial sums, then the shifted encoder. absmax: the fp32
-// absmax vector of the 4-bit blocks (n values, device); partial: scratch of 256 floats; offset_out: 1 float; out: n codes;
+// absmax vector of the 4-bit blocks (n values, device); partial: scratch of 256 + 1280 floats (the partial sums, then the encoder's
+// tables); offset_out: 1 float; out: n codes;
 // absmax2: ceil(n / 256) floats.
 void quantize_absmax_nested(const float* code, const float* absmax, long n, float* partial, float* offset_out, uint8_t* out,
                             float* absmax2, hipStream_t stream) {
@@ -559,7 +598,8 @@ void quantize_absmax_nested(const float* code, const float* absmax, long n, floa
     const long per = static_cast<long>(kSumChunk) * kSumPartials;
     const int steps = static_cast<int>((n + per - 1) / per);
     const int chunks = static_cast<int>((n + static_cast<long>(kSumChunk) * steps - 1) / (static_cast<long>(kSumChunk) * steps));
-    hipLaunchKernelGGL(absmax_partial_sums_kernel, dim3(static_cast<unsigned>(chunks)), dim3(256), 0, stream, absmax, partial, n, steps);
+    uint32_t* const tables = reinterpret_cast<uint32_t*>(partial + kSumPartials);
+    hipLaunchKernelGGL(absmax_partial_sums_kernel, dim3(static_cast<unsigned>(chunks + 1)), dim3(256), 0, stream, absmax, partial, n, steps, code, tables);
     BNB_CHECK_LAUNCH();
     const int vec_ok = aligned_to(absmax, 16) && aligned_to(out, 4);
     const long units = (n + 255) / 256;
@@ -567,7 +607,7 @@ void quantize_absmax_nested(const float* code, const float* absmax, long n, floa
     if (grid > 2048)
         grid = 2048;
     hipLaunchKernelGGL((quantize8_kernel<float, 256, true>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, stream, code, absmax, absmax2,
-                       out, n, vec_ok, partial, chunks, offset_out);
+                       out, n, vec_ok, partial, chunks, offset_out, tables);
     BNB_CHECK_LAUNCH();
 }
 

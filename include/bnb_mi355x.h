@@ -108,8 +108,8 @@ void bnb_mi355x_quantize_8bit(const float* code, const void* A, int dtype, float
 
 /* quantize_4bit(compress_statistics=True) as ONE call (reference bitsandbytes/functional.py:925-951: quantize_4bit, absmax.mean(),
  * absmax - offset, quantize_blockwise(..., blocksize=256) - four to six launches and host dispatches; here three launches behind one).
- * A: n elements of dtype; out: (n + 1) / 2 packed bytes; scratch: device buffer of ceil(n / blocksize) + 256 floats (the fp32 absmax of
- * the 4-bit blocks, then 256 partial sums; contents are unspecified afterwards); code8: the 256-entry 8-bit code (fp32, device, ascending:
+ * A: n elements of dtype; out: (n + 1) / 2 packed bytes; scratch: device buffer of ceil(n / blocksize) + 1536 floats (the fp32 absmax of
+ * the 4-bit blocks, then 256 partial sums, then 1280 dwords of encoder tables built once per call; contents are unspecified afterwards); code8: the 256-entry 8-bit code (fp32, device, ascending:
  * the dynamic map); absmax_8bit: ceil(n / blocksize) codes; absmax2: ceil(ceil(n / blocksize) / 256) floats; offset: 1 float =
  * the mean of the fp32 absmax, summed in a FIXED order (a balanced binary tree over 1024-element steps, see csrc/blockwise8.hip:
  * the same bits on every launch, any device). absmax_8bit / absmax2 are bit for bit what quantize_blockwise gives on absmax - offset. */

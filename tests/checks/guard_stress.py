@@ -110,7 +110,7 @@ def main():
               and torch.equal(read(c_am, torch.int32, blocks), am_ref.view(torch.int32)), label)
         # nested: one call
         _, st = F.quantize_4bit(X, blocksize=bs, quant_type=qt, compress_statistics=True)
-        c_q2, c_scr = carve_out((n + 1) // 2, rng, 1), carve_out((blocks + 256) * 4, rng, 4)
+        c_q2, c_scr = carve_out((n + 1) // 2, rng, 1), carve_out((blocks + 1536) * 4, rng, 4)
         c_a8, c_a2, c_off = carve_out(blocks, rng, 1), carve_out(-(blocks // -256) * 4, rng, 4), carve_out(4, rng, 4)
         c_code = carve_in(code8, rng)
         lib.bnb_mi355x_quantize_4bit_nested(cx.ptr(), DT_CODE[dt], n, bs, QT_CODE[qt], c_q2.ptr(), c_scr.ptr(), c_code.ptr(), c_a8.ptr(),

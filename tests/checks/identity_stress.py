@@ -64,7 +64,7 @@ def main():
                             # kernel - another summation order and 16-bit code values: the matmul tolerance, not the bits)
                             assert M == 2, (M, fam_full)
                             ref = y[:, r * ns:(r + 1) * ns].float()
-                            bad += 0 if float((ys.float() - ref).norm() / ref.norm()) < 1e-2 else 1
+                            bad += 0 if float((ys.detach().float() - ref).norm() / ref.norm()) < 1e-2 else 1
     report("row shards (world 2/4/8) == rows of the unsharded layer, M = 1 (bits), 2 (bits where both ran the streaming kernel)", n, bad)
 
     # 2. grouped launch
