@@ -104,28 +104,48 @@ __device__ __forceinline__ float workgroup_sum_256(float v, float* slots /* [4] 
 // below the cell, bits 8-15 thresholds inside it, bits 16-21 offset of the first one inside (what the common single-threshold case
 // compares against).
 __device__ __forceinline__ void build_cell_tables(const float* __restrict__ code, uint32_t* thr /* [256] LDS */, uint32_t* cell /* [1024] LDS */) {
-    __shared__ float mid[256];
-    __shared__ uint8_t below_s[1025];
+    // below[c] = #{i < 255 : T_i < 64 c}, c = 0 .. 1024, as a prefix sum: a threshold T counts from cell (T >> 6) + 1 on, so mark it
+    // there (LDS atomic: thresholds may share a cell) and scan. (A binary search per cell was 40 dependent LDS reads per thread:
+    // ~1.7 us on the critical path of every launch.) cnt[0] stays 0; T = 65536 - no bin above the mid-point - lands in the spare slot.
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[1028];
+    __shared__ uint32_t wave_tot[4];
     const int tid = threadIdx.x;
-    mid[tid] = (tid < 255) ? 0.5f * (code[tid] + code[tid + 1]) : __builtin_inff();
-    __syncthreads();
-    thr[tid] = first_bin_above(mid[tid]);
-    __syncthreads();
-    for (int c = tid; c < 1025; c += 256) {
-        // thresholds below bin 64c, by binary search over the ascending thr[0..254]
-        const unsigned first = static_cast<unsigned>(c) * 64u;
-        int below = 0;
+    const float lo = code[tid], hi = (tid < 255) ? code[tid + 1] : 0.0f;
 #pragma unroll
-        for (int step = 128; step >= 1; step >>= 1)
-            below += (below + step - 1 < 255 && thr[below + step - 1] < first) ? step : 0;
-        below_s[c] = static_cast<uint8_t>(below);
-    }
+    for (int c = tid; c < 1028; c += 256)
+        cnt[c] = 0u;
+    const unsigned t = first_bin_above((tid < 255) ? 0.5f * (lo + hi) : __builtin_inff());
+    thr[tid] = t;
     __syncthreads();
-    for (int c = tid; c < 1024; c += 256) {
-        const int below = below_s[c];
-        const int inside = static_cast<int>(below_s[c + 1]) - below;
-        const unsigned off = (inside > 0) ? (thr[below] - static_cast<unsigned>(c) * 64u) : 0u;
-        cell[c] = static_cast<uint32_t>(below) | (static_cast<uint32_t>(inside) << 8) | (off << 16);
+    if (tid < 255)
+        atomicAdd(&cnt[(t >> 6) + 1u], 1u);
+    __syncthreads();
+    // thread tid owns c = 4 tid + 1 .. 4 tid + 4
+    const u32x4_t mine = *reinterpret_cast<const u32x4_t*>(&cnt[4 * tid]); // cnt[4 tid .. 4 tid + 3]
+    const uint32_t last = cnt[4 * tid + 4];
+    const unsigned own[4] = {mine[1], mine[2], mine[3], last};
+    const unsigned sum = own[0] + own[1] + own[2] + own[3];
+    unsigned incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(incl, off, 64);
+        incl += ((tid & 63) >= off) ? o : 0u;
+    }
+    if ((tid & 63) == 63)
+        wave_tot[tid >> 6] = incl;
+    __syncthreads();
+    unsigned run = incl - sum; // thresholds below cell 4 tid (= below[4 tid]: cnt[0 .. 4 tid] summed)
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+        run += (w < (tid >> 6)) ? wave_tot[w] : 0u;
+    // cell c = 4 tid + j: below[c] = run + own[0 .. j - 1], inside = below[c + 1] - below[c] = own[j]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned c = 4u * tid + j;
+        const unsigned below = run, inside = own[j];
+        const unsigned off = (inside > 0u) ? (thr[below] - c * 64u) : 0u;
+        cell[c] = below | (inside << 8) | (off << 16);
+        run += inside;
     }
     __syncthreads();
 }
@@ -144,7 +164,7 @@ constexpr int kSumPartials = 256; // at most this many partial sums, whatever th
 // them in `tables` (kQ8TableWords dwords) - once per call instead of once per encoder workgroup, and beside the sums, not after them.
 __global__ __launch_bounds__(256) void absmax_partial_sums_kernel(const float* __restrict__ A, float* __restrict__ partial, long n, int steps,
                                                                   const float* __restrict__ code, uint32_t* __restrict__ tables) {
-    if (blockIdx.x == gridDim.x - 1) {
+    if (tables != nullptr && blockIdx.x == gridDim.x - 1) {
         __shared__ uint32_t thr[256];
         __shared__ uint32_t cell[1024];
         build_cell_tables(code, thr, cell);
@@ -189,12 +209,15 @@ __global__ __launch_bounds__(256) void quantize8_kernel(const float* __restrict_
                                                         float* __restrict__ offset_out = nullptr, const uint32_t* __restrict__ tables = nullptr) {
     float shift = 0.0f;
     [[maybe_unused]] uint32_t t_thr = 0, t_cell[4] = {0, 0, 0, 0};
-    if constexpr (SHIFT) {
+    const bool shared_tables = SHIFT && tables != nullptr; // (nullptr: tuning knob reserved0 = 9, the per-workgroup build, for A/B)
+    if (shared_tables) {
         // (requested before the sum of the partials, used after it)
         t_thr = tables[threadIdx.x];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             t_cell[j] = tables[256 + j * 256 + threadIdx.x];
+    }
+    if constexpr (SHIFT) {
         __shared__ float slots[4];
         const float total = workgroup_sum_256(static_cast<int>(threadIdx.x) < n_partial ? partial[threadIdx.x] : 0.0f, slots);
         shift = total / static_cast<float>(n); // IEEE division
@@ -204,7 +227,7 @@ __global__ __launch_bounds__(256) void quantize8_kernel(const float* __restrict_
     __shared__ uint32_t thr[256];   // T_i, ascending; thr[255] = 65536
     __shared__ uint32_t cell[1024]; // see build_cell_tables
     const int tid = threadIdx.x;
-    if constexpr (SHIFT) {
+    if (shared_tables) {
         // double quantisation: the tables were built once, by the extra workgroup of the partial-sum launch
         thr[tid] = t_thr;
 #pragma unroll
@@ -598,8 +621,9 @@ void quantize_absmax_nested(const float* code, const float* absmax, long n, floa
     const long per = static_cast<long>(kSumChunk) * kSumPartials;
     const int steps = static_cast<int>((n + per - 1) / per);
     const int chunks = static_cast<int>((n + static_cast<long>(kSumChunk) * steps - 1) / (static_cast<long>(kSumChunk) * steps));
-    uint32_t* const tables = reinterpret_cast<uint32_t*>(partial + kSumPartials);
-    hipLaunchKernelGGL(absmax_partial_sums_kernel, dim3(static_cast<unsigned>(chunks + 1)), dim3(256), 0, stream, absmax, partial, n, steps, code, tables);
+    uint32_t* const tables = g_q8_variant.load(std::memory_order_relaxed) == 9 ? nullptr : reinterpret_cast<uint32_t*>(partial + kSumPartials);
+    static_assert(kQ8TableWords == 1280, "include/bnb_mi355x.h: scratch of blocks + 256 + 1280 floats");
+    hipLaunchKernelGGL(absmax_partial_sums_kernel, dim3(static_cast<unsigned>(chunks + (tables != nullptr ? 1 : 0))), dim3(256), 0, stream, absmax, partial, n, steps, code, tables);
     BNB_CHECK_LAUNCH();
     const int vec_ok = aligned_to(absmax, 16) && aligned_to(out, 4);
     const long units = (n + 255) / 256;
