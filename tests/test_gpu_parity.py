@@ -1534,6 +1534,33 @@ def test_mfma_sm_kernel_geometries(M, N, K):
         assert worst < 2 * REL_TOL, (dtype, qt, bs, dq, float(worst))
 
 
+def test_mfma_sm_kernel_large_blocksizes_and_blocks_that_span_rows():
+    """Quantization blocks are blocks of the FLAT weight tensor (reference functional.py:925-936): with K % blocksize != 0 a block
+    ends in one row and continues in the next, with blocksize > K one block covers several rows. The Python route sends such calls to
+    dequantize + linear as the reference does (backends/cuda/ops.py:956-962), the C ABI takes them: the streaming MFMA kernel indexes
+    the statistics by flat 64-k group, so every blocksize from 64 to 4096 and every K % 64 == 0 is the same code path. Forced and
+    routed, fp32 and nested statistics, against the oracle."""
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    for (N, K, bs) in ((3200, 192, 128), (3200, 320, 256), (3072, 64, 4096), (4096, 1088, 2048), (3328, 8192, 4096), (3200, 4096, 1024), (200, 704, 512)):
+        assert (N * K) % bs == 0
+        for dq in (False, True):
+            g = torch.Generator().manual_seed(N + K + bs)
+            W = (torch.randn(N, K, generator=g) / K**0.5).to(torch.bfloat16)
+            q, st = F.quantize_4bit(W.to(DEV), blocksize=bs, quant_type="nf4", compress_statistics=dq)
+            for M in (2, 7, 16):
+                x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+                y_ref = _oracle_y_full(x, q, st)
+                with _forced(5000, K_SM):
+                    y = _run_kernel(2, x.to(DEV), q, st)
+                assert rel_err(y.cpu(), y_ref) < REL_TOL, (N, K, bs, dq, M)
+                y0 = _run_kernel(0, x.to(DEV), q, st)  # the library's own route
+                if N >= 3072 and M <= 8:
+                    assert bnb.lib.bnb_mi355x_last_gemm_kernel() == K_SM, (N, K, bs, M)
+                assert rel_err(y0.cpu(), y_ref) < REL_TOL, (N, K, bs, dq, M)
+
+
 def test_mfma_sm_kernel_exact_on_representable_inputs():
     """Small-integer activations, exactly representable FP4 codes and a different power-of-two scale per 64-k block: every product
     and partial sum is exact in fp32, so the streaming MFMA kernel equals the oracle bit for bit - for every staged-row count, for
