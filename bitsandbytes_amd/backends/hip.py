@@ -48,7 +48,8 @@ STREAM_ONLY_MAX_M = 16
 # (profiles/r6_sm_ktail_ab.txt): 4096 x 2752 M = 32 / 64 / 96 / 128 8.9 / 15.6 / 22.2 / 28.9 vs 25.5 / 29.4 / 36.2 / 36.5; 11008 x 1344 10.8 /
 # 20.2 / 29.4 / 38.6 vs 29.4 / 30.5 / 29.8 / 29.3; 8192 x 2752 12.0 / 21.7 / 31.3 / 41.0 vs 37.9 / 44.0 / 44.5 / 44.2: ahead up to 64 rows.
 SM_TAIL_MAX_M = 64
-SM_MIN_ROWS = 3072  # 12 x 256 CUs (csrc/gemm4_mfma.hip: sm_selected)
+SM_MIN_ROWS = 128  # (csrc/gemm4_mfma.hip: sm_selected / kSmMinRows; small matrices, profiles/r6_sm_small_n_ab.txt: 1376 x 2752 M = 16 / 64 4.5 / 8.1 us
+# against 16.2 / 56.6 for the streaming kernel's passes)
 # Blocksize 32 (plain statistics) runs the register-transposed kernel's BS32 instances, 64-row passes one after the other: 4096^2
 # fused vs unfused 11.5 vs 28.9 us at 64 rows, 21.0 vs 37.5 at 128, 39.1 vs 33.1 at 256, 75 vs 40 at 512 (profiles/r5_tall_small_ab.txt, table 3).
 FUSED_MAX_M_BS32 = 128
@@ -496,8 +497,8 @@ def _(grad_out, B, shapeB: Sequence[int], absmax, blocksize: int, quant_type: st
 
 def gemm_4bit_grouped(A: torch.Tensor, mats, blocksize: int, quant_type: str, outs=None):
     """``[A @ dequant(B_i).T (+ bias_i) for i]`` for several packed weights that share the activations, in ONE launch
-    of the streaming kernel when M <= 4 (``bnb_mi355x_gemm_4bit_grouped``; larger M and odd shapes are issued matrix
-    by matrix inside the library). ``mats``: sequence of ``(B, shapeB, absmax, bias, absmax_8bit, absmax_code,
+    (``bnb_mi355x_gemm_4bit_grouped``): of the streaming MFMA kernel at 2 ... 16 rows, of the streaming kernel at M <= 4 where
+    that is the members' own route; other groups are issued matrix by matrix. ``mats``: sequence of ``(B, shapeB, absmax, bias, absmax_8bit, absmax_code,
     absmax_offset)`` with the argument meaning of the ``gemm_4bit`` op; all matrices share K, blocksize, quant_type
     and nested-ness. Results are bit-identical to separate ``gemm_4bit`` calls. ``outs``: optional pre-allocated contiguous
     ``[*, N_i]`` result tensors (e.g. slices of one communication buffer); they are returned."""
@@ -513,11 +514,14 @@ def gemm_4bit_grouped(A: torch.Tensor, mats, blocksize: int, quant_type: str, ou
     if count == 0:
         return []
     nested = mats[0][4] is not None
-    to_mfma = M >= 3 and any(lib.bnb_mi355x_gemm_4bit_route(0, _DT_CODE[A.dtype], M, int(m[1][0]), K, blocksize) for m in mats)
-    if K % blocksize != 0 or M > 4 or count > 8 or to_mfma:
-        # outside the grouped kernel's range - or a member that the single-matrix op hands to the MFMA kernels (three or four
-        # rows on a big matrix: other arithmetic, and faster there): the single-matrix op (its own routing, its own split-K
-        # workspace from torch's allocator)
+    one_launch = False
+    if K % blocksize == 0 and 0 < count <= 8 and M > 0:
+        ns = (ct.c_int * count)(*[int(m[1][0]) for m in mats])
+        one_launch = lib.bnb_mi355x_gemm_4bit_grouped_route(_DT_CODE[A.dtype], count, ns, M, K, blocksize) != 0
+    if not one_launch:
+        # not a group the library serves with one launch (a member that the single-matrix op hands to another MFMA kernel: other
+        # arithmetic, and faster there; more than 16 rows; more than 8 matrices): the single-matrix op (its own routing, its own
+        # split-K workspace from torch's allocator)
         res = [torch.ops.bitsandbytes.gemm_4bit.default(A, B, shapeB, absmax, blocksize, quant_type, bias, a8, ac, ao)
                for (B, shapeB, absmax, bias, a8, ac, ao) in mats]
         if outs is None:

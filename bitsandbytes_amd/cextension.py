@@ -78,6 +78,7 @@ def _declare(dll: ct.CDLL) -> None:
     sig(["bnb_mi355x_last_gemm_kernel"], [], _I32)
     # (dtype, A, count, B[], absmax[], absmax_8bit[], absmax_code[], absmax_offset[], out[], bias[], N[], M, K, blocksize, quant_type, stream)
     sig(["bnb_mi355x_gemm_4bit_grouped"], [_I32, _VOID_P, _I32] + [_VOID_P] * 8 + [_I32] * 4 + [_VOID_P])
+    sig(["bnb_mi355x_gemm_4bit_grouped_route"], [_I32, _I32, _VOID_P, _I32, _I32, _I32], _I32)  # (dtype, count, N[], M, K, blocksize)
     # (dtype, grad_out, B, absmax, absmax_8bit, absmax_code, absmax_offset, grad_A, M, N, K, blocksize, quant_type, ws, ws_bytes, stream)
     sig(["bnb_mi355x_gemm_4bit_grad_input"], [_I32] + [_VOID_P] * 7 + [_I32] * 5 + [_VOID_P, ct.c_size_t, _VOID_P])
     sig(["bnb_mi355x_gemm_4bit_grad_input_workspace_bytes"], [_I32] * 3, ct.c_size_t)
@@ -129,7 +130,7 @@ EXPORTED_SYMBOLS = tuple(
     + [f"cgemm_4bit_inference_naive_{d}" for d in ("fp32", "bf16", "fp16")]
     + ["get_context", "cget_managed_ptr", "bnb_mi355x_quantize_4bit", "bnb_mi355x_quantize_8bit", "bnb_mi355x_quantize_4bit_nested", "bnb_mi355x_dequantize_4bit_nested", "bnb_mi355x_dequantize_4bit_rows",
        "bnb_mi355x_gemm_4bit", "bnb_mi355x_gemm_4bit_workspace_bytes", "bnb_mi355x_gemm_4bit_route", "bnb_mi355x_last_gemm_kernel",
-       "bnb_mi355x_gemm_4bit_grouped",
+       "bnb_mi355x_gemm_4bit_grouped", "bnb_mi355x_gemm_4bit_grouped_route",
        "bnb_mi355x_gemm_4bit_grad_input", "bnb_mi355x_gemm_4bit_grad_input_workspace_bytes", "bnb_mi355x_gemm_4bit_grad_input_supported",
        "bnb_mi355x_peer_buffer_bytes", "bnb_mi355x_peer_alloc", "bnb_mi355x_peer_free", "bnb_mi355x_peer_export", "bnb_mi355x_peer_open",
        "bnb_mi355x_peer_close", "bnb_mi355x_peer_allgather", "bnb_mi355x_peer_status",

@@ -52,6 +52,10 @@ void gemm_4bit_mfma(int dtype, const void* A, const uint8_t* B, const float* abs
 size_t gemm_4bit_mfma_workspace_bytes(int M, int N, int K, int blocksize);
 bool gemm_4bit_sm_routes(int dtype, int M, int N, int K, int blocksize);
 bool gemm_4bit_sm_supported(int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize);
+bool gemm_4bit_sm_grouped(int dtype, const void* A, int count, const uint8_t* const* B, const float* const* absmax,
+                          const uint8_t* const* absmax8, const float* const* absmax_code, const float* const* absmax_offset,
+                          void* const* out, const void* const* bias, const int* N, int M, int K, int blocksize, int quant_type,
+                          hipStream_t stream);
 extern thread_local TlsKnob g_mfma_knob0, g_mfma_knob1;
 // gemm4_grad_input.hip
 bool gemm_4bit_grad_input_supported(int dtype, const void* G, const uint8_t* B, int M, int N, int K, int blocksize);
@@ -78,8 +82,8 @@ constexpr int kStreamMaxM = 4;
 bool route_to_mfma(int kernel, int dtype, const void* A, const uint8_t* B, const float* code16, int M, int N, int K, int blocksize, bool plain_absmax) {
     if (kernel == 1 || kernel == 3)
         return false;
-    // the streaming MFMA kernel's own reach: 2 ... 16 rows on matrices of >= 3072 rows, any K % 64 == 0 (the other MFMA kernels
-    // need whole 256-k chunks) - round 6
+    // the streaming MFMA kernel's own reach: 2 ... 16 rows on matrices of >= 128 rows (csrc/gemm4_mfma.hip: sm_selected has the
+    // measured exceptions), any K % 64 == 0 (the other MFMA kernels need whole 256-k chunks) - round 6
     const bool sm = gemm_4bit_sm_routes(dtype, M, N, K, blocksize) && gemm_4bit_sm_supported(dtype, A, B, code16, M, N, K, blocksize);
     if (kernel == 2)
         return sm || gemm_4bit_mfma_supported(dtype, A, B, code16, M, N, K, blocksize, plain_absmax);
@@ -302,12 +306,20 @@ void bnb_mi355x_gemm_4bit_grouped(int dtype, const void* A, int count, const uin
         fprintf(stderr, "bitsandbytes_amd: gemm_4bit_grouped: quant_type must be 1 (FP4) or 2 (NF4), got %d\n", quant_type);
         exit(1);
     }
-    // "bit-identical to separate calls": a matrix that the single-matrix entry point would hand to the MFMA kernels (three or
-    // four rows on a big matrix) must not run the streaming kernel's arithmetic here - then the whole group goes matrix by matrix
-    bool any_mfma = false;
-    for (int i = 0; i < count; ++i)
+    // "bit-identical to separate calls": every member runs the kernel FAMILY the single-matrix entry point would give it.
+    //  * every member routed to the streaming MFMA kernel (2 ... 16 rows, csrc/gemm4_mfma.hip: sm_selected): ONE launch of that
+    //    kernel over the members' rows (its summation order does not depend on the launch geometry) - round 6;
+    //  * no member routed to an MFMA kernel: ONE launch of the streaming kernel (M <= 4);
+    //  * anything else (mixed routes, M > 16, more than 8 matrices, odd K ...): matrix by matrix.
+    bool any_mfma = false, all_sm = count <= 8;
+    for (int i = 0; i < count; ++i) {
         any_mfma = any_mfma || route_to_mfma(0, dtype, A, B[i], nullptr, M, N[i], K, blocksize,
                                              (absmax_8bit == nullptr || absmax_8bit[i] == nullptr) && aligned_to(absmax[i], 16));
+        all_sm = all_sm && gemm_4bit_sm_routes(dtype, M, N[i], K, blocksize);
+    }
+    if (all_sm && gemm_4bit_sm_grouped(dtype, A, count, B, absmax, absmax_8bit, absmax_code, absmax_offset, out, bias, N, M, K, blocksize,
+                                       quant_type, S(s)))
+        return;
     if (!any_mfma && gemv_4bit_grouped(dtype, A, count, B, absmax, absmax_8bit, absmax_code, absmax_offset, out, bias, N, M, K,
                                        blocksize, quant_type, S(s)))
         return;
@@ -316,6 +328,23 @@ void bnb_mi355x_gemm_4bit_grouped(int dtype, const void* A, int count, const uin
         gemm_4bit_dispatch(0, dtype, A, B[i], absmax[i], absmax_8bit ? absmax_8bit[i] : nullptr,
                            absmax_code ? absmax_code[i] : nullptr, absmax_offset ? absmax_offset[i] : nullptr, nullptr, out[i],
                            bias ? bias[i] : nullptr, M, N[i], K, blocksize, quant_type, nullptr, 0, S(s));
+}
+int bnb_mi355x_gemm_4bit_grouped_route(int dtype, int count, const int* N, int M, int K, int blocksize) {
+    // what bnb_mi355x_gemm_4bit_grouped does with such a group, assuming aligned pointers and members of one kind of statistics:
+    // 2 = one launch of the streaming MFMA kernel, 1 = one launch of the streaming kernel, 0 = matrix by matrix
+    static const int dummy_aligned[4] __attribute__((aligned(16))) = {0, 0, 0, 0};
+    const void* a = dummy_aligned;
+    if (count <= 0 || count > 8 || M <= 0 || blocksize <= 0 || K % blocksize != 0)
+        return 0;
+    bool any_mfma = false, all_sm = true;
+    for (int i = 0; i < count; ++i) {
+        any_mfma = any_mfma || route_to_mfma(0, dtype, a, reinterpret_cast<const uint8_t*>(a), nullptr, M, N[i], K, blocksize, true);
+        all_sm = all_sm && gemm_4bit_sm_routes(dtype, M, N[i], K, blocksize) &&
+                 gemm_4bit_sm_supported(dtype, a, reinterpret_cast<const uint8_t*>(a), nullptr, M, N[i], K, blocksize);
+    }
+    if (all_sm)
+        return 2;
+    return (!any_mfma && M <= 4) ? 1 : 0;
 }
 size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N, int K, int blocksize) {
     // alignment of A/B is unknown here; assume the aligned (fast) case, an unused workspace is harmless

@@ -830,20 +830,36 @@ bool rt_selected(int M, int N, int K, int knob1, int* force_ks, int* force_waves
 // 9.7 / 10.0 / 10.6 / 11.9 vs 10.3 / 13.6 / 14.6 / 15.6; 5120^2 (blocksize 128) 6.5 / 6.7 / 7.4 / 8.9 vs 6.8 / 8.7 / 9.3 / 10.9; nested
 // statistics level with plain ones. Behind only on long rows with more than 8 batch rows (4096 x 11008, M = 9 / 16: 11.9 / 12.2 vs
 // 10.7 / 11.9: eight wavefronts there, one chunk switch per item) and at one row (the streaming kernel: 4.20 vs 4.43).
+constexpr int kSmMinRows = 128; // (below: a handful of tiles - the kernels of round 5)
 bool sm_selected(int M, int N, int K, int knob0, int knob1) {
     const int cfg = knob1 / 100;
     if (cfg == 50)
         return true;
     if (cfg != 0 || (knob0 & 2)) // (knob0 bit 1: the routing as it was before this kernel - A/B runs)
         return false;
-    // one persistent workgroup per CU needs >= ~3/4 of the chip's CUs in 16-row tiles
-    if (M < 2 || N < 12 * device_cu_count_or_default())
+    if (M < 2 || N < kSmMinRows)
         return false;
     // rows that are not whole 256-k chunks (K % 64 == 0) are this kernel's alone: row passes of 16 over grid.y up to 64 rows
-    // (4096 x 2752 M = 64: 15.6 us against 29.4 for dequantize + GEMM and 91 for the streaming kernel's 4-row passes)
+    // (4096 x 2752 M = 64: 15.6 us against 29.4 for dequantize + GEMM and 91 for the streaming kernel's 4-row passes; 1376 x 2752
+    // M = 16 / 64: 4.5 / 8.1 against 16.2 / 56.6)
     if (K % kKC)
         return M <= 64;
-    return M <= 16 && !(M > 8 && K > 2 * N);
+    // matrices that give every CU a 16-row tile (>= ~3/4 of the chip): up to 16 rows, long rows up to 8
+    if (N >= 12 * device_cu_count_or_default())
+        return M <= 16 && !(M > 8 && K > 2 * N);
+    // fewer tiles than CUs (a rank's shard of a projection, small models; profiles/r6_sm_small_n_ab.txt, us against the routing
+    // of round 5 = streaming kernel to 4 rows, register-transposed kernel above): 1376 x 4096 M = 2 / 4 / 8 3.81 / 3.83 / 4.11 vs
+    // 4.09 / 4.75 / 5.13; 2048 x 4096 3.88 / 3.91 / 4.52 / 5.66 (M = 16) vs 4.32 / 5.12 / 5.40 / 6.01; 2560^2 3.66 / 3.67 / 3.99 /
+    // 4.69 vs 4.82 / 5.63 / 4.61 / 5.00; 512 x 4096 3.66 / 3.68 / 4.00 / 5.07 vs 3.90 / 4.18 / 5.79 / 6.01. Behind: two rows on long
+    // rows (2048 x 5632 5.12 vs 4.91, 1024 x 8192 5.66 vs 4.64: the streaming kernel splits K over workgroups, this one does not),
+    // 5 ... 8 rows on K <= 2048 (level, -3 %) and on 512 x 11008, 9 ... 16 rows on long rows (1280 x 5120 6.35 vs 6.19).
+    if (M == 2)
+        return K <= 5120;
+    if (M <= 4)
+        return true;
+    if (M <= 8)
+        return K >= 2560 && (N >= 1024 || K <= 4096);
+    return M <= 16 && (K <= 4096 || K <= 2 * N);
 }
 // Which problems go to the K-quarter kernel (tuning knob cfg 40 forces it; knob % 100 = K slices).
 bool kq_selected(int M, int N, int K, int knob1, int* force_ks) {

@@ -80,6 +80,7 @@ constexpr int kSmCode2 = 1024;   // nested absmax code (256 floats)
 constexpr int kSmScratch = 1536; // per wavefront: one transposition tile (1 KiB) + the scale tile (256 B), padded to 512 B
 constexpr int kSmChunk = 256;    // k per item: four 64-k MFMA pairs
 constexpr int kSmMaxTiles = 4;   // 16-row tiles of weight rows per workgroup
+constexpr int kSmMaxGroup = 8;   // weight matrices per grouped launch
 
 struct SmArgs {
 #ifdef BNB_PROFILING
@@ -88,6 +89,18 @@ struct SmArgs {
     const float* absmax_offset;
     void* out;
     const void* bias;
+    // grouped launch (several weight matrices that share the activations, gemm_4bit_sm_grouped): count > 0, and workgroup b works
+    // on member i with start[i] <= b < start[i + 1] - its own packed weights, statistics, bias and output, rows of ONE member only
+    int count;
+    int start[kSmMaxGroup + 1];
+    int gN[kSmMaxGroup];
+    const uint8_t* gB[kSmMaxGroup];
+    const float* gabsmax[kSmMaxGroup];
+    const uint8_t* gabsmax8[kSmMaxGroup];
+    const float* gcode2[kSmMaxGroup];
+    const float* goffset[kSmMaxGroup];
+    void* gout[kSmMaxGroup];
+    const void* gbias[kSmMaxGroup];
 };
 
 // Time stamps (measurement build): s_memtime values collect in scalar registers and are stored ONCE, at the end of the kernel
@@ -144,7 +157,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     constexpr int THREADS = WAVES * 64;
     constexpr int NA = ROWS / 2;         // DMA instructions per chunk (1 KiB each)
     constexpr int STAGE = ROWS * 512;    // bytes of a wavefront's staging area
-    constexpr int REGION = (STAGE + kSmScratch) > TT * 1024 ? (STAGE + kSmScratch) : TT * 1024;
+    // Summation order = that of SIXTEEN wavefronts, whatever the instance runs on: an 8-wavefront instance of a 4- or 8-row batch
+    // (three or four tiles per workgroup) keeps two accumulator sets per tile - chunks c with c % 16 < 8 and >= 8, i.e. the chunk
+    // lists of the "virtual" wavefronts w and w + 8 - and the combine step adds sixteen partial tiles in the 16-wavefront order:
+    // a row's bits do not depend on how many tiles its workgroup holds (the launch geometry: matrix size, grouped launches, shards).
+    // (Sixteen staged rows always run 8 wavefronts: nothing to match.)
+    constexpr int V = (ROWS < 16 && WAVES == 8) ? 2 : 1;
+    constexpr int REGION = (STAGE + kSmScratch) > V * TT * 1024 ? (STAGE + kSmScratch) : V * TT * 1024;
     // vector-memory loads per ring stage: two weight loads + the lane's scale (fp32 absmax: one dword; nested: its 8-bit code and
     // the second-level absmax)
     constexpr int LPS = 2 + (NESTED ? 2 : 1);
@@ -164,11 +183,37 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     BNB_SM_STAMP(0)
     const int r = lane >> 2, pp = lane & 3;   // weight-load roles: row r of the 16-row tile, 16-byte piece pp of its 64 bytes
     const int ln = lane & 15, lg = lane >> 4; // MFMA roles: row / column ln, k group lg
-    const int M = hot_M, N = hot_N, K = hot_K;
+    const int M = hot_M, K = hot_K;
+    int N = hot_N;
     const int R = hot_geom & 0xFFFF;
     const bool fp4 = (hot_geom >> 16) & 1;
     const int bs_shift = (hot_geom >> 20) & 31;
-    const int row0 = blockIdx.x * R;
+    // the matrix of this workgroup: the preloaded arguments, or - grouped launch - the member whose block range holds blockIdx.x
+    // (scalar loads from the kernarg segment: they return while the activation requests below are formed)
+    const uint8_t* g_B = hot_B;
+    const float* g_absmax = hot_absmax;
+    const uint8_t* g_absmax8 = hot_absmax8;
+    const float* g_code2 = hot_code2;
+    const float* g_offset = p.absmax_offset;
+    void* g_out = p.out;
+    const void* g_bias = p.bias;
+    int block = blockIdx.x;
+    if (p.count > 0) {
+        int member = 0;
+#pragma unroll
+        for (int i = 1; i < kSmMaxGroup; ++i)
+            member += (i < p.count && static_cast<int>(blockIdx.x) >= p.start[i]) ? 1 : 0;
+        block -= p.start[member];
+        N = p.gN[member];
+        g_B = p.gB[member];
+        g_absmax = p.gabsmax[member];
+        g_absmax8 = p.gabsmax8[member];
+        g_code2 = p.gcode2[member];
+        g_offset = p.goffset[member];
+        g_out = p.gout[member];
+        g_bias = p.gbias[member];
+    }
+    const int row0 = block * R;
     int row_end = row0 + R;
     row_end = row_end < N ? row_end : N;
     const int m_base = blockIdx.y * 16;
@@ -217,7 +262,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
         // address arrives in a preloaded argument, so nothing waits for the kernarg segment here. Landed behind the wait for the
         // first fragments, published by the barrier behind it.
         if (wave == 0)
-            sm_dma16(sm_rsrc(hot_code2), static_cast<uint32_t>(kSmLut), static_cast<uint32_t>(lane) * 16u, 0u);
+            sm_dma16(sm_rsrc(g_code2), static_cast<uint32_t>(kSmLut), static_cast<uint32_t>(lane) * 16u, 0u);
     }
     // ORDER (experiment, single-item instances): 0 = activations first (the DMAs are the oldest entries: fragments in registers
     // before the weights land), 1 = weights first (every wavefront's weight requests go out before anybody's activation requests;
@@ -232,9 +277,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
         uint32_t s;  // lane (r, pp): the fp32 absmax of 64-k sub-block pp of row r's chunk (nested: its 8-bit code)
         uint32_t s2; // nested: the second-level absmax of that block
     };
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hot_B), 0, 0x7FFFFFFF, 0x00020000);
-    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hot_absmax), 0, 0x7FFFFFFF, 0x00020000);
-    [[maybe_unused]] const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hot_absmax8), 0, 0x7FFFFFFF, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(g_B), 0, 0x7FFFFFFF, 0x00020000);
+    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g_absmax), 0, 0x7FFFFFFF, 0x00020000);
+    [[maybe_unused]] const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(g_absmax8), 0, 0x7FFFFFFF, 0x00020000);
     // item q of this wavefront = (chunk q / TT of its list, tile q % TT). Every load is branch-free: an item past the end of
     // the list, and a tile row past the end of the workgroup's rows, is an out-of-range offset (zeros, nothing fetched).
     auto issue = [&](Stage& st, int q) {
@@ -293,7 +338,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     if constexpr (NESTED) {
         // a scalar load (constant address space): a vector load here would sit in the counted queue behind the ring
         typedef const __attribute__((address_space(4))) float* cfloat_ptr;
-        int ob = __builtin_bit_cast(int, *(cfloat_ptr)(reinterpret_cast<uintptr_t>(p.absmax_offset)));
+        int ob = __builtin_bit_cast(int, *(cfloat_ptr)(reinterpret_cast<uintptr_t>(g_offset)));
         asm volatile("" : "+s"(ob));
         offset = __builtin_bit_cast(float, ob);
     }
@@ -349,14 +394,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     const uint32_t lane4 = static_cast<uint32_t>(lane) * 4u;
     const uint32_t perm_sel = 0x0C0C0400u + static_cast<uint32_t>(opaque_zero()); // {lane offset, weight byte, 0, 0}
 
-    f32x4 acc[TT];
+    f32x4 acc[V][TT];
 #pragma unroll
-    for (int t = 0; t < TT; ++t)
-        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < V; ++z)
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+            acc[z][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // nb = 64-k blocks of the item's chunk (4; fewer in the last chunk of a K % 256 != 0 row: the MFMA pairs of the missing blocks are
     // skipped - wave-uniform - so neither the staging slots nor the weight registers behind the end of the row are ever multiplied)
-    auto compute = [&](const Stage& s, int t, int nb) {
+    auto compute = [&](const Stage& s, f32x4& accv, int nb) {
         // the lane's scale: lane (r, pp) = 4 r + pp writes dword pp of row r's 16 bytes, lane (ln, lg) reads row ln's four
         float sc;
         if constexpr (NESTED)
@@ -407,7 +454,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
                 const float sb = scale[blk];
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq)
-                    acc[t][qq] = fmaf(sb, part[qq], acc[t][qq]);
+                    accv[qq] = fmaf(sb, part[qq], accv[qq]);
             }
             if (g0 + GROUP < 8)
                 __builtin_amdgcn_sched_barrier(0);
@@ -417,14 +464,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     if constexpr (SINGLE) {
         if (nitems > 0) {
             const int left = (K >> 6) - 4 * wave;
-            compute(st[0], 0, left < 4 ? left : 4);
+            compute(st[0], acc[0][0], left < 4 ? left : 4);
         }
         BNB_SM_STAMP(7)
     } else {
         // ---- items, UNROLL at a time: the ring stage (q & 1) and the tile (q % TT) of an item are compile-time values. Every item
         // is followed by the request of item q + 2 into the stage just emptied - valid or not (see issue): LPS loads are in flight
         // behind the stage about to be consumed at every point of the loop.
-        constexpr int UNROLL = (TT % 2) ? 2 * TT : TT;
+        constexpr int UNROLL = (V == 2 || (TT % 2)) ? 2 * TT : TT; // (a multiple of V TT: the accumulator set of an item is a compile-time index)
         for (int q0 = 0; q0 < nitems; q0 += UNROLL) {
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
@@ -442,7 +489,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
                 }
                 if (q < nitems) {
                     const int left = (K >> 6) - 4 * (wave + (q / TT) * WAVES);
-                    compute(st[u & 1], t, left < 4 ? left : 4);
+                    compute(st[u & 1], acc[(u / TT) % V][t], left < 4 ? left : 4);
                 }
                 if (q == 0)
                     BNB_SM_STAMP(7)
@@ -458,11 +505,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     // DMA was waited for at its last chunk switch; the ring's dummy requests do not write LDS).
     BNB_SM_STAMP(8)
 #pragma unroll
-    for (int t = 0; t < TT; ++t)
-        *reinterpret_cast<f32x4*>(region + t * 1024 + lane * 16) = acc[t];
+    for (int z = 0; z < V; ++z)
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+            *reinterpret_cast<f32x4*>(region + (z * TT + t) * 1024 + lane * 16) = acc[z][t];
     __syncthreads();
     BNB_SM_STAMP(9)
-    constexpr int PARTS = 4, WPP = WAVES / PARTS;
+    constexpr int PARTS = 4, WPP = WAVES * V / PARTS; // (virtual wavefront v = set v / WAVES of wavefront v % WAVES)
     const int nout = TT * 16 * ROWS;
     for (int idx = tid; idx < nout * PARTS; idx += THREADS) {
         const int o = idx >> 2, part = idx & 3;
@@ -471,7 +520,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
         float pv[WPP];
 #pragma unroll
         for (int w = 0; w < WPP; ++w)
-            pv[w] = reinterpret_cast<const float*>(smem + kRegions + (part * WPP + w) * REGION + t * 1024)[src];
+            pv[w] = reinterpret_cast<const float*>(smem + kRegions + ((part * WPP + w) % WAVES) * REGION + (((part * WPP + w) / WAVES) * TT + t) * 1024)[src];
         float v = pv[0];
 #pragma unroll
         for (int w = 1; w < WPP; ++w)
@@ -481,9 +530,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
         v = dpp_add<0x4E>(v);
         const int mm = m_base + m, n = row0 + 16 * t + col;
         if (part == 0 && mm < M && n < row_end) {
-            const T* bias = static_cast<const T*>(p.bias);
+            const T* bias = static_cast<const T*>(g_bias);
             const float b = bias ? static_cast<float>(bias[n]) : 0.0f;
-            static_cast<T*>(p.out)[static_cast<long>(mm) * N + n] = static_cast<T>(v + b);
+            static_cast<T*>(g_out)[static_cast<long>(mm) * N + n] = static_cast<T>(v + b);
         }
     }
 #ifdef BNB_PROFILING
@@ -522,7 +571,8 @@ SmPlan sm_plan(int M, int N) {
 template <typename T, int ROWS, int WAVES, int TT, bool NESTED, bool SINGLE, int ORDER = 0>
 void sm_launch_one(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, const float* code2, int M, int N, int K, int geom,
                    const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
-    constexpr size_t region = (ROWS * 512 + kSmScratch) > TT * 1024 ? (ROWS * 512 + kSmScratch) : TT * 1024;
+    constexpr int V = (ROWS < 16 && WAVES == 8) ? 2 : 1; // (accumulator sets per tile: the kernel's V)
+    constexpr size_t region = (ROWS * 512 + kSmScratch) > V * TT * 1024 ? (ROWS * 512 + kSmScratch) : V * TT * 1024;
     constexpr size_t lds = kSmLut + kSmCode2 + static_cast<size_t>(WAVES) * region;
     auto kern = gemm4_mfma_sm_kernel<T, ROWS, WAVES, TT, NESTED, SINGLE, ORDER>;
     static LdsLimit lim;
@@ -596,19 +646,87 @@ void gemm_4bit_sm(int dtype, const void* A, const uint8_t* B, const float* absma
     g_last_gemm_kernel = kKernelSm;
     SmPlan pl = sm_plan(M, N);
     pl.variant = variant;
-    SmArgs a;
+    SmArgs a{};
 #ifdef BNB_PROFILING
     a.dbg = g_dbg_buf;
 #endif
     a.absmax_offset = absmax_offset;
     a.out = out;
     a.bias = bias;
+    a.count = 0;
     const int geom = pl.R | ((quant_type == kFP4) ? (1 << 16) : 0) | (ilog2(blocksize) << 20);
     if (dtype == 2)
         sm_launch_rows<bf16>(A, B, absmax, absmax8, absmax_code, M, N, K, geom, pl, a, stream);
     else
         sm_launch_rows<f16>(A, B, absmax, absmax8, absmax_code, M, N, K, geom, pl, a, stream);
     BNB_CHECK_LAUNCH();
+}
+
+// Several weight matrices that share the activations (Q/K/V, gate/up; reference: one gemm_4bit per Linear4bit, nn/modules.py:609-637)
+// in ONE launch: the workgroups are dealt to the members in proportion to their rows, a workgroup works on one member only, and
+// every output row is computed exactly as the single-matrix launch computes it (the kernel's summation order does not depend on the
+// number of tiles per workgroup). false = not a shape this launch takes (the caller issues the members one by one); nothing was
+// launched then. All members share K, blocksize, quant_type and the kind of statistics.
+bool gemm_4bit_sm_grouped(int dtype, const void* A, int count, const uint8_t* const* B, const float* const* absmax,
+                          const uint8_t* const* absmax8, const float* const* absmax_code, const float* const* absmax_offset,
+                          void* const* out, const void* const* bias, const int* N, int M, int K, int blocksize, int quant_type,
+                          hipStream_t stream) {
+    if (count < 1 || count > kSmMaxGroup || M < 1)
+        return false;
+    const bool nested = absmax8 != nullptr && absmax8[0] != nullptr;
+    long total = 0;
+    for (int i = 0; i < count; ++i) {
+        if ((absmax8 != nullptr && absmax8[i] != nullptr) != nested || !gemm_4bit_sm_supported(dtype, A, B[i], nullptr, M, N[i], K, blocksize) ||
+            !gemm_4bit_sm_serves(absmax[i], nested ? absmax8[i] : nullptr, blocksize))
+            return false;
+        if (nested && (absmax_code == nullptr || absmax_code[i] == nullptr || absmax_offset == nullptr || absmax_offset[i] == nullptr))
+            return false;
+        total += N[i];
+    }
+    if (total >= (1L << 30))
+        return false;
+    SmPlan pl = sm_plan(M, static_cast<int>(total));
+    // rows per workgroup: every member rounds its own share up - not more workgroups than the plan's whole rounds of the chip
+    const long limit = static_cast<long>(pl.grid_x) > sm_cu_count() ? static_cast<long>(pl.grid_x) : sm_cu_count();
+    SmArgs a{};
+    for (;; ++pl.R) {
+        long blocks = 0;
+        for (int i = 0; i < count; ++i)
+            blocks += (N[i] + pl.R - 1) / pl.R;
+        if (blocks <= limit || pl.R >= 16 * kSmMaxTiles) {
+            pl.grid_x = static_cast<int>(blocks);
+            break;
+        }
+    }
+    pl.tt = (pl.R + 15) / 16;
+#ifdef BNB_PROFILING
+    a.dbg = g_dbg_buf;
+#endif
+    a.absmax_offset = nested ? absmax_offset[0] : nullptr;
+    a.out = out[0];
+    a.bias = bias ? bias[0] : nullptr;
+    a.count = count;
+    a.start[0] = 0;
+    for (int i = 0; i < kSmMaxGroup; ++i) {
+        const int j = i < count ? i : 0;
+        a.start[i + 1] = a.start[i] + (i < count ? (N[i] + pl.R - 1) / pl.R : 0);
+        a.gN[i] = N[j];
+        a.gB[i] = B[j];
+        a.gabsmax[i] = absmax[j];
+        a.gabsmax8[i] = nested ? absmax8[j] : nullptr;
+        a.gcode2[i] = nested ? absmax_code[j] : nullptr;
+        a.goffset[i] = nested ? absmax_offset[j] : nullptr;
+        a.gout[i] = out[j];
+        a.gbias[i] = bias ? bias[j] : nullptr;
+    }
+    g_last_gemm_kernel = kKernelSm;
+    const int geom = pl.R | ((quant_type == kFP4) ? (1 << 16) : 0) | (ilog2(blocksize) << 20);
+    if (dtype == 2)
+        sm_launch_rows<bf16>(A, B[0], absmax[0], a.gabsmax8[0], a.gcode2[0], M, N[0], K, geom, pl, a, stream);
+    else
+        sm_launch_rows<f16>(A, B[0], absmax[0], a.gabsmax8[0], a.gcode2[0], M, N[0], K, geom, pl, a, stream);
+    BNB_CHECK_LAUNCH();
+    return true;
 }
 
 } // namespace bnb

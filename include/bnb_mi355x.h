@@ -72,9 +72,9 @@ void cdequantize_blockwise_bf16(float* code, unsigned char* A, float* absmax, vo
  *   scale of block b = absmax[b]                                            (absmax_8bit == NULL)
  *                    = absmax_code[absmax_8bit[b]] * absmax[b >> 8] + *absmax_offset   (nested)
  * K % blocksize == 0 is guaranteed by the caller (reference backends/cuda/ops.py:956-962);
- * absmax_offset is fp32; bias has A's dtype. M is any positive value: M = 1 (and M <= 4 on matrices with fewer than 12 CUs
- * x 16 rows, M = 3, 4 below 12 M weights) runs the streaming kernel (gemv4_stream.hip: persistent workgroups, weights through a
- * register ring, any M in row passes of up to four); 2 ... 16 rows on matrices of >= 3072 rows the streaming MFMA kernel
+ * absmax_offset is fp32; bias has A's dtype. M is any positive value: M = 1 (and M <= 4 on matrices of fewer than 128 rows,
+ * M = 2 on long rows of small matrices) runs the streaming kernel (gemv4_stream.hip: persistent workgroups, weights through a
+ * register ring, any M in row passes of up to four); 2 ... 16 rows on matrices of >= 128 rows the streaming MFMA kernel
  * (gemm4_mfma_sm.hip: one persistent workgroup per CU, one decode for all rows, activations once per CU); larger M and smaller
  * matrices the other MFMA kernels (gemm4_mfma_rt.hip / gemm4_mfma.hip / gemm4_mfma_kq.hip: bf16 / fp16, K % 256 == 0, blocksize
  * >= 64, aligned pointers; any M in row tiles); shapes the MFMA kernels do not take (fp32, odd K, small blocks) run the
@@ -152,9 +152,12 @@ int bnb_mi355x_last_gemm_kernel(void);
  * (the Q/K/V projections of an attention block, the gate/up projections of an MLP: reference callers issue one
  * gemm_4bit per matrix, bitsandbytes/nn/modules.py:609-637). All matrices share K, blocksize, quant_type and
  * nested-ness (absmax_8bit is NULL, or non-NULL for every matrix). The arrays are HOST arrays of device pointers
- * / ints, read during the call. For M <= 4 and count <= 8 this is ONE launch of the streaming kernel over the
- * concatenated rows (one kernel boundary, one decode-table build, one activation copy per CU); otherwise the
- * matrices are launched one by one. Results are bit-identical to `count` separate cgemm_4bit_* calls. */
+ * / ints, read during the call. count <= 8: ONE launch - of the streaming MFMA kernel when every member's own route is that
+ * kernel (2 ... 16 rows; workgroups dealt to the members by rows), of the streaming kernel over the concatenated rows when no
+ * member's route is an MFMA kernel (M <= 4) - one kernel boundary, one decode-table build, one activation copy per CU;
+ * otherwise the matrices are launched one by one. Results are bit-identical to `count` separate cgemm_4bit_* calls.
+ * bnb_mi355x_gemm_4bit_grouped_route: which of these a group takes (2 / 1 / 0), from shapes alone (aligned pointers assumed). */
+int bnb_mi355x_gemm_4bit_grouped_route(int dtype, int count, const int* N, int M, int K, int blocksize);
 void bnb_mi355x_gemm_4bit_grouped(int dtype, const void* A, int count, const uint8_t* const* B, const float* const* absmax, const uint8_t* const* absmax_8bit, const float* const* absmax_code, const float* const* absmax_offset, void* const* out, const void* const* bias, const int* N, int M, int K, int blocksize, int quant_type, bnb_stream_t stream);
 
 /* Fused backward of the 4-bit linear layer (MatMul4Bit.backward, reference bitsandbytes/autograd/_functions.py:365-386, which

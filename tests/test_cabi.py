@@ -435,9 +435,10 @@ def test_native_dispatch_routing_constants_match_python():
     # K = 64 is not a multiple of 256: the MFMA kernels do not serve it, the streaming kernel's passes stop at STREAM_ONLY_MAX_M
     assert hip._gemm_4bit_route(torch.bfloat16, hip.STREAM_ONLY_MAX_M, 64, 64, 64) == "fused"
     assert hip._gemm_4bit_route(torch.bfloat16, hip.STREAM_ONLY_MAX_M + 1, 64, 64, 64) == "unfused"
-    # (round 6: K % 64 == 0 rows on >= 3072-row matrices take the streaming MFMA kernel's row passes up to SM_TAIL_MAX_M rows)
+    # (round 6: K % 64 == 0 rows on >= SM_MIN_ROWS-row matrices take the streaming MFMA kernel's row passes up to SM_TAIL_MAX_M rows)
     assert hip._gemm_4bit_route(torch.bfloat16, 64, 4096, 2752, 64) == "fused" and hip._gemm_4bit_route(torch.bfloat16, 65, 4096, 2752, 64) == "unfused"
-    assert hip._gemm_4bit_route(torch.bfloat16, 64, 1376, 2752, 64) == "unfused" and hip._gemm_4bit_route(torch.bfloat16, 12, 1376, 2752, 64) == "fused"
+    assert hip._gemm_4bit_route(torch.bfloat16, 64, 1376, 2752, 64) == "fused" and hip._gemm_4bit_route(torch.bfloat16, 65, 1376, 2752, 64) == "unfused"
+    assert hip._gemm_4bit_route(torch.bfloat16, 17, 96, 2752, 64) == "unfused" and hip._gemm_4bit_route(torch.bfloat16, 12, 96, 2752, 64) == "fused"
     assert hip._gemm_4bit_route(torch.bfloat16, 17, 4096, 2752 + 32, 64) == "unfused"
     assert hip._gemm_4bit_route(torch.bfloat16, 64, 4096, 4096, 32, True) == "unfused" and hip._gemm_4bit_route(torch.bfloat16, 64, 4096, 4096, 32) == "fused"
     assert hip._gemm_4bit_route(torch.bfloat16, hip.FUSED_MAX_M, 8192, 8192, 64) == "fused"

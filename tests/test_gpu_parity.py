@@ -1971,10 +1971,13 @@ def test_matmul_4bit_grouped_equals_separate_calls(dtype, dq, M):
             assert y.shape == y1.shape and torch.equal(y, y1)
 
 
-@pytest.mark.parametrize("M", [3, 4])
+@pytest.mark.parametrize("M", [2, 3, 4, 7, 8, 16])
 def test_matmul_4bit_grouped_big_members_equal_separate_calls(M):
-    """Three or four rows on a matrix of >= 12 M weights go to the MFMA kernel in the single-matrix op; a group with such a
-    member is issued matrix by matrix (other arithmetic than the streaming kernel's): still bit-identical to separate calls."""
+    """Two to sixteen rows: every member's own route is the streaming MFMA kernel, and the group is ONE launch of that kernel over
+    the members' rows (round 6; until then a group with an MFMA-routed member was issued matrix by matrix) - bit-identical to
+    separate calls, because the kernel's summation order does not depend on the number of tiles a workgroup holds."""
+    import ctypes as ct
+
     import bitsandbytes_amd as bnb
 
     F = _F()
@@ -1986,10 +1989,72 @@ def test_matmul_4bit_grouped_big_members_equal_separate_calls(M):
         q, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4")
         ws.append(q)
         sts.append(st)
-    assert bnb.lib.bnb_mi355x_gemm_4bit_route(0, 2, M, 4096, K, 64) == 1 and bnb.lib.bnb_mi355x_gemm_4bit_route(0, 2, M, 1024, K, 64) == 0
+    assert bnb.lib.bnb_mi355x_gemm_4bit_route(0, 2, M, 4096, K, 64) == 1 and bnb.lib.bnb_mi355x_gemm_4bit_route(0, 2, M, 1024, K, 64) == 1
+    assert bnb.lib.bnb_mi355x_gemm_4bit_grouped_route(2, 3, (ct.c_int * 3)(4096, 1024, 1024), M, K, 64) == 2
     ys = bnb.matmul_4bit_grouped(x, ws, sts, [None] * 3)
+    assert bnb.lib.bnb_mi355x_last_gemm_kernel() == K_SM
     for y, w, s in zip(ys, ws, sts):
         assert torch.equal(y, bnb.matmul_4bit(x, w, s))
+
+
+@pytest.mark.parametrize("dtype,qt,bs,dq", [(torch.bfloat16, "nf4", 64, False), (torch.bfloat16, "nf4", 64, True), (torch.float16, "fp4", 128, True),
+                                             (torch.float16, "nf4", 256, False)])
+def test_grouped_launch_of_the_streaming_mfma_kernel(dtype, qt, bs, dq):
+    """bnb_mi355x_gemm_4bit_grouped as one launch of the streaming MFMA kernel: groups of two to eight members of different heights
+    (one to four tiles per workgroup, members that are not whole workgroup shares, a member of 144 rows), K with a partial last chunk,
+    fp32 and nested statistics, bias on some members - against the oracle, bit-identical to the members' separate calls, the family
+    that ran asserted; a group with a member below the kernel's range (64 rows) is issued matrix by matrix, same bits."""
+    import ctypes as ct
+
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    for (K, heights) in ((4096, (4096, 4096, 4096, 4096)), (2048, (11008, 11008)), (1024, (144, 3200, 528)), (2752, (1376, 1376)),
+                         (512, (256,) * 8), (8192, (8192, 1024, 1024)), (4096, (4096, 64))):
+        g = torch.Generator().manual_seed(K + len(heights))
+        ws, sts, bs_ = [], [], []
+        for i, N in enumerate(heights):
+            W = (torch.randn(N, K, generator=g) / K**0.5).to(dtype)
+            q, st = F.quantize_4bit(W.to(DEV), blocksize=bs, quant_type=qt, compress_statistics=dq)
+            ws.append(q)
+            sts.append(st)
+            bs_.append(torch.randn(N, generator=g).to(dtype).to(DEV) if i % 2 else None)
+        for M in (2, 5, 16):
+            x = torch.randn(M, K, generator=g).to(dtype)
+            want = bnb.lib.bnb_mi355x_gemm_4bit_grouped_route(1 if dtype == torch.float16 else 2, len(heights), (ct.c_int * len(heights))(*heights), M, K, bs)
+            ys = bnb.matmul_4bit_grouped(x.to(DEV), ws, sts, bs_)
+            if want == 2:
+                assert bnb.lib.bnb_mi355x_last_gemm_kernel() == K_SM, (K, heights, M)
+            if (heights == (4096,) * 4 or heights == (1376, 1376)) and K % bs == 0:
+                assert want == 2, (K, heights, M)
+            if min(heights) < 128:
+                assert want != 2, (K, heights, M)
+            for y, w, s, b in zip(ys, ws, sts, bs_):
+                assert torch.equal(y, bnb.matmul_4bit(x.to(DEV), w, s, bias=b)), (K, heights, M)
+                assert rel_err(y.cpu(), _oracle_y_full(x, w, s, b)) < REL_TOL, (K, heights, M)
+
+
+def test_mfma_sm_kernel_rows_do_not_depend_on_the_launch_geometry():
+    """A weight row's result is the same bits whether its matrix gives a workgroup one tile (16 wavefronts) or four (8 wavefronts, two
+    accumulator sets per tile = the sixteen wavefronts' chunk lists): rows [a, b) of a tall matrix equal the result of the matrix
+    made of those rows alone - what row shards (parallel.py) and grouped launches rely on. 2 ... 8 rows (sixteen staged rows run 8
+    wavefronts in every instance), K of one, several and a partial chunk per wavefront."""
+    F = _F()
+    for (N, K, cut) in ((16384, 4096, (4096, 5120)), (12288, 8192, (0, 2048)), (20000, 1344, (16000, 17024)), (11008, 2048, (5504, 8256))):
+        from bitsandbytes_amd.backends import hip
+
+        g = torch.Generator().manual_seed(N + K)
+        W = (torch.randn(N, K, generator=g) / K**0.5).to(torch.bfloat16).to(DEV)
+        q, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4")
+        a, b = cut
+        qs = q.view(N, K // 2)[a:b].contiguous().view(-1, 1)
+        absmax_s = st.absmax.view(N, K // 64)[a:b].contiguous().view(-1)
+        for M in (2, 3, 4, 7, 8):
+            x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+            with _forced(5000, K_SM):
+                y_all = hip._gemm_4bit_fused(x, q, (N, K), st.absmax, 64, "nf4", None, None, None, None, kernel=2)
+                y_cut = hip._gemm_4bit_fused(x, qs, (b - a, K), absmax_s, 64, "nf4", None, None, None, None, kernel=2)
+            assert torch.equal(y_all[:, a:b], y_cut), (N, K, cut, M)
 
 
 def test_matmul_4bit_double_backward_gpu():
