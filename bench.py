@@ -48,7 +48,7 @@ Extra objects on the JSON line:
   "config3"       BASELINE.json configs[2] (gemm_4bit M = 64, N = K = 8192) through the public op: kernel, us, frac_hbm, frac_mfma and the
                   HBM traffic per call from the PMC counters (--no-config3 skips it).
   "grouped"       the same 128 layers launched as 32 groups of 4 through matmul_4bit_grouped (one launch per group):
-                  what the boundary costs, reported beside the headline, never instead of it.
+                  what the boundary costs, reported beside the headline, never instead of it; "sweep": the same at M = 1 ... 16.
 """
 import argparse
 import json
@@ -737,15 +737,27 @@ def main():
                           "frac_hbm": round(gbps / HBM_PEAK_GBS, 4), "frac_mfma": round(tfl / MFMA_PEAK_TFLOPS, 4)})
         gsz = 4
 
-        def grouped_fn():
-            for i in range(0, LAYERS, gsz):
-                grp = layers[i:i + gsz]
-                bnb.matmul_4bit_grouped(x, [q for q, _ in grp], [st for _, st in grp])
-        t_grp = graph_us_per_launch(grouped_fn, LAYERS, reps=5)
+        def grouped_us(m_rows):
+            xm = x if m_rows == M else torch.randn(m_rows, K, device=device).to(torch.bfloat16)
+
+            def grouped_fn():
+                for i in range(0, LAYERS, gsz):
+                    grp = layers[i:i + gsz]
+                    bnb.matmul_4bit_grouped(xm, [q for q, _ in grp], [st for _, st in grp])
+            t = graph_us_per_launch(grouped_fn, LAYERS, reps=5)
+            return t, KERNEL_FAMILIES.get(int(bnb.lib.bnb_mi355x_last_gemm_kernel()), "?")
+        t_grp, _ = grouped_us(M)
         grouped = {"group_size": gsz, "us_per_layer": round(t_grp, 3), "GBps": round(nbytes_layer / t_grp / 1e3, 1),
                    "frac_of_hbm_peak": round(nbytes_layer / t_grp / 1e3 / HBM_PEAK_GBS, 4),
                    "what": "the same 128 layers as 32 launches of matmul_4bit_grouped (4 matrices sharing x per launch: Q/K/V/O- or "
-                           "gate/up-style); informational - the headline keeps one launch per layer"}
+                           "gate/up-style); informational - the headline keeps one launch per layer. sweep: the same at M = 1 ... 16 rows "
+                           "(one launch of the streaming kernel at one row, of the streaming MFMA kernel from two rows on)"}
+        gsweep = []
+        for m_rows in (1, 2, 4, 8, 16):
+            t_us, fam = grouped_us(m_rows)
+            gbps = algorithmic_bytes(m_rows, N, K, bs) / t_us / 1e3
+            gsweep.append({"M": m_rows, "us_per_layer": round(t_us, 2), "kernel": fam, "GBps": round(gbps, 1), "frac_hbm": round(gbps / HBM_PEAK_GBS, 4)})
+        grouped["sweep"] = gsweep
 
     config3 = None
     if not multi and not args.no_config3 and rank == 0 and (M, N, K) == (1, 4096, 4096):

@@ -91,7 +91,7 @@ struct SmArgs {
     const void* bias;
     // grouped launch (several weight matrices that share the activations, gemm_4bit_sm_grouped): count > 0, and workgroup b works
     // on member i with start[i] <= b < start[i + 1] - its own packed weights, statistics, bias and output, rows of ONE member only
-    int count;
+    // (the count travels in hot_geom)
     int start[kSmMaxGroup + 1];
     int gN[kSmMaxGroup];
     const uint8_t* gB[kSmMaxGroup];
@@ -148,8 +148,8 @@ __device__ __forceinline__ int sm_swz(int m) { return (m & 3) | ((m & 4) << 1); 
 // TT = 16-row tiles of weight rows per workgroup (compile time: the accumulators of a wavefront's TT tiles live in registers and
 // the ring stage of an item must be a compile-time index); NESTED: double-quantised statistics; SINGLE: no wavefront has more
 // than ONE item (K <= 256 WAVES and one tile - the headline shape): no ring, no refill requests.
-// grid = (ceil(N / R), ceil(M / 16)); hot_geom = R | fp4 << 16 | bs_shift << 20.
-template <typename T, int ROWS, int WAVES, int TT, bool NESTED, bool SINGLE, int ORDER = 0>
+// grid = (ceil(N / R), ceil(M / 16)); hot_geom = R | fp4 << 16 | bs_shift << 20 | members of a grouped launch << 25.
+template <typename T, int ROWS, int WAVES, int TT, bool NESTED, bool SINGLE, int ORDER = 0, bool GROUPED = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     // hot arguments as separate scalars: preloaded into SGPRs by the command processor (14 dwords)
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, const float* hot_code2, int hot_M,
@@ -198,11 +198,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     void* g_out = p.out;
     const void* g_bias = p.bias;
     int block = blockIdx.x;
-    if (p.count > 0) {
+    // (a compile-time variant: as a run-time branch the member's pointers were loaded from the kernarg segment - speculatively - in
+    // front of the first weight request of EVERY launch: +0.2 ... 0.3 us on the single-matrix launch at two and four rows)
+    if constexpr (GROUPED) {
+        const int gcount = (hot_geom >> 25) & 15;
         int member = 0;
 #pragma unroll
         for (int i = 1; i < kSmMaxGroup; ++i)
-            member += (i < p.count && static_cast<int>(blockIdx.x) >= p.start[i]) ? 1 : 0;
+            member += (i < gcount && static_cast<int>(blockIdx.x) >= p.start[i]) ? 1 : 0;
         block -= p.start[member];
         N = p.gN[member];
         g_B = p.gB[member];
@@ -551,6 +554,7 @@ int sm_cu_count() { return device_cu_count_or_default(); }
 struct SmPlan {
     int R, tt, grid_x, rows;
     int variant = 0; // experiment bits (bnb_mi355x_set_tuning knob0)
+    bool grouped = false;
 };
 
 // rows per workgroup: one workgroup per CU when 64 rows are enough, else whole rounds of workgroups
@@ -568,13 +572,13 @@ SmPlan sm_plan(int M, int N) {
     return pl;
 }
 
-template <typename T, int ROWS, int WAVES, int TT, bool NESTED, bool SINGLE, int ORDER = 0>
+template <typename T, int ROWS, int WAVES, int TT, bool NESTED, bool SINGLE, int ORDER = 0, bool GROUPED = false>
 void sm_launch_one(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, const float* code2, int M, int N, int K, int geom,
                    const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
     constexpr int V = (ROWS < 16 && WAVES == 8) ? 2 : 1; // (accumulator sets per tile: the kernel's V)
     constexpr size_t region = (ROWS * 512 + kSmScratch) > V * TT * 1024 ? (ROWS * 512 + kSmScratch) : V * TT * 1024;
     constexpr size_t lds = kSmLut + kSmCode2 + static_cast<size_t>(WAVES) * region;
-    auto kern = gemm4_mfma_sm_kernel<T, ROWS, WAVES, TT, NESTED, SINGLE, ORDER>;
+    auto kern = gemm4_mfma_sm_kernel<T, ROWS, WAVES, TT, NESTED, SINGLE, ORDER, GROUPED>;
     static LdsLimit lim;
     ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(pl.grid_x, (M + 15) / 16), dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, code2, M, N, K, geom, a);
@@ -584,6 +588,11 @@ template <typename T, int ROWS, int WAVES, int TT>
 void sm_launch_kind(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, const float* code2, int M, int N, int K, int geom,
                     const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
     const bool nested = absmax8 != nullptr;
+    if (pl.grouped) { // (ring instances only)
+        if (nested)
+            return sm_launch_one<T, ROWS, WAVES, TT, true, false, 0, true>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+        return sm_launch_one<T, ROWS, WAVES, TT, false, false, 0, true>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+    }
     if constexpr (TT == 1) {
         if ((K + kSmChunk - 1) / kSmChunk <= WAVES) { // one item per wavefront at most: no ring
             if (nested)
@@ -653,7 +662,6 @@ void gemm_4bit_sm(int dtype, const void* A, const uint8_t* B, const float* absma
     a.absmax_offset = absmax_offset;
     a.out = out;
     a.bias = bias;
-    a.count = 0;
     const int geom = pl.R | ((quant_type == kFP4) ? (1 << 16) : 0) | (ilog2(blocksize) << 20);
     if (dtype == 2)
         sm_launch_rows<bf16>(A, B, absmax, absmax8, absmax_code, M, N, K, geom, pl, a, stream);
@@ -699,13 +707,13 @@ bool gemm_4bit_sm_grouped(int dtype, const void* A, int count, const uint8_t* co
         }
     }
     pl.tt = (pl.R + 15) / 16;
+    pl.grouped = true;
 #ifdef BNB_PROFILING
     a.dbg = g_dbg_buf;
 #endif
     a.absmax_offset = nested ? absmax_offset[0] : nullptr;
     a.out = out[0];
     a.bias = bias ? bias[0] : nullptr;
-    a.count = count;
     a.start[0] = 0;
     for (int i = 0; i < kSmMaxGroup; ++i) {
         const int j = i < count ? i : 0;
@@ -720,7 +728,7 @@ bool gemm_4bit_sm_grouped(int dtype, const void* A, int count, const uint8_t* co
         a.gbias[i] = bias ? bias[j] : nullptr;
     }
     g_last_gemm_kernel = kKernelSm;
-    const int geom = pl.R | ((quant_type == kFP4) ? (1 << 16) : 0) | (ilog2(blocksize) << 20);
+    const int geom = pl.R | ((quant_type == kFP4) ? (1 << 16) : 0) | (ilog2(blocksize) << 20) | (count << 25);
     if (dtype == 2)
         sm_launch_rows<bf16>(A, B[0], absmax[0], a.gabsmax8[0], a.gcode2[0], M, N[0], K, geom, pl, a, stream);
     else
