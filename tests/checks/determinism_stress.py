@@ -100,6 +100,31 @@ def main():
                 c = seen.setdefault(fam, [0, 0])
                 c[0] += 1
                 c[1] += d
+    # round 6: matrices with fewer tiles than CUs (routed to the streaming MFMA kernel by a table) and groups that share x as ONE launch
+    for (N, K) in ((1376, 4096), (512, 4096), (2560, 2560), (1376, 2752)):
+        torch.manual_seed(N + K)
+        W = (torch.randn(N, K, device=DEV) / K**0.5).bfloat16()
+        q, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4")
+        for M in (2, 4, 8, 16):
+            x = torch.randn(M, K, device=DEV).bfloat16()
+            d = repeat(lambda: [hip._gemm_4bit_fused(x, q, st.shape, st.absmax, 64, "nf4", None, None, None, None)], f"small matrix {N} x {K} M = {M}")
+            c = seen.setdefault("small " + FAMILY.get(bnb.lib.bnb_mi355x_last_gemm_kernel(), "?"), [0, 0])
+            c[0] += 1
+            c[1] += d
+    for heights, K, dq in (((4096,) * 4, 4096, False), ((4096, 1024, 1024), 4096, True), ((11008, 11008), 4096, False), ((512,) * 3, 4096, False)):
+        torch.manual_seed(len(heights) + K)
+        qs, sts = [], []
+        for N in heights:
+            W = (torch.randn(N, K, device=DEV) / K**0.5).bfloat16()
+            q, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4", compress_statistics=dq)
+            qs.append(q)
+            sts.append(st)
+        for M in (1, 2, 4, 16):
+            x = torch.randn(M, K, device=DEV).bfloat16()
+            d = repeat(lambda: bnb.matmul_4bit_grouped(x, qs, sts), f"group {heights} M = {M} nested {int(dq)}")
+            c = seen.setdefault("group " + FAMILY.get(bnb.lib.bnb_mi355x_last_gemm_kernel(), "?"), [0, 0])
+            c[0] += 1
+            c[1] += d
     for fam, (cases, diff) in seen.items():
         print(f"{fam:12s} {cases:3d} cases x {a.runs} runs: {diff} differing runs" + ("   <-- FAIL" if diff else ""), flush=True)
 
