@@ -160,8 +160,9 @@ def matmul_4bit_grouped(A: torch.Tensor, weights, quant_states, biases=None, out
     """``[matmul_4bit(A, B_i, state_i, bias=bias_i) for i]`` for 4-bit weights that share their input - the Q/K/V
     projections of an attention block, the gate/up projections of an MLP. On MI355X a decode-sized batch (M <= 4) is
     ONE launch of the streaming kernel over the concatenated output rows (``bnb_mi355x_gemm_4bit_grouped``): one
-    kernel boundary, one decode-table build and one activation copy per CU instead of one per matrix. Outputs are
-    bit-identical to the separate calls; anything the grouped launch does not cover (autograd, mixed statistics
+    kernel boundary, one decode-table build and one activation copy per CU instead of one per matrix; 2 ... 16 rows: one launch
+    of the streaming MFMA kernel; small groups of 17 ... 64 rows: the same in row passes. Outputs are bit-identical to the separate
+    calls up to 16 rows (above: within the fused calls' tolerance); anything the grouped launch does not cover (autograd, mixed statistics
     formats, legacy [K, N] weights, CPU tensors) takes the separate calls.
     ``outs``: optional pre-allocated contiguous result tensors (slices of one communication buffer - the sharded block of
     ``parallel.py`` gathers a whole group with one collective); they are filled and returned.

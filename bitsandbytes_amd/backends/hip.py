@@ -500,7 +500,8 @@ def gemm_4bit_grouped(A: torch.Tensor, mats, blocksize: int, quant_type: str, ou
     (``bnb_mi355x_gemm_4bit_grouped``): of the streaming MFMA kernel at 2 ... 16 rows, of the streaming kernel at M <= 4 where
     that is the members' own route; other groups are issued matrix by matrix. ``mats``: sequence of ``(B, shapeB, absmax, bias, absmax_8bit, absmax_code,
     absmax_offset)`` with the argument meaning of the ``gemm_4bit`` op; all matrices share K, blocksize, quant_type
-    and nested-ness. Results are bit-identical to separate ``gemm_4bit`` calls. ``outs``: optional pre-allocated contiguous
+    and nested-ness. Results are bit-identical to separate ``gemm_4bit`` calls up to 16 rows; a group of 17 ... 64 rows that the library
+    takes as one launch (row passes of the streaming MFMA kernel, include/bnb_mi355x.h) equals them within the fused calls' tolerance. ``outs``: optional pre-allocated contiguous
     ``[*, N_i]`` result tensors (e.g. slices of one communication buffer); they are returned."""
     import ctypes as ct
 
@@ -522,12 +523,19 @@ def gemm_4bit_grouped(A: torch.Tensor, mats, blocksize: int, quant_type: str, ou
         # not a group the library serves with one launch (a member that the single-matrix op hands to another MFMA kernel: other
         # arithmetic, and faster there; more than 16 rows; more than 8 matrices): the single-matrix op (its own routing, its own
         # split-K workspace from torch's allocator)
-        res = [torch.ops.bitsandbytes.gemm_4bit.default(A, B, shapeB, absmax, blocksize, quant_type, bias, a8, ac, ao)
-               for (B, shapeB, absmax, bias, a8, ac, ao) in mats]
         if outs is None:
-            return res
-        for o, r in zip(outs, res):
-            o.copy_(r.view(o.shape))
+            return [torch.ops.bitsandbytes.gemm_4bit.default(A, B, shapeB, absmax, blocksize, quant_type, bias, a8, ac, ao)
+                    for (B, shapeB, absmax, bias, a8, ac, ao) in mats]
+        if len(outs) != count:
+            raise ValueError("outs must have one tensor per matrix")
+        for o, (B, shapeB, absmax, bias, a8, ac, ao) in zip(outs, mats):
+            N = int(shapeB[0])
+            direct = (K % blocksize == 0 and A.dtype in _DT_CODE and o.dtype == A.dtype and o.is_contiguous() and o.numel() == M * N and o.device == A.device
+                      and _gemm_4bit_route(A.dtype, M, N, K, blocksize, a8 is not None) == "fused")
+            if direct:  # (the fused call writes the caller's tensor: no copy launch behind it)
+                _gemm_4bit_fused(A, B, shapeB, absmax, blocksize, quant_type, bias, a8, ac, ao, out=o)
+            else:
+                o.copy_(torch.ops.bitsandbytes.gemm_4bit.default(A, B, shapeB, absmax, blocksize, quant_type, bias, a8, ac, ao).view(o.shape))
         return list(outs)
     A = A.contiguous()
     given = None if outs is None else list(outs)

@@ -296,6 +296,22 @@ void bnb_mi355x_gemm_4bit(int kernel, int dtype, const void* A, const uint8_t* B
     gemm_4bit_dispatch(kernel, dtype, A, B, absmax, absmax_8bit, absmax_code, absmax_offset, code16, out, bias, M, N, K,
                        blocksize, quant_type, workspace, workspace_bytes, S(s));
 }
+// Groups of 17 ... 64 rows as ONE launch of the streaming MFMA kernel in row passes of 16 (grid.y) - although no member's own route
+// at that many rows is this kernel: the passes of a group fill the chip's second and third round of workgroups with work that shares
+// one boundary, and small members leave CUs idle that the passes use. Measured (profiles/r6_grouped_ab.txt, second table; us per group,
+// grouped launch vs the members one by one): 4 x 4096^2 M = 24 / 32 / 48 / 64 22.2 / 22.5 / 32.0 / 42.1 vs 32.7 / 33.4 / 39.8 / 44.3;
+// 4096 + 2 x 1024 (x 4096) 14.5 / 14.7 / 20.5 / 26.5 vs 19.4 / 20.0 / 21.7 / 22.7; 3 x 512 x 4096 5.8 / 5.9 / 9.7 / 9.8 vs 15.1 / 15.3 /
+// 15.5 / 15.5; 2 x 11008 x 4096 36.7 / 37.0 vs 27.8 / 28.1 (behind: big members keep their own kernels). Such a group is NOT bit-identical
+// to separate calls (another kernel family: the oracle's tolerance, like every fused call).
+static bool grouped_sm_passes(int dtype, int count, const int* N, int M, int K, int blocksize) {
+    if (dtype == 0 || M <= 16 || M > 64 || count < 2 || count > 8 || blocksize < 64 || (K % 64) != 0 || g_mfma_knob0.load(std::memory_order_relaxed) != 0 ||
+        g_mfma_knob1.load(std::memory_order_relaxed) != 0)
+        return false;
+    long long weights = 0;
+    for (int i = 0; i < count; ++i)
+        weights += static_cast<long long>(N[i]) * K;
+    return weights <= (M <= 48 ? (72LL << 20) : (12LL << 20));
+}
 void bnb_mi355x_gemm_4bit_grouped(int dtype, const void* A, int count, const uint8_t* const* B, const float* const* absmax,
                                   const uint8_t* const* absmax_8bit, const float* const* absmax_code,
                                   const float* const* absmax_offset, void* const* out, const void* const* bias, const int* N,
@@ -317,8 +333,8 @@ void bnb_mi355x_gemm_4bit_grouped(int dtype, const void* A, int count, const uin
                                              (absmax_8bit == nullptr || absmax_8bit[i] == nullptr) && aligned_to(absmax[i], 16));
         all_sm = all_sm && gemm_4bit_sm_routes(dtype, M, N[i], K, blocksize);
     }
-    if (all_sm && gemm_4bit_sm_grouped(dtype, A, count, B, absmax, absmax_8bit, absmax_code, absmax_offset, out, bias, N, M, K, blocksize,
-                                       quant_type, S(s)))
+    if ((all_sm || grouped_sm_passes(dtype, count, N, M, K, blocksize)) &&
+        gemm_4bit_sm_grouped(dtype, A, count, B, absmax, absmax_8bit, absmax_code, absmax_offset, out, bias, N, M, K, blocksize, quant_type, S(s)))
         return;
     if (!any_mfma && gemv_4bit_grouped(dtype, A, count, B, absmax, absmax_8bit, absmax_code, absmax_offset, out, bias, N, M, K,
                                        blocksize, quant_type, S(s)))
@@ -344,6 +360,13 @@ int bnb_mi355x_gemm_4bit_grouped_route(int dtype, int count, const int* N, int M
     }
     if (all_sm)
         return 2;
+    if (grouped_sm_passes(dtype, count, N, M, K, blocksize)) {
+        bool ok = true;
+        for (int i = 0; i < count; ++i)
+            ok = ok && gemm_4bit_sm_supported(dtype, a, reinterpret_cast<const uint8_t*>(a), nullptr, M, N[i], K, blocksize);
+        if (ok)
+            return 2;
+    }
     return (!any_mfma && M <= 4) ? 1 : 0;
 }
 size_t bnb_mi355x_gemm_4bit_workspace_bytes(int kernel, int dtype, int M, int N, int K, int blocksize) {

@@ -2034,6 +2034,45 @@ def test_grouped_launch_of_the_streaming_mfma_kernel(dtype, qt, bs, dq):
                 assert rel_err(y.cpu(), _oracle_y_full(x, w, s, b)) < REL_TOL, (K, heights, M)
 
 
+@pytest.mark.parametrize("M", [17, 24, 32, 33, 48, 64])
+def test_grouped_launch_in_row_passes_from_17_rows(M):
+    """Groups of 17 ... 64 rows up to a measured size (csrc/c_api.hip: grouped_sm_passes) are ONE launch of the streaming MFMA kernel
+    in row passes of 16 - the members' own route at that many rows is another MFMA kernel, so this is the one grouped form that is
+    NOT bit-identical to separate calls: values against the oracle (per row of the batch), the family that ran, bit-reproducible run
+    to run; a group beyond the size keeps the members' own kernels."""
+    import ctypes as ct
+
+    import bitsandbytes_amd as bnb
+
+    F = _F()
+    for (K, heights, dq) in ((4096, (4096, 1024, 1024), False), (4096, (512, 512, 512), True), (2752, (1376, 1376), False), (4096, (11008, 11008), False)):
+        g = torch.Generator().manual_seed(K + len(heights) + M)
+        ws, sts, bs_ = [], [], []
+        for i, N in enumerate(heights):
+            W = (torch.randn(N, K, generator=g) / K**0.5).to(torch.bfloat16)
+            q, st = F.quantize_4bit(W.to(DEV), blocksize=64, quant_type="nf4", compress_statistics=dq)
+            ws.append(q)
+            sts.append(st)
+            bs_.append(torch.randn(N, generator=g).to(torch.bfloat16).to(DEV) if i % 2 else None)
+        x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+        want = bnb.lib.bnb_mi355x_gemm_4bit_grouped_route(2, len(heights), (ct.c_int * len(heights))(*heights), M, K, 64)
+        weights = sum(heights) * K
+        assert (want == 2) == (weights <= ((72 << 20) if M <= 48 else (12 << 20))), (K, heights, M, want)
+        ys = bnb.matmul_4bit_grouped(x.to(DEV), ws, sts, bs_)
+        if want == 2:
+            assert bnb.lib.bnb_mi355x_last_gemm_kernel() == K_SM, (K, heights, M)
+            ys2 = bnb.matmul_4bit_grouped(x.to(DEV), ws, sts, bs_)
+        for i, (y, w, s, b) in enumerate(zip(ys, ws, sts, bs_)):
+            y_ref = _oracle_y_full(x, w, s, b)
+            assert rel_err(y.cpu(), y_ref) < REL_TOL, (K, heights, M)
+            worst = ((y.double().cpu() - y_ref.double()).norm(dim=1) / y_ref.double().norm(dim=1)).max()
+            assert worst < 2 * REL_TOL, (K, heights, M, float(worst))
+            if want == 2:
+                assert torch.equal(y, ys2[i])
+            else:
+                assert torch.equal(y, bnb.matmul_4bit(x.to(DEV), w, s, bias=b))
+
+
 def test_mfma_sm_kernel_rows_do_not_depend_on_the_launch_geometry():
     """A weight row's result is the same bits whether its matrix gives a workgroup one tile (16 wavefronts) or four (8 wavefronts, two
     accumulator sets per tile = the sixteen wavefronts' chunk lists): rows [a, b) of a tall matrix equal the result of the matrix

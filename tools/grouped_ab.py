@@ -53,6 +53,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--m", default="1,2,3,4")
+    ap.add_argument("--force-sm", action="store_true", help="third column: the grouped call with the streaming MFMA kernel forced (knob cfg 50)")
     args = ap.parse_args()
     print(torch.cuda.get_device_name(0), bnb.lib.bnb_mi355x_version().decode())
     groups = [("Q/K/V/O 4 x 4096^2", [(4096, 4096)] * 4), ("GQA Q + K + V 4096 + 2 x 1024", [(4096, 4096), (1024, 4096), (1024, 4096)]),
@@ -98,7 +99,10 @@ def main():
             hip.lib = real_lib
             real_lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
             g_sep = capture(separate)
+            if args.force_sm:  # (experiment: the grouped streaming MFMA launch beyond its routed range - row passes of 16 over grid.y)
+                real_lib.bnb_mi355x_set_tuning(0, 0, 0, 5000)
             g_now = capture(grouped)  # the shipped rule
+            real_lib.bnb_mi355x_set_tuning(0, 0, 0, 0)
             ns = (ct.c_int * len(shapes))(*[n for n, _ in shapes])
             route = real_lib.bnb_mi355x_gemm_4bit_grouped_route(2, len(shapes), ns, M, K, 64)
             graphs = (g_grouped, g_sep, g_now)
