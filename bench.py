@@ -48,7 +48,7 @@ Extra objects on the JSON line:
   "config3"       BASELINE.json configs[2] (gemm_4bit M = 64, N = K = 8192) through the public op: kernel, us, frac_hbm, frac_mfma and the
                   HBM traffic per call from the PMC counters (--no-config3 skips it).
   "grouped"       the same 128 layers launched as 32 groups of 4 through matmul_4bit_grouped (one launch per group):
-                  what the boundary costs, reported beside the headline, never instead of it; "sweep": the same at M = 1 ... 16.
+                  what the boundary costs, reported beside the headline, never instead of it; "sweep": the same at M = 1 ... 32.
 """
 import argparse
 import json
@@ -750,10 +750,10 @@ def main():
         grouped = {"group_size": gsz, "us_per_layer": round(t_grp, 3), "GBps": round(nbytes_layer / t_grp / 1e3, 1),
                    "frac_of_hbm_peak": round(nbytes_layer / t_grp / 1e3 / HBM_PEAK_GBS, 4),
                    "what": "the same 128 layers as 32 launches of matmul_4bit_grouped (4 matrices sharing x per launch: Q/K/V/O- or "
-                           "gate/up-style); informational - the headline keeps one launch per layer. sweep: the same at M = 1 ... 16 rows "
-                           "(one launch of the streaming kernel at one row, of the streaming MFMA kernel from two rows on)"}
+                           "gate/up-style); informational - the headline keeps one launch per layer. sweep: the same at M = 1 ... 32 rows "
+                           "(one launch of the streaming kernel at one row, of the streaming MFMA kernel from two rows on - in row passes of 16 above 16 rows)"}
         gsweep = []
-        for m_rows in (1, 2, 4, 8, 16):
+        for m_rows in (1, 2, 4, 8, 16, 32):
             t_us, fam = grouped_us(m_rows)
             gbps = algorithmic_bytes(m_rows, N, K, bs) / t_us / 1e3
             gsweep.append({"M": m_rows, "us_per_layer": round(t_us, 2), "kernel": fam, "GBps": round(gbps, 1), "frac_hbm": round(gbps / HBM_PEAK_GBS, 4)})
