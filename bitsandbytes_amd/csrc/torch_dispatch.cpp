@@ -284,6 +284,97 @@ at::Tensor linear4bit_prepared(const at::Tensor& x, int64_t handle) {
     return y.scalar_type() == inp ? y : y.to(inp);
 }
 
+// [layer(x) for layer in layers] for prepared layers that consume the same input (Q/K/V, gate/up): ONE native call, and - where the
+// library takes the group as one launch (bnb_mi355x_gemm_4bit_grouped_route: the streaming kernel at one row, the streaming MFMA kernel
+// from two rows on) - ONE kernel launch into one allocation. Eager decode is host-bound: the Python path of a grouped call (lists,
+// ctypes arrays, one op call per fallback member) costs more than the launch it saves. Anything the grouped launch does not cover
+// (mixed dtypes / statistics / blocksizes, a group the library would issue matrix by matrix) is the layers' prepared calls one by one.
+std::vector<at::Tensor> linear4bit_group_prepared(const at::Tensor& x, at::IntArrayRef handles) {
+    std::vector<std::shared_ptr<const Prepared>> ps;
+    {
+        const std::lock_guard<std::mutex> lock(g_prepared_mutex);
+        for (const int64_t h : handles) {
+            const auto it = g_prepared.find(h);
+            TORCH_CHECK(it != g_prepared.end(), "linear4bit_group_prepared: unknown handle ", h);
+            ps.push_back(it->second);
+        }
+    }
+    const auto one_by_one = [&]() {
+        std::vector<at::Tensor> ys;
+        for (const int64_t h : handles)
+            ys.push_back(linear4bit_prepared(x, h));
+        return ys;
+    };
+    const size_t count = ps.size();
+    if (count == 0)
+        return {};
+    const Prepared& p0 = *ps[0];
+    const int64_t K = x.dim() > 0 ? x.size(-1) : 0;
+    const int64_t M = K ? x.numel() / K : 0;
+    bool same = count <= 8 && x.is_cuda() && M > 0 && p0.blocksize > 0 && K % p0.blocksize == 0;
+    int64_t total = 0;
+    for (const auto& p : ps) {
+        same = same && p->compute_dtype == p0.compute_dtype && p->blocksize == p0.blocksize && p->quant_type == p0.quant_type &&
+               p->a8.has_value() == p0.a8.has_value() && p->shape[1] == K && p->absmax.scalar_type() == at::kFloat &&
+               (!p->a8.has_value() || (p->code.has_value() && p->offset.has_value() && p->code->scalar_type() == at::kFloat));
+        total += p->shape[0];
+    }
+    const at::ScalarType inp = x.scalar_type();
+    const at::ScalarType ct = p0.compute_dtype.value_or(inp);
+    same = same && (ct == at::kHalf || ct == at::kBFloat16 || ct == at::kFloat) && M * total <= std::numeric_limits<int>::max();
+    if (!same)
+        return one_by_one();
+    const int dt = dtype_code(ct);
+    std::vector<int> Ns(count);
+    for (size_t i = 0; i < count; ++i) {
+        check_c_int(ps[i]->shape[0], "gemm_4bit N");
+        Ns[i] = static_cast<int>(ps[i]->shape[0]);
+    }
+    check_c_int(M, "gemm_4bit M");
+    check_c_int(K, "gemm_4bit K");
+    if (bnb_mi355x_gemm_4bit_grouped_route(dt, static_cast<int>(count), Ns.data(), static_cast<int>(M), static_cast<int>(K), static_cast<int>(p0.blocksize)) == 0)
+        return one_by_one();
+    const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(std::optional<c10::Device>(x.device()));
+    hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(x.get_device()).stream();
+    const at::Tensor xc = (ct != inp ? x.to(ct) : x).contiguous();
+    const int qt = quant_code(p0.quant_type);
+    // one allocation, carved into the members' contiguous [*, N_i] results
+    at::Tensor buf = at::empty({M * total}, xc.options());
+    auto lead = xc.sizes().vec();
+    std::vector<at::Tensor> outs, keep;
+    std::vector<const uint8_t*> B(count), a8(count);
+    std::vector<const float*> am(count), code(count), off(count);
+    std::vector<void*> out(count);
+    std::vector<const void*> bias(count);
+    int64_t at_elem = 0;
+    for (size_t i = 0; i < count; ++i) {
+        const Prepared& p = *ps[i];
+        lead.back() = p.shape[0];
+        outs.push_back(buf.narrow(0, at_elem, M * p.shape[0]).view(lead));
+        at_elem += M * p.shape[0];
+        B[i] = static_cast<const uint8_t*>(p.B.const_data_ptr());
+        am[i] = static_cast<const float*>(p.absmax.const_data_ptr());
+        a8[i] = static_cast<const uint8_t*>(ptr(p.a8));
+        code[i] = static_cast<const float*>(ptr(p.code));
+        off[i] = static_cast<const float*>(ptr(p.offset));
+        out[i] = outs.back().data_ptr();
+        bias[i] = nullptr;
+        if (p.bias.has_value()) {
+            keep.push_back(p.bias->scalar_type() == ct ? *p.bias : p.bias->to(ct));
+            TORCH_CHECK(keep.back().dim() == 1 && keep.back().numel() == p.shape[0], "bias must be 1D with one value per output feature");
+            bias[i] = keep.back().const_data_ptr();
+        }
+    }
+    const bool nested = p0.a8.has_value();
+    bnb_mi355x_gemm_4bit_grouped(dt, xc.const_data_ptr(), static_cast<int>(count), B.data(), am.data(), nested ? a8.data() : nullptr,
+                                 nested ? code.data() : nullptr, nested ? off.data() : nullptr, out.data(), bias.data(), Ns.data(), static_cast<int>(M),
+                                 static_cast<int>(K), static_cast<int>(p0.blocksize), qt, stream);
+    if (ct != inp)
+        for (auto& y : outs)
+            y = y.to(inp);
+    return outs;
+}
+
 } // namespace
 
 // The schema is defined by bitsandbytes_amd/_ops.py (string-identical to the reference's bitsandbytes/_ops.py:239-295), or by the
@@ -297,4 +388,5 @@ TORCH_LIBRARY_FRAGMENT(bitsandbytes_amd, m) {
           &linear4bit_prepare);
     m.def("linear4bit_prepared(Tensor x, int handle) -> Tensor", &linear4bit_prepared);
     m.def("linear4bit_release(int handle) -> ()", &linear4bit_release);
+    m.def("linear4bit_group_prepared(Tensor x, int[] handles) -> Tensor[]", &linear4bit_group_prepared);
 }

@@ -385,6 +385,12 @@ def linear4bit_group_forward(layers, x: torch.Tensor):
     from ..autograd import matmul_4bit_grouped
 
     layers = list(layers)
+    # eager decode: every layer already holds a prepared call (csrc/torch_dispatch.cpp) -> ONE native call for the group
+    if x.is_cuda and not torch.compiler.is_compiling():
+        preps = [layer._prepared for layer in layers]
+        if all(prep is not None and prep.matches(layer._parameters["weight"], layer._parameters["bias"], layer.compute_dtype)
+               for prep, layer in zip(preps, layers)) and not (torch.is_grad_enabled() and (x.requires_grad or any(p.bias_grad for p in preps))):
+            return list(torch.ops.bitsandbytes_amd.linear4bit_group_prepared(x, [p.handle for p in preps]))
     for layer in layers:
         fix_4bit_weight_quant_state_from_module(layer)
         if not layer.compute_type_is_set:
@@ -404,6 +410,11 @@ def linear4bit_group_forward(layers, x: torch.Tensor):
                 bias.data = bias.data.to(xc.dtype)
             bias = bias.to(compute_dtype)
         biases.append(bias)
+    if x.is_cuda and not torch.compiler.is_compiling():
+        for layer in layers:  # (prepared for the NEXT call, as Linear4bit.forward does)
+            qs = layer.weight.quant_state
+            if qs is not None and layer._prepared is None and K_matches(xc, qs):
+                layer._prepared_make(layer.weight, qs, layer.bias)
     ys = matmul_4bit_grouped(xc, [layer.weight for layer in layers], [layer.weight.quant_state for layer in layers], biases)
     return [y.to(inp_dtype) for y in ys]
 

@@ -2034,6 +2034,42 @@ def test_grouped_launch_of_the_streaming_mfma_kernel(dtype, qt, bs, dq):
                 assert rel_err(y.cpu(), _oracle_y_full(x, w, s, b)) < REL_TOL, (K, heights, M)
 
 
+@pytest.mark.parametrize("dq", [False, True], ids=["absmax32", "nested"])
+def test_linear4bit_group_forward_prepared_call_equals_the_layers(dq):
+    """linear4bit_group_forward on layers that hold a prepared call is ONE native call (csrc/torch_dispatch.cpp:
+    linear4bit_group_prepared) and, where the library groups, one launch: results equal the layers called one by one - bit for bit up
+    to 16 rows -, for bf16 and fp16 inputs, an fp32 input on bf16-compute layers (dtype policy of Linear4bit.forward), with and
+    without bias, leading batch dimensions; a layer whose bias was replaced drops out of the prepared form and the Python path gives
+    the same values."""
+    import bitsandbytes_amd as bnb
+    import bitsandbytes_amd.nn as bnn
+
+    torch.manual_seed(11)
+    K = 2048
+    for dt in (torch.bfloat16, torch.float16):
+        layers = [bnn.Linear4bit(K, n, bias=b, compute_dtype=dt, quant_type="nf4", compress_statistics=dq).to(DEV) for n, b in ((2048, True), (512, False), (512, True))]
+        for shape, xdt in (((1, K), dt), ((3, K), dt), ((2, 5, K), dt), ((16, K), dt), ((4, K), torch.float32), ((40, K), dt)):
+            x = torch.randn(*shape, device=DEV).to(xdt)
+            with torch.no_grad():
+                ref = [layer(x) for layer in layers]
+                ref = [layer(x) for layer in layers]  # (second call: the prepared form)
+                assert all(layer._prepared is not None for layer in layers)
+                ys = bnn.linear4bit_group_forward(layers, x)
+            M = x.numel() // K
+            for y, r in zip(ys, ref):
+                assert y.shape == r.shape and y.dtype == r.dtype
+                if M <= 16:
+                    assert torch.equal(y, r), (dt, shape, xdt)
+                else:
+                    assert rel_err(y.float().cpu(), r.float().cpu()) < REL_TOL
+        with torch.no_grad():
+            layers[0].bias = torch.nn.Parameter(torch.randn(2048, device=DEV).to(dt))
+            x = torch.randn(2, K, device=DEV).to(dt)
+            ys = bnn.linear4bit_group_forward(layers, x)
+            for y, layer in zip(ys, layers):
+                assert torch.equal(y, layer(x))
+
+
 @pytest.mark.parametrize("M", [17, 24, 32, 33, 48, 64])
 def test_grouped_launch_in_row_passes_from_17_rows(M):
     """Groups of 17 ... 64 rows up to a measured size (csrc/c_api.hip: grouped_sm_passes) are ONE launch of the streaming MFMA kernel

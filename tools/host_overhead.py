@@ -47,6 +47,21 @@ with torch.no_grad():
     print(f"# native dispatch (csrc/torch_dispatch.cpp) loaded: {hip.NATIVE_DISPATCH}")
     for name, fn in rows:
         print(f"{name:40s} {timeit(fn):7.1f} us per call")
+    # round 6: a group of four layers that share x (Q/K/V/O) in eager mode, us per GROUP - wall time with the queue full
+    group = []
+    for _ in range(4):
+        lay = bnb.nn.Linear4bit(K, N, bias=False, quant_type="nf4", compress_statistics=False, compute_dtype=torch.bfloat16)
+        lay.weight = bnb.nn.Params4bit((torch.randn(N, K, device="cuda") / 64).bfloat16(), requires_grad=False, quant_type="nf4", compress_statistics=False, module=lay)
+        group.append(lay.cuda())
+    qs, sts = [g.weight.data for g in group], [g.weight.quant_state for g in group]
+    for m_rows in (1, 4, 16):
+        xm = torch.randn(m_rows, K, device="cuda", dtype=torch.bfloat16)
+        [g(xm) for g in group]  # (prepares the layers)
+        print(f"# group of 4 x 4096^2, M = {m_rows}")
+        for name, fn in (("  4 x Linear4bit.forward (prepared)", lambda: [g(xm) for g in group]),
+                         ("  linear4bit_group_forward (prepared)", lambda: bnb.nn.linear4bit_group_forward(group, xm)),
+                         ("  matmul_4bit_grouped (Python glue)", lambda: bnb.matmul_4bit_grouped(xm, qs, sts))):
+            print(f"{name:40s} {timeit(fn, 1000):7.1f} us per group")
 
 
 # ---- load time (round 5): what quantizing one 4096^2 layer costs end to end in eager mode, wall time per call with the queue full
