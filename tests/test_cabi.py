@@ -369,6 +369,42 @@ def test_launch_plan_workspace_query_is_pure_host_logic():
     assert q(0, BF16, 64, 4096, 4100, 64) == 0, "K % 256 != 0 falls back to the dot kernel"
 
 
+def test_streaming_mfma_routing_and_grouped_route_are_pure_host_logic():
+    """The route queries run on the host (256 CUs assumed without a device): the streaming MFMA kernel's measured table
+    (csrc/gemm4_mfma.hip: sm_selected - profiles/r6_sm_v3_ab_full.txt, r6_sm_small_n_ab.txt) and what a group that shares x becomes
+    (bnb_mi355x_gemm_4bit_grouped_route: 2 = one launch of the streaming MFMA kernel, 1 = one launch of the streaming kernel,
+    0 = matrix by matrix; csrc/c_api.hip, profiles/r6_grouped_ab.txt). K % 64 == 0 shapes take no split-K workspace there."""
+    import ctypes as ct
+
+    from bitsandbytes_amd import cextension as ce
+
+    lib = ce.lib
+    BF16 = 2
+    route, ws = lib.bnb_mi355x_gemm_4bit_route, lib.bnb_mi355x_gemm_4bit_workspace_bytes
+
+    def grouped(heights, M, K, bs=64, dt=BF16):
+        return lib.bnb_mi355x_gemm_4bit_grouped_route(dt, len(heights), (ct.c_int * len(heights))(*heights), M, K, bs)
+
+    # single matrices: 2 ... 16 rows on >= 128-row matrices (MFMA route = 1), K tails to 64 rows, the measured exceptions
+    for (M, N, K, want) in ((2, 4096, 4096, 1), (16, 4096, 4096, 1), (2, 1376, 4096, 1), (4, 512, 11008, 1), (2, 1024, 8192, 0), (2, 64, 4096, 0),
+                            (64, 1376, 2752, 1), (64, 4096, 2752, 1), (12, 96, 2752, 0), (1, 4096, 4096, 0)):
+        assert route(0, BF16, M, N, K, 64) == want, (M, N, K)
+        if want and M <= 16:
+            assert ws(0, BF16, M, N, K, 64) == 0, (M, N, K)
+    assert route(0, 0, 4, 4096, 4096, 64) == 0, "fp32 activations never take the MFMA path"
+    # groups
+    qkvo = (4096,) * 4
+    assert grouped(qkvo, 1, 4096) == 1
+    assert all(grouped(qkvo, M, 4096) == 2 for M in (2, 3, 4, 8, 16, 17, 32, 48))
+    assert grouped(qkvo, 64, 4096) == 0 and grouped((512,) * 3, 64, 4096) == 2          # (row passes: <= 72 M weights to 48 rows, 12 M to 64)
+    assert grouped((11008, 11008), 16, 4096) == 2 and grouped((11008, 11008), 32, 4096) == 0
+    assert grouped((4096, 64), 4, 4096) == 0, "a member below the streaming MFMA kernel's range, another above the streaming kernel's: one by one"
+    assert grouped((64, 64), 4, 4096) == 1 and grouped((64, 64), 5, 4096) == 0
+    assert grouped((4096,) * 9, 2, 4096) == 0 and grouped(qkvo, 2, 4096 + 32) == 0 and grouped(qkvo, 2, 4096, bs=32) in (0, 1)
+    assert grouped(qkvo, 4, 4096, dt=0) == 1 and grouped(qkvo, 5, 4096, dt=0) == 0, "fp32 activations: the streaming kernel's grouped launch to 4 rows"
+    assert grouped(qkvo, 8, 4096) == grouped(qkvo, 8, 4096), "pure function"
+
+
 def test_bench_sharded_chain_geometry():
     """bench.py --gpus N: every rank's shard of every layer of the N-sharded MLP chain holds the headline layer's 4096^2 weights
     at N = 1, 2, 4, 8; each layer's gathered y is the next layer's x; every shape lies inside the fused peer chain's
