@@ -1590,7 +1590,7 @@ def test_mfma_sm_kernel_exact_on_representable_inputs():
 @pytest.mark.parametrize("N,K,dq", [(4096, 4096, False), (4096, 4096, True), (8192, 8192, False), (11008, 4096, True), (14336, 4096, False),
                                     (4096, 11008 - 11008 % 256, True), (5120, 5120, False), (4096, 2752, False), (4096, 2752, True)])
 def test_mfma_sm_kernel_is_routed_and_deterministic(N, K, dq):
-    """The BUILT-IN route takes the streaming MFMA kernel for 2 ... 16 rows on matrices of >= 3072 rows (one row: the streaming
+    """The BUILT-IN route takes the streaming MFMA kernel for 2 ... 16 rows on these matrices (one row: the streaming
     kernel; long rows with more than 8 batch rows: the register-transposed kernel). 30 launches each with other work in between, all
     bit-identical; the first within tolerance of fp32 dequantize + matmul on the device."""
     import bitsandbytes_amd as bnb
@@ -1811,7 +1811,7 @@ def test_native_dispatch_matches_python_kernel():
         ((700,), 1024, 1024, 64, "nf4", False, torch.float16, True),     # square: fused up to 640 rows, this one unfused
         ((12,), 512, 2752, 64, "nf4", True, torch.bfloat16, False),      # K % 256 != 0: the streaming kernel's passes up to 16 rows
         ((48,), 512, 2752, 64, "nf4", True, torch.bfloat16, True),       # ... above that dequantize + GEMM (round 5: was fused to 512)
-        ((48,), 3200, 1344, 64, "nf4", True, torch.bfloat16, True),      # ... but >= 3072 rows: the streaming MFMA kernel's row passes up to 64 rows (round 6)
+        ((48,), 3200, 1344, 64, "nf4", True, torch.bfloat16, True),      # ... but >= 128 rows: the streaming MFMA kernel's row passes up to 64 rows (round 6)
         ((70,), 3200, 1344, 64, "nf4", False, torch.bfloat16, False),    # ... and dequantize + GEMM above
         ((48,), 512, 2048, 32, "nf4", True, torch.bfloat16, False),      # blocksize 32 with nested statistics: likewise
         ((5,), 64, 96, 64, "nf4", False, torch.bfloat16, True),          # K % blocksize != 0: warning + unfused
