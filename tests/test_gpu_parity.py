@@ -2062,6 +2062,23 @@ def test_linear4bit_group_forward_prepared_call_equals_the_layers(dq):
                     assert torch.equal(y, r), (dt, shape, xdt)
                 else:
                     assert rel_err(y.float().cpu(), r.float().cpu()) < REL_TOL
+        # under hipGraph capture (no allocation outside torch's allocator, no synchronisation): replays compute on new inputs
+        xg = torch.randn(4, K, device=DEV).to(dt)
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                bnn.linear4bit_group_forward(layers, xg)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                yg = bnn.linear4bit_group_forward(layers, xg)
+            for _ in range(3):
+                xg.copy_(torch.randn(4, K, device=DEV).to(dt))
+                graph.replay()
+                torch.cuda.synchronize()
+                for y, layer in zip(yg, layers):
+                    assert torch.equal(y, layer(xg))
         with torch.no_grad():
             layers[0].bias = torch.nn.Parameter(torch.randn(2048, device=DEV).to(dt))
             x = torch.randn(2, K, device=DEV).to(dt)
