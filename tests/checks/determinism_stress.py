@@ -119,7 +119,7 @@ def main():
             q, st = F.quantize_4bit(W, blocksize=64, quant_type="nf4", compress_statistics=dq)
             qs.append(q)
             sts.append(st)
-        for M in (1, 2, 4, 16):
+        for M in (1, 2, 4, 16, 32):  # (32 rows: row passes of the grouped launch where the group is small enough)
             x = torch.randn(M, K, device=DEV).bfloat16()
             d = repeat(lambda: bnb.matmul_4bit_grouped(x, qs, sts), f"group {heights} M = {M} nested {int(dq)}")
             c = seen.setdefault("group " + FAMILY.get(bnb.lib.bnb_mi355x_last_gemm_kernel(), "?"), [0, 0])
