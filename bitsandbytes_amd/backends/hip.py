@@ -44,10 +44,10 @@ FUSED_TALL_WEIGHTS = 48 << 20
 # level at 16, 3 - 4 x behind at 64 (profiles/r5_tall_small_ab.txt, second table; until round 5 they were sent there up to 512 rows).
 STREAM_ONLY_MAX_M = 16
 # Round 6: rows that are not whole 256-k chunks (K % 64 == 0: K = 2752, 1344, 1088 ...) on matrices of >= SM_MIN_ROWS rows run the
-# streaming MFMA kernel (csrc/gemm4_mfma_sm.hip), above 16 rows in row passes of 16 over grid.y. Fused vs dequantize + GEMM, us
-# (profiles/r6_sm_ktail_ab.txt): 4096 x 2752 M = 32 / 64 / 96 / 128 8.9 / 15.6 / 22.2 / 28.9 vs 25.5 / 29.4 / 36.2 / 36.5; 11008 x 1344 10.8 /
-# 20.2 / 29.4 / 38.6 vs 29.4 / 30.5 / 29.8 / 29.3; 8192 x 2752 12.0 / 21.7 / 31.3 / 41.0 vs 37.9 / 44.0 / 44.5 / 44.2: ahead up to 64 rows.
-SM_TAIL_MAX_M = 64
+# streaming MFMA kernel (csrc/gemm4_mfma_sm.hip), above 16 rows its 32-row instances in row passes over grid.y. Fused vs dequantize + GEMM,
+# us (profiles/r6_sm_rows32_ab.txt): 4096 x 2752 M = 64 / 96 / 128 11.5 / 16.7 / 21.2 vs 30.2 / 36.8 / 36.7; 11008 x 1344 13.9 / 20.0 / 25.7 vs
+# 31.6 / 29.9 / 30.2; 8192 x 2752 15.5 / 21.7 / 28.4 vs 43.4 / 44.1 / 44.5; 14336 x 1088 15.6 / 22.3 / 29.0 vs 30.9 / 32.6 / 28.8: ahead or level to 128 rows.
+SM_TAIL_MAX_M = 128
 SM_MIN_ROWS = 128  # (csrc/gemm4_mfma.hip: sm_selected / kSmMinRows; small matrices, profiles/r6_sm_small_n_ab.txt: 1376 x 2752 M = 16 / 64 4.5 / 8.1 us
 # against 16.2 / 56.6 for the streaming kernel's passes)
 # Blocksize 32 (plain statistics) runs the register-transposed kernel's BS32 instances, 64-row passes one after the other: 4096^2

@@ -296,13 +296,14 @@ void bnb_mi355x_gemm_4bit(int kernel, int dtype, const void* A, const uint8_t* B
     gemm_4bit_dispatch(kernel, dtype, A, B, absmax, absmax_8bit, absmax_code, absmax_offset, code16, out, bias, M, N, K,
                        blocksize, quant_type, workspace, workspace_bytes, S(s));
 }
-// Groups of 17 ... 64 rows as ONE launch of the streaming MFMA kernel in row passes of 16 (grid.y) - although no member's own route
-// at that many rows is this kernel: the passes of a group fill the chip's second and third round of workgroups with work that shares
-// one boundary, and small members leave CUs idle that the passes use. Measured (profiles/r6_grouped_ab.txt, second table; us per group,
-// grouped launch vs the members one by one): 4 x 4096^2 M = 24 / 32 / 48 / 64 22.2 / 22.5 / 32.0 / 42.1 vs 32.7 / 33.4 / 39.8 / 44.3;
-// 4096 + 2 x 1024 (x 4096) 14.5 / 14.7 / 20.5 / 26.5 vs 19.4 / 20.0 / 21.7 / 22.7; 3 x 512 x 4096 5.8 / 5.9 / 9.7 / 9.8 vs 15.1 / 15.3 /
-// 15.5 / 15.5; 2 x 11008 x 4096 36.7 / 37.0 vs 27.8 / 28.1 (behind: big members keep their own kernels). Such a group is NOT bit-identical
-// to separate calls (another kernel family: the oracle's tolerance, like every fused call).
+// Groups of 17 ... 64 rows as ONE launch of the streaming MFMA kernel - although no member's own route at that many rows is this
+// kernel: its 32-row instances multiply two 16-row blocks against every decoded weight fragment (row passes of 32 over grid.y above
+// that; small groups: passes of 16 side by side on the CUs they leave idle), and the group shares one boundary, one table build and one
+// activation fetch per CU. Measured (profiles/r6_grouped_ab.txt, third table; us per group, grouped launch vs the members one by one):
+// 4 x 4096^2 M = 24 / 32 / 48 / 64 17.2 / 17.3 / 29.6 / 30.2 vs 32.9 / 33.4 / 39.4 / 44.4; 4096 + 2 x 1024 (x 4096) 11.0 / 11.3 / 19.7 / 20.0
+// vs 19.4 / 20.2 / 21.6 / 22.8; 3 x 512 x 4096 5.9 / 5.9 / 7.9 / 7.9 vs 15.1 / 15.3 / 15.4 / 15.4; 2 x 11008 x 4096 26.8 / 27.0 vs 28.0 / 28.4
+// but 47.4 / 48.4 vs 35.0 / 35.5 at 48 / 64 rows; 2 x 14336 x 4096 and 3 x 8192^2 behind (big members keep their own kernels).
+// Such a group is NOT bit-identical to separate calls (another kernel family: the oracle's tolerance, like every fused call).
 static bool grouped_sm_passes(int dtype, int count, const int* N, int M, int K, int blocksize) {
     if (dtype == 0 || M <= 16 || M > 64 || count < 2 || count > 8 || blocksize < 64 || (K % 64) != 0 || g_mfma_knob0.load(std::memory_order_relaxed) != 0 ||
         g_mfma_knob1.load(std::memory_order_relaxed) != 0)
@@ -310,7 +311,7 @@ static bool grouped_sm_passes(int dtype, int count, const int* N, int M, int K, 
     long long weights = 0;
     for (int i = 0; i < count; ++i)
         weights += static_cast<long long>(N[i]) * K;
-    return weights <= (M <= 48 ? (72LL << 20) : (12LL << 20));
+    return weights <= (M <= 32 ? (96LL << 20) : (72LL << 20));
 }
 void bnb_mi355x_gemm_4bit_grouped(int dtype, const void* A, int count, const uint8_t* const* B, const float* const* absmax,
                                   const uint8_t* const* absmax_8bit, const float* const* absmax_code,

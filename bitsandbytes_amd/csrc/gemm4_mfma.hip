@@ -839,11 +839,12 @@ bool sm_selected(int M, int N, int K, int knob0, int knob1) {
         return false;
     if (M < 2 || N < kSmMinRows)
         return false;
-    // rows that are not whole 256-k chunks (K % 64 == 0) are this kernel's alone: row passes of 16 over grid.y up to 64 rows
-    // (4096 x 2752 M = 64: 15.6 us against 29.4 for dequantize + GEMM and 91 for the streaming kernel's 4-row passes; 1376 x 2752
-    // M = 16 / 64: 4.5 / 8.1 against 16.2 / 56.6)
+    // rows that are not whole 256-k chunks (K % 64 == 0) are this kernel's alone: its 32-row instances in row passes over grid.y up to
+    // 128 rows (profiles/r6_sm_rows32_ab.txt, us, fused vs dequantize + GEMM: 4096 x 2752 M = 64 / 96 / 128 11.5 / 16.7 / 21.2 vs 30.2 /
+    // 36.8 / 36.7; 11008 x 1344 13.9 / 20.0 / 25.7 vs 31.6 / 29.9 / 30.2; 14336 x 1088 15.6 / 22.3 / 29.0 vs 30.9 / 32.6 / 28.8; 1376 x 2752
+    // 6.6 / 11.1 / 11.5 vs 22.6 / 21.4 / 21.3; the streaming kernel's 4-row passes: 89 us at 64 rows)
     if (K % kKC)
-        return M <= 64;
+        return M <= 128;
     // matrices that give every CU a 16-row tile (>= ~3/4 of the chip): up to 16 rows, long rows up to 8
     if (N >= 12 * device_cu_count_or_default())
         return M <= 16 && !(M > 8 && K > 2 * N);

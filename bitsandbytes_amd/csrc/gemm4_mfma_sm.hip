@@ -155,20 +155,29 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     const void* hot_A, const uint8_t* hot_B, const float* hot_absmax, const uint8_t* hot_absmax8, const float* hot_code2, int hot_M,
     int hot_N, int hot_K, int hot_geom, const SmArgs p) {
     constexpr int THREADS = WAVES * 64;
-    constexpr int NA = ROWS / 2;         // DMA instructions per chunk (1 KiB each)
-    constexpr int STAGE = ROWS * 512;    // bytes of a wavefront's staging area
+    // ROWS = 32 (17 ... 32 batch rows): TWO 16-row blocks against every decoded weight fragment, in 128-k chunks - the staging area
+    // holds 16 "virtual" rows of 512 bytes = [row m, k 0 .. 127 | row m + 16, k 0 .. 127], so the DMA lane map, the swizzle and the
+    // fragment addresses are those of sixteen staged rows of a 256-k chunk: fragment steps 0 - 3 are row block 0, steps 4 - 7 row block 1.
+    constexpr int RB = ROWS == 32 ? 2 : 1;        // 16-row blocks of the batch per workgroup pass
+    constexpr int SROWS = ROWS == 32 ? 16 : ROWS; // staged (virtual) rows
+    constexpr int CKB = ROWS == 32 ? 128 : 256;   // k per chunk
+    constexpr int HALVES = CKB / 128;             // 128-k weight loads per item
+    constexpr int NBLK = CKB / 64;                // 64-k blocks per item
+    constexpr int NA = SROWS / 2;        // DMA instructions per chunk (1 KiB each)
+    constexpr int STAGE = SROWS * 512;   // bytes of a wavefront's staging area
     // Summation order = that of SIXTEEN wavefronts, whatever the instance runs on: an 8-wavefront instance of a 4- or 8-row batch
     // (three or four tiles per workgroup) keeps two accumulator sets per tile - chunks c with c % 16 < 8 and >= 8, i.e. the chunk
     // lists of the "virtual" wavefronts w and w + 8 - and the combine step adds sixteen partial tiles in the 16-wavefront order:
     // a row's bits do not depend on how many tiles its workgroup holds (the launch geometry: matrix size, grouped launches, shards).
     // (Sixteen staged rows always run 8 wavefronts: nothing to match.)
     constexpr int V = (ROWS < 16 && WAVES == 8) ? 2 : 1;
-    constexpr int REGION = (STAGE + kSmScratch) > V * TT * 1024 ? (STAGE + kSmScratch) : V * TT * 1024;
+    constexpr int REGION = (STAGE + kSmScratch) > V * TT * RB * 1024 ? (STAGE + kSmScratch) : V * TT * RB * 1024;
     // vector-memory loads per ring stage: two weight loads + the lane's scale (fp32 absmax: one dword; nested: its 8-bit code and
     // the second-level absmax)
-    constexpr int LPS = 2 + (NESTED ? 2 : 1);
+    constexpr int LPS = HALVES + (NESTED ? 2 : 1);
     constexpr int NS = SINGLE ? 1 : 2;   // ring stages
-    static_assert(ROWS == 4 || ROWS == 8 || ROWS == 16, "staged activation rows");
+    static_assert(ROWS == 4 || ROWS == 8 || ROWS == 16 || ROWS == 32, "staged activation rows");
+    static_assert(ROWS != 32 || (!SINGLE && WAVES == 8), "32-row instances: ring, 8 wavefronts");
     static_assert(TT >= 1 && TT <= kSmMaxTiles && (!SINGLE || TT == 1), "tiles per workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -219,8 +228,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     const int row0 = block * R;
     int row_end = row0 + R;
     row_end = row_end < N ? row_end : N;
-    const int m_base = blockIdx.y * 16;
-    const int C = (K + 255) >> 8; // chunks of a row (K % 64 == 0: the last one may hold one to three 64-k blocks only)
+    const int m_base = blockIdx.y * (16 * RB);
+    const int C = (K + CKB - 1) / CKB; // chunks of a row (K % 64 == 0: the last one may hold fewer 64-k blocks)
     // chunks of this wavefront: wave, wave + WAVES, ... < C
     const int nchunks = (C - wave + WAVES - 1) / WAVES > 0 ? (C - wave + WAVES - 1) / WAVES : 0;
     const int nitems = nchunks * TT;
@@ -242,11 +251,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = 2 * i + (lane >> 5);
-        int mr = m_base + m;
-        mr = mr < M ? mr : M - 1;
         const int piece = (lane & 31) ^ sm_swz(m);
-        a_k[i] = 8 * piece;
-        a_voff[i] = static_cast<uint32_t>(mr) * static_cast<uint32_t>(K) * 2u + static_cast<uint32_t>(piece << 4);
+        const int kp = ROWS == 32 ? (piece & 15) : piece;                 // 16-byte piece of the chunk's k range
+        int mr = m_base + m + (ROWS == 32 ? 16 * (piece >> 4) : 0);
+        mr = mr < M ? mr : M - 1;
+        a_k[i] = 8 * kp;
+        a_voff[i] = static_cast<uint32_t>(mr) * static_cast<uint32_t>(K) * 2u + static_cast<uint32_t>(kp << 4);
     }
     constexpr uint32_t kOob = 0xFFFFFFF0u; // beyond num_records
     auto issue_a = [&](int ci) {
@@ -255,10 +265,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
         // that would consume them are skipped, see compute: no value of those slots is ever used).
         int c = wave + ci * WAVES;
         c = c < C ? c : C - 1;
-        const int tail = K - (c << 8);
+        const int tail = K - c * CKB;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            sm_dma16(rs_a, stage_lds + static_cast<uint32_t>(i * 1024), a_voff[i] | (a_k[i] < tail ? 0u : kOob), static_cast<uint32_t>(c) * 512u);
+            sm_dma16(rs_a, stage_lds + static_cast<uint32_t>(i * 1024), a_voff[i] | (a_k[i] < tail ? 0u : kOob), static_cast<uint32_t>(c) * static_cast<uint32_t>(CKB * 2));
     };
     if constexpr (NESTED) {
         // the second-level code table (256 floats): ONE 1-KiB DMA by wavefront 0, the oldest entry of its queue - the table's
@@ -291,15 +301,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
         const int wrow = row0 + 16 * t + r;
         const uint32_t inval = (q < nitems && wrow < row_end) ? 0u : kOob;
         const uint32_t w_off = static_cast<uint32_t>(wrow) * static_cast<uint32_t>(K >> 1) + static_cast<uint32_t>(pp * 16);
-        const uint32_t soff_w = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(c) * 128u);
-        const int tail = K - (c << 8); // k left in the row from this chunk on (>= 256 except in the last chunk of a K % 256 != 0 row)
+        const uint32_t soff_w = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(c) * static_cast<uint32_t>(CKB / 2));
+        const int tail = K - c * CKB; // k left in the row from this chunk on (>= CKB except in the last chunk of a K % CKB != 0 row)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < HALVES; ++h)
             st.w[h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off | inval | (128 * h + 32 * pp < tail ? 0u : kOob),
                                                                                        soff_w + static_cast<uint32_t>(h * 64), 0));
         // quantization block of the lane's 64-k sub-block (N K < 2^32: gemm_4bit_sm_supported)
-        const uint32_t blk = (static_cast<uint32_t>(wrow) * static_cast<uint32_t>(K) + (static_cast<uint32_t>(c) << 8) + static_cast<uint32_t>(pp * 64)) >> bs_shift;
-        const uint32_t inval_s = inval | (64 * pp < tail ? 0u : kOob);
+        const int sub = pp % NBLK; // the lane's 64-k block of the item (128-k items: lanes pp = 2, 3 repeat 0, 1)
+        const uint32_t blk = (static_cast<uint32_t>(wrow) * static_cast<uint32_t>(K) + static_cast<uint32_t>(c * CKB) + static_cast<uint32_t>(sub * 64)) >> bs_shift;
+        const uint32_t inval_s = inval | (64 * sub < tail ? 0u : kOob);
         if constexpr (NESTED) {
             st.s = static_cast<uint32_t>(__builtin_amdgcn_raw_buffer_load_b8(rs_q, blk | inval_s, 0, 0));
             st.s2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(rs_s, ((blk >> 8) << 2) | inval_s, 0, 0));
@@ -350,7 +361,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     // fragment of step s = 4 h + 2 a + b, lane (m = ln, kg = lg): 8 k from 128 h + 64 a + 8 b + 32 (kg & 1) + 16 (kg >> 1) of row m,
     // i.e. piece 16 h + 8 a + b + 4 (kg & 1) + 2 (kg >> 1) - the k order the weight regrouping below produces. Lanes of rows past
     // ROWS read a staged row again (their MFMA rows are never stored).
-    const int mrow = ln & (ROWS - 1);
+    const int mrow = ln & (SROWS - 1);
     const uint32_t frag_base = stage_lds + static_cast<uint32_t>(mrow * 512) +
                                static_cast<uint32_t>(((4 * (lg & 1) + 2 * (lg >> 1)) ^ sm_swz(mrow)) << 4);
     u32x4 af[8];
@@ -397,16 +408,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     const uint32_t lane4 = static_cast<uint32_t>(lane) * 4u;
     const uint32_t perm_sel = 0x0C0C0400u + static_cast<uint32_t>(opaque_zero()); // {lane offset, weight byte, 0, 0}
 
-    f32x4 acc[V][TT];
+    f32x4 acc[V][TT][RB];
 #pragma unroll
     for (int z = 0; z < V; ++z)
 #pragma unroll
         for (int t = 0; t < TT; ++t)
-            acc[z][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                acc[z][t][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // nb = 64-k blocks of the item's chunk (4; fewer in the last chunk of a K % 256 != 0 row: the MFMA pairs of the missing blocks are
     // skipped - wave-uniform - so neither the staging slots nor the weight registers behind the end of the row are ever multiplied)
-    auto compute = [&](const Stage& s, f32x4& accv, int nb) {
+    auto compute = [&](const Stage& s, f32x4 (&accv)[RB], int nb) {
         // the lane's scale: lane (r, pp) = 4 r + pp writes dword pp of row r's 16 bytes, lane (ln, lg) reads row ln's four
         float sc;
         if constexpr (NESTED)
@@ -417,14 +430,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
         *reinterpret_cast<__attribute__((address_space(3))) float*>(stile_lds + lane4) = sc;
         // weights: transpose (one tile, the two halves in turn: same wavefront, in-order LDS), then regroup so that dwords 0/1
         // (2/3) of every lane group belong to block 2h (2h + 1)
-        u32x4 wt[2];
+        u32x4 wt[HALVES];
         tile[wslot] = s.w[0];
         wt[0] = tile[rslot];
-        tile[wslot] = s.w[1];
-        wt[1] = tile[rslot];
+        if constexpr (HALVES == 2) {
+            tile[wslot] = s.w[1];
+            wt[1] = tile[rslot];
+        }
         const f32x4 scale = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(stile_lds + static_cast<uint32_t>(ln * 16));
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < HALVES; ++h) {
             const auto s02 = __builtin_amdgcn_permlane32_swap(wt[h][0], wt[h][2], false, false);
             const auto s13 = __builtin_amdgcn_permlane32_swap(wt[h][1], wt[h][3], false, false);
             wt[h][0] = s02[0];
@@ -435,10 +450,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
         // all look-ups first (one v_perm_b32 + one ds_read_b32 per packed byte), then the MFMAs: written look-up by look-up, every
         // MFMA waited for its own four LDS round trips (2100 cycles per item with four wavefronts per SIMD). With several tiles'
         // accumulators in 128 registers: half a chunk (16 look-ups, four MFMAs) at a time.
-        constexpr int GROUP = (TT == 1 || WAVES == 8) ? 8 : 4; // MFMA steps decoded together
+        constexpr int STEPS = 4 * HALVES;                                              // MFMA k steps (32 k) of an item's weights
+        constexpr int GROUP = (ROWS == 32) ? 4 : (TT == 1 || WAVES == 8) ? 8 : 4; // MFMA steps decoded together
         u32x4 bf[GROUP];
 #pragma unroll
-        for (int g0 = 0; g0 < 8; g0 += GROUP) {
+        for (int g0 = 0; g0 < STEPS; g0 += GROUP) {
 #pragma unroll
             for (int sidx = g0; sidx < g0 + GROUP; ++sidx) {
                 const uint32_t w = wt[sidx >> 2][sidx & 3];
@@ -451,15 +467,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
             for (int blk = g0 / 2; blk < (g0 + GROUP) / 2; ++blk) {
                 if (blk >= nb)
                     continue;
-                f32x4 part = {0.f, 0.f, 0.f, 0.f};
-                part = SmMma<T>::run(af[2 * blk], bf[2 * blk - g0], part);
-                part = SmMma<T>::run(af[2 * blk + 1], bf[2 * blk + 1 - g0], part);
                 const float sb = scale[blk];
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq)
-                    accv[qq] = fmaf(sb, part[qq], accv[qq]);
+                for (int rb = 0; rb < RB; ++rb) {
+                    // (32 rows: fragment steps 4 rb + 2 blk, + 1 - the row block's half of the virtual rows)
+                    f32x4 part = {0.f, 0.f, 0.f, 0.f};
+                    part = SmMma<T>::run(af[4 * rb * (RB - 1) + 2 * blk], bf[2 * blk - g0], part);
+                    part = SmMma<T>::run(af[4 * rb * (RB - 1) + 2 * blk + 1], bf[2 * blk + 1 - g0], part);
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        accv[rb][qq] = fmaf(sb, part[qq], accv[rb][qq]);
+                }
             }
-            if (g0 + GROUP < 8)
+            if (g0 + GROUP < STEPS)
                 __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -491,8 +511,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
                     }
                 }
                 if (q < nitems) {
-                    const int left = (K >> 6) - 4 * (wave + (q / TT) * WAVES);
-                    compute(st[u & 1], acc[(u / TT) % V][t], left < 4 ? left : 4);
+                    const int left = (K >> 6) - NBLK * (wave + (q / TT) * WAVES);
+                    compute(st[u & 1], acc[(u / TT) % V][t], left < NBLK ? left : NBLK);
                 }
                 if (q == 0)
                     BNB_SM_STAMP(7)
@@ -511,7 +531,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     for (int z = 0; z < V; ++z)
 #pragma unroll
         for (int t = 0; t < TT; ++t)
-            *reinterpret_cast<f32x4*>(region + (z * TT + t) * 1024 + lane * 16) = acc[z][t];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                *reinterpret_cast<f32x4*>(region + ((z * TT + t) * RB + rb) * 1024 + lane * 16) = acc[z][t][rb];
     __syncthreads();
     BNB_SM_STAMP(9)
     constexpr int PARTS = 4, WPP = WAVES * V / PARTS; // (virtual wavefront v = set v / WAVES of wavefront v % WAVES)
@@ -519,11 +541,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm4_mfma_sm_kernel(
     for (int idx = tid; idx < nout * PARTS; idx += THREADS) {
         const int o = idx >> 2, part = idx & 3;
         const int col = o & 15, m = (o >> 4) & (ROWS - 1), t = o / (16 * ROWS);
-        const int src = (col + 16 * (m >> 2)) * 4 + (m & 3);
+        const int rb = m >> 4, mm16 = m & 15; // (row block of the batch row - 32-row instances -, row inside it)
+        const int src = (col + 16 * (mm16 >> 2)) * 4 + (mm16 & 3);
         float pv[WPP];
 #pragma unroll
         for (int w = 0; w < WPP; ++w)
-            pv[w] = reinterpret_cast<const float*>(smem + kRegions + ((part * WPP + w) % WAVES) * REGION + (((part * WPP + w) / WAVES) * TT + t) * 1024)[src];
+            pv[w] = reinterpret_cast<const float*>(smem + kRegions + ((part * WPP + w) % WAVES) * REGION + ((((part * WPP + w) / WAVES) * TT + t) * RB + rb) * 1024)[src];
         float v = pv[0];
 #pragma unroll
         for (int w = 1; w < WPP; ++w)
@@ -568,7 +591,9 @@ SmPlan sm_plan(int M, int N) {
     pl.R = R;
     pl.tt = (R + 15) / 16;
     pl.grid_x = (N + R - 1) / R;
-    pl.rows = M <= 4 ? 4 : M <= 8 ? 8 : 16;
+    // Above 16 rows: TWO row blocks per decoded fragment in row passes of 32 (ROWS = 32) once passes of 16 would not all find a free CU;
+    // while they do (small matrices: 1376 x 4096 at 32 rows 5.4 us against 7.3), passes of 16 side by side (profiles/r6_sm_rows32_ab.txt)
+    pl.rows = M <= 4 ? 4 : M <= 8 ? 8 : (M <= 16 || static_cast<long>(pl.grid_x) * ((M + 15) / 16) <= cus) ? 16 : 32;
     return pl;
 }
 
@@ -576,12 +601,13 @@ template <typename T, int ROWS, int WAVES, int TT, bool NESTED, bool SINGLE, int
 void sm_launch_one(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, const float* code2, int M, int N, int K, int geom,
                    const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
     constexpr int V = (ROWS < 16 && WAVES == 8) ? 2 : 1; // (accumulator sets per tile: the kernel's V)
-    constexpr size_t region = (ROWS * 512 + kSmScratch) > V * TT * 1024 ? (ROWS * 512 + kSmScratch) : V * TT * 1024;
+    constexpr int RB = ROWS == 32 ? 2 : 1, SROWS = ROWS == 32 ? 16 : ROWS;
+    constexpr size_t region = (SROWS * 512 + kSmScratch) > V * TT * RB * 1024 ? (SROWS * 512 + kSmScratch) : V * TT * RB * 1024;
     constexpr size_t lds = kSmLut + kSmCode2 + static_cast<size_t>(WAVES) * region;
     auto kern = gemm4_mfma_sm_kernel<T, ROWS, WAVES, TT, NESTED, SINGLE, ORDER, GROUPED>;
     static LdsLimit lim;
     ensure_dynamic_lds(lim, reinterpret_cast<const void*>(kern), lds);
-    hipLaunchKernelGGL(kern, dim3(pl.grid_x, (M + 15) / 16), dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, code2, M, N, K, geom, a);
+    hipLaunchKernelGGL(kern, dim3(pl.grid_x, (M + 16 * RB - 1) / (16 * RB)), dim3(WAVES * 64), lds, stream, A, B, absmax, absmax8, code2, M, N, K, geom, a);
 }
 
 template <typename T, int ROWS, int WAVES, int TT>
@@ -593,7 +619,7 @@ void sm_launch_kind(const void* A, const uint8_t* B, const float* absmax, const 
             return sm_launch_one<T, ROWS, WAVES, TT, true, false, 0, true>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
         return sm_launch_one<T, ROWS, WAVES, TT, false, false, 0, true>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
     }
-    if constexpr (TT == 1) {
+    if constexpr (TT == 1 && ROWS != 32) {
         if ((K + kSmChunk - 1) / kSmChunk <= WAVES) { // one item per wavefront at most: no ring
             if (nested)
                 return sm_launch_one<T, ROWS, WAVES, 1, true, true>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
@@ -612,7 +638,7 @@ void sm_launch_kind(const void* A, const uint8_t* B, const float* absmax, const 
 template <typename T, int ROWS>
 void sm_launch_tt(const void* A, const uint8_t* B, const float* absmax, const uint8_t* absmax8, const float* code2, int M, int N, int K, int geom,
                   const SmPlan& pl, const SmArgs& a, hipStream_t stream) {
-    constexpr int W = ROWS == 16 ? 8 : 16;
+    constexpr int W = ROWS >= 16 ? 8 : 16;
     switch (pl.tt) {
     case 1: return sm_launch_kind<T, ROWS, W, 1>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
     case 2: return sm_launch_kind<T, ROWS, W, 2>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
@@ -627,7 +653,8 @@ void sm_launch_rows(const void* A, const uint8_t* B, const float* absmax, const 
     switch (pl.rows) {
     case 4: return sm_launch_tt<T, 4>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
     case 8: return sm_launch_tt<T, 8>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
-    default: return sm_launch_tt<T, 16>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+    case 16: return sm_launch_tt<T, 16>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
+    default: return sm_launch_tt<T, 32>(A, B, absmax, absmax8, code2, M, N, K, geom, pl, a, stream);
     }
 }
 
@@ -655,6 +682,8 @@ void gemm_4bit_sm(int dtype, const void* A, const uint8_t* B, const float* absma
     g_last_gemm_kernel = kKernelSm;
     SmPlan pl = sm_plan(M, N);
     pl.variant = variant;
+    if ((variant & 16) && pl.rows == 32) // (A/B: row passes of 16, as before the 32-row instances)
+        pl.rows = 16;
     SmArgs a{};
 #ifdef BNB_PROFILING
     a.dbg = g_dbg_buf;

@@ -38,7 +38,7 @@ constexpr int64_t kFusedMaxMLongRows = 1024; // K >= 2 N
 constexpr int64_t kFusedMaxMSquare = 640;    // 10 K >= 7 N
 constexpr int64_t kFusedTallWeights = 50331648; // 48 << 20
 constexpr int64_t kStreamOnlyMaxM = 16;
-constexpr int64_t kSmTailMaxM = 64;   // rows that are not whole 256-k chunks: the streaming MFMA kernel's row passes (>= kSmMinRows rows)
+constexpr int64_t kSmTailMaxM = 128;  // rows that are not whole 256-k chunks: the streaming MFMA kernel's row passes (>= kSmMinRows rows)
 constexpr int64_t kSmMinRows = 128;
 constexpr int64_t kFusedMaxMBs32 = 128; // blocksize 32, plain statistics: the register-transposed kernel's row passes
 constexpr int64_t kFusedMaxMFp32 = 4;

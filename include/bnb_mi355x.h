@@ -156,9 +156,9 @@ int bnb_mi355x_last_gemm_kernel(void);
  * kernel (2 ... 16 rows; workgroups dealt to the members by rows), of the streaming kernel over the concatenated rows when no
  * member's route is an MFMA kernel (M <= 4) - one kernel boundary, one decode-table build, one activation copy per CU;
  * otherwise the matrices are launched one by one. Results are bit-identical to `count` separate cgemm_4bit_* calls - with ONE
- * exception: groups of 17 ... 64 rows up to 72 M weights (12 M from 49 rows) are one launch of the streaming MFMA kernel in row passes
- * of 16 although the members' own route at that many rows is another MFMA kernel (4 x 4096^2 at 32 rows: 22.5 us against 33.4 matrix by
- * matrix): same values within the fused calls' tolerance, bit-reproducible, not bit-identical to separate calls.
+ * exception: groups of 17 ... 64 rows up to 96 M weights (72 M from 33 rows) are one launch of the streaming MFMA kernel - its 32-row
+ * instances - although the members' own route at that many rows is another MFMA kernel (4 x 4096^2 at 32 rows: 17.3 us against 33.4
+ * matrix by matrix): same values within the fused calls' tolerance, bit-reproducible, not bit-identical to separate calls.
  * bnb_mi355x_gemm_4bit_grouped_route: which of these a group takes (2 / 1 / 0), from shapes alone (aligned pointers assumed). */
 int bnb_mi355x_gemm_4bit_grouped_route(int dtype, int count, const int* N, int M, int K, int blocksize);
 void bnb_mi355x_gemm_4bit_grouped(int dtype, const void* A, int count, const uint8_t* const* B, const float* const* absmax, const uint8_t* const* absmax_8bit, const float* const* absmax_code, const float* const* absmax_offset, void* const* out, const void* const* bias, const int* N, int M, int K, int blocksize, int quant_type, bnb_stream_t stream);

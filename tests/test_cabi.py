@@ -298,7 +298,7 @@ def test_sm_kernel_isa_counts_its_waits_and_keeps_the_ring_in_flight():
     ring): the hand-written wait for the first fragments must leave EXACTLY the ring in flight - vmcnt(NS x LPS), LPS = two weight
     loads + the lane's scale (nested: + the second-level absmax), NS = 1 for the single-item instances, else 2 - and in the ring
     instances nothing between the table barrier and the first MFMA may drain the queue (the second stage stays in flight while the
-    first item is decoded). Every instance stages its first chunk with ROWS / 2 DMA instructions in front of the barrier (+ one for
+    first item is decoded). Every instance stages its first chunk with (staged rows) / 2 DMA instructions in front of the barrier (+ one for
     the nested code table)."""
     import re
 
@@ -308,11 +308,13 @@ def test_sm_kernel_isa_counts_its_waits_and_keeps_the_ring_in_flight():
         m = re.search(r"sm_kernelI(\w+?)Li(\d+)ELi(\d+)ELi(\d)ELb([01])ELb([01])ELi(\d)E", name)  # <T, ROWS, WAVES, TT, NESTED, SINGLE, ORDER>
         assert m, name
         rows, nested, single, order = int(m.group(2)), m.group(5) == "1", m.group(6) == "1", int(m.group(7))
-        ns, lps = (1 if single else 2), (4 if nested else 3)
+        # (32-row instances: 16 virtual staged rows - two 16-row blocks of a 128-k chunk - and ONE 128-k weight load per stage)
+        staged, halves = (16, 1) if rows == 32 else (rows, 2)
+        ns, lps = (1 if single else 2), halves + (2 if nested else 1)
         ops = [ln.split()[0] for ln in lines]
         bar = ops.index("s_barrier")
         dmas = sum(1 for ln in lines[:bar] if ln.startswith("buffer_load_dwordx4") and " lds" in ln)
-        assert dmas == rows // 2 + (1 if nested else 0), f"{name}: {dmas} DMA instructions in front of the table barrier"
+        assert dmas == staged // 2 + (1 if nested else 0), f"{name}: {dmas} DMA instructions in front of the table barrier"
         first_mfma = next(i for i, op in enumerate(ops) if op.startswith("v_mfma"))
         waits = [int(re.search(r"vmcnt\((\d+)\)", ln).group(1)) for ln in lines[bar:first_mfma] if ln.startswith("s_waitcnt") and "vmcnt(" in ln]
         assert waits, name
@@ -387,7 +389,7 @@ def test_streaming_mfma_routing_and_grouped_route_are_pure_host_logic():
 
     # single matrices: 2 ... 16 rows on >= 128-row matrices (MFMA route = 1), K tails to 64 rows, the measured exceptions
     for (M, N, K, want) in ((2, 4096, 4096, 1), (16, 4096, 4096, 1), (2, 1376, 4096, 1), (4, 512, 11008, 1), (2, 1024, 8192, 0), (2, 64, 4096, 0),
-                            (64, 1376, 2752, 1), (64, 4096, 2752, 1), (12, 96, 2752, 0), (1, 4096, 4096, 0)):
+                            (64, 1376, 2752, 1), (128, 4096, 2752, 1), (129, 4096, 2752, 0), (12, 96, 2752, 0), (1, 4096, 4096, 0)):
         assert route(0, BF16, M, N, K, 64) == want, (M, N, K)
         if want and M <= 16:
             assert ws(0, BF16, M, N, K, 64) == 0, (M, N, K)
@@ -395,9 +397,10 @@ def test_streaming_mfma_routing_and_grouped_route_are_pure_host_logic():
     # groups
     qkvo = (4096,) * 4
     assert grouped(qkvo, 1, 4096) == 1
-    assert all(grouped(qkvo, M, 4096) == 2 for M in (2, 3, 4, 8, 16, 17, 32, 48))
-    assert grouped(qkvo, 64, 4096) == 0 and grouped((512,) * 3, 64, 4096) == 2          # (row passes: <= 72 M weights to 48 rows, 12 M to 64)
-    assert grouped((11008, 11008), 16, 4096) == 2 and grouped((11008, 11008), 32, 4096) == 0
+    assert all(grouped(qkvo, M, 4096) == 2 for M in (2, 3, 4, 8, 16, 17, 32, 48, 64))
+    assert grouped(qkvo, 65, 4096) == 0 and grouped((512,) * 3, 64, 4096) == 2          # (17 ... 64 rows: <= 96 M weights to 32 rows, 72 M to 64)
+    assert grouped((11008, 11008), 16, 4096) == 2 and grouped((11008, 11008), 32, 4096) == 2 and grouped((11008, 11008), 48, 4096) == 0
+    assert grouped((14336, 14336), 32, 4096) == 0
     assert grouped((4096, 64), 4, 4096) == 0, "a member below the streaming MFMA kernel's range, another above the streaming kernel's: one by one"
     assert grouped((64, 64), 4, 4096) == 1 and grouped((64, 64), 5, 4096) == 0
     assert grouped((4096,) * 9, 2, 4096) == 0 and grouped(qkvo, 2, 4096 + 32) == 0 and grouped(qkvo, 2, 4096, bs=32) in (0, 1)
@@ -472,8 +475,8 @@ def test_native_dispatch_routing_constants_match_python():
     assert hip._gemm_4bit_route(torch.bfloat16, hip.STREAM_ONLY_MAX_M, 64, 64, 64) == "fused"
     assert hip._gemm_4bit_route(torch.bfloat16, hip.STREAM_ONLY_MAX_M + 1, 64, 64, 64) == "unfused"
     # (round 6: K % 64 == 0 rows on >= SM_MIN_ROWS-row matrices take the streaming MFMA kernel's row passes up to SM_TAIL_MAX_M rows)
-    assert hip._gemm_4bit_route(torch.bfloat16, 64, 4096, 2752, 64) == "fused" and hip._gemm_4bit_route(torch.bfloat16, 65, 4096, 2752, 64) == "unfused"
-    assert hip._gemm_4bit_route(torch.bfloat16, 64, 1376, 2752, 64) == "fused" and hip._gemm_4bit_route(torch.bfloat16, 65, 1376, 2752, 64) == "unfused"
+    assert hip._gemm_4bit_route(torch.bfloat16, 128, 4096, 2752, 64) == "fused" and hip._gemm_4bit_route(torch.bfloat16, 129, 4096, 2752, 64) == "unfused"
+    assert hip._gemm_4bit_route(torch.bfloat16, 128, 1376, 2752, 64) == "fused" and hip._gemm_4bit_route(torch.bfloat16, 129, 1376, 2752, 64) == "unfused"
     assert hip._gemm_4bit_route(torch.bfloat16, 17, 96, 2752, 64) == "unfused" and hip._gemm_4bit_route(torch.bfloat16, 12, 96, 2752, 64) == "fused"
     assert hip._gemm_4bit_route(torch.bfloat16, 17, 4096, 2752 + 32, 64) == "unfused"
     assert hip._gemm_4bit_route(torch.bfloat16, 64, 4096, 4096, 32, True) == "unfused" and hip._gemm_4bit_route(torch.bfloat16, 64, 4096, 4096, 32) == "fused"

@@ -1809,10 +1809,11 @@ def test_native_dispatch_matches_python_kernel():
         ((600,), 256, 1024, 64, "nf4", True, torch.bfloat16, True),      # long rows (K >= 2 N): fused up to 1024 rows
         ((1100,), 256, 1024, 64, "nf4", True, torch.bfloat16, True),     # ... and unfused above (nested: ONE dequantize launch)
         ((700,), 1024, 1024, 64, "nf4", False, torch.float16, True),     # square: fused up to 640 rows, this one unfused
-        ((12,), 512, 2752, 64, "nf4", True, torch.bfloat16, False),      # K % 256 != 0: the streaming kernel's passes up to 16 rows
-        ((48,), 512, 2752, 64, "nf4", True, torch.bfloat16, True),       # ... above that dequantize + GEMM (round 5: was fused to 512)
-        ((48,), 3200, 1344, 64, "nf4", True, torch.bfloat16, True),      # ... but >= 128 rows: the streaming MFMA kernel's row passes up to 64 rows (round 6)
-        ((70,), 3200, 1344, 64, "nf4", False, torch.bfloat16, False),    # ... and dequantize + GEMM above
+        ((12,), 96, 2752, 64, "nf4", True, torch.bfloat16, False),       # K % 256 != 0 on < 128 rows: the streaming kernel's passes up to 16 rows
+        ((48,), 96, 2752, 64, "nf4", True, torch.bfloat16, True),        # ... above that dequantize + GEMM (round 5: was fused to 512)
+        ((48,), 512, 2752, 64, "nf4", True, torch.bfloat16, True),       # ... from 128 rows on: the streaming MFMA kernel (round 6) ...
+        ((100,), 3200, 1344, 64, "nf4", True, torch.bfloat16, True),     # ... its 32-row instances in row passes up to 128 rows
+        ((140,), 3200, 1344, 64, "nf4", False, torch.bfloat16, False),   # ... and dequantize + GEMM above
         ((48,), 512, 2048, 32, "nf4", True, torch.bfloat16, False),      # blocksize 32 with nested statistics: likewise
         ((5,), 64, 96, 64, "nf4", False, torch.bfloat16, True),          # K % blocksize != 0: warning + unfused
     ]:
@@ -2110,7 +2111,7 @@ def test_grouped_launch_in_row_passes_from_17_rows(M):
         x = torch.randn(M, K, generator=g).to(torch.bfloat16)
         want = bnb.lib.bnb_mi355x_gemm_4bit_grouped_route(2, len(heights), (ct.c_int * len(heights))(*heights), M, K, 64)
         weights = sum(heights) * K
-        assert (want == 2) == (weights <= ((72 << 20) if M <= 48 else (12 << 20))), (K, heights, M, want)
+        assert (want == 2) == (weights <= ((96 << 20) if M <= 32 else (72 << 20))), (K, heights, M, want)
         ys = bnb.matmul_4bit_grouped(x.to(DEV), ws, sts, bs_)
         if want == 2:
             assert bnb.lib.bnb_mi355x_last_gemm_kernel() == K_SM, (K, heights, M)
