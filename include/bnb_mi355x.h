@@ -75,7 +75,7 @@ void cdequantize_blockwise_bf16(float* code, unsigned char* A, float* absmax, vo
  * absmax_offset is fp32; bias has A's dtype. M is any positive value: M = 1 (and M <= 4 on matrices of fewer than 128 rows,
  * M = 2 on long rows of small matrices) runs the streaming kernel (gemv4_stream.hip: persistent workgroups, weights through a
  * register ring, any M in row passes of up to four); 2 ... 16 rows on matrices of >= 128 rows the streaming MFMA kernel
- * (gemm4_mfma_sm.hip: one persistent workgroup per CU, one decode for all rows, activations once per CU); larger M and smaller
+ * (gemm4_mfma_sm.hip: one persistent workgroup per CU, one decode for all rows, activations once per CU; K % 256 != 0: to 128 rows); larger M and smaller
  * matrices the other MFMA kernels (gemm4_mfma_rt.hip / gemm4_mfma.hip / gemm4_mfma_kq.hip: bf16 / fp16, K % 256 == 0, blocksize
  * >= 64, aligned pointers; any M in row tiles); shapes the MFMA kernels do not take (fp32, odd K, small blocks) run the
  * streaming kernel at any M. */
