@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Round 6: groups of weight matrices that share x (Q/K/V, gate/up) at 1 ... 4 rows - ONE launch of the streaming kernel over the
-concatenated rows (bnb_mi355x_gemm_4bit_grouped) against the members issued one by one through the single-matrix op (whose route at
-2 ... 4 rows is the streaming MFMA kernel since this round). us per GROUP, hipGraph-replayed over an HBM-resident rotation of
-distinct groups, regions >= 12 ms, round-robin, median. The basis of the `to_mfma` rule in backends/hip.py: gemm_4bit_grouped.
-    python tools/grouped_ab.py [--rounds 5]"""
+"""Round 6: groups of weight matrices that share x (Q/K/V/O, gate/up) at 1 ... 64 rows, us per GROUP, hipGraph-replayed over an HBM-resident
+rotation of distinct groups, regions >= 12 ms, round-robin, median. Three columns: the grouped call under round 5's routing (one launch of the
+streaming kernel where no member went to an MFMA kernel, else matrix by matrix), the members one by one through the single-matrix op, and the
+shipped grouped call (bnb_mi355x_gemm_4bit_grouped: one launch of the streaming MFMA kernel from two rows on where the library's rule says so;
+--force-sm: that launch forced, for measuring beyond the rule). The basis of c_api.hip: grouped_sm_passes and of the grouped route.
+    python tools/grouped_ab.py [--rounds 5] [--m 1,2,4,8,16,32] [--force-sm]"""
 import argparse
 import ctypes as ct
 import os
